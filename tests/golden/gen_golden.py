@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs only where /root/reference is mounted (the build container); the reference's Python
+never travels -- what is committed are the inputs and the reference's outputs (data), plus
+this script and the tiny stand-in modules under _stubs/ for the reference's un-vendored
+imports (torch_scatter, diffdist, wget, braceexpand).
+
+    python tests/golden/gen_golden.py            # all three groups
+    python tests/golden/gen_golden.py kmeans|mi|rng
+
+Groups:
+  rng.npz     torch.manual_seed/rand/randperm and random.shuffle streams (G6)
+  kmeans_*.npz   KMeans state after every epoch, warm-up labels, per-step means, labels (G1/G2)
+  mi_*.npz    per-iteration trace of EfficientBatchMI greedy: batch ids, fp32 scores [B,P],
+              picked positions / ids; final S and GAIN (G3)
+The two reference stages have clashing top-level module names, so each group runs in its own
+interpreter.
+"""
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+STUBS = os.path.join(HERE, "_stubs")
+
+
+def mixture(seed, n, d, g, noise=0.3):
+    """Synthetic features of SURVEY 8(d): G Gaussian components, centre ~ N(0,1)^d, row = centre + 0.3 N(0,1)."""
+    rs = np.random.RandomState(seed)
+    cen = rs.randn(g, d).astype(np.float32)
+    comp = rs.randint(0, g, size=n)
+    x = cen[comp] + noise * rs.randn(n, d).astype(np.float32)
+    return x.astype(np.float32), comp
+
+
+# ----------------------------------------------------------------------------- rng
+def gen_rng():
+    import torch
+    out = {}
+    for s in (0, 1, 1234):
+        torch.manual_seed(s)
+        out[f"s{s}_rand_7x5"] = torch.rand(7, 5).numpy()
+        out[f"s{s}_perm10"] = torch.randperm(10).numpy()
+        out[f"s{s}_perm1000"] = torch.randperm(1000).numpy()
+        out[f"s{s}_perm100003_head"] = torch.randperm(100003).numpy()[:2000]
+        out[f"s{s}_rand_after"] = torch.rand(3).numpy()
+        out[f"s{s}_init_16x8"] = (torch.rand(16, 8) * 1e-5).numpy()
+        random.seed(s)
+        lst = list(range(1000))
+        random.shuffle(lst)
+        out[f"s{s}_pyshuffle1000"] = np.array(lst, np.int64)
+    np.savez_compressed(os.path.join(HERE, "rng.npz"), **out)
+    print("rng.npz written")
+
+
+# -------------------------------------------------------------------------- kmeans
+class _NS:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def gen_kmeans():
+    sys.path.insert(0, STUBS)
+    sys.path.insert(1, os.path.join(REF, "clustering", "code"))
+    import torch
+    torch.Tensor.cuda = lambda self, *a, **k: self  # sgd_clustering.py:113 hard-codes .cuda()
+    from sgd_clustering import KMeans  # noqa: E402  (the reference)
+
+    args = _NS(computation=_NS(device="cpu", num_gpus=1))
+    cases = {
+        # name: (seed, N, d, K, b, epochs)
+        "a": (0, 2048, 64, 16, 32, 2),
+        "b": (1, 1024, 200, 24, 32, 2),   # d not a multiple of 32; K not a power of two
+        "c": (2, 1536, 128, 48, 32, 2),   # more centres than mixture components -> discount rows
+    }
+    for name, (seed, n, d, k, b, epochs) in cases.items():
+        g = k if name != "c" else 12
+        x, _ = mixture(100 + seed, n, d, g)
+        xt = torch.from_numpy(x)
+        torch.manual_seed(seed)
+        km = KMeans(args, d, k)
+        out = dict(x=x, seed=seed, K=k, b=b, epochs=epochs, centers0=km.centers.numpy().copy())
+        warm, means, thr_hits = [], [], []
+        for epoch in range(epochs):
+            km.lr = 0.1 ** (2 + epoch // 5)  # run_clustering.py:233
+            for t in range(n // b):  # drop_last=True (run_clustering.py:204)
+                batch = xt[t * b:(t + 1) * b]
+                if km.count < km.initial_rounds * k:
+                    # replay calc_best's warm-up draw to record the labels, then rewind the stream
+                    st = torch.get_rng_state()
+                    best, _ = km.calc_best(batch)
+                    warm.append(best.numpy().copy())
+                    torch.set_rng_state(st)
+                means.append(km.add(batch))
+            out[f"centers_e{epoch}"] = km.centers.numpy().copy()
+            out[f"counts_e{epoch}"] = km.counts.numpy().copy()
+            out[f"count_e{epoch}"] = km.count
+            out[f"fallback_e{epoch}"] = km.fallback
+        out["warm_best"] = np.stack(warm) if warm else np.zeros((0, b), np.int64)
+        out["add_means"] = np.array(means, np.float32)
+        labels, lmeans = [], []
+        for t in range(0, n, b):
+            best, m = km.calc_best(xt[t:t + b])
+            labels.append(best.numpy())
+            lmeans.append(m)
+        out["labels"] = np.concatenate(labels).astype(np.int64)
+        out["label_means"] = np.array(lmeans, np.float32)
+        big, _ = km.calc_best(xt)  # one batch of N: assign is batch-size invariant
+        out["labels_onebatch"] = big.numpy().astype(np.int64)
+        thr = (km.count / k) ** km.reinit[0]
+        out["n_discounted"] = int((km.counts < thr).sum())
+        # top-2 gap of the reference's own distances (near-tie census for the label comparison)
+        with torch.no_grad():
+            dist = -2 * torch.matmul(km.centers, xt.T)
+            dist += (torch.norm(xt, dim=1) ** 2)[None, :]
+            dist += (torch.norm(km.centers, dim=1) ** 2)[:, None]
+            dist[km.counts < thr, :] /= km.reinit[1]
+            top2 = torch.topk(dist, 2, dim=0, largest=False).values
+            out["top2_gap"] = (top2[1] - top2[0]).numpy()
+        # G2: assign with doctored usage counts so the under-use discount (sgd_clustering.py:76-77) fires
+        saved = km.counts.clone()
+        km.counts[::3] = 1.0
+        doc, _ = km.calc_best(xt)
+        out["labels_doctored"] = doc.numpy().astype(np.int64)
+        out["n_changed_by_discount"] = int((doc != big).sum())
+        km.counts = saved
+        np.savez_compressed(os.path.join(HERE, f"kmeans_{name}.npz"), **out)
+        print(f"kmeans_{name}.npz written: discounted centres at assign = {out['n_discounted']}, "
+              f"fallback = {km.fallback}, labels moved by doctored discount = {out['n_changed_by_discount']}, min top-2 gap = {out['top2_gap'].min():.3e}")
+
+
+# ------------------------------------------------------------------------------ mi
+def gen_mi():
+    sys.path.insert(0, os.path.join(REF, "subset_selection", "code"))
+    import torch
+    import run_greedy as ref_run_greedy  # noqa: E402  (the reference)
+    from measures.batch import EfficientBatchMI  # noqa: E402
+
+    cases = {
+        # name: (seed, V, D, C, ratio)
+        "a": (0, 2000, 2, 16, 0.2),
+        "b": (1, 1500, 4, 64, 0.2),
+        "c": (2, 3000, 2, 256, 0.2),
+        "d": (3, 403, 3, 8, 0.25),  # subset not a multiple of k: exercises the S[:subset] cut
+    }
+    for name, (seed, v, dd, c, ratio) in cases.items():
+        rs = np.random.RandomState(200 + seed)
+        comp = rs.randint(0, c, size=v)
+        cols = []
+        for _ in range(dd):
+            indep = rs.randint(0, c, size=v)
+            share = rs.rand(v) < 0.5  # views share the component id with prob 0.5
+            cols.append(np.where(share, comp, indep))
+        assignments = np.stack(cols, 1).astype(np.int64)
+        assignments[0, :] = c - 1  # make max()+1 == c regardless of the draw
+        types = [("m%d" % i, "layer_0") for i in range(dd)]
+
+        rec = dict(ids=[], scores=[], pick_pos=[], pick_scores=[])
+        orig_operate, orig_calc_ids = EfficientBatchMI.operate_block, EfficientBatchMI.calc_ids
+
+        def operate_block(self, batch_range=None):
+            scores, samples = orig_operate(self, batch_range)
+            rec["scores"].append(scores.cpu().numpy().copy())
+            rec["ids"].append(samples.cpu().numpy().copy())
+            return scores, samples
+
+        def calc_ids(self, scores):
+            s, ids = orig_calc_ids(self, scores)
+            rec["pick_scores"].append(s.cpu().numpy().copy())
+            rec["pick_pos"].append(ids.cpu().numpy().copy())
+            return s, ids
+
+        EfficientBatchMI.operate_block, EfficientBatchMI.calc_ids = operate_block, calc_ids
+        args = _NS(batch=_NS(batch_size=20, selection_size=4, keep_unselected=True),
+                   computation=_NS(device="cpu"), log_every=10 ** 9, log_times=None,
+                   node_rank=None, parent_pid=None)
+        random.seed(seed)
+        torch.manual_seed(seed)
+        S, GAIN, _ = ref_run_greedy._run_greedy(args, assignments, types, None, ratio, "batch_mi",
+                                                "combination", True, False)
+        EfficientBatchMI.operate_block, EfficientBatchMI.calc_ids = orig_operate, orig_calc_ids
+        # the shuffled candidate order the reference used (run_greedy.py:37-44)
+        random.seed(seed)
+        cand = list(range(v))
+        random.shuffle(cand)
+        out = dict(assignments=assignments, seed=seed, C=c, ratio=ratio,
+                   shuffled=np.array(cand, np.int64), S=np.array(S, np.int64),
+                   GAIN=np.array(GAIN, np.float64),
+                   ids=np.stack(rec["ids"]).astype(np.int64),
+                   scores=np.stack(rec["scores"]).astype(np.float32),
+                   pick_pos=np.stack(rec["pick_pos"]).astype(np.int64),
+                   pick_scores=np.stack(rec["pick_scores"]).astype(np.float32))
+        np.savez_compressed(os.path.join(HERE, f"mi_{name}.npz"), **out)
+        print(f"mi_{name}.npz written: {len(S)} selected in {len(rec['ids'])} iterations")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["rng", "kmeans", "mi"]
+    if len(which) > 1:
+        for w in which:
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
+    else:
+        {"rng": gen_rng, "kmeans": gen_kmeans, "mi": gen_mi}[which[0]]()
