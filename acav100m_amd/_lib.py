@@ -1,0 +1,108 @@
+"""ctypes binding of libacav_hip.so (the C ABI declared in include/acav_hip.h).
+
+The product path has no CPU fallback: if the library is missing, or no HIP device is visible
+when a handle is created, the caller gets a loud RuntimeError.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libacav_hip.so")
+
+vp, i64, i32, f32, f64, u32 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double, C.c_uint32
+pp = C.POINTER(C.c_void_p)
+
+# name -> argtypes (every function returns int except acav_last_error); mirrors include/acav_hip.h
+SIGNATURES = {
+    "acav_version": [],
+    "acav_device_count": [C.POINTER(i32)],
+    "acav_device_info": [i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i64)],
+    "acav_rng_create": [pp, u32],
+    "acav_rng_destroy": [vp],
+    "acav_rng_seed": [vp, u32],
+    "acav_rng_u32": [vp, C.POINTER(u32)],
+    "acav_rng_rand_f32": [vp, vp, i64],
+    "acav_rng_randperm": [vp, i64, vp],
+    "acav_rng_get_state": [vp, vp, C.POINTER(i32)],
+    "acav_rng_set_state": [vp, vp, i32],
+    "acav_rng_warmup_best": [vp, i32, i64, vp, C.POINTER(f32)],
+    "acav_kmeans_create": [pp, i32, i32, i32, vp, vp],
+    "acav_kmeans_destroy": [vp],
+    "acav_kmeans_get_state": [vp, vp, vp, C.POINTER(i64), C.POINTER(i64)],
+    "acav_kmeans_set_state": [vp, vp, vp, i64, i64],
+    "acav_kmeans_set_hyper": [vp, i32, f64, f64],
+    "acav_kmeans_assign": [vp, vp, i64, vp, C.POINTER(f32)],
+    "acav_kmeans_step": [vp, vp, i64, f64, vp, C.POINTER(f32)],
+    "acav_kmeans_train": [vp, vp, i64, i64, f64, vp, i64],
+    "acav_kmeans_apply_update": [vp, vp, i64, vp, f64],
+    "acav_kmeans_sync": [vp],
+    "acav_kmeans_timer_begin": [vp],
+    "acav_kmeans_timer_end": [vp, C.POINTER(f32)],
+    "acav_kmeans_stats": [vp, C.POINTER(i64), C.POINTER(i64)],
+    "acav_mi_create": [pp, i32, vp, i64, i32, i32, vp, i32, vp],
+    "acav_mi_destroy": [vp],
+    "acav_mi_add_samples": [vp, vp, i64],
+    "acav_mi_score_batch": [vp, vp, i32, vp],
+    "acav_mi_run_greedy": [vp, vp, i64, vp, i32, i64, i32, i32, i32, vp, vp, vp, C.POINTER(i64),
+                           C.POINTER(i64), vp, vp, vp, vp, i64],
+    "acav_mi_get_counts": [vp, vp, vp, vp, C.POINTER(i64)],
+    "acav_mi_sync": [vp],
+    "acav_mi_timer_begin": [vp],
+    "acav_mi_timer_end": [vp, C.POINTER(f32)],
+}
+
+_lib = None
+
+
+class AcavError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load libacav_hip.so.  torch (when installed) is imported first so that the process ends up
+    with ONE HIP runtime: torch's bundled libamdhip64.so.7 has the same SONAME as ROCm's."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AcavError(
+            f"{LIB_PATH} is missing: run `python __graft_entry__.py` (hipcc --offload-arch=gfx950) first. "
+            "There is no CPU fallback.")
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    lib.acav_last_error.restype = C.c_char_p
+    lib.acav_last_error.argtypes = []
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library drift
+        fn.restype = i32
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = _lib.acav_last_error().decode("utf-8", "replace") if _lib is not None else ""
+        if rc == -1:
+            raise ValueError(f"acav: {msg}")
+        if rc == -5:
+            raise RuntimeError(f"acav: {msg}")
+        raise AcavError(f"acav error {rc}: {msg}")
+
+
+def device_count():
+    n = i32(0)
+    check(load_library().acav_device_count(C.byref(n)))
+    return n.value
+
+
+def ptr(obj):
+    """void* of a numpy array / torch tensor (host or device) / None."""
+    if obj is None:
+        return None
+    if hasattr(obj, "data_ptr"):
+        return C.c_void_p(obj.data_ptr())
+    return obj.ctypes.data_as(C.c_void_p)

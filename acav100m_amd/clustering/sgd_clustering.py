@@ -1,0 +1,299 @@
+"""KMeans -- drop-in for the reference's clustering/code/sgd_clustering.py:10-129.
+
+Same constructor, methods and public attributes (centers, counts, count, lr, fallback,
+initial_rounds, reinit, sequential, args), so run_clustering.init_clusterings
+(run_clustering.py:32-52), process_batch._train_batch / _extract_batch (process_batch.py:6-17,
+37-56) and the checkpoint code (run_clustering.py:87-116) work unchanged.  All arithmetic runs in
+libacav_hip.so on the MI355X; torch tensors are containers only.  There is no CPU path: the
+object must be moved to a GPU with .to('cuda') before calc_best/add.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from ..rng import default_generator
+
+
+def _as_f32_2d(batch):
+    """-> (object keeping the memory alive, void*, rows, is_torch_cuda)"""
+    if hasattr(batch, "data_ptr"):  # torch tensor (cpu or cuda)
+        import torch
+        t = batch.detach()
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(torch.float32).contiguous()
+        return t, C.c_void_p(t.data_ptr()), t.shape[0], t.is_cuda
+    a = np.ascontiguousarray(batch, dtype=np.float32)
+    return a, a.ctypes.data_as(C.c_void_p), a.shape[0], False
+
+
+def _device_index(device):
+    s = str(device)
+    if s == "cpu":
+        raise _lib.AcavError("acav100m_amd.KMeans has no CPU path: move it to a GPU (device='cuda')")
+    if not s.startswith("cuda"):
+        raise ValueError(f"unsupported device {device!r}")
+    if ":" in s:
+        return int(s.split(":")[1])
+    try:
+        import torch
+        return torch.cuda.current_device()
+    except Exception:
+        return 0
+
+
+class KMeans:
+    """KMeans by Gradient Descent (reference docstring: sgd_clustering.py:11-17)."""
+
+    def __init__(self, args=None, d=None, k=None, lr=1e-2, initial_rounds=10, reinit=(.7, 5.0),
+                 saved_dt=None, generator=None):
+        self._h = None
+        self._device = None
+        self._generator = generator if generator is not None else default_generator
+        if saved_dt is not None:
+            self.load_from_saves(saved_dt)
+        else:
+            self.args = args
+            # torch.rand(k, d) * 1e-5 from the CPU generator (sgd_clustering.py:24)
+            self._centers0 = self._generator.rand(k, d) * np.float32(1e-5)
+            self._counts0 = np.zeros(k, np.float32)
+            self._count0 = 0
+            self._fallback0 = 0
+            self.lr = lr
+            self.initial_rounds = initial_rounds
+            self.reinit = reinit
+            self.sequential = False
+
+    # ------------------------------------------------------------------ handle management
+    def __del__(self):
+        self._release()
+
+    def _release(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib._lib is not None:
+            _lib._lib.acav_kmeans_destroy(h)
+
+    def _require_handle(self):
+        if self._h is None:
+            raise _lib.AcavError("KMeans is not on a GPU yet: call .to('cuda') (there is no CPU fallback)")
+        return self._h
+
+    def to(self, device):
+        """sgd_clustering.py:59-61.  Creates the device-side state on `device` (cuda only)."""
+        idx = _device_index(device)
+        centers, counts, count, fallback = self._host_state()
+        self._release()
+        lib = _lib.load_library()
+        h = C.c_void_p()
+        k, d = centers.shape
+        _lib.check(lib.acav_kmeans_create(C.byref(h), idx, k, d, _lib.ptr(centers), None))
+        self._h, self._device = h, idx
+        p, r = self.reinit
+        _lib.check(lib.acav_kmeans_set_hyper(h, int(self.initial_rounds), float(p), float(r)))
+        _lib.check(lib.acav_kmeans_set_state(h, None, _lib.ptr(counts), int(count), int(fallback)))
+        return self
+
+    def _host_state(self):
+        if self._h is None:
+            return self._centers0, self._counts0, self._count0, self._fallback0
+        k, d = self._shape
+        centers = np.empty((k, d), np.float32)
+        counts = np.empty(k, np.float32)
+        count, fb = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib._lib.acav_kmeans_get_state(self._h, _lib.ptr(centers), _lib.ptr(counts), C.byref(count),
+                                                   C.byref(fb)))
+        return centers, counts, count.value, fb.value
+
+    @property
+    def _shape(self):
+        return self._centers0.shape
+
+    # ------------------------------------------------------------- reference attributes
+    @property
+    def centers(self):
+        import torch
+        return torch.from_numpy(self._host_state()[0])
+
+    @centers.setter
+    def centers(self, value):
+        v = np.ascontiguousarray(value.detach().cpu().numpy() if hasattr(value, "detach") else value, np.float32)
+        if self._h is None:
+            self._centers0 = v
+        else:
+            c = self._host_state()
+            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, _lib.ptr(v), None, c[2], c[3]))
+
+    @property
+    def counts(self):
+        import torch
+        return torch.from_numpy(self._host_state()[1])
+
+    @counts.setter
+    def counts(self, value):
+        v = np.ascontiguousarray(value.detach().cpu().numpy() if hasattr(value, "detach") else value, np.float32)
+        if self._h is None:
+            self._counts0 = v
+        else:
+            c = self._host_state()
+            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, None, _lib.ptr(v), c[2], c[3]))
+
+    @property
+    def count(self):
+        return self._host_state()[2]
+
+    @count.setter
+    def count(self, value):
+        if self._h is None:
+            self._count0 = int(value)
+        else:
+            c = self._host_state()
+            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, None, None, int(value), c[3]))
+
+    @property
+    def fallback(self):
+        return self._host_state()[3]
+
+    @fallback.setter
+    def fallback(self, value):
+        if self._h is None:
+            self._fallback0 = int(value)
+        else:
+            c = self._host_state()
+            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, None, None, c[2], int(value)))
+
+    # ------------------------------------------------------------------- save / load
+    def get_attrs(self):
+        """sgd_clustering.py:34-46"""
+        centers, counts, count, fallback = self._host_state()
+        return {
+            'args': self.args,
+            'count': count,
+            'lr': self.lr,
+            'initial_rounds': self.initial_rounds,
+            'reinit': self.reinit,
+            'fallback': fallback,
+            'sequential': self.sequential,
+            'centers': centers,
+            'counts': counts,
+        }
+
+    def load_from_saves(self, dt):
+        """sgd_clustering.py:48-52"""
+        self.args = dt.get('args')
+        self.lr = dt.get('lr', 1e-2)
+        self.initial_rounds = dt.get('initial_rounds', 10)
+        self.reinit = tuple(dt.get('reinit', (.7, 5.0)))
+        self.sequential = dt.get('sequential', False)
+        self._centers0 = np.ascontiguousarray(dt['centers'], np.float32)
+        self._counts0 = np.ascontiguousarray(dt['counts'], np.float32)
+        self._count0 = int(dt.get('count', 0))
+        self._fallback0 = int(dt.get('fallback', 0))
+
+    @classmethod
+    def load(cls, dt):
+        return cls(saved_dt=dt)
+
+    def __getstate__(self):  # torch.save(dict of KMeans) -- run_clustering.py:110-116
+        st = self.get_attrs()
+        st['_device'] = self._device
+        return st
+
+    def __setstate__(self, st):
+        self._h = None
+        self._device = None
+        self._generator = default_generator
+        self.load_from_saves(st)
+        if st.get('_device') is not None and _lib.device_count() > 0:
+            self.to(f"cuda:{st['_device']}")
+
+    # ---------------------------------------------------------------------- compute
+    def calc_best(self, batch):
+        """sgd_clustering.py:63-79 -> (best LongTensor[b], mean of the minima)."""
+        import torch
+        h = self._require_handle()
+        k = self._shape[0]
+        keep, xp, b, on_gpu = _as_f32_2d(batch)
+        if self.count < self.initial_rounds * k:
+            best, mean = self._generator.warmup_best(k, b)
+            out = torch.from_numpy(best)
+            return (out.cuda(self._device) if on_gpu else out), mean
+        labels = torch.empty(b, dtype=torch.long, device=(batch.device if on_gpu else "cpu"))
+        mean = C.c_float(0)
+        _lib.check(_lib._lib.acav_kmeans_assign(h, xp, b, _lib.ptr(labels), C.byref(mean)))
+        return labels, mean.value
+
+    @property
+    def is_distributed(self):
+        """sgd_clustering.py:81-86"""
+        return (
+            self.args is not None and
+            self.args.computation.device == 'cuda' and
+            self.args.computation.num_gpus > 1
+        )
+
+    def initialize(self):
+        """sgd_clustering.py:88-92: average centers/counts over ranks so every rank starts equal
+        (mps/distributed.py:139-155: all_reduce SUM then 1/world)."""
+        if self.is_distributed:
+            import torch
+            import torch.distributed as dist
+            centers, counts, count, fb = self._host_state()
+            buf = torch.from_numpy(np.concatenate([centers.ravel(), counts])).cuda(self._device)
+            dist.all_reduce(buf)
+            buf = (buf * (1.0 / dist.get_world_size())).cpu().numpy()
+            k, d = centers.shape
+            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, _lib.ptr(np.ascontiguousarray(buf[:k * d])),
+                                                       _lib.ptr(np.ascontiguousarray(buf[k * d:])), count, fb))
+
+    def add(self, batch):
+        """sgd_clustering.py:94-129 (fast parallel update).  Returns the mean min-distance."""
+        h = self._require_handle()
+        if self.sequential:
+            raise NotImplementedError("the reference's slow `sequential` branch is never enabled (sequential=False)")
+        k = self._shape[0]
+        lr = self.lr(self.count) if callable(self.lr) else self.lr
+        keep, xp, b, on_gpu = _as_f32_2d(batch)
+        if self.is_distributed:
+            return self._add_distributed(batch, lr)
+        mean = C.c_float(0)
+        if self.count < self.initial_rounds * k:
+            best, m = self._generator.warmup_best(k, b)
+            _lib.check(_lib._lib.acav_kmeans_step(h, xp, b, float(lr), _lib.ptr(best), None))
+            return m
+        _lib.check(_lib._lib.acav_kmeans_step(h, xp, b, float(lr), None, C.byref(mean)))
+        return mean.value
+
+    def _add_distributed(self, batch, lr):
+        """Multi-GPU add(): every rank labels its b/W local rows, rows and labels are all-gathered
+        (RCCL), and every rank applies the identical global-batch update -- the same state as a
+        single process fed the rank-major concatenation (multi-GPU)."""
+        import torch
+        import torch.distributed as dist
+        from ..parallel import gather_rows_and_labels
+        best, mean = self.calc_best(batch)
+        xg, bg = gather_rows_and_labels(batch, best, self._device)
+        _lib.check(_lib._lib.acav_kmeans_apply_update(self._h, _lib.ptr(xg), xg.shape[0], _lib.ptr(bg), float(lr)))
+        m = torch.tensor([mean], dtype=torch.float64, device=xg.device)
+        dist.all_reduce(m)
+        return float(m.item() / dist.get_world_size())
+
+    # ----------------------------------------------------------- bulk (device-resident) API
+    def train_epoch(self, x, batch_size, lr=None):
+        """The train-loop body of run_clustering.py:229-241 for this clustering over a resident
+        feature matrix x [n,d]: floor(n/b) add() steps with no host sync in between."""
+        h = self._require_handle()
+        k = self._shape[0]
+        lr = self.lr if lr is None else lr
+        keep, xp, n, _ = _as_f32_2d(x)
+        steps = n // batch_size
+        lim = self.initial_rounds * k
+        cnt = self.count
+        need = 0 if cnt >= lim else min(steps, -(-(lim - cnt) // batch_size))
+        warm = np.empty((need, batch_size), np.int64)
+        for t in range(need):
+            warm[t], _ = self._generator.warmup_best(k, batch_size)
+        _lib.check(_lib._lib.acav_kmeans_train(h, xp, n, int(batch_size), float(lr),
+                                               _lib.ptr(warm) if need else None, need))
+
+    def synchronize(self):
+        _lib.check(_lib._lib.acav_kmeans_sync(self._require_handle()))

@@ -1,0 +1,90 @@
+// acav_common.h -- shared plumbing of libacav_hip.so (error model, device buffers, pointer kinds).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/acav_hip.h"
+
+#define ACAV_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace acav {
+
+void set_error(const char *fmt, ...);
+
+#define ACAV_HIP_TRY(expr)                                                                         \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            acav::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return ACAV_EHIP;                                                                      \
+        }                                                                                          \
+    } while (0)
+
+#define ACAV_REQUIRE(cond, code, ...)      \
+    do {                                   \
+        if (!(cond)) {                     \
+            acav::set_error(__VA_ARGS__);  \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+#define ACAV_TRY(expr)             \
+    do {                           \
+        int _rc = (expr);          \
+        if (_rc != ACAV_OK) return _rc; \
+    } while (0)
+
+// true when p is a device (or managed) pointer usable from kernels
+bool is_device_ptr(const void *p);
+
+// A device allocation that frees itself.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    int ensure(size_t n)
+    {
+        if (n <= bytes) return ACAV_OK;
+        release();
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+            return ACAV_ENOMEM;
+        }
+        bytes = n;
+        return ACAV_OK;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// Returns a device pointer for `src` (n bytes): src itself when it already is one, otherwise a
+// staged copy in `stage` (async on stream).
+int to_device(const void *src, size_t bytes, DevBuf &stage, hipStream_t stream, const void **out);
+// Copies a device result to `dst` (host or device), async on stream.
+int from_device(void *dst, const void *src_dev, size_t bytes, hipStream_t stream);
+
+struct StreamCtx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int init(int dev, void *user_stream);
+    void fini();
+    int timer_begin();
+    int timer_end(float *ms);
+};
+
+}  // namespace acav

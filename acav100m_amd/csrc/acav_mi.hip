@@ -1,0 +1,597 @@
+// acav_mi.hip -- greedy batch mutual-information subset selection on gfx950.
+// Reference: subset_selection/code/measures/mi.py:14-148 (EfficientMI tables / calc_MI) and
+// measures/batch.py:10-260 (EfficientBatchMI greedy loop).
+//
+// What one greedy iteration is in the reference, and what runs here instead:
+//   shuffle_candidate_ids (batch.py:29-32)  candidate_ids[torch.randperm(L)]: L-1 MT19937 draws and a
+//        sequential Fisher-Yates.  Here: k_mt_generate continues the same MT19937 stream on the
+//        GPU, k_fy_build / k_fy_apply evaluate the SAME swap sequence in parallel (dependence
+//        chains instead of a serial loop) -- integer work, bit-identical by construction.
+//   sample_batch + get_last + calc_MI (batch.py:34-54, mi.py:85-98)  dense [B,P,C,C] fp32 tensors.
+//        Here: O(1) delta-MI per (candidate, pair) from the integer contingency tables
+//        (k_mi_select), float64, formula in oracle/acav_oracle.c "canon".
+//   calc_ids top-k, update_cache, update_candidates (batch.py:143-171)  k_mi_select.
+// The whole loop is enqueued without host synchronisation: L shrinks deterministically.
+#include <cmath>
+
+#include "acav_common.h"
+
+using namespace acav;
+
+namespace {
+
+struct MiScalars {
+    long long nc;  // n of the tables: number of samples added so far
+};
+
+// -------------------------------------------------------------------------- table kernels
+// cache += one-hots of ids (mi.py:127-148): thread p owns pair p, ids applied in order so the
+// running sums see the same sequence of float64 updates as the oracle.
+__global__ __launch_bounds__(256) void k_mi_commit(const int *__restrict__ asg, int D, int C, int P,
+                                                   const int *__restrict__ pairs, const int *__restrict__ ids,
+                                                   int n, int *__restrict__ Nc, int *__restrict__ ac,
+                                                   int *__restrict__ bc, double *__restrict__ SN,
+                                                   double *__restrict__ Sa, double *__restrict__ Sb,
+                                                   const double *__restrict__ phi, MiScalars *__restrict__ sc)
+{
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        const int d0 = pairs[2 * p], d1 = pairs[2 * p + 1];
+        double sN = SN[p], sa = Sa[p], sb = Sb[p];
+        for (int w = 0; w < n; ++w) {
+            const int *row = asg + (size_t)ids[w] * D;
+            const int i = row[d0], j = row[d1];
+            const size_t cell = ((size_t)p * C + i) * C + j;
+            const int cN = Nc[cell], ca = ac[(size_t)p * C + j], cb = bc[(size_t)p * C + i];
+            Nc[cell] = cN + 1;
+            ac[(size_t)p * C + j] = ca + 1;
+            bc[(size_t)p * C + i] = cb + 1;
+            sN = sN - phi[cN] + phi[cN + 1];
+            sa = sa - phi[ca] + phi[ca + 1];
+            sb = sb - phi[cb] + phi[cb + 1];
+        }
+        SN[p] = sN;
+        Sa[p] = sa;
+        Sb[p] = sb;
+    }
+    if (threadIdx.x == 0) sc->nc += n;
+}
+
+// score of candidate `id` for pair p if it alone were added (canonical float64 closed form)
+__device__ __forceinline__ double mi_pair_score(const int *__restrict__ asg, int D, int C, int p,
+                                                const int *__restrict__ pairs, int id,
+                                                const int *__restrict__ Nc, const int *__restrict__ ac,
+                                                const int *__restrict__ bc, const double *__restrict__ SN,
+                                                const double *__restrict__ Sa, const double *__restrict__ Sb,
+                                                const double *__restrict__ phi, long long nc)
+{
+    const int *row = asg + (size_t)id * D;
+    const int i = row[pairs[2 * p]], j = row[pairs[2 * p + 1]];
+    const int cN = Nc[((size_t)p * C + i) * C + j];
+    const int ca = ac[(size_t)p * C + j], cb = bc[(size_t)p * C + i];
+    const double sN = SN[p] - phi[cN] + phi[cN + 1];
+    const double sa = Sa[p] - phi[ca] + phi[ca + 1];
+    const double sb = Sb[p] - phi[cb] + phi[cb + 1];
+    return (((sN - sa) - sb) + phi[nc + 1]) / (double)(nc + 1);
+}
+
+constexpr int SEL_MAXB = 64;
+constexpr int SEL_MAXBP = 8192;
+
+// One workgroup per greedy iteration: score the B candidates (mean over P pairs), pick the top k
+// (descending, ties -> lower batch position), commit them, emit S/GAIN, and append the
+// unselected ids in ascending order to the new candidate array (batch.py:132-171).
+// ids == batch_in when called for plain scoring (k = 0: nothing committed).
+__global__ __launch_bounds__(256) void k_mi_select(
+    const int *__restrict__ asg, int D, int C, int P, const int *__restrict__ pairs,
+    const int *__restrict__ batch, int B, int k, int *__restrict__ Nc, int *__restrict__ ac,
+    int *__restrict__ bc, double *__restrict__ SN, double *__restrict__ Sa, double *__restrict__ Sb,
+    const double *__restrict__ phi, MiScalars *__restrict__ sc, double *__restrict__ scores_out,
+    long long *__restrict__ S_out, double *__restrict__ G_out, const int *__restrict__ forced_pos,
+    int *__restrict__ trace_pos, long long *__restrict__ trace_ids, double *__restrict__ trace_scores,
+    int keep_unselected, int *__restrict__ requeue_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double *sS = reinterpret_cast<double *>(smem_raw);  // [B*P]
+    __shared__ double sScore[SEL_MAXB];
+    __shared__ int sPos[SEL_MAXB];
+    __shared__ int sPick[SEL_MAXB];
+    const int tid = threadIdx.x;
+    const long long nc = sc->nc;
+    for (int t = tid; t < B * P; t += blockDim.x) {
+        const int w = t / P, p = t - w * P;
+        sS[t] = mi_pair_score(asg, D, C, p, pairs, batch[w], Nc, ac, bc, SN, Sa, Sb, phi, nc);
+    }
+    __syncthreads();
+    if (tid < B) {
+        double tot = 0.0;
+        for (int p = 0; p < P; ++p) tot = tot + sS[tid * P + p];
+        const double s = tot / (double)P;
+        sScore[tid] = s;
+        if (scores_out) scores_out[tid] = s;
+        if (trace_scores) trace_scores[tid] = s;
+        if (trace_ids) trace_ids[tid] = batch[tid];
+    }
+    __syncthreads();
+    if (k == 0) return;
+    if (tid == 0) {
+        unsigned long long used = 0ull;
+        for (int r = 0; r < k; ++r) {
+            int bi = -1;
+            for (int w = 0; w < B; ++w) {
+                if (used >> w & 1ull) continue;
+                if (bi < 0 || sScore[w] > sScore[bi]) bi = w;
+            }
+            used |= 1ull << bi;
+            if (trace_pos) trace_pos[r] = bi;
+            sPos[r] = bi;
+        }
+        if (forced_pos) {
+            used = 0ull;
+            for (int r = 0; r < k; ++r) {
+                sPos[r] = forced_pos[r];
+                used |= 1ull << forced_pos[r];
+            }
+        }
+        for (int r = 0; r < k; ++r) {
+            sPick[r] = batch[sPos[r]];
+            S_out[r] = (long long)sPick[r];
+            G_out[r] = sScore[sPos[r]];
+        }
+        if (keep_unselected) {  // get_unselected: torch.unique -> ascending ids (batch.py:167-171)
+            int u[SEL_MAXB];
+            int nu = 0;
+            for (int w = 0; w < B; ++w) {
+                if (used >> w & 1ull) continue;
+                const int v = batch[w];
+                int q = nu++;
+                while (q > 0 && u[q - 1] > v) {
+                    u[q] = u[q - 1];
+                    --q;
+                }
+                u[q] = v;
+            }
+            for (int q = 0; q < nu; ++q) requeue_out[q] = u[q];
+        }
+    }
+    __syncthreads();
+    // update_cache (batch.py:152-154): commit the k winners, pair-parallel, pick order preserved
+    for (int p = tid; p < P; p += blockDim.x) {
+        const int d0 = pairs[2 * p], d1 = pairs[2 * p + 1];
+        double sN = SN[p], sa = Sa[p], sb = Sb[p];
+        for (int r = 0; r < k; ++r) {
+            const int *row = asg + (size_t)sPick[r] * D;
+            const int i = row[d0], j = row[d1];
+            const size_t cell = ((size_t)p * C + i) * C + j;
+            const int cN = Nc[cell], ca = ac[(size_t)p * C + j], cb = bc[(size_t)p * C + i];
+            Nc[cell] = cN + 1;
+            ac[(size_t)p * C + j] = ca + 1;
+            bc[(size_t)p * C + i] = cb + 1;
+            sN = sN - phi[cN] + phi[cN + 1];
+            sa = sa - phi[ca] + phi[ca + 1];
+            sb = sb - phi[cb] + phi[cb + 1];
+        }
+        SN[p] = sN;
+        Sa[p] = sa;
+        Sb[p] = sb;
+    }
+    if (tid == 0) sc->nc = nc + k;
+}
+
+// ------------------------------------------------------------------------------ MT19937
+// Continues torch's CPU generator stream on the device: mt[624] + idx in global memory, one
+// workgroup.  A block of 624 words is regenerated in three dependent phases (k<227, <454, <624).
+__device__ __forceinline__ unsigned mt_temper(unsigned y)
+{
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+__device__ __forceinline__ unsigned mt_twist(unsigned y) { return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+
+__global__ __launch_bounds__(256) void k_mt_generate(unsigned *__restrict__ mt_state, unsigned *__restrict__ out,
+                                                     long long n)
+{
+    __shared__ unsigned mt[624];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < 624; k += 256) mt[k] = mt_state[k];
+    int idx = (int)mt_state[624];
+    __syncthreads();
+    long long produced = 0;
+    while (produced < n) {
+        if (idx >= 624) {
+            // the sequential refill reads mt[k], mt[k+1] BEFORE they are rewritten and mt[k+397 mod 624]
+            // already rewritten for k >= 227; each phase therefore reads, barriers, then writes.
+            unsigned v = 0;
+            if (tid < 227) {  // phase 1: k in [0,227)
+                const unsigned y = (mt[tid] & 0x80000000u) | (mt[tid + 1] & 0x7fffffffu);
+                v = mt[tid + 397] ^ mt_twist(y);
+            }
+            __syncthreads();
+            if (tid < 227) mt[tid] = v;
+            __syncthreads();
+            if (tid < 227) {  // phase 2: k in [227,454), mt[k-227] is new
+                const int k = tid + 227;
+                const unsigned y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu);
+                v = mt[k - 227] ^ mt_twist(y);
+            }
+            __syncthreads();
+            if (tid < 227) mt[tid + 227] = v;
+            __syncthreads();
+            if (tid < 170) {  // phase 3: k in [454,624); k = 623 pairs with the NEW mt[0]
+                const int k = tid + 454;
+                const unsigned nxt = (k == 623) ? mt[0] : mt[k + 1];
+                const unsigned y = (mt[k] & 0x80000000u) | (nxt & 0x7fffffffu);
+                v = mt[k - 227] ^ mt_twist(y);
+            }
+            __syncthreads();
+            if (tid < 170) mt[tid + 454] = v;
+            __syncthreads();
+            idx = 0;
+        }
+        const long long left = n - produced;
+        const int m = (624 - idx) < left ? (624 - idx) : (int)left;
+        for (int t = tid; t < m; t += 256) out[produced + t] = mt_temper(mt[idx + t]);
+        produced += m;
+        idx += m;
+    }
+    __syncthreads();
+    for (int k = tid; k < 624; k += 256) mt_state[k] = mt[k];
+    if (tid == 0) mt_state[624] = (unsigned)idx;
+}
+
+// ------------------------------------------------------------------- parallel Fisher-Yates
+// Sequential semantics (torch.randperm + index_select == in-place):  for i in 0..L-2:
+//   swap(A[i], A[h_i]),  h_i = i + draw_i % (L - i).
+// Parallel evaluation.  list(p) = { j < p : h_j = p } (steps that drop a value into position p),
+// g(p) = max list(p).  The ORIGINAL index of the value sitting at position p just before step p
+// is f(p) = p if list(p) is empty, else f(g(p))  (a chain of expected length ~1).  The final
+// value at position i is the content of h_i just before step i:
+//   h_i == i            -> A[f(i)]
+//   pred = max{ j in list(h_i) : j < i } exists  -> A[f(pred)]
+//   otherwise                                     -> A[h_i]
+// and position L-1 ends with A[f(L-1)].
+__global__ __launch_bounds__(256) void k_fy_build(const unsigned *__restrict__ draws, int L, int *__restrict__ h,
+                                                  int *__restrict__ head, int *__restrict__ next,
+                                                  int *__restrict__ g)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    if (i == L - 1) {
+        h[i] = i;
+        next[i] = -1;
+        return;
+    }
+    const int hh = i + (int)(draws[i] % (unsigned)(L - i));
+    h[i] = hh;
+    if (hh != i) {
+        next[i] = atomicExch(&head[hh], i);
+        atomicMax(&g[hh], i);
+    } else {
+        next[i] = -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fy_apply(const int *__restrict__ A, int L, int B,
+                                                  const int *__restrict__ h, const int *__restrict__ head,
+                                                  const int *__restrict__ next, const int *__restrict__ g,
+                                                  int *__restrict__ batch_out, int *__restrict__ A_new)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    const int p = h[i];
+    int j;
+    if (p == i) {
+        j = i;
+    } else {
+        int pred = -1;
+        for (int q = head[p]; q >= 0; q = next[q])
+            if (q < i && q > pred) pred = q;
+        j = pred;
+    }
+    int src;
+    if (j < 0) {
+        src = p;
+    } else {
+        while (g[j] >= 0) j = g[j];
+        src = j;
+    }
+    const int v = A[src];
+    if (i < B)
+        batch_out[i] = v;
+    else
+        A_new[i - B] = v;
+}
+
+__global__ void k_i64_to_i32(const long long *__restrict__ in, int *__restrict__ out, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int)in[i];
+}
+
+}  // namespace
+
+// =============================================================================== handle
+struct acav_mi {
+    StreamCtx ctx;
+    int64_t V = 0;
+    int D = 0, C = 0, P = 0;
+    DevBuf asg, pairs, Nc, ac, bc, SN, Sa, Sb, phi, scalars;
+    DevBuf stage, ids32, scores;
+    // greedy buffers
+    DevBuf A0, A1, draws, h, head, next, g, mt, batch, S, G, tr_pos, tr_ids, tr_sc, forced;
+};
+
+struct acav_rng;  // state access through the C ABI below
+
+static int ids_to_device32(acav_mi *mi, const int64_t *ids, int64_t n, DevBuf &stage, DevBuf &out32)
+{
+    hipStream_t st = mi->ctx.stream;
+    if (!is_device_ptr(ids)) {
+        for (int64_t i = 0; i < n; ++i)
+            ACAV_REQUIRE(ids[i] >= 0 && ids[i] < mi->V, ACAV_EINVAL, "id %lld out of range [0,%lld)",
+                         (long long)ids[i], (long long)mi->V);
+    }
+    const void *d = nullptr;
+    ACAV_TRY(to_device(ids, sizeof(int64_t) * (size_t)n, stage, st, &d));
+    ACAV_TRY(out32.ensure(sizeof(int) * (size_t)(n > 0 ? n : 1)));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_i64_to_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           static_cast<const long long *>(d), out32.as<int>(), (long long)n);
+        ACAV_HIP_TRY(hipGetLastError());
+    }
+    return ACAV_OK;
+}
+
+ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignments, int64_t V, int D, int C,
+                               const int32_t *pairs, int P, void *stream)
+{
+    ACAV_REQUIRE(out && assignments && pairs, ACAV_EINVAL, "NULL argument");
+    ACAV_REQUIRE(V > 0 && V < 0x7fffffff && D > 0 && C > 0 && P > 0, ACAV_EINVAL, "bad sizes V=%lld D=%d C=%d P=%d",
+                 (long long)V, D, C, P);
+    ACAV_REQUIRE(!is_device_ptr(assignments) && !is_device_ptr(pairs), ACAV_EINVAL,
+                 "assignments and pairs are host arrays (as in the reference constructor)");
+    for (int p = 0; p < 2 * P; ++p)
+        ACAV_REQUIRE(pairs[p] >= 0 && pairs[p] < D, ACAV_EINVAL, "pair index %d out of range", pairs[p]);
+    std::vector<int> a32((size_t)V * D);
+    for (size_t i = 0; i < a32.size(); ++i) {
+        ACAV_REQUIRE(assignments[i] >= 0 && assignments[i] < C, ACAV_EINVAL,
+                     "assignment %lld outside [0,%d) (one_hot would fail: mi.py:69-74)", (long long)assignments[i], C);
+        a32[i] = (int)assignments[i];
+    }
+    acav_mi *mi = new (std::nothrow) acav_mi;
+    ACAV_REQUIRE(mi, ACAV_ENOMEM, "out of host memory");
+    int rc = mi->ctx.init(device, stream);
+    if (rc != ACAV_OK) {
+        delete mi;
+        return rc;
+    }
+    mi->V = V;
+    mi->D = D;
+    mi->C = C;
+    mi->P = P;
+    hipStream_t st = mi->ctx.stream;
+    const size_t cc = (size_t)P * C * C, pc = (size_t)P * C;
+    std::vector<double> phi((size_t)V + 2);
+    phi[0] = 0.0;
+    for (int64_t k = 1; k < V + 2; ++k) phi[(size_t)k] = (double)k * log((double)k);
+    auto body = [&]() -> int {
+        ACAV_TRY(mi->asg.ensure(sizeof(int) * a32.size()));
+        ACAV_TRY(mi->pairs.ensure(sizeof(int) * 2 * (size_t)P));
+        ACAV_TRY(mi->Nc.ensure(sizeof(int) * cc));
+        ACAV_TRY(mi->ac.ensure(sizeof(int) * pc));
+        ACAV_TRY(mi->bc.ensure(sizeof(int) * pc));
+        ACAV_TRY(mi->SN.ensure(sizeof(double) * P));
+        ACAV_TRY(mi->Sa.ensure(sizeof(double) * P));
+        ACAV_TRY(mi->Sb.ensure(sizeof(double) * P));
+        ACAV_TRY(mi->phi.ensure(sizeof(double) * phi.size()));
+        ACAV_TRY(mi->scalars.ensure(sizeof(MiScalars)));
+        ACAV_HIP_TRY(hipMemcpyAsync(mi->asg.p, a32.data(), sizeof(int) * a32.size(), hipMemcpyHostToDevice, st));
+        ACAV_HIP_TRY(hipMemcpyAsync(mi->pairs.p, pairs, sizeof(int) * 2 * (size_t)P, hipMemcpyHostToDevice, st));
+        ACAV_HIP_TRY(hipMemcpyAsync(mi->phi.p, phi.data(), sizeof(double) * phi.size(), hipMemcpyHostToDevice, st));
+        ACAV_HIP_TRY(hipMemsetAsync(mi->Nc.p, 0, sizeof(int) * cc, st));
+        ACAV_HIP_TRY(hipMemsetAsync(mi->ac.p, 0, sizeof(int) * pc, st));
+        ACAV_HIP_TRY(hipMemsetAsync(mi->bc.p, 0, sizeof(int) * pc, st));
+        ACAV_HIP_TRY(hipMemsetAsync(mi->SN.p, 0, sizeof(double) * P, st));
+        ACAV_HIP_TRY(hipMemsetAsync(mi->Sa.p, 0, sizeof(double) * P, st));
+        ACAV_HIP_TRY(hipMemsetAsync(mi->Sb.p, 0, sizeof(double) * P, st));
+        ACAV_HIP_TRY(hipMemsetAsync(mi->scalars.p, 0, sizeof(MiScalars), st));
+        ACAV_HIP_TRY(hipStreamSynchronize(st));
+        return ACAV_OK;
+    };
+    rc = body();
+    if (rc != ACAV_OK) {
+        mi->ctx.fini();
+        delete mi;
+        return rc;
+    }
+    *out = mi;
+    return ACAV_OK;
+}
+
+ACAV_EXPORT int acav_mi_destroy(acav_mi *mi)
+{
+    if (!mi) return ACAV_OK;
+    (void)hipSetDevice(mi->ctx.device);
+    (void)hipStreamSynchronize(mi->ctx.stream);
+    mi->ctx.fini();
+    delete mi;
+    return ACAV_OK;
+}
+ACAV_EXPORT int acav_mi_sync(acav_mi *mi)
+{
+    ACAV_REQUIRE(mi, ACAV_EINVAL, "handle is NULL");
+    ACAV_HIP_TRY(hipStreamSynchronize(mi->ctx.stream));
+    return ACAV_OK;
+}
+ACAV_EXPORT int acav_mi_timer_begin(acav_mi *mi)
+{
+    ACAV_REQUIRE(mi, ACAV_EINVAL, "handle is NULL");
+    return mi->ctx.timer_begin();
+}
+ACAV_EXPORT int acav_mi_timer_end(acav_mi *mi, float *ms)
+{
+    ACAV_REQUIRE(mi && ms, ACAV_EINVAL, "NULL argument");
+    return mi->ctx.timer_end(ms);
+}
+
+ACAV_EXPORT int acav_mi_add_samples(acav_mi *mi, const int64_t *ids, int64_t n)
+{
+    ACAV_REQUIRE(mi && (ids || n == 0) && n >= 0 && n < 0x7fffffff, ACAV_EINVAL, "bad argument");
+    if (n == 0) return ACAV_OK;
+    ACAV_HIP_TRY(hipSetDevice(mi->ctx.device));
+    ACAV_TRY(ids_to_device32(mi, ids, n, mi->stage, mi->ids32));
+    hipLaunchKernelGGL(k_mi_commit, dim3(1), dim3(256), 0, mi->ctx.stream, mi->asg.as<int>(), mi->D, mi->C, mi->P,
+                       mi->pairs.as<int>(), mi->ids32.as<int>(), (int)n, mi->Nc.as<int>(), mi->ac.as<int>(),
+                       mi->bc.as<int>(), mi->SN.as<double>(), mi->Sa.as<double>(), mi->Sb.as<double>(),
+                       mi->phi.as<double>(), mi->scalars.as<MiScalars>());
+    ACAV_HIP_TRY(hipGetLastError());
+    ACAV_HIP_TRY(hipStreamSynchronize(mi->ctx.stream));
+    return ACAV_OK;
+}
+
+static int launch_select(acav_mi *mi, const int *batch, int B, int k, double *scores_out, long long *S_out,
+                         double *G_out, const int *forced_pos, int *trace_pos, long long *trace_ids,
+                         double *trace_scores, int keep, int *requeue_out)
+{
+    const size_t smem = sizeof(double) * (size_t)B * mi->P;
+    hipLaunchKernelGGL(k_mi_select, dim3(1), dim3(256), smem, mi->ctx.stream, mi->asg.as<int>(), mi->D, mi->C, mi->P,
+                       mi->pairs.as<int>(), batch, B, k, mi->Nc.as<int>(), mi->ac.as<int>(), mi->bc.as<int>(),
+                       mi->SN.as<double>(), mi->Sa.as<double>(), mi->Sb.as<double>(), mi->phi.as<double>(),
+                       mi->scalars.as<MiScalars>(), scores_out, S_out, G_out, forced_pos, trace_pos, trace_ids,
+                       trace_scores, keep, requeue_out);
+    ACAV_HIP_TRY(hipGetLastError());
+    return ACAV_OK;
+}
+
+ACAV_EXPORT int acav_mi_score_batch(acav_mi *mi, const int64_t *ids, int B, double *scores_host)
+{
+    ACAV_REQUIRE(mi && ids && scores_host, ACAV_EINVAL, "NULL argument");
+    ACAV_REQUIRE(B > 0 && B <= SEL_MAXB && (int64_t)B * mi->P <= SEL_MAXBP, ACAV_EINVAL,
+                 "batch %d x pairs %d outside the supported range (B<=%d, B*P<=%d)", B, mi->P, SEL_MAXB, SEL_MAXBP);
+    ACAV_HIP_TRY(hipSetDevice(mi->ctx.device));
+    ACAV_TRY(ids_to_device32(mi, ids, B, mi->stage, mi->ids32));
+    ACAV_TRY(mi->scores.ensure(sizeof(double) * SEL_MAXB));
+    ACAV_TRY(launch_select(mi, mi->ids32.as<int>(), B, 0, mi->scores.as<double>(), nullptr, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, 0, nullptr));
+    ACAV_TRY(from_device(scores_host, mi->scores.p, sizeof(double) * (size_t)B, mi->ctx.stream));
+    ACAV_HIP_TRY(hipStreamSynchronize(mi->ctx.stream));
+    return ACAV_OK;
+}
+
+ACAV_EXPORT int acav_mi_get_counts(acav_mi *mi, int32_t *N, int32_t *a, int32_t *b, int64_t *n)
+{
+    ACAV_REQUIRE(mi, ACAV_EINVAL, "handle is NULL");
+    ACAV_HIP_TRY(hipSetDevice(mi->ctx.device));
+    hipStream_t st = mi->ctx.stream;
+    const size_t cc = (size_t)mi->P * mi->C * mi->C, pc = (size_t)mi->P * mi->C;
+    if (N) ACAV_TRY(from_device(N, mi->Nc.p, sizeof(int) * cc, st));
+    if (a) ACAV_TRY(from_device(a, mi->ac.p, sizeof(int) * pc, st));
+    if (b) ACAV_TRY(from_device(b, mi->bc.p, sizeof(int) * pc, st));
+    MiScalars s{};
+    ACAV_HIP_TRY(hipMemcpyAsync(&s, mi->scalars.p, sizeof(s), hipMemcpyDeviceToHost, st));
+    ACAV_HIP_TRY(hipStreamSynchronize(st));
+    if (n) *n = (int64_t)s.nc;
+    return ACAV_OK;
+}
+
+ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64_t L, const int64_t *start, int ns,
+                                   int64_t subset, int B, int k, int keep_unselected, acav_rng *rng,
+                                   int64_t *S_out, double *GAIN_out, int64_t *n_selected, int64_t *n_iters,
+                                   int64_t *trace_ids, double *trace_scores, int32_t *trace_pos,
+                                   const int32_t *forced_pos, int64_t max_iters)
+{
+    ACAV_REQUIRE(mi && candidates && rng && S_out && GAIN_out, ACAV_EINVAL, "NULL argument");
+    ACAV_REQUIRE(L > 0 && L <= mi->V && ns >= 0 && (start || ns == 0) && subset >= 0, ACAV_EINVAL, "bad sizes");
+    ACAV_REQUIRE(B > 0 && B <= SEL_MAXB && k > 0 && k <= B && (int64_t)B * mi->P <= SEL_MAXBP, ACAV_EINVAL,
+                 "batch_size %d / selection_size %d / pairs %d outside the supported range (B<=%d, B*P<=%d)", B, k,
+                 mi->P, SEL_MAXB, SEL_MAXBP);
+    ACAV_HIP_TRY(hipSetDevice(mi->ctx.device));
+    hipStream_t st = mi->ctx.stream;
+    if (ns) ACAV_TRY(acav_mi_add_samples(mi, start, ns));  // batch.py:215
+
+    // plan: the number of iterations and every L_t are known on the host (no device feedback)
+    int64_t iters = 0;
+    {
+        int64_t nS = 0, l = L;
+        while (nS < subset && (max_iters < 0 || iters < max_iters)) {
+            ACAV_REQUIRE(l >= B, ACAV_ERANGE,
+                         "%lld candidates left < batch_size %d: the reference's topk(k=floor(B/k*B')) raises here "
+                         "(batch.py:143-150)", (long long)l, B);
+            nS += k;
+            l = l - B + (keep_unselected ? B - k : 0);
+            ++iters;
+        }
+    }
+    const int64_t cap = iters * k + 1;
+    ACAV_TRY(mi->A0.ensure(sizeof(int) * (size_t)(L + B)));  // before the conversion: ensure() does not copy
+    ACAV_TRY(ids_to_device32(mi, candidates, L, mi->stage, mi->A0));
+    ACAV_TRY(mi->A1.ensure(sizeof(int) * (size_t)(L + B)));
+    ACAV_TRY(mi->draws.ensure(sizeof(unsigned) * (size_t)L));
+    ACAV_TRY(mi->h.ensure(sizeof(int) * (size_t)L));
+    ACAV_TRY(mi->head.ensure(sizeof(int) * (size_t)L));
+    ACAV_TRY(mi->next.ensure(sizeof(int) * (size_t)L));
+    ACAV_TRY(mi->g.ensure(sizeof(int) * (size_t)L));
+    ACAV_TRY(mi->mt.ensure(sizeof(unsigned) * 625));
+    ACAV_TRY(mi->batch.ensure(sizeof(int) * SEL_MAXB));
+    ACAV_TRY(mi->S.ensure(sizeof(long long) * (size_t)cap));
+    ACAV_TRY(mi->G.ensure(sizeof(double) * (size_t)cap));
+    if (trace_pos) ACAV_TRY(mi->tr_pos.ensure(sizeof(int) * (size_t)(iters * k + 1)));
+    if (trace_ids) ACAV_TRY(mi->tr_ids.ensure(sizeof(long long) * (size_t)(iters * B + 1)));
+    if (trace_scores) ACAV_TRY(mi->tr_sc.ensure(sizeof(double) * (size_t)(iters * B + 1)));
+    if (forced_pos) {
+        for (int64_t i = 0; i < iters * k; ++i)
+            ACAV_REQUIRE(forced_pos[i] >= 0 && forced_pos[i] < B, ACAV_EINVAL, "forced position out of range");
+        ACAV_TRY(mi->forced.ensure(sizeof(int) * (size_t)(iters * k + 1)));
+        ACAV_HIP_TRY(hipMemcpyAsync(mi->forced.p, forced_pos, sizeof(int) * (size_t)(iters * k), hipMemcpyHostToDevice, st));
+    }
+    // hand the host MT19937 stream to the device
+    unsigned mtbuf[625];
+    int idx = 0;
+    ACAV_TRY(acav_rng_get_state(rng, mtbuf, &idx));
+    mtbuf[624] = (unsigned)idx;
+    ACAV_HIP_TRY(hipMemcpyAsync(mi->mt.p, mtbuf, sizeof(mtbuf), hipMemcpyHostToDevice, st));
+
+    int *Acur = mi->A0.as<int>(), *Anew = mi->A1.as<int>();
+    int64_t l = L;
+    for (int64_t it = 0; it < iters; ++it) {
+        const int Li = (int)l;
+        const unsigned grid = (unsigned)((Li + 255) / 256);
+        if (Li > 1) {
+            hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(256), 0, st, mi->mt.as<unsigned>(),
+                               mi->draws.as<unsigned>(), (long long)(Li - 1));
+        }
+        ACAV_HIP_TRY(hipMemsetAsync(mi->head.p, 0xFF, sizeof(int) * (size_t)Li, st));
+        ACAV_HIP_TRY(hipMemsetAsync(mi->g.p, 0xFF, sizeof(int) * (size_t)Li, st));
+        hipLaunchKernelGGL(k_fy_build, dim3(grid), dim3(256), 0, st, mi->draws.as<unsigned>(), Li, mi->h.as<int>(),
+                           mi->head.as<int>(), mi->next.as<int>(), mi->g.as<int>());
+        hipLaunchKernelGGL(k_fy_apply, dim3(grid), dim3(256), 0, st, Acur, Li, B, mi->h.as<int>(), mi->head.as<int>(),
+                           mi->next.as<int>(), mi->g.as<int>(), mi->batch.as<int>(), Anew);
+        ACAV_HIP_TRY(hipGetLastError());
+        ACAV_TRY(launch_select(mi, mi->batch.as<int>(), B, k, nullptr, mi->S.as<long long>() + it * k,
+                               mi->G.as<double>() + it * k, forced_pos ? mi->forced.as<int>() + it * k : nullptr,
+                               trace_pos ? mi->tr_pos.as<int>() + it * k : nullptr,
+                               trace_ids ? mi->tr_ids.as<long long>() + it * B : nullptr,
+                               trace_scores ? mi->tr_sc.as<double>() + it * B : nullptr, keep_unselected,
+                               Anew + (Li - B)));
+        l = l - B + (keep_unselected ? B - k : 0);
+        int *t = Acur;
+        Acur = Anew;
+        Anew = t;
+    }
+    const int64_t nsel = iters * k < subset ? iters * k : subset;
+    if (iters > 0) {
+        ACAV_HIP_TRY(hipMemcpyAsync(S_out, mi->S.p, sizeof(long long) * (size_t)nsel, hipMemcpyDeviceToHost, st));
+        ACAV_HIP_TRY(hipMemcpyAsync(GAIN_out, mi->G.p, sizeof(double) * (size_t)(iters * k), hipMemcpyDeviceToHost, st));
+        if (trace_pos) ACAV_HIP_TRY(hipMemcpyAsync(trace_pos, mi->tr_pos.p, sizeof(int) * (size_t)(iters * k), hipMemcpyDeviceToHost, st));
+        if (trace_ids) ACAV_HIP_TRY(hipMemcpyAsync(trace_ids, mi->tr_ids.p, sizeof(long long) * (size_t)(iters * B), hipMemcpyDeviceToHost, st));
+        if (trace_scores) ACAV_HIP_TRY(hipMemcpyAsync(trace_scores, mi->tr_sc.p, sizeof(double) * (size_t)(iters * B), hipMemcpyDeviceToHost, st));
+    }
+    ACAV_HIP_TRY(hipMemcpyAsync(mtbuf, mi->mt.p, sizeof(mtbuf), hipMemcpyDeviceToHost, st));
+    ACAV_HIP_TRY(hipStreamSynchronize(st));
+    ACAV_TRY(acav_rng_set_state(rng, mtbuf, (int)mtbuf[624]));  // the stream continues on the host
+    if (n_selected) *n_selected = nsel;
+    if (n_iters) *n_iters = iters;
+    return ACAV_OK;
+}

@@ -1,0 +1,11 @@
+"""Multi-GPU plumbing for the hot path: one process per GPU, torch.distributed (backend "nccl" is
+RCCL over xGMI on ROCm; "gloo" in the CPU tests).  Only the exchanges the path really has:
+
+  k-means training   one all-gather per SGD step of the rank-local rows and their labels
+                     (replaces the reference's all_gather([batch]) + all_reduce([counts]) +
+                     all_reduce([deltas]) -- sgd_clustering.py:97,115,126 -- with b*d*4 bytes
+                     instead of K*d*4, and makes every rank apply the bit-identical update)
+  k-means assign     none: shards are strided rank::world (mps/distributed.py:439)
+  MI selection       none: chunks are independent (chunk.py:21-53)
+"""
+from .collectives import gather_rows_and_labels, shard_slice, world  # noqa: F401

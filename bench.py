@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X: clips/sec curated by the k-means hot path.
+
+Workload (config.workload): BASELINE.json configs[1] -- 1M clips, 1024-d features, K=256,
+k-means only (update + assign), one GPU.  One bench "step" = one k-means pass over the resident
+feature matrix exactly as the reference runs it: one training epoch of KMeans.add at the
+reference's batch size b=32 (floor(N/32) sequentially dependent SGD steps,
+run_clustering.py:229-241) followed by one assign sweep (KMeans.calc_best over all N rows,
+run_clustering.py:290-296).  value = N * n_gpus * steps / time, inputs resident in HBM.
+
+    python bench.py                      # 1 GPU, defaults
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1 (weak scaling): every rank holds its own N-row shard; assign is embarrassingly parallel;
+training uses the distributed add() (per step: local labels for 32 local rows, one RCCL
+all-gather of rows+labels, identical global update on every rank -- i.e. the reference run with
+--data.batch_size=32*W).
+
+The JSON line also carries
+  roofline      for k_assign_f32 (the row-streaming sweep): algorithmic bytes N*d*4 + N*8 per launch
+                over the launch duration measured with HIP events on the library's stream; the kernel
+                computes exact fp32 distances on the f32 matrix cores, so the binding roof is the f32
+                MFMA peak (2*N*K*d flop) -- both fractions are reported.
+  cpu_baseline  the oracle (oracle/libacav_oracle.so, a C port of the reference algorithm) timed on
+                this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3   # f32-input MFMA = fp32 vector peak
+
+
+def synth_features(torch, n, d, k, seed, device):
+    """SURVEY 8(d) generator: K Gaussian components, centre ~ N(0,1)^d, row = centre + 0.3 N(0,1)."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    cen = torch.randn(k, d, device=device, generator=gen)
+    comp = torch.randint(0, k, (n,), device=device, generator=gen)
+    x = torch.empty(n, d, device=device, dtype=torch.float32)
+    step = 65536
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        x[s:e] = cen[comp[s:e]] + 0.3 * torch.randn(e - s, d, device=device, generator=gen)
+    return x
+
+
+def cpu_baseline(n, d, k, b, seed, budget_s=20.0):
+    """Oracle on the host cores, bounded sample: SGD steps (after the warm-up) + an assign slice."""
+    from oracle import oracle as O
+    rs = np.random.RandomState(seed)
+    cen = rs.randn(k, d).astype(np.float32)
+    n_train_rows = 64 * b
+    n_assign_rows = 8192
+    xs = (cen[rs.randint(0, k, n_train_rows + n_assign_rows)] +
+          0.3 * rs.randn(n_train_rows + n_assign_rows, d)).astype(np.float32)
+    rng = O.Rng(seed)
+    km = O.KMeans(d, k, rng, centers=(cen + 0.1 * rs.randn(k, d)).astype(np.float32))
+    km.set_state(None, np.full(k, 50.0, np.float32), 10 * k + 12800)
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 64:
+        km.add(xs[steps * b:(steps + 1) * b])
+        steps += 1
+        if time.perf_counter() - t0 > budget_s / 2:
+            break
+    t_train = (time.perf_counter() - t0) / (steps * b)      # s per clip
+    t0 = time.perf_counter()
+    km.calc_best(xs[n_train_rows:])
+    t_assign = (time.perf_counter() - t0) / n_assign_rows   # s per clip
+    return {
+        "value": 1.0 / (t_train + t_assign), "unit": "clips/s", "cores": O.num_threads(), "kind": "port",
+        "sample": f"{steps} add() steps of b={b} + calc_best over {n_assign_rows} rows at d={d}, K={k} "
+                  f"(oracle C port, OpenMP over rows); per-clip times summed and inverted",
+        "train_clips_per_s": 1.0 / t_train, "assign_clips_per_s": 1.0 / t_assign,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--d", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device(dev))
+
+    import acav100m_amd
+    from acav100m_amd import _lib
+    from acav100m_amd.clustering import KMeans
+    lib = acav100m_amd.load_library()
+
+    n, d, k, b = args.n, args.d, args.k, args.batch
+    x = synth_features(torch, n, d, k, 1234 + rank, dev)
+    acav100m_amd.manual_seed(0)
+
+    class _A:  # the reference's args.computation view
+        pass
+    cargs = _A()
+    cargs.computation = _A()
+    cargs.computation.device = "cuda"
+    cargs.computation.num_gpus = world
+    km = KMeans(cargs, d, k).to(dev)
+    km.initialize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    labels = torch.empty(n, dtype=torch.long, device=dev)
+    assign_ms = []
+
+    def one_pass(timed):
+        # --- update: one epoch of add() at b=32
+        if world == 1:
+            km.train_epoch(x, b, lr=0.01)
+        else:
+            km.lr = 0.01
+            for t in range(n // b):
+                km.add(x[t * b:(t + 1) * b])
+        # --- assign sweep, timed with HIP events on the library's own stream
+        _lib.check(lib.acav_kmeans_timer_begin(km._h))
+        _lib.check(lib.acav_kmeans_assign(km._h, _lib.ptr(x), n, _lib.ptr(labels), None))
+        ms = C.c_float(0)
+        _lib.check(lib.acav_kmeans_timer_end(km._h, C.byref(ms)))
+        if timed:
+            assign_ms.append(ms.value)
+
+    for _ in range(args.warmup):
+        one_pass(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = n * world * args.steps / elapsed
+        a_ms = float(np.mean(assign_ms))
+        bytes_per_launch = n * d * 4 + n * 8
+        flops_per_launch = 2.0 * n * k * d
+        gbs = bytes_per_launch / (a_ms * 1e-3) / 1e9
+        tfs = flops_per_launch / (a_ms * 1e-3) / 1e12
+        out = {
+            "metric": "clips/sec curated (k-means update epoch at b=32 + assign sweep)",
+            "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {n} clips x {d}-d, K={k}, k-means only "
+                                   f"(1 training epoch at b={b} = {n // b} SGD steps + 1 assign sweep per step)",
+                       "global_batch": b * world, "rows_per_gpu": n},
+            "roofline": {"kernel": "k_assign_f32", "bound": "mfma", "achieved": tfs, "peak": MFMA_F32_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": tfs / MFMA_F32_PEAK_TF, "traffic": None,
+                         "hbm_achieved_GBs": gbs, "hbm_peak_GBs": HBM_PEAK_GBS, "hbm_frac": gbs / HBM_PEAK_GBS,
+                         "launch_ms": a_ms, "algorithmic_bytes": bytes_per_launch,
+                         "algorithmic_flops": flops_per_launch},
+            "stages": {"assign_ms": a_ms, "assign_clips_per_s": n / (a_ms * 1e-3),
+                       "train_epoch_ms": ms_per_step - a_ms,
+                       "train_clips_per_s": n / ((ms_per_step - a_ms) * 1e-3),
+                       "train_us_per_sgd_step": (ms_per_step - a_ms) * 1e3 / (n // b)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(n, d, k, b, 1234)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,160 @@
+"""The oracle (oracle/acav_oracle.c) pinned against the golden vectors recorded from the reference
+itself (tests/golden/gen_golden.py) and against sklearn's mutual_info_score.  CPU only."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+def test_rng_streams(golden_dir):
+    g = np.load(os.path.join(golden_dir, "rng.npz"))
+    for s in (0, 1, 1234):
+        r = O.Rng(s)
+        assert np.array_equal(r.rand(7, 5), g[f"s{s}_rand_7x5"])
+        assert np.array_equal(r.randperm(10), g[f"s{s}_perm10"])
+        assert np.array_equal(r.randperm(1000), g[f"s{s}_perm1000"])
+        assert np.array_equal(r.randperm(100003)[:2000], g[f"s{s}_perm100003_head"])
+        assert np.array_equal(r.rand(3), g[f"s{s}_rand_after"])
+        assert np.array_equal((r.rand(16, 8) * np.float32(1e-5)).astype(np.float32), g[f"s{s}_init_16x8"])
+
+
+def test_python_shuffle_is_stdlib(golden_dir):
+    import random
+    g = np.load(os.path.join(golden_dir, "rng.npz"))
+    for s in (0, 1, 1234):
+        random.seed(s)
+        lst = list(range(1000))
+        random.shuffle(lst)
+        assert lst == list(g[f"s{s}_pyshuffle1000"])
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_kmeans_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"kmeans_{name}.npz"))
+    x, K, b = g["x"], int(g["K"]), int(g["b"])
+    n, d = x.shape
+    km = O.KMeans(d, K, O.Rng(int(g["seed"])))
+    assert np.array_equal(km.centers, g["centers0"])
+    warm, means = [], []
+    for e in range(int(g["epochs"])):
+        km.lr = 0.1 ** (2 + e // 5)
+        for t in range(n // b):
+            w = km.count < 10 * K
+            m, best = km.add(x[t * b:(t + 1) * b], return_best=True)
+            means.append(m)
+            if w:
+                warm.append(best)
+        c, cnt, count, fb = km.get_state()
+        # identical labels at every step => identical update arithmetic => bit-identical centres
+        assert np.array_equal(c, g[f"centers_e{e}"])
+        assert np.array_equal(cnt, g[f"counts_e{e}"])
+        assert count == int(g[f"count_e{e}"]) and fb == int(g[f"fallback_e{e}"])
+    assert np.array_equal(np.stack(warm), g["warm_best"])
+    np.testing.assert_allclose(np.array(means), g["add_means"], rtol=2e-6)
+    lab, _ = km.calc_best(x)
+    near_ties = int((g["top2_gap"] < 1e-3).sum())
+    assert np.array_equal(lab, g["labels"]) and np.array_equal(lab, g["labels_onebatch"]), \
+        f"labels differ from the reference ({near_ties} reference near-ties below 1e-3)"
+    c, cnt, count, fb = km.get_state()
+    cnt2 = cnt.copy()
+    cnt2[::3] = 1.0
+    km.set_state(None, cnt2, count, fb)
+    lab2, _ = km.calc_best(x)
+    assert np.array_equal(lab2, g["labels_doctored"])
+    assert int(g["n_changed_by_discount"]) > 0  # the discount path really was exercised
+
+
+def _mi_case(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"mi_{name}.npz"))
+    a, c, seed = g["assignments"], int(g["C"]), int(g["seed"])
+    v, dd = a.shape
+    assert a.max() + 1 == c
+    pairs = list(itertools.combinations(range(dd), 2))
+    subset = round(float(g["ratio"]) * v)
+    cand = list(g["shuffled"])
+    return g, a, c, seed, pairs, subset, [cand[0]], cand[1:]
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_mi_golden_teacher_forced(golden_dir, name):
+    g, a, c, seed, pairs, subset, start, cand = _mi_case(golden_dir, name)
+    mi = O.BatchMI(a, c, pairs)
+    res = mi.run_greedy(cand, start, subset, 20, 4, O.Rng(seed), trace=True, forced_pos=g["pick_pos"])
+    # randperm stream + in-place Fisher-Yates + drop-B + ascending re-queue == the reference
+    assert np.array_equal(res["ids"], g["ids"])
+    assert np.array_equal(res["S"], g["S"]) and len(res["GAIN"]) == len(g["GAIN"])
+    ref_mean = g["scores"].astype(np.float64).mean(-1)
+    np.testing.assert_allclose(res["scores"], ref_mean, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(res["GAIN"], g["GAIN"], rtol=1e-5, atol=1e-6)
+    k = g["pick_pos"].shape[1]
+    for t in range(len(g["ids"])):
+        if set(res["pos"][t]) != set(g["pick_pos"][t]):
+            srt = np.sort(ref_mean[t])[::-1]
+            assert abs(srt[k - 1] - srt[k]) <= 2e-6 * max(abs(srt[k - 1]), 1e-3)
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_mi_dense_literal_scores(golden_dir, name):
+    """the literal fp32 dense calc_MI restatement reproduces the reference scores to fp32 round-off,
+    and the canonical float64 closed form agrees with it"""
+    g, a, c, seed, pairs, subset, start, cand = _mi_case(golden_dir, name)
+    mi = O.BatchMI(a, c, pairs)
+    mi.add_samples(start)
+    for t in range(len(g["ids"])):
+        ids = g["ids"][t]
+        dense = mi.scores_dense(ids)
+        np.testing.assert_allclose(dense, g["scores"][t], rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(mi.scores_canon(ids), dense.astype(np.float64).mean(-1), rtol=2e-6, atol=1e-7)
+        mi.add_samples(ids[g["pick_pos"][t]])
+
+
+def test_mi_known_answer_sklearn():
+    from sklearn.metrics import mutual_info_score
+    rs = np.random.RandomState(0)
+    v, c = 1500, 32
+    comp = rs.randint(0, c, v)
+    a = np.stack([comp, np.where(rs.rand(v) < 0.5, comp, rs.randint(0, c, v))], 1).astype(np.int64)
+    mi = O.BatchMI(a, c, [(0, 1)])
+    sel = list(range(1000))
+    mi.add_samples(sel)
+    ids = np.arange(1000, 1020)
+    s = mi.scores_canon(ids)
+    for w, i in enumerate(ids):
+        rows = a[sel + [int(i)]]
+        kat = mutual_info_score(rows[:, 0], rows[:, 1])
+        assert abs(s[w] - kat) <= 1e-6 * kat
+
+
+def test_mi_free_running_invariants():
+    rs = np.random.RandomState(4)
+    v, dd, c = 1200, 3, 16
+    a = rs.randint(0, c, (v, dd)).astype(np.int64)
+    pairs = list(itertools.combinations(range(dd), 2))
+    cand = [int(i) for i in rs.permutation(v)]
+    res = O.BatchMI(a, c, pairs).run_greedy(cand[1:], cand[:1], 241, 20, 4, O.Rng(5), trace=True)
+    assert len(res["S"]) == 241 == len(set(res["S"])) and cand[0] not in res["S"]   # batch.py:238-241
+    assert len(res["GAIN"]) == 244                                                  # GAIN is not cut
+    with pytest.raises(RuntimeError):
+        O.BatchMI(a[:30], c, pairs).run_greedy(list(range(1, 30)), [0], 28, 20, 4, O.Rng(0))
+
+
+def test_canonical_arithmetic_definitions():
+    """the oracle's canonical dot / sumsq are what their header says (pure-Python restatement)"""
+    rs = np.random.RandomState(1)
+    for d in (1, 31, 32, 33, 200, 1024):
+        v = rs.randn(d).astype(np.float32)
+        w = rs.randn(d).astype(np.float32)
+        acc = np.float32(0)
+        for j in range(d):  # one sequential FMA chain: exact product in float64, one rounding
+            acc = np.float32(np.float64(v[j]) * np.float64(w[j]) + np.float64(acc))
+        assert O.dot(v, w) == float(acc)
+        p = np.zeros(32, np.float32)
+        for j in range(d):
+            p[j & 31] = np.float32(np.float64(v[j]) * np.float64(v[j]) + np.float64(p[j & 31]))
+        gq = [(p[4 * q] + p[4 * q + 1]) + (p[4 * q + 2] + p[4 * q + 3]) for q in range(8)]
+        ss = ((gq[0] + gq[1]) + (gq[2] + gq[3])) + ((gq[4] + gq[5]) + (gq[6] + gq[7]))
+        assert O.sumsq(v) == float(ss)
+        assert O.norm2(v) == float(np.float32(np.sqrt(np.float32(ss))) ** 2)
