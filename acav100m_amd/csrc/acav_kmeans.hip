@@ -260,25 +260,148 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
     }
 }
 
-// ---------------------------------------------------------------------------- k_step_dist
-// grid (ceil(K/32), ceil(b/32)); 4 waves, each one 16x16 tile via v_mfma_f32_16x16x4_f32
-// (32-cycle issue, 40-cycle dependent latency: the shortest exact-fp32 chain on the chip).
+// ------------------------------------------------------------------------- SGD step kernels
+// One add() = k_step_dist* (labels of the batch) + k_step_update (centre update).  The batch is
+// tiny (b = 32 rows in the reference), so both kernels are latency-optimised, not throughput-optimised.
+//
+// Cross-workgroup argmin: every workgroup folds its (distance, centre) candidates into one 64-bit
+// key per batch row with a global atomicMin -- key = orderable(distance) << 32 | centre, so the
+// minimum is the lexicographic (distance, first index) minimum whatever the arrival order.
+__device__ __forceinline__ unsigned long long pack_key(float v, int k)
+{
+    unsigned u = __float_as_uint(v);
+    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;  // total order of finite floats as unsigned
+    return ((unsigned long long)u << 32) | (unsigned)k;
+}
+__device__ __forceinline__ float key_value(unsigned long long key)
+{
+    unsigned u = (unsigned)(key >> 32);
+    u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+    return __uint_as_float(u);
+}
+
+// k_step_dist_dma: grid (ceil(K/8), ceil(b/8)), ONE wave per workgroup.  Lane l: centre l>>3, row l&7.
+// The 8 centre rows + 8 batch rows of a stage (up to 1024 columns = 64 KB) are pulled into LDS with
+// direct global->LDS DMA (global_load_lds_dwordx4, no VGPR staging), issued column-block by
+// column-block; the wave then waits with COUNTED s_waitcnt vmcnt(N) for block 0, 1, ... and runs
+// one dependent v_fma_f32 chain per lane over the columns in ascending order while the later blocks
+// are still landing (no barrier: a wave only reads what its own DMA wrote).  The FMA chain is
+// bitwise the f32 MFMA's, at 4-cycle instead of 10-cycle dependent latency per column.
+// LDS rows keep their 16-byte chunks XOR-permuted by (row & 7) -- applied to the DMA SOURCE address,
+// the LDS image stays lane-linear -- so the 8 rows one ds_read_b128 touches sit in 8 bank groups.
+constexpr int SD_NC = 8;
+constexpr int SD_NR = 8;
+constexpr int SD_DS = 1024;
+
+#define ACAV_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+__global__ __launch_bounds__(64) void k_step_dist_dma(const float *__restrict__ x, int b, int d,
+                                                      const float *__restrict__ centers,
+                                                      const float *__restrict__ cn,
+                                                      const float *__restrict__ counts,
+                                                      const float *__restrict__ xn, int K, float thr, float r,
+                                                      unsigned long long *__restrict__ keys)
+{
+    __shared__ __attribute__((aligned(16))) float sT[(SD_NC + SD_NR) * SD_DS];
+    const int lane = threadIdx.x;
+    const int kk = lane >> 3;
+    const int ii = lane & 7;
+    const int kbase = blockIdx.x * SD_NC, rbase = blockIdx.y * SD_NR;
+    const bool ragged_rows = (kbase + SD_NC > K) || (rbase + SD_NR > b);
+
+    float acc = 0.f;
+    for (int j0 = 0; j0 < d; j0 += SD_DS) {
+        const int ncols = min(SD_DS, d - j0);
+        const int nblk = (ncols + 255) >> 8;
+        const bool ragged = ragged_rows || (ncols & 255);
+        if (ragged) {
+            // slots the DMA will not write must read as 0 (fma(c, 0, acc) == acc)
+            for (int i = lane; i < (SD_NC + SD_NR) * nblk * 64; i += 64) {
+                const int row = i / (nblk * 64), c4 = i - row * (nblk * 64);
+                *reinterpret_cast<float4 *>(sT + row * SD_DS + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        for (int blk = 0; blk < nblk; ++blk) {
+#pragma unroll
+            for (int row = 0; row < SD_NC + SD_NR; ++row) {
+                const bool is_c = row < SD_NC;
+                const int grow = is_c ? kbase + row : rbase + row - SD_NC;
+                const bool row_ok = is_c ? grow < K : grow < b;
+                const float *src = (is_c ? centers : x) + (size_t)grow * d;
+                const int col = j0 + blk * 256 + ((lane ^ (row & 7)) << 2);
+                if (row_ok && col < d) {
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(src + col),
+                        (__attribute__((address_space(3))) void *)(sT + row * SD_DS + blk * 256), 16, 0, 0);
+                }
+            }
+        }
+        const float *pc = sT + kk * SD_DS;
+        const float *px = sT + (SD_NC + ii) * SD_DS;
+        const int sc = kk << 2, sx = ii << 2;
+        for (int blk = 0; blk < nblk; ++blk) {
+            // 16 DMA instructions per block were issued in block order: wait until block `blk` landed
+            const int later = ragged ? 0 : (nblk - 1 - blk);
+            if (later == 3) ACAV_WAIT_VMCNT(48);
+            else if (later == 2) ACAV_WAIT_VMCNT(32);
+            else if (later == 1) ACAV_WAIT_VMCNT(16);
+            else ACAV_WAIT_VMCNT(0);
+            // 64 chunks of 4 columns, software-pipelined in groups of 8: the ds_read_b128 of group g+1
+            // are in flight while the dependent FMA chain consumes group g
+            const float *pcb = pc + blk * 256, *pxb = px + blk * 256;
+            float4 cA[8], xA[8], cB[8], xB[8];
+#define ACAV_LD_GROUP(C, X, g)                                                                 \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                             \
+        C[u] = *reinterpret_cast<const float4 *>(pcb + ((((g) * 8 + u) << 2) ^ sc));            \
+        X[u] = *reinterpret_cast<const float4 *>(pxb + ((((g) * 8 + u) << 2) ^ sx));            \
+    }
+#define ACAV_FMA_GROUP(C, X)                                  \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {            \
+        acc = __builtin_fmaf(C[u].x, X[u].x, acc);             \
+        acc = __builtin_fmaf(C[u].y, X[u].y, acc);             \
+        acc = __builtin_fmaf(C[u].z, X[u].z, acc);             \
+        acc = __builtin_fmaf(C[u].w, X[u].w, acc);             \
+    }
+            ACAV_LD_GROUP(cA, xA, 0)
+#pragma unroll
+            for (int g = 0; g < 8; g += 2) {
+                ACAV_LD_GROUP(cB, xB, g + 1)
+                ACAV_FMA_GROUP(cA, xA)
+                if (g + 2 < 8) { ACAV_LD_GROUP(cA, xA, g + 2) }
+                ACAV_FMA_GROUP(cB, xB)
+            }
+#undef ACAV_LD_GROUP
+#undef ACAV_FMA_GROUP
+        }
+        // the next stage overwrites sT: all ds_reads above have returned (acc depends on them)
+    }
+    const int k = kbase + kk, row = rbase + ii;
+    unsigned long long key = ~0ull;
+    if (k < K && row < b) key = pack_key(dist_epilogue(acc, xn[row], cn[k], counts[k] < thr, r), k);
+    unsigned long long o = __shfl_xor(key, 8);
+    key = o < key ? o : key;
+    o = __shfl_xor(key, 16);
+    key = o < key ? o : key;
+    o = __shfl_xor(key, 32);
+    key = o < key ? o : key;
+    if (lane < 8 && rbase + lane < b) atomicMin(&keys[rbase + lane], key);
+}
+
+// k_step_dist_mfma: generic fallback (any d, any alignment).  grid (ceil(K/32), ceil(b/32)); 4 waves,
+// each one 16x16 tile on v_mfma_f32_16x16x4_f32, operands staged through registers.
 constexpr int SD_BK = 64;
 constexpr int SD_LD = 66;  // ds_read_b32 of [i][4t+g]: bank = 2i+g (+4t) -> conflict-free per 32 lanes
 
-__global__ __launch_bounds__(256) void k_step_dist(const float *__restrict__ x, int b, int d,
-                                                   const float *__restrict__ centers,
-                                                   const float *__restrict__ cn,
-                                                   const float *__restrict__ counts, int K, float thr,
-                                                   float r, float *__restrict__ part_v,
-                                                   int *__restrict__ part_i)
+__global__ __launch_bounds__(256) void k_step_dist_mfma(const float *__restrict__ x, int b, int d,
+                                                        const float *__restrict__ centers,
+                                                        const float *__restrict__ cn,
+                                                        const float *__restrict__ counts,
+                                                        const float *__restrict__ xn, int K, float thr, float r,
+                                                        unsigned long long *__restrict__ keys)
 {
     __shared__ __attribute__((aligned(16))) float sC[32 * SD_LD];
     __shared__ __attribute__((aligned(16))) float sX[32 * SD_LD];
-    __shared__ float sXn[32];
-    __shared__ float sMinV[2][32];
-    __shared__ int sMinI[2][32];
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -291,7 +414,6 @@ __global__ __launch_bounds__(256) void k_step_dist(const float *__restrict__ x, 
     const int nchunks = (d + SD_BK - 1) / SD_BK;
 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float ssq[4] = {0.f, 0.f, 0.f, 0.f};
     float4 xr[2], cr[2];
     auto issue_loads = [&](int c) {
 #pragma unroll
@@ -312,10 +434,6 @@ __global__ __launch_bounds__(256) void k_step_dist(const float *__restrict__ x, 
             *reinterpret_cast<float2 *>(px + 2) = make_float2(xr[m].z, xr[m].w);
             *reinterpret_cast<float2 *>(pc) = make_float2(cr[m].x, cr[m].y);
             *reinterpret_cast<float2 *>(pc + 2) = make_float2(cr[m].z, cr[m].w);
-            ssq[0] = __builtin_fmaf(xr[m].x, xr[m].x, ssq[0]);
-            ssq[1] = __builtin_fmaf(xr[m].y, xr[m].y, ssq[1]);
-            ssq[2] = __builtin_fmaf(xr[m].z, xr[m].z, ssq[2]);
-            ssq[3] = __builtin_fmaf(xr[m].w, xr[m].w, ssq[3]);
         }
         __syncthreads();
         if (c + 1 < nchunks) issue_loads(c + 1);
@@ -325,54 +443,32 @@ __global__ __launch_bounds__(256) void k_step_dist(const float *__restrict__ x, 
         for (int t = 0; t < SD_BK / 4; ++t)
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * t], pb[4 * t], acc, 0, 0, 0);
     }
-    {
-        float t = (ssq[0] + ssq[1]) + (ssq[2] + ssq[3]);
-        t = t + __shfl_xor(t, 1);
-        t = t + __shfl_xor(t, 2);
-        t = t + __shfl_xor(t, 4);
-        if (sq == 0) sXn[srow] = norm2_from_sumsq(t);
-    }
-    __syncthreads();
     // D[i][j]: column j = lane&15 (row of x), row i = 4*(lane>>4) + reg (centre)
-    const float xn = sXn[rw * 16 + l15];
-    float bv = INFINITY;
-    int bi = 0x7fffffff;
+    const int row = rbase + rw * 16 + l15;
+    unsigned long long key = ~0ull;
+    if (row < b) {
+        const float xnv = xn[row];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int k = kbase + cw * 16 + 4 * g + e;
-        if (k < K) {
-            const float t = dist_epilogue(acc[e], xn, cn[k], counts[k] < thr, r);
-            lexmin(bv, bi, t, k);
+        for (int e = 0; e < 4; ++e) {
+            const int k = kbase + cw * 16 + 4 * g + e;
+            if (k < K) {
+                const unsigned long long kc = pack_key(dist_epilogue(acc[e], xnv, cn[k], counts[k] < thr, r), k);
+                key = kc < key ? kc : key;
+            }
         }
     }
-    {
-        float ov = __shfl_xor(bv, 16);
-        int oi = __shfl_xor(bi, 16);
-        lexmin(bv, bi, ov, oi);
-        ov = __shfl_xor(bv, 32);
-        oi = __shfl_xor(bi, 32);
-        lexmin(bv, bi, ov, oi);
-    }
-    if (g == 0) {
-        sMinV[cw][rw * 16 + l15] = bv;
-        sMinI[cw][rw * 16 + l15] = bi;
-    }
-    __syncthreads();
-    if (tid < 32 && rbase + tid < b) {
-        float v = sMinV[0][tid];
-        int i = sMinI[0][tid];
-        lexmin(v, i, sMinV[1][tid], sMinI[1][tid]);
-        part_v[(size_t)blockIdx.x * b + rbase + tid] = v;
-        part_i[(size_t)blockIdx.x * b + rbase + tid] = i;
-    }
+    unsigned long long o = __shfl_xor(key, 16);
+    key = o < key ? o : key;
+    o = __shfl_xor(key, 32);
+    key = o < key ? o : key;
+    if (g == 0 && row < b) atomicMin(&keys[row], key);
 }
 
-// -------------------------------------------------------------------------- k_step_update
-// grid = b blocks.  Block i owns centre best[i] iff no earlier row of the batch has the same
-// label; it then applies   c <- c*(1 - n_k*lr) + sum_{rows of the batch with label k, in batch
-// order} lr*x   (sgd_clustering.py:120-127; the sum order is torch_scatter's CPU order) and
-// refreshes ||c||^2.  Block 0 also folds the batch histogram into counts and handles the
-// lr fallback bookkeeping (:116-119).
+// k_step_update: grid = b blocks.  Block i owns centre best[i] iff no earlier row of the batch has
+// the same label; it then applies   c <- c*(1 - n_k*lr) + sum_{rows of the batch with label k, in
+// batch order} lr*x   (sgd_clustering.py:120-127; the sum order is torch_scatter's CPU order) and
+// refreshes ||c||^2.  Block 0 also folds the batch histogram (LDS) into counts and does the
+// lr-fallback bookkeeping (:116-119).  keys_next: the key buffer of the following step, reset here.
 struct StepScalars {
     long long fallback;  // self.fallback
     float mean;          // return value of add(): mean of the row minima
@@ -380,54 +476,49 @@ struct StepScalars {
 };
 
 constexpr int SU_MAXB = 1024;
+constexpr int SU_MAXK = 8192;
 
 __global__ __launch_bounds__(256) void k_step_update(const float *__restrict__ x, int b, int d,
                                                      float *__restrict__ centers, float *__restrict__ cn,
                                                      float *__restrict__ counts, int K,
-                                                     const float *__restrict__ part_v,
-                                                     const int *__restrict__ part_i, int nparts,
+                                                     const unsigned long long *__restrict__ keys,
+                                                     unsigned long long *__restrict__ keys_next,
                                                      const int64_t *__restrict__ forced, double lr,
-                                                     StepScalars *__restrict__ sc, float forced_mean)
+                                                     StepScalars *__restrict__ sc)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    int *sBest = reinterpret_cast<int *>(smem_raw);            // [b]
-    float *sMin = reinterpret_cast<float *>(sBest + SU_MAXB);  // [b]
-    float *sRow = sMin + SU_MAXB;                              // [d]
+    int *sBest = reinterpret_cast<int *>(smem_raw);  // [b]
+    float *sMin = reinterpret_cast<float *>(sBest + b);   // [b]
+    int *sCnt = reinterpret_cast<int *>(sMin + b);         // [K] batch histogram
+    int *sFirst = sCnt + K;                                // [K] first batch row of each label
+    float *sRow = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(sFirst + K) + 15) & ~uintptr_t(15));  // [d]
     __shared__ int sCmax;
     const int tid = threadIdx.x;
     const int me = blockIdx.x;
     if (tid == 0) sCmax = 0;
+    for (int k = tid; k < K; k += blockDim.x) {
+        sCnt[k] = 0;
+        sFirst[k] = 0x7fffffff;
+    }
     for (int i = tid; i < b; i += blockDim.x) {
         if (forced) {
             sBest[i] = (int)forced[i];
             sMin[i] = 0.f;
         } else {
-            float v = part_v[i];
-            int k = part_i[i];
-            for (int p = 1; p < nparts; ++p) lexmin(v, k, part_v[(size_t)p * b + i], part_i[(size_t)p * b + i]);
-            sBest[i] = k;
-            sMin[i] = v;
+            const unsigned long long key = keys[i];
+            sBest[i] = (int)(key & 0xffffffffull);
+            sMin[i] = key_value(key);
         }
     }
     __syncthreads();
-    const int mine = sBest[me];
-    // my centre's batch count, and the batch maximum (each block recomputes: b is small)
-    int cnt_mine = 0;
-    bool first = true;
-    for (int i = 0; i < b; ++i) {
-        const bool same = sBest[i] == mine;
-        cnt_mine += same;
-        if (same && i < me) first = false;
-    }
-    // max count over centres = max over rows of (count of that row's label)
-    int local_max = 0;
     for (int i = tid; i < b; i += blockDim.x) {
-        int c = 0;
-        const int ki = sBest[i];
-        for (int i2 = 0; i2 < b; ++i2) c += (sBest[i2] == ki);
-        local_max = max(local_max, c);
+        atomicAdd(&sCnt[sBest[i]], 1);
+        atomicMin(&sFirst[sBest[i]], i);
     }
-    atomicMax(&sCmax, local_max);
+    __syncthreads();
+    int local_max = 0;
+    for (int k = tid; k < K; k += blockDim.x) local_max = max(local_max, sCnt[k]);
+    if (local_max) atomicMax(&sCmax, local_max);
     __syncthreads();
     const float cmax = (float)sCmax;
     bool fell = false;
@@ -436,52 +527,62 @@ __global__ __launch_bounds__(256) void k_step_update(const float *__restrict__ x
         fell = true;
     }
     const float lr32 = (float)lr;
+    const int mine = sBest[me];
+    const int cnt_mine = sCnt[mine];
+    const bool first = sFirst[mine] == me;
 
     if (me == 0) {
-        // counts += histogram (exact small integers in fp32), one thread per first-occurrence row
-        for (int i = tid; i < b; i += blockDim.x) {
-            const int ki = sBest[i];
-            bool f = true;
-            int c = 0;
-            for (int i2 = 0; i2 < b; ++i2) {
-                const bool same = sBest[i2] == ki;
-                c += same;
-                if (same && i2 < i) f = false;
-            }
-            if (f) counts[ki] = counts[ki] + (float)c;
-        }
+        for (int k = tid; k < K; k += blockDim.x)
+            if (sCnt[k]) counts[k] = counts[k] + (float)sCnt[k];  // exact small integers in fp32
+        if (keys_next)
+            for (int i = tid; i < b; i += blockDim.x) keys_next[i] = ~0ull;
         if (tid == 0) {
             if (fell) sc->fallback += 1;
             sc->lr_used = lr32;
-            if (forced) {
-                sc->mean = forced_mean;
-            } else {
-                double s = 0.0;
-                for (int i = 0; i < b; ++i) s += (double)sMin[i];
-                sc->mean = (float)(s / (double)b);
-            }
+            double s = 0.0;
+            for (int i = 0; i < b; ++i) s += (double)sMin[i];
+            sc->mean = (float)(s / (double)b);
         }
     }
     if (!first) return;  // uniform per block
 
     const float f = 1.0f - (float)cnt_mine * lr32;
     float *crow = centers + (size_t)mine * d;
-    for (int j = tid; j < d; j += blockDim.x) {
-        float delta = 0.f;
-        bool have = false;
-        for (int i = me; i < b; ++i) {
-            if (sBest[i] != mine) continue;
-            const float v = x[(size_t)i * d + j] * lr32;
-            delta = have ? (delta + v) : v;
-            have = true;
+    if ((d & 3) == 0) {
+        for (int j = tid * 4; j < d; j += blockDim.x * 4) {
+            const float4 c4 = *reinterpret_cast<const float4 *>(crow + j);
+            float4 dl = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool have = false;
+            for (int i = me; i < b; ++i) {
+                if (sBest[i] != mine) continue;
+                const float4 x4 = *reinterpret_cast<const float4 *>(x + (size_t)i * d + j);
+                const float4 v = make_float4(x4.x * lr32, x4.y * lr32, x4.z * lr32, x4.w * lr32);
+                dl = have ? make_float4(dl.x + v.x, dl.y + v.y, dl.z + v.z, dl.w + v.w) : v;
+                have = true;
+            }
+            const float4 nv = make_float4(c4.x * f + dl.x, c4.y * f + dl.y, c4.z * f + dl.z, c4.w * f + dl.w);
+            *reinterpret_cast<float4 *>(crow + j) = nv;
+            *reinterpret_cast<float4 *>(sRow + j) = nv;
         }
-        const float nv = crow[j] * f + delta;
-        crow[j] = nv;
-        sRow[j] = nv;
+    } else {
+        for (int j = tid; j < d; j += blockDim.x) {
+            float delta = 0.f;
+            bool have = false;
+            for (int i = me; i < b; ++i) {
+                if (sBest[i] != mine) continue;
+                const float v = x[(size_t)i * d + j] * lr32;
+                delta = have ? (delta + v) : v;
+                have = true;
+            }
+            const float nv = crow[j] * f + delta;
+            crow[j] = nv;
+            sRow[j] = nv;
+        }
     }
     __syncthreads();
     if (tid < 32) {
         float p = 0.f;
+#pragma unroll 8
         for (int j = tid; j < d; j += 32) p = __builtin_fmaf(sRow[j], sRow[j], p);
         p = p + __shfl_xor(p, 1);
         p = p + __shfl_xor(p, 2);
@@ -490,6 +591,12 @@ __global__ __launch_bounds__(256) void k_step_update(const float *__restrict__ x
         p = p + __shfl_xor(p, 16);
         if (tid == 0) cn[mine] = norm2_from_sumsq(p);
     }
+}
+
+__global__ void k_fill_u64(unsigned long long *p, int n, unsigned long long v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
 }
 
 }  // namespace
@@ -502,7 +609,8 @@ struct acav_kmeans {
     double reinit_p = 0.7, reinit_r = 5.0;
     int64_t count = 0;  // python int self.count (deterministic on the host)
     DevBuf centers, cn, counts, scalars;
-    DevBuf stage_x, stage_lab, stage_forced, part_v, part_i, wg_sum, minval;
+    DevBuf stage_x, stage_lab, stage_forced, keys, xn, wg_sum, minval;
+    int key_phase = 0;  // which half of `keys` the next step's distance kernel folds into
     int64_t n_assign_launches = 0, n_step_launches = 0;
 
     float threshold() const { return (float)pow((double)count / (double)K, reinit_p); }
@@ -673,28 +781,49 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
     return ACAV_OK;
 }
 
-// one add() on device-resident x [b,d]; forced (device) optional
+// one add() on device-resident x [b,d]; forced (device) optional; xn_dev: ||x||^2 of the b rows
+// when the caller already has them (bulk training), else computed here.
 static int step_device(acav_kmeans *km, const float *dx, int64_t b, double lr, const int64_t *dforced,
-                       float forced_mean)
+                       const float *xn_dev)
 {
     ACAV_REQUIRE(b > 0 && b <= SU_MAXB, ACAV_EINVAL, "batch size %lld outside 1..%d", (long long)b, SU_MAXB);
+    ACAV_REQUIRE(km->K <= SU_MAXK, ACAV_EINVAL, "k=%d exceeds the %d supported by the SGD step kernels", km->K, SU_MAXK);
     hipStream_t st = km->ctx.stream;
-    const int nct = (km->K + 31) / 32;
+    if (!km->keys.p) {
+        ACAV_TRY(km->keys.ensure(sizeof(unsigned long long) * 2 * SU_MAXB));
+        hipLaunchKernelGGL(k_fill_u64, dim3((2 * SU_MAXB + 255) / 256), dim3(256), 0, st,
+                           km->keys.as<unsigned long long>(), 2 * SU_MAXB, ~0ull);
+        ACAV_HIP_TRY(hipGetLastError());
+        km->key_phase = 0;
+    }
+    unsigned long long *kcur = km->keys.as<unsigned long long>() + (size_t)km->key_phase * SU_MAXB;
+    unsigned long long *knext = km->keys.as<unsigned long long>() + (size_t)(km->key_phase ^ 1) * SU_MAXB;
     if (!dforced) {
         ACAV_REQUIRE(!km->warm(), ACAV_ESTATE, "warm-up step needs forced labels (acav_rng_warmup_best)");
-        ACAV_TRY(km->part_v.ensure(sizeof(float) * (size_t)nct * b));
-        ACAV_TRY(km->part_i.ensure(sizeof(int) * (size_t)nct * b));
-        hipLaunchKernelGGL(k_step_dist, dim3(nct, (unsigned)((b + 31) / 32)), dim3(256), 0, st, dx, (int)b, km->d,
-                           km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
-                           km->threshold(), (float)km->reinit_r, km->part_v.as<float>(), km->part_i.as<int>());
+        if (!xn_dev) {
+            ACAV_TRY(km->xn.ensure(sizeof(float) * SU_MAXB));
+            hipLaunchKernelGGL(k_row_norm2, dim3((unsigned)((b + 7) / 8)), dim3(256), 0, st, dx, (int)b, km->d,
+                               km->xn.as<float>());
+            xn_dev = km->xn.as<float>();
+        }
+        const bool dma_ok = (km->d & 3) == 0 && ((uintptr_t)dx & 15) == 0;
+        if (dma_ok) {
+            hipLaunchKernelGGL(k_step_dist_dma, dim3((km->K + SD_NC - 1) / SD_NC, (unsigned)((b + SD_NR - 1) / SD_NR)),
+                               dim3(64), 0, st, dx, (int)b, km->d, km->centers.as<float>(), km->cn.as<float>(),
+                               km->counts.as<float>(), xn_dev, km->K, km->threshold(), (float)km->reinit_r, kcur);
+        } else {
+            hipLaunchKernelGGL(k_step_dist_mfma, dim3((km->K + 31) / 32, (unsigned)((b + 31) / 32)), dim3(256), 0, st, dx,
+                               (int)b, km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), xn_dev,
+                               km->K, km->threshold(), (float)km->reinit_r, kcur);
+        }
         ACAV_HIP_TRY(hipGetLastError());
     }
-    const size_t smem = sizeof(int) * SU_MAXB + sizeof(float) * SU_MAXB + sizeof(float) * (size_t)km->d;
+    const size_t smem = sizeof(int) * 2 * (size_t)b + sizeof(int) * 2 * (size_t)km->K + sizeof(float) * (size_t)km->d + 32;
     hipLaunchKernelGGL(k_step_update, dim3((unsigned)b), dim3(256), smem, st, dx, (int)b, km->d,
-                       km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
-                       km->part_v.as<float>(), km->part_i.as<int>(), nct, dforced, lr,
-                       km->scalars.as<StepScalars>(), forced_mean);
+                       km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K, kcur,
+                       dforced ? (unsigned long long *)nullptr : knext, dforced, lr, km->scalars.as<StepScalars>());
     ACAV_HIP_TRY(hipGetLastError());
+    if (!dforced) km->key_phase ^= 1;
     km->count += b;
     km->n_step_launches += 1;
     return ACAV_OK;
@@ -714,8 +843,7 @@ ACAV_EXPORT int acav_kmeans_step(acav_kmeans *km, const float *x, int64_t b, dou
                          (long long)forced_best[i]);
         ACAV_TRY(to_device(forced_best, sizeof(int64_t) * (size_t)b, km->stage_forced, st, &df));
     }
-    ACAV_TRY(step_device(km, static_cast<const float *>(dx), b, lr, static_cast<const int64_t *>(df),
-                         mean_dist ? *mean_dist : 0.f));
+    ACAV_TRY(step_device(km, static_cast<const float *>(dx), b, lr, static_cast<const int64_t *>(df), nullptr));
     if (mean_dist && !forced_best) {
         StepScalars s{};
         ACAV_HIP_TRY(hipMemcpyAsync(&s, km->scalars.p, sizeof(s), hipMemcpyDeviceToHost, st));
@@ -755,9 +883,17 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
     ACAV_TRY(to_device(x, sizeof(float) * (size_t)n * km->d, km->stage_x, st, &dx));
     if (need) ACAV_TRY(to_device(warm_best, sizeof(int64_t) * (size_t)need * b, km->stage_forced, st, &dw));
     const float *fx = static_cast<const float *>(dx);
+    // ||x||^2 of every row once per call (it does not depend on the centres)
+    if (steps > need) {
+        const int64_t rows = steps * b;
+        ACAV_TRY(km->xn.ensure(sizeof(float) * (size_t)(rows > SU_MAXB ? rows : SU_MAXB)));
+        hipLaunchKernelGGL(k_row_norm2, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, fx, (int)rows, km->d,
+                           km->xn.as<float>());
+        ACAV_HIP_TRY(hipGetLastError());
+    }
     for (int64_t t = 0; t < steps; ++t) {
         const int64_t *f = t < need ? static_cast<const int64_t *>(dw) + t * b : nullptr;
-        ACAV_TRY(step_device(km, fx + (size_t)t * b * km->d, b, lr, f, 0.f));
+        ACAV_TRY(step_device(km, fx + (size_t)t * b * km->d, b, lr, f, km->xn.as<float>() + t * b));
     }
     if (dx != x || (need && dw != warm_best)) ACAV_HIP_TRY(hipStreamSynchronize(st));
     return ACAV_OK;

@@ -127,12 +127,16 @@ def test_exact_ties_take_first_index(env):
     assert (lab.cpu().numpy() == 5).all()
 
 
-@pytest.mark.parametrize("b,lr", [(32, 0.01), (16, 0.01), (48, 0.01), (32, 0.2), (7, 0.5)])
-def test_step_matches_oracle(env, b, lr):
-    """add() at several batch sizes; lr large enough to trigger the fallback (sgd_clustering.py:116-119)."""
+@pytest.mark.parametrize("b,lr,d,K", [(32, 0.01, 96, 24), (16, 0.01, 96, 24), (48, 0.01, 256, 40),
+                                      (32, 0.2, 96, 24), (7, 0.5, 96, 24), (32, 0.01, 130, 24),
+                                      (32, 0.01, 2304, 20), (20, 0.01, 200, 70), (256, 0.01, 64, 33)])
+def test_step_matches_oracle(env, b, lr, d, K):
+    """add() at several batch sizes / shapes: DMA path (d % 4 == 0, incl. d > 1024 = two LDS stages and
+    ragged 256-column blocks), MFMA fallback (d = 130), ragged centre / row groups; lr large enough to
+    trigger the fallback (sgd_clustering.py:116-119)."""
     torch, acav, O = env
     from acav100m_amd.clustering import KMeans
-    d, K, steps = 96, 24, 40
+    steps = 40 if d < 1000 else 16
     x = _mixture(b, b * steps, d, K)
     acav.manual_seed(2)
     km = KMeans(None, d, K).to("cuda:0")
