@@ -1,0 +1,49 @@
+"""`python cli.py cluster --feature_path=<brace glob .pkl> --out_path=<dir> --meta_path=<dir> [--a.b=v]`
+-- the entry point of clustering/code/cli.py:12-27 + args.py:11-24 on the MI355X hot path."""
+import sys
+
+from .. import shards as io
+from ..config import CLUSTERING_DEFAULTS, merge, parse_cli
+from .run_clustering import run_clustering, store_shards_set
+
+
+def get_args(**kwargs):
+    if 'out_path' in kwargs:
+        kwargs['data.output.path'] = kwargs.pop('out_path')
+    if 'feature_path' in kwargs:
+        kwargs['shards_path'] = kwargs.pop('feature_path')
+    if 'shards_path' in kwargs:
+        kwargs['data.path'] = kwargs.pop('shards_path')
+    if 'meta_path' in kwargs:
+        kwargs['data.meta.path'] = kwargs.pop('meta_path')
+    args = merge(CLUSTERING_DEFAULTS, kwargs)
+    if args.computation.num_gpus is None:
+        import torch
+        args.computation.num_gpus = torch.cuda.device_count()
+    from ..parallel import world
+    args.computation.num_gpus = max(1, min(args.computation.num_gpus, world()[1]))
+    args.run_info = io.run_info()
+    args.run_id = io.run_id(args.run_info)
+    return args
+
+
+class Cli:
+    def run(self, **kwargs):
+        return self.cluster(**kwargs)
+
+    def cluster(self, **kwargs):
+        args = get_args(**kwargs)
+        args.data.output.path.mkdir(parents=True, exist_ok=True)
+        saved = run_clustering(args)
+        store_shards_set(args, saved)
+        print('done')
+        return saved
+
+
+def main(argv=None):
+    command, kwargs = parse_cli(sys.argv[1:] if argv is None else argv)
+    return getattr(Cli(), command)(**kwargs)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,184 @@
+"""Clustering stage: train_clusters + assign_clusters (clustering/code/run_clustering.py:25-272),
+restructured for a 288 GB-HBM GPU: the feature shards are read once into resident [N,d] matrices
+(one per (model, layer) view), every KMeans trains on its matrix with the bulk C-ABI call (no host
+synchronisation per step), then one assign sweep per view labels all rows; the reference's per-row
+dict / pkl schema only exists at the file boundary (acav100m_amd/shards.py).
+
+Same observable behaviour as the reference with a single-stream loader (--computation.num_workers=0):
+  * KMeans objects are created in args.models order, layer by layer (RNG order of run_clustering.py:32-44)
+  * per batch of 32 consecutive rows, every clustering takes one add() -- the warm-up draws are
+    interleaved across clusterings exactly like the reference's per-batch loop (:229-241)
+  * lr = 0.1 ** (2 + epoch // 5), epochs = ceil(epochs / num_gpus), drop_last batches
+  * cache_epoch_{e}_{name} checkpoints, skip of already written shards, log_*.json manifest
+"""
+import math
+import pickle
+from collections import OrderedDict
+from pathlib import Path
+
+import numpy as np
+
+from .. import shards as io
+from ..parallel import world
+from .sgd_clustering import KMeans
+
+
+def _device(args):
+    import torch
+    return f"cuda:{torch.cuda.current_device()}"
+
+
+def _cache_path(args, epoch):
+    return Path(args.data.output.path) / "cache_epoch_{}_{}".format(epoch, Path(args.data.path).name)
+
+
+def init_clusterings(args, table):
+    """run_clustering.py:32-52 -- one KMeans per view, created in view order (RNG order)."""
+    cl = OrderedDict()
+    for view, mat in table.views.items():
+        cl[view] = KMeans(args, mat.shape[1], args.clustering.ncentroids)
+    return _to_device(args, cl)
+
+
+def _to_device(args, cl):
+    dev = _device(args)
+    for km in cl.values():
+        km.to(dev)
+        km.initialize()
+    return cl
+
+
+def load_clusterings(args, table):
+    """run_clustering.py:55-107: resume from cache_epoch_{e}_{name} (or a cache trained on a subset of
+    these shards) when --clustering.cached_epoch is set."""
+    epoch = args.clustering.cached_epoch
+    if isinstance(epoch, int):
+        path = _cache_path(args, epoch)
+        if not path.is_file() and args.clustering.load_cache_from_shard_subset:
+            path = _subset_cache(args, epoch)
+        if path is not None and path.is_file():
+            with open(path, 'rb') as f:
+                saved = pickle.load(f)
+            if set(saved.keys()) >= set(table.views.keys()):
+                print("loading from clustering cache: {}".format(path))
+                cl = OrderedDict((v, KMeans.load(saved[v])) for v in table.views)
+                for km in cl.values():
+                    km.args = args
+                return _to_device(args, cl), True
+            print("clustering cache features does not match with the given models")
+        print("no clustering cache found.")
+    return init_clusterings(args, table), False
+
+
+def _subset_cache(args, epoch):
+    want = set(io.brace_expand(Path(args.data.path).name))
+    best = None
+    for p in Path(args.data.output.path).glob("cache_epoch_{}_*".format(epoch)):
+        have = set(io.brace_expand(p.name[p.name.find('shard-'):]))
+        if have and not (have - want) and (best is None or len(have) > best[0]):
+            best = (len(have), p)
+    return None if best is None else best[1]
+
+
+def save_clusterings(args, epoch, cl):
+    path = _cache_path(args, epoch)
+    print("saving clustering cache to: {}".format(path))
+    path.parent.mkdir(parents=True, exist_ok=True)
+    with open(path, 'wb') as f:
+        pickle.dump(OrderedDict((v, km.get_attrs_plain()) for v, km in cl.items()), f)
+
+
+def train_clusters(args, table, resident):
+    cl, loaded = load_clusterings(args, table)
+    if loaded and not args.clustering.resume_training:
+        return cl
+    pre = args.clustering.cached_epoch if loaded else 0
+    rank, w = world()
+    epochs = math.ceil(args.clustering.epochs / max(1, args.computation.num_gpus or 1))
+    b = int(args.data.batch_size)
+    n = len(table)
+    steps = n // b  # drop_last (run_clustering.py:139)
+    print("training sgd kmeans for views: {}".format([v[1:] for v in cl]))
+    for epoch in range(pre, pre + epochs):
+        lr = 0.1 ** (2 + epoch // 5)
+        for km in cl.values():
+            km.lr = lr
+        if w > 1:
+            _train_epoch_distributed(cl, resident, b, steps, rank, w)
+        else:
+            # warm-up labels, drawn batch by batch across the clusterings like the reference loop
+            need = {v: km.warmup_steps(b, steps) for v, km in cl.items()}
+            warm = {v: np.empty((need[v], b), np.int64) for v in cl}
+            for t in range(max(need.values(), default=0)):
+                for v, km in cl.items():
+                    if t < need[v]:
+                        warm[v][t] = km.draw_warmup(b)
+            for v, km in cl.items():
+                km.train_epoch(resident[v], b, lr=lr, warm_best=warm[v])
+        save_clusterings(args, epoch, cl)
+    return cl
+
+
+def _train_epoch_distributed(cl, resident, b, steps, rank, w):
+    """row-striped global batches: rank r labels rows [r*b/w, (r+1)*b/w) of each batch, so the result is
+    the single-process result (acav100m_amd/parallel/kmeans_dp.py)."""
+    lb = b // w
+    for t in range(steps):
+        for v, km in cl.items():
+            x = resident[v]
+            km.add(x[t * b + rank * lb: t * b + (rank + 1) * lb])
+
+
+def assign_clusters(args, table, resident, cl, shard_names):
+    """run_clustering.py:180-272: label every row of this rank's shards, write {out}/{shard}.pkl."""
+    out_dir = Path(args.data.output.path)
+    prefix = '' if args.clustering.cached_epoch is None else 'epoch_{}_'.format(args.clustering.cached_epoch)
+    print("extracting clustering for views: {}".format([v[1:] for v in cl]))
+    labels = OrderedDict()
+    for v, km in cl.items():
+        best, _ = km.calc_best(resident[v])
+        labels[v] = best.cpu().numpy()
+    saved = []
+    for shard in shard_names:
+        out_path = out_dir / (prefix + shard + '.pkl')
+        plain = out_dir / (shard + '.pkl')
+        if plain.is_file():  # already processed (run_clustering.py:248-250)
+            continue
+        ids = table.shard_rows[shard]
+        size = table.shard_size[ids[0]] if ids else 0
+        if len(ids) < round(size * args.data.output.shard_ok_ratio):
+            continue  # too incomplete to save (:261-268)
+        io.dump_pickle(io.assignment_rows(table, labels, ids), out_path)
+        saved.append(out_path)
+    return saved
+
+
+def run_clustering(args):
+    import torch
+    paths = [Path(p) for p in sorted(io.brace_expand(args.data.path))]
+    sizes = io.shard_sizes_from_meta(paths, args.data.meta.path)
+    if args.data.meta.path is not None:  # side effect of the reference: meta_cache.pkl in the meta dir
+        io.dump_pickle(dict(sizes), Path(args.data.meta.path) / 'meta_cache.pkl')
+    paths = [p for p in paths if p.stem in sizes]
+    if not paths:
+        print(f"All shards of {args.data.path} processing already done!")
+        return []
+    print(f"processing {len(paths)} shards")
+    rank, w = world()
+    table = io.load_feature_shards(paths, model_order=list(args.models or []),
+                                   audio_models=tuple(args.model_types.audio or ()))
+    dev = _device(args)
+    resident = OrderedDict((v, torch.from_numpy(m).to(dev)) for v, m in table.views.items())
+    cl = train_clusters(args, table, resident)
+    mine = [p.stem for p in paths][rank::w]  # assign: shards strided over ranks (mps/distributed.py:439)
+    return assign_clusters(args, table, resident, cl, mine)
+
+
+def store_shards_set(args, saved_paths):
+    """clustering/code/save.py:9-17"""
+    if len(saved_paths) == 0:
+        print("All shards already processed")
+        return None
+    out_path = saved_paths[0].parent / ('log_' + args.run_id + '.json')
+    io.dump_json({**args.run_info, 'shards': [p.stem for p in saved_paths]}, out_path, indent=None)
+    return out_path

@@ -232,18 +232,15 @@ class KMeans:
         )
 
     def initialize(self):
-        """sgd_clustering.py:88-92: average centers/counts over ranks so every rank starts equal
-        (mps/distributed.py:139-155: all_reduce SUM then 1/world)."""
+        """sgd_clustering.py:88-92: average centers/counts over ranks so every rank starts equal."""
         if self.is_distributed:
             import torch
-            import torch.distributed as dist
+            from ..parallel import average_state
             centers, counts, count, fb = self._host_state()
-            buf = torch.from_numpy(np.concatenate([centers.ravel(), counts])).cuda(self._device)
-            dist.all_reduce(buf)
-            buf = (buf * (1.0 / dist.get_world_size())).cpu().numpy()
-            k, d = centers.shape
-            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, _lib.ptr(np.ascontiguousarray(buf[:k * d])),
-                                                       _lib.ptr(np.ascontiguousarray(buf[k * d:])), count, fb))
+            dev = f"cuda:{self._device}"
+            c, n = average_state(torch.from_numpy(centers).to(dev), torch.from_numpy(counts).to(dev))
+            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, _lib.ptr(c.contiguous()), _lib.ptr(n.contiguous()),
+                                                       count, fb))
 
     def add(self, batch):
         """sgd_clustering.py:94-129 (fast parallel update).  Returns the mean min-distance."""
@@ -264,36 +261,54 @@ class KMeans:
         return mean.value
 
     def _add_distributed(self, batch, lr):
-        """Multi-GPU add(): every rank labels its b/W local rows, rows and labels are all-gathered
-        (RCCL), and every rank applies the identical global-batch update -- the same state as a
-        single process fed the rank-major concatenation (multi-GPU)."""
-        import torch
-        import torch.distributed as dist
-        from ..parallel import gather_rows_and_labels
-        best, mean = self.calc_best(batch)
-        xg, bg = gather_rows_and_labels(batch, best, self._device)
-        _lib.check(_lib._lib.acav_kmeans_apply_update(self._h, _lib.ptr(xg), xg.shape[0], _lib.ptr(bg), float(lr)))
-        m = torch.tensor([mean], dtype=torch.float64, device=xg.device)
-        dist.all_reduce(m)
-        return float(m.item() / dist.get_world_size())
+        """Multi-GPU add(): see acav100m_amd/parallel/kmeans_dp.py."""
+        from ..parallel import distributed_add
+        return distributed_add(self, batch, lr)
+
+    def apply_update(self, x, best, lr):
+        """The update half of add() on an already-labelled global batch (sgd_clustering.py:113-128)."""
+        keep, xp, b, _ = _as_f32_2d(x)
+        if hasattr(best, "data_ptr"):
+            import torch
+            lab = best.detach().to(torch.long).contiguous()
+        else:
+            lab = np.ascontiguousarray(best, np.int64)
+        _lib.check(_lib._lib.acav_kmeans_apply_update(self._require_handle(), xp, b, _lib.ptr(lab), float(lr)))
 
     # ----------------------------------------------------------- bulk (device-resident) API
-    def train_epoch(self, x, batch_size, lr=None):
+    def warmup_steps(self, batch_size, steps):
+        """number of the next `steps` add() calls that still fall in the warm-up (count < initial_rounds*k)"""
+        lim, cnt = self.initial_rounds * self._shape[0], self.count
+        return 0 if cnt >= lim else min(int(steps), -(-(lim - cnt) // int(batch_size)))
+
+    def draw_warmup(self, batch_size):
+        """labels of one warm-up step: argmin_k torch.rand(k, b) (sgd_clustering.py:67-68,78)"""
+        return self._generator.warmup_best(self._shape[0], int(batch_size))[0]
+
+    def train_epoch(self, x, batch_size, lr=None, warm_best=None):
         """The train-loop body of run_clustering.py:229-241 for this clustering over a resident
-        feature matrix x [n,d]: floor(n/b) add() steps with no host sync in between."""
+        feature matrix x [n,d]: floor(n/b) add() steps with no host sync in between.
+        warm_best [need,b]: pre-drawn warm-up labels (when several clusterings share the RNG stream
+        and must consume it batch by batch); drawn here otherwise."""
         h = self._require_handle()
-        k = self._shape[0]
         lr = self.lr if lr is None else lr
         keep, xp, n, _ = _as_f32_2d(x)
-        steps = n // batch_size
-        lim = self.initial_rounds * k
-        cnt = self.count
-        need = 0 if cnt >= lim else min(steps, -(-(lim - cnt) // batch_size))
-        warm = np.empty((need, batch_size), np.int64)
-        for t in range(need):
-            warm[t], _ = self._generator.warmup_best(k, batch_size)
+        need = self.warmup_steps(batch_size, n // batch_size)
+        if warm_best is None:
+            warm = np.empty((need, batch_size), np.int64)
+            for t in range(need):
+                warm[t] = self.draw_warmup(batch_size)
+        else:
+            warm = np.ascontiguousarray(warm_best, np.int64)
+            assert warm.shape == (need, batch_size), (warm.shape, need, batch_size)
         _lib.check(_lib._lib.acav_kmeans_train(h, xp, n, int(batch_size), float(lr),
                                                _lib.ptr(warm) if need else None, need))
+
+    def get_attrs_plain(self):
+        """get_attrs() without the args object (what the checkpoint files hold)"""
+        dt = self.get_attrs()
+        dt['args'] = None
+        return dt
 
     def synchronize(self):
         _lib.check(_lib._lib.acav_kmeans_sync(self._require_handle()))

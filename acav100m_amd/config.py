@@ -1,0 +1,132 @@
+"""CLI argument handling shared by the two stages.
+
+Behavioural contract of the reference (clustering/code/args.py:11-83 + config.py, and
+subset_selection/code/args.py:11-89 + config.py): keyword arguments with dotted names override a
+nested default dict (`--a.b.c=v`), unknown keys are created, every `path` entry becomes an absolute
+pathlib.Path, and missing attributes read as None (munch.DefaultMunch(None)).
+"""
+import ast
+import copy
+from pathlib import Path
+
+
+class Namespace(dict):
+    """dict with attribute access; missing keys read as None (DefaultMunch(None) semantics)."""
+
+    def __getattr__(self, key):
+        if key.startswith("__"):
+            raise AttributeError(key)
+        return self.get(key)
+
+    def __setattr__(self, key, value):
+        self[key] = value
+
+    def __deepcopy__(self, memo):
+        return Namespace({k: copy.deepcopy(v, memo) for k, v in self.items()})
+
+
+def _wrap(tree):
+    return Namespace({k: _wrap(v) if isinstance(v, dict) else v for k, v in tree.items()})
+
+
+def _resolve_paths(tree):
+    for key, val in tree.items():
+        if isinstance(val, dict):
+            _resolve_paths(val)
+        elif val is not None and (key == 'path' or key.endswith('_file') or key.endswith('_dir')):
+            tree[key] = Path(val).resolve()
+    return tree
+
+
+def merge(defaults, overrides):
+    """defaults (nested dict) <- {'a.b.c': v}; returns a Namespace tree with resolved paths."""
+    tree = copy.deepcopy(defaults)
+    for dotted, value in overrides.items():
+        node = tree
+        parts = dotted.split('.')
+        for part in parts[:-1]:
+            if not isinstance(node.get(part), dict):
+                node[part] = {}
+            node = node[part]
+        node[parts[-1]] = value
+    return _wrap(_resolve_paths(tree))
+
+
+def parse_cli(argv):
+    """`<command> --key=value --flag ...` -> (command, kwargs); values go through literal_eval like
+    python-fire does (numbers, booleans, None, lists), everything else stays a string."""
+    if not argv:
+        raise SystemExit("usage: cli.py <command> [--key=value ...]")
+    command, kwargs, i = argv[0], {}, 1
+    while i < len(argv):
+        tok = argv[i]
+        if not tok.startswith('--'):
+            raise SystemExit(f"unexpected argument {tok!r}")
+        if '=' in tok:
+            key, raw = tok[2:].split('=', 1)
+        elif i + 1 < len(argv) and not argv[i + 1].startswith('--'):
+            key, raw = tok[2:], argv[i + 1]
+            i += 1
+        else:
+            key, raw = tok[2:], 'True'
+        try:
+            val = ast.literal_eval(raw)
+        except (ValueError, SyntaxError):
+            val = raw
+        kwargs[key] = val
+        i += 1
+    return command, kwargs
+
+
+# clustering/code/config.py:1-58 (only the keys the hot path reads; the rest is accepted and ignored)
+CLUSTERING_DEFAULTS = {
+    'models': ['layer_vggish', 'layer_slow_fast'],
+    'model_types': {'audio': ['vggish', 'layer_vggish'], 'visual': ['slow_fast', 'layer_slowfast']},
+    'data': {
+        'path': 'data',
+        'batch_size': 32,
+        'meta': {'path': None},
+        'output': {'path': 'output', 'shard_ok_ratio': 0.99},
+    },
+    'computation': {
+        'random_seed': 0,
+        'device': 'cuda',
+        'num_workers': 40,
+        'num_gpus': None,
+        'dist_backend': 'nccl',
+        'dist_init_method': 'tcp://localhost:9999',
+    },
+    'clustering': {
+        'ncentroids': 32,
+        'epochs': 2,
+        'cached_epoch': None,
+        'resume_training': False,
+        'load_cache_from_shard_subset': True,
+    },
+    'debug': False,
+}
+
+# subset_selection/code/config.py:1-53
+SUBSET_DEFAULTS = {
+    'data': {'path': 'data', 'output': {'path': 'output.csv'}, 'meta': {'path': None}},
+    'computation': {
+        'random_seed': 0,
+        'num_workers': 40,
+        'use_gpu': True,
+        'num_gpus': None,
+        'dist_backend': 'nccl',
+        'dist_init_method': 'tcp://localhost:9967',
+        'load_async': False,
+    },
+    'subset': {'ratio': 0.2, 'size': None},
+    'clustering': {'pairing': 'combination'},
+    'batch': {'batch_size': 20, 'selection_size': 4, 'keep_unselected': True},
+    'measure_name': 'batch_mi',
+    'shuffle_candidates': True,
+    'chunk_size': None,
+    'save_cache_as_csvs': True,
+    'log_every': 1000,
+    'log_times': 10,
+    'verbose': True,
+    'debug': False,
+}

@@ -9,3 +9,4 @@ RCCL over xGMI on ROCm; "gloo" in the CPU tests).  Only the exchanges the path r
   MI selection       none: chunks are independent (chunk.py:21-53)
 """
 from .collectives import gather_rows_and_labels, shard_slice, world  # noqa: F401
+from .kmeans_dp import average_state, distributed_add  # noqa: F401

@@ -1,0 +1,74 @@
+"""`python cli.py run|reduce_csvs --shards_path=<brace glob .pkl> --meta_path=<dir> --out_path=<file|dir>`
+-- the entry points of subset_selection/code/cli.py:17-100 + args.py:11-34 on the MI355X hot path."""
+import datetime
+import sys
+import time
+from pathlib import Path
+
+from ..config import SUBSET_DEFAULTS, merge, parse_cli
+from .run import merge_all_csvs, run_chunks, run_single
+
+
+def get_args(**kwargs):
+    args = merge(SUBSET_DEFAULTS, {k: v for k, v in kwargs.items() if k not in ('out_path', 'shards_path', 'meta_path')})
+    import torch
+    args.computation.device = 'cuda' if (args.computation.use_gpu and torch.cuda.device_count() > 0) else 'cpu'
+    if args.computation.device == 'cpu':
+        print("no gpu available: the acav100m_amd measures have no CPU path and will refuse to run")
+    if args.computation.num_gpus is None:
+        args.computation.num_gpus = sys.maxsize
+    args.computation.num_gpus = min(args.computation.num_gpus, torch.cuda.device_count())
+    return args
+
+
+def prepare(**kwargs):
+    """cli.py:18-43"""
+    args = get_args(**kwargs)
+    if 'out_path' in kwargs:
+        args.data.output.path = Path(kwargs['out_path']).resolve()
+    opath = Path(args.data.output.path)
+    if opath.stem == opath.name:  # potential dir
+        opath = opath / 'output.csv'
+    opath.parent.mkdir(parents=True, exist_ok=True)
+    args.data.output.path = opath
+    if 'shards_path' in kwargs:
+        args.data.path = Path(kwargs['shards_path']).resolve()
+    if 'meta_path' in kwargs:
+        args.data.meta.path = Path(kwargs['meta_path']).resolve()
+    mpath = args.data.meta.path
+    if mpath is None:
+        mpath = Path(args.data.path).parent
+    if not mpath.is_dir() and mpath.parent.is_dir():
+        mpath = mpath.parent
+    args.data.meta.path = mpath
+    return args
+
+
+def run(args):
+    assert args.measure_name != 'contrastive', "the contrastive baseline is outside the hot path (SURVEY 8(f))"
+    return run_single(args) if args.chunk_size is None else run_chunks(args)
+
+
+class Cli:
+    def run(self, **kwargs):
+        start = time.time()
+        out = run(prepare(**kwargs))
+        print('done. total time elasped: {}'.format(datetime.timedelta(seconds=time.time() - start)))
+        return out
+
+    def reduce_csvs(self, **kwargs):
+        start = time.time()
+        out = merge_all_csvs(prepare(**kwargs))
+        print('done. total time elasped: {}'.format(datetime.timedelta(seconds=time.time() - start)))
+        return out
+
+    reduce = reduce_csvs
+
+
+def main(argv=None):
+    command, kwargs = parse_cli(sys.argv[1:] if argv is None else argv)
+    return getattr(Cli(), command)(**kwargs)
+
+
+if __name__ == '__main__':
+    main()

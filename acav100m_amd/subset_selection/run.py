@@ -1,0 +1,106 @@
+"""Selection stage drivers: run_single / run_partition (subset_selection/code/run.py:6-48) and the
+chunked mode (chunk.py:21-53,95-131) -- host orchestration around the GPU measure.
+
+Chunks are independent (no collective anywhere on this path): with several GPUs each process takes a
+contiguous block of ceil(num_chunks / num_gpus) chunks (utils.split_chunks) and writes per-chunk CSVs
+to caches/, merged later by `cli.py reduce_csvs`.
+"""
+import copy
+import math
+import os
+from collections import defaultdict
+from pathlib import Path
+
+from .. import shards as io
+from ..parallel import world
+from .run_greedy import run_greedy
+
+
+def load_data(shard_paths, metas_path, verbose=False):
+    """dataloader.load_data (dataloader.py:152-203): shards grouped into partitions by the clustering
+    run manifests (shards without a log form partition -1), plus the metadata."""
+    if not isinstance(shard_paths, list):
+        shard_paths = io.brace_expand(shard_paths)
+    paths = sorted(Path(p) for p in shard_paths if Path(p).is_file())
+    if not paths:
+        return {}, {}
+    parts = io.load_partitions(paths[0].parent)
+    grouped = defaultdict(list)
+    for p in paths:
+        grouped[parts.get(p.stem, -1)].append(p)
+    if verbose:
+        print("num_shards: {} (clustering_partitions: {})".format(len(paths), {k: len(v) for k, v in grouped.items()}))
+    return dict(grouped), io.load_metas(paths, metas_path)
+
+
+def run_partition(args, shard_paths):
+    assignments, clustering_types, shard_names, filenames = io.load_assignment_shards(shard_paths)
+    return run_greedy(args, assignments, shard_names, filenames, clustering_types, args.subset.size,
+                      args.subset.ratio, measure_name=args.measure_name, cluster_pairing=args.clustering.pairing,
+                      shuffle_candidates=args.shuffle_candidates, verbose=args.verbose)
+
+
+def _run(args, path):
+    partitions, metas = load_data(path, args.data.meta.path, args.verbose)
+    results = []
+    for k in sorted(partitions):
+        print('running partition {}/{}'.format(k, len(partitions)))
+        results.append(run_partition(args, partitions[k]))
+    return results, metas
+
+
+def run_single(args):
+    results, metas = _run(args, args.data.path)
+    counts, out_path = 0, None
+    for samples in results:
+        out_path, count = io.append_output_csv(samples, metas, args.data.output.path)
+        counts += count
+    if out_path is None:
+        print("No files saved")
+    if args.verbose:
+        print("Saved Results: added {} lines to {}".format(counts, out_path))
+    return out_path, counts
+
+
+def run_chunks(args):
+    """chunk.py:21-53 + run_chunks_node :115-131 for THIS process's rank (one process per GPU)."""
+    args.parent_pid = str(args.parent_pid or os.getpid())
+    paths = [p for p in sorted(io.brace_expand(args.data.path)) if Path(p).is_file()]
+    chunks = list(enumerate(io.chunked(paths, int(args.chunk_size))))
+    num_chunks = len(chunks)
+    rank, w = world()
+    gpus = max(1, min(w, num_chunks))
+    chunk_args = copy.deepcopy(args)
+    if isinstance(chunk_args.subset.size, int):
+        chunk_args.subset.size = math.ceil(chunk_args.subset.size / num_chunks)
+    per = math.ceil(num_chunks / gpus)
+    mine = chunks[rank * per:(rank + 1) * per] if rank < gpus else []
+    print("running {} chunks in {} gpus".format(num_chunks, gpus))
+    chunk_args.node_rank = rank
+    written = []
+    for i, (num, chunk) in enumerate(mine):
+        print("running chunk {}".format(num))
+        results, metas = _run(chunk_args, chunk)
+        res = results[0] if results else []  # a chunk is assumed to be a single partition (chunk.py:152)
+        name = "cache_{}_{}_{}".format(chunk_args.parent_pid, rank, i)
+        cache_out = Path(args.data.output.path).parent / 'caches' / Path(args.data.output.path).name
+        out_path, _ = io.append_output_csv(res, metas, cache_out, name + '_')
+        written.append(out_path)
+    return written
+
+
+def merge_all_csvs(args):
+    """save.merge_all_csvs (save.py:106-121): caches/cache_{pid}_{rank}_{i}_{name} -> output.csv"""
+    cache_dir = Path(args.data.output.path).parent / 'caches'
+    name = Path(args.data.output.path).name
+    groups = defaultdict(list)
+    for p in cache_dir.glob('cache_*_*_{}'.format(name)):
+        groups['_'.join(p.stem.split('_')[:2])].append(p)
+    total = 0
+    for key in sorted(groups):
+        print('processing cache set {}'.format(key))
+        counts = io.merge_csvs(sorted(groups[key]), args.data.output.path)
+        total += counts
+        if args.verbose:
+            print("Saved Results: added {} lines to {}".format(counts, args.data.output.path))
+    return total

@@ -7,13 +7,15 @@ this script and the tiny stand-in modules under _stubs/ for the reference's un-v
 imports (torch_scatter, diffdist, wget, braceexpand).
 
     python tests/golden/gen_golden.py            # all three groups
-    python tests/golden/gen_golden.py kmeans|mi|rng
+    python tests/golden/gen_golden.py kmeans|mi|rng|cli
 
 Groups:
   rng.npz     torch.manual_seed/rand/randperm and random.shuffle streams (G6)
   kmeans_*.npz   KMeans state after every epoch, warm-up labels, per-step means, labels (G1/G2)
   mi_*.npz    per-iteration trace of EfficientBatchMI greedy: batch ids, fp32 scores [B,P],
               picked positions / ids; final S and GAIN (G3)
+  cli_clustering.npz / cli_output.csv   the reference's two CLIs end to end on synthetic shards
+              regenerated from a seed by tests/golden/synth.py (G5)
 The two reference stages have clashing top-level module names, so each group runs in its own
 interpreter.
 """
@@ -199,10 +201,80 @@ def gen_mi():
         print(f"mi_{name}.npz written: {len(S)} selected in {len(rec['ids'])} iterations")
 
 
+# ----------------------------------------------------------------------------- cli
+def gen_cli_clustering(root):
+    """reference `cli.py cluster` on 4 synthetic shards (real 5+5 layer dims, K=32, 2 epochs)"""
+    sys.path.insert(0, STUBS)
+    sys.path.insert(1, os.path.join(REF, "clustering", "code"))
+    import pickle
+    import torch
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(2, HERE)
+    import synth
+    glob = synth.write_feature_shards(root, n_shards=4, rows=256, seed=0)
+    from cli import Cli  # noqa: E402  (the reference)
+    torch.manual_seed(0)
+    Cli().cluster(feature_path=glob, out_path=os.path.join(root, "clusters"), meta_path=os.path.join(root, "videos"),
+                  **{"computation.device": "cpu", "computation.num_gpus": 1, "computation.num_workers": 0})
+    out = {}
+    for s in range(4):
+        name = "shard-%06d" % s
+        rows = pickle.load(open(os.path.join(root, "clusters", name + ".pkl"), "rb"))
+        lab = []
+        for r in rows:
+            a = r["audio_assignments"][0]["array"]
+            v = r["video_assignments"][0]["array"]
+            lab.append([int(a["layer_%d" % i]) for i in range(5)] + [int(v["layer_%d" % i]) for i in range(5)])
+        out[name] = np.array(lab, np.int64)
+        out[name + "_files"] = np.array([r["filename"] for r in rows])
+    r0 = rows[0]
+    out["row_keys"] = np.array(sorted(r0.keys()))
+    out["audio_entry_keys"] = np.array(sorted(r0["audio_assignments"][0].keys()))
+    out["audio_model_key"] = r0["audio_assignments"][0]["model_key"]
+    out["video_model_key"] = r0["video_assignments"][0]["model_key"]
+    out["label_type"] = type(r0["audio_assignments"][0]["array"]["layer_0"]).__name__
+    logs = [f for f in os.listdir(os.path.join(root, "clusters")) if f.startswith("log_")]
+    import json
+    out["log_keys"] = np.array(sorted(json.load(open(os.path.join(root, "clusters", logs[0]))).keys()))
+    out["out_files"] = np.array(sorted(os.listdir(os.path.join(root, "clusters"))))
+    np.savez_compressed(os.path.join(HERE, "cli_clustering.npz"), **out)
+    print("cli_clustering.npz written:", sorted(os.listdir(os.path.join(root, "clusters"))))
+
+
+def gen_cli_subset(root):
+    """reference `cli.py run` on the assignment shards the reference clustering CLI just wrote"""
+    sys.path.insert(0, STUBS)
+    sys.path.insert(1, os.path.join(REF, "subset_selection", "code"))
+    import torch
+    from cli import Cli  # noqa: E402  (the reference)
+    random.seed(0)
+    torch.manual_seed(0)
+    out_csv = os.path.join(root, "output.csv")
+    Cli().run(shards_path=os.path.join(root, "clusters", "shard-{000000..000003}.pkl"),
+              meta_path=os.path.join(root, "videos"), out_path=out_csv, **{"computation.num_workers": 1})
+    text = open(out_csv).read()
+    with open(os.path.join(HERE, "cli_output.csv"), "w") as f:
+        f.write(text)
+    print("cli_output.csv written:", len(text.splitlines()), "lines; first:", text.splitlines()[0])
+
+
+def gen_cli():
+    import tempfile
+    root = tempfile.mkdtemp(prefix="acav_golden_")
+    subprocess.check_call([sys.executable, os.path.abspath(__file__), "cli_clustering", root])
+    subprocess.check_call([sys.executable, os.path.abspath(__file__), "cli_subset", root])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "kmeans", "mi"]
+    if sys.argv[1:2] == ["cli_clustering"]:
+        gen_cli_clustering(sys.argv[2])
+        sys.exit(0)
+    if sys.argv[1:2] == ["cli_subset"]:
+        gen_cli_subset(sys.argv[2])
+        sys.exit(0)
+    which = sys.argv[1:] or ["rng", "kmeans", "mi", "cli"]
     if len(which) > 1:
         for w in which:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
-        {"rng": gen_rng, "kmeans": gen_kmeans, "mi": gen_mi}[which[0]]()
+        {"rng": gen_rng, "kmeans": gen_kmeans, "mi": gen_mi, "cli": gen_cli}[which[0]]()

@@ -1,0 +1,81 @@
+"""world_size-2 tests (gloo, CPU) of the multi-GPU host logic: the per-step all-gather of rows+labels,
+the identical global update on every rank, initialize()'s averaging, and the shard striding.
+The compute engine is the oracle stand-in (no GPU here); on the GPU box the same plumbing drives the
+HIP KMeans over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Engine:
+    """host stand-in with the engine surface of acav100m_amd KMeans (calc_best / apply_update)"""
+
+    def __init__(self, O, d, k, centers, counts, count):
+        self.km = O.KMeans(d, k, O.Rng(0), centers=centers)
+        self.km.set_state(None, counts, count)
+
+    def calc_best(self, batch):
+        best, mean = self.km.calc_best(np.asarray(batch))
+        return torch.from_numpy(best), mean
+
+    def apply_update(self, x, best, lr):
+        self.km.apply_update(x.numpy(), best.numpy(), lr)
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import oracle as O
+        from acav100m_amd.parallel import average_state, distributed_add, shard_slice, world as wfn
+        assert wfn() == (rank, world)
+        d, k, b_local, steps = 48, 12, 16, 12
+        rs = np.random.RandomState(0)
+        cen = rs.randn(k, d).astype(np.float32)
+        x = (cen[rs.randint(0, k, steps * world * b_local)] + 0.3 * rs.randn(steps * world * b_local, d)).astype(np.float32)
+        # initialize(): ranks start from different centres, end with the average
+        c0 = torch.from_numpy((cen + rank).astype(np.float32))
+        n0 = torch.full((k,), float(rank))
+        c_avg, n_avg = average_state(c0, n0)
+        assert torch.allclose(c_avg, torch.from_numpy(cen) + 0.5) and torch.allclose(n_avg, torch.full((k,), 0.5))
+        counts = np.full(k, 40, np.float32)
+        eng = _Engine(O, d, k, cen, counts, 10 * k + 100)
+        for t in range(steps):
+            gb = x[t * world * b_local:(t + 1) * world * b_local]          # global batch, rank-major
+            distributed_add(eng, torch.from_numpy(gb[rank * b_local:(rank + 1) * b_local]), 0.01)
+        c, cnt, count, fb = eng.km.get_state()
+        np.savez(os.path.join(tmp, f"rank{rank}.npz"), c=c, cnt=cnt, count=count)
+        if rank == 0:  # single-process reference on the concatenated batches
+            ref = _Engine(O, d, k, cen, counts, 10 * k + 100)
+            for t in range(steps):
+                ref.km.add(x[t * world * b_local:(t + 1) * world * b_local])
+            rc, rcnt, rcount, _ = ref.km.get_state()
+            np.savez(os.path.join(tmp, "single.npz"), c=rc, cnt=rcnt, count=rcount)
+        assert list(shard_slice(7)) == list(range(rank, 7, world))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_add_two_ranks(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1, s = (np.load(tmp_path / f) for f in ("rank0.npz", "rank1.npz", "single.npz"))
+    assert np.array_equal(r0["c"], r1["c"]) and np.array_equal(r0["cnt"], r1["cnt"])      # ranks identical
+    assert np.array_equal(r0["c"], s["c"]) and np.array_equal(r0["cnt"], s["cnt"])        # == single process
+    assert int(r0["count"]) == int(s["count"])

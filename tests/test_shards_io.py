@@ -1,0 +1,78 @@
+"""CPU tests of the shard / csv / config layer (the reference's file contract)."""
+import os
+import pickle
+import sys
+
+import numpy as np
+
+from acav100m_amd import shards as io
+from acav100m_amd.config import CLUSTERING_DEFAULTS, SUBSET_DEFAULTS, merge, parse_cli
+
+
+def test_brace_expand_and_cli_parsing():
+    assert io.brace_expand("d/shard-{000008..000011}.pkl") == ["d/shard-%06d.pkl" % i for i in range(8, 12)]
+    assert io.brace_expand("x{a,b}.pkl") == ["xa.pkl", "xb.pkl"] and io.brace_expand("plain") == ["plain"]
+    assert io.to_brace(["a", "b"]) == "{a,b}" and io.to_brace(["a"]) == "a"
+    cmd, kw = parse_cli(["cluster", "--feature_path=/x/s-{0..1}.pkl", "--clustering.ncentroids=64", "--debug",
+                         "--subset.ratio", "0.3"])
+    assert cmd == "cluster" and kw == {"feature_path": "/x/s-{0..1}.pkl", "clustering.ncentroids": 64,
+                                       "debug": True, "subset.ratio": 0.3}
+    a = merge(CLUSTERING_DEFAULTS, {"clustering.ncentroids": 64, "data.output.path": "rel/out", "brand.new": 1})
+    assert a.clustering.ncentroids == 64 and a.clustering.epochs == 2 and a.brand.new == 1
+    assert a.data.output.path.is_absolute() and a.no_such_key is None and a.data.batch_size == 32
+    s = merge(SUBSET_DEFAULTS, {})
+    assert (s.batch.batch_size, s.batch.selection_size, s.batch.keep_unselected) == (20, 4, True)
+    assert s.subset.ratio == 0.2 and s.measure_name == "batch_mi" and s.clustering.pairing == "combination"
+
+
+def test_feature_table_and_assignment_schema(tmp_path, golden_dir):
+    sys.path.insert(0, golden_dir)
+    import synth
+    glob = synth.write_feature_shards(str(tmp_path), n_shards=2, rows=8, seed=1, audio_dims=[4, 6], video_dims=[5])
+    paths = io.brace_expand(glob)
+    table = io.load_feature_shards(paths, model_order=["layer_vggish", "layer_slow_fast"],
+                                   audio_models=("vggish", "layer_vggish"))
+    assert len(table) == 16 and list(table.shard_rows) == ["shard-000000", "shard-000001"]
+    # KMeans construction order of the reference: args.models order, then layer index
+    assert list(table.views) == [("audio", "layer_vggish", "layer_0"), ("audio", "layer_vggish", "layer_1"),
+                                 ("video", "layer_slow_fast", "layer_0")]
+    assert [m.shape for m in table.views.values()] == [(16, 4), (16, 6), (16, 5)]
+    raw = pickle.load(open(paths[1], "rb"))
+    assert np.array_equal(table.views[("audio", "layer_vggish", "layer_1")][8], raw[0]["audio_features"][0]["array"]["layer_1"])
+    labels = {v: np.arange(16, dtype=np.int64) * (i + 1) for i, v in enumerate(table.views)}
+    rows = io.assignment_rows(table, labels, table.shard_rows["shard-000001"])
+    r = rows[3]
+    assert set(r) == {"video_assignments", "audio_assignments", "filename", "shard_size", "shard_name"}
+    assert r["audio_assignments"][0]["array"] == {"layer_0": 11, "layer_1": 22}
+    assert isinstance(r["audio_assignments"][0]["array"]["layer_0"], np.int64)
+    assert r["video_assignments"][0]["extractor_name"] == "SLOWFAST_8x8_R50" and r["shard_name"] == "shard-000001"
+    out = tmp_path / "clusters" / "shard-000001.pkl"
+    io.dump_pickle(rows, out)
+    mat, types, shard_names, filenames = io.load_assignment_shards([out])
+    assert types == [("layer_slow_fast", "layer_0"), ("layer_vggish", "layer_0"), ("layer_vggish", "layer_1")]
+    assert np.array_equal(mat[:, 1], np.arange(8, 16)) and mat.dtype == np.int64 and filenames[0] == rows[0]["filename"]
+    # corrupt shard: reported and skipped like the reference
+    open(tmp_path / "features" / "shard-000002.pkl", "wb").close()
+    t2 = io.load_feature_shards(paths + [str(tmp_path / "features" / "shard-000002.pkl")])
+    assert len(t2) == 16
+    assert io.shard_sizes_from_meta(paths, tmp_path / "videos") == {"shard-000000": 8, "shard-000001": 8}
+
+
+def test_partitions_metas_and_output_csv(tmp_path, golden_dir):
+    d = tmp_path / "clusters"
+    io.dump_json({"hostname": "h", "pid": 1, "timestamp": 100, "time": "t", "shards": ["s0", "s1"]}, d / "log_h_1_100.json")
+    io.dump_json({"hostname": "h", "pid": 2, "timestamp": 200, "time": "t", "shards": ["s1", "s2"]}, d / "log_h_2_200.json")
+    assert io.load_partitions(d) == {"s0": 0, "s1": 1, "s2": 1}  # newer manifest wins
+    io.dump_json([{"filename": "v1_010.mp4", "id": "v1", "segment": [10, 20]}], tmp_path / "m" / "s0.json")
+    metas = io.load_metas([d / "s0.pkl", d / "s9.pkl"], tmp_path / "m")
+    assert list(metas) == ["s0"] and metas["s0"]["v1_010"]["id"] == "v1"
+    out = tmp_path / "o" / "output.csv"
+    data = [{"filename": "v1_010.mp4", "shard_name": "s0"}, {"filename": "zz.mp4", "shard_name": "s7"}]
+    p, n = io.append_output_csv(data, metas, out)
+    p, n2 = io.append_output_csv(data[:1], metas, out)  # append mode ('a+')
+    lines = open(p).read().splitlines()
+    assert (n, n2) == (2, 1) and lines == ['s0,v1_010.mp4,v1,"[10, 20]"', 'zz,zz.mp4,-1,"[-1.0, -1.0]"'.replace("zz,", "s7,", 1),
+                                           's0,v1_010.mp4,v1,"[10, 20]"']
+    ref_first = open(os.path.join(golden_dir, "cli_output.csv")).readline().strip()
+    assert ref_first == 'shard-000000,vid000000000_010.mp4,vid000000000,"[10, 20]"'  # the reference's own line format
+    assert [list(b) for b in io.chunked(list(range(5)), 2)] == [[0, 1], [2, 3], [4]]
