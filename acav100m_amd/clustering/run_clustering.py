@@ -103,6 +103,14 @@ def train_clusters(args, table, resident):
         lr = 0.1 ** (2 + epoch // 5)
         for km in cl.values():
             km.lr = lr
+        # `for batch in dataloader` (run_clustering.py:235) creates a DataLoader iterator, which draws its
+        # 64-bit base seed from the global CPU generator (torch/utils/data/dataloader.py,
+        # _BaseDataLoaderIter.__init__: torch.empty((), dtype=int64).random_()) = two mt19937 words per
+        # epoch, between the centre initialisation and the first warm-up draw.  Consumed here so that a
+        # seeded run reproduces the reference CLI's files bit for bit (tests/test_gpu_cli.py).
+        gen = next(iter(cl.values()))._generator
+        gen.u32()
+        gen.u32()
         if w > 1:
             _train_epoch_distributed(cl, resident, b, steps, rank, w)
         else:
