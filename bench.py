@@ -174,6 +174,13 @@ def main():
         flops_per_launch = 2.0 * n * k * d
         gbs = bytes_per_launch / (a_ms * 1e-3) / 1e9
         tfs = flops_per_launch / (a_ms * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+            if name.endswith("_pmc_assign.json"):  # summary of the separate rocprofv3 --pmc passes of this command
+                pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if (pm.get("rows"), pm.get("d"), pm.get("K")) == (n, d, k):
+                    traffic, traffic_src = pm["traffic_bytes_per_launch"], "profiles/" + name
+                    break
         out = {
             "metric": "clips/sec curated (k-means update epoch at b=32 + assign sweep)",
             "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -183,7 +190,7 @@ def main():
                                    f"(1 training epoch at b={b} = {n // b} SGD steps + 1 assign sweep per step)",
                        "global_batch": b * world, "rows_per_gpu": n},
             "roofline": {"kernel": "k_assign_f32", "bound": "mfma", "achieved": tfs, "peak": MFMA_F32_PEAK_TF,
-                         "unit": "TFLOP/s", "frac": tfs / MFMA_F32_PEAK_TF, "traffic": None,
+                         "unit": "TFLOP/s", "frac": tfs / MFMA_F32_PEAK_TF, "traffic": traffic, "traffic_source": traffic_src,
                          "hbm_achieved_GBs": gbs, "hbm_peak_GBs": HBM_PEAK_GBS, "hbm_frac": gbs / HBM_PEAK_GBS,
                          "launch_ms": a_ms, "algorithmic_bytes": bytes_per_launch,
                          "algorithmic_flops": flops_per_launch},
