@@ -22,6 +22,9 @@ def _as_f32_2d(batch):
         t = batch.detach()
         if t.dtype != torch.float32 or not t.is_contiguous():
             t = t.to(torch.float32).contiguous()
+        if t.is_cuda:
+            # the library runs on its own stream: whatever torch still has queued for this tensor must land first
+            torch.cuda.current_stream(t.device).synchronize()
         return t, C.c_void_p(t.data_ptr()), t.shape[0], t.is_cuda
     a = np.ascontiguousarray(batch, dtype=np.float32)
     return a, a.ctypes.data_as(C.c_void_p), a.shape[0], False

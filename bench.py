@@ -117,6 +117,7 @@ def main():
 
     n, d, k, b = args.n, args.d, args.k, args.batch
     x = synth_features(torch, n, d, k, 1234 + rank, dev)
+    torch.cuda.synchronize()
     acav100m_amd.manual_seed(0)
 
     class _A:  # the reference's args.computation view
