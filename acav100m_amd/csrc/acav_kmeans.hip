@@ -100,6 +100,11 @@ __device__ __forceinline__ void stage_row4(float *srow, int q, float4 v)
     *reinterpret_cast<float2 *>(srow + base + 4) = make_float2(v.y, v.w);  // odd columns  (h = 1)
 }
 
+// GUARD = false: d % 32 == 0 and 16-byte aligned rows -> unconditional float4 loads with CLAMPED row /
+// centre indices (rows >= n and centres >= K compute on a duplicate and are discarded), so the
+// compiler keeps all 10 prefetch loads in flight under the MFMAs.  GUARD = true: element-guarded loads
+// for ragged d (hipcc serialises those behind vmcnt(0) -- correctness path only).
+template <bool GUARD>
 __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__ x, int64_t n, int d,
                                                        const float *__restrict__ centers,
                                                        const float *__restrict__ cn,
@@ -111,6 +116,8 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
     __shared__ __attribute__((aligned(16))) float sC[AS_CG * AS_LD];
     __shared__ __attribute__((aligned(16))) float sX[AS_ROWS * AS_LD];
     __shared__ float sXn[AS_ROWS];
+    __shared__ float sCn[AS_CG];    // ||c||^2 of the current centre group
+    __shared__ int sDisc[AS_CG];    // 1 = under-used centre (distance / r), -1 = centre index >= K
     __shared__ float sMinV[4][AS_ROWS];
     __shared__ int sMinI[4][AS_ROWS];
 
@@ -142,18 +149,29 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+        {   // epilogue operands of this centre group: one element per thread, read back from LDS later
+            const int k = kbase + tid;
+            sCn[tid] = k < K ? cn[k] : 0.f;
+            sDisc[tid] = k < K ? (counts[k] < thr ? 1 : 0) : -1;
+        }
         float4 xr[2], cr[8];
         auto issue_loads = [&](int c) {
             const int j = c * AS_BK + sq * 4;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int64_t gr = row0 + srow + 32 * m;
-                xr[m] = ld4_guard(x + (size_t)gr * d, j, d, gr < n, vec_ok);
+                if (GUARD)
+                    xr[m] = ld4_guard(x + (size_t)gr * d, j, d, gr < n, vec_ok);
+                else
+                    xr[m] = *reinterpret_cast<const float4 *>(x + (size_t)(gr < n ? gr : n - 1) * d + j);
             }
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const int k = kbase + srow + 32 * m;
-                cr[m] = ld4_guard(centers + (size_t)k * d, j, d, k < K, vec_ok);
+                if (GUARD)
+                    cr[m] = ld4_guard(centers + (size_t)k * d, j, d, k < K, vec_ok);
+                else
+                    cr[m] = *reinterpret_cast<const float4 *>(centers + (size_t)(k < K ? k : K - 1) * d + j);
             }
         };
         issue_loads(0);
@@ -220,10 +238,11 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
             for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int k = kbase + (2 * wave + ct) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (k < K) {
-                        const float t = dist_epilogue(acc[ct][rt][e], xn, cn[k], counts[k] < thr, r);
-                        lexmin(bv, bi, t, k);
+                    const int kl = (2 * wave + ct) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int disc = sDisc[kl];
+                    if (disc >= 0) {
+                        const float t = dist_epilogue(acc[ct][rt][e], xn, sCn[kl], disc != 0, r);
+                        lexmin(bv, bi, t, kbase + kl);
                     }
                 }
             }
@@ -762,9 +781,15 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
     const int64_t grid = (n + AS_ROWS - 1) / AS_ROWS;
     ACAV_REQUIRE(grid <= 0x7fffffff, ACAV_EINVAL, "n too large for one launch");
     ACAV_TRY(km->wg_sum.ensure(sizeof(double) * (size_t)grid));
-    hipLaunchKernelGGL(k_assign_f32, dim3((unsigned)grid), dim3(256), 0, st, static_cast<const float *>(dx), n,
-                       km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
-                       km->threshold(), (float)km->reinit_r, dlab, (float *)nullptr, km->wg_sum.as<double>());
+    const bool fast = (km->d % AS_BK) == 0 && ((uintptr_t)dx & 15) == 0;
+    if (fast)
+        hipLaunchKernelGGL(k_assign_f32<false>, dim3((unsigned)grid), dim3(256), 0, st, static_cast<const float *>(dx), n,
+                           km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
+                           km->threshold(), (float)km->reinit_r, dlab, (float *)nullptr, km->wg_sum.as<double>());
+    else
+        hipLaunchKernelGGL(k_assign_f32<true>, dim3((unsigned)grid), dim3(256), 0, st, static_cast<const float *>(dx), n,
+                           km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
+                           km->threshold(), (float)km->reinit_r, dlab, (float *)nullptr, km->wg_sum.as<double>());
     ACAV_HIP_TRY(hipGetLastError());
     km->n_assign_launches += 1;
     if (!lab_dev) ACAV_HIP_TRY(hipMemcpyAsync(labels, dlab, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, st));
