@@ -11,10 +11,12 @@
 //                    in-order segmented centroid update, ||c||^2 refresh
 //
 // Bit-exactness contract with oracle/acav_oracle.c ("canonical arithmetic" in its header):
-//   dot = one sequential fp32 FMA chain over j (what the f32 MFMA computes, k-ordered);
+//   dot = 256-column segments, each one sequential fp32 FMA chain (what the f32 MFMA computes,
+//         k-ordered), segment sums folded left to right;
 //   sumsq = 32 interleaved FMA chains (class = j mod 32) + fixed butterfly tree;
 //   every other op is a single correctly-rounded fp32 op, compiled with -ffp-contract=off.
 #include <cmath>
+#include <cstdlib>
 
 #include "acav_common.h"
 
@@ -141,13 +143,16 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
 
     for (int cg = 0; cg < ngroups; ++cg) {
         const int kbase = cg * AS_CG;
-        f32x16 acc[2][2];
+        f32x16 acc[2][2], tot[2][2];  // acc: the running 256-column segment chain; tot: folded segments
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+                for (int e = 0; e < 16; ++e) {
+                    acc[a][b][e] = 0.f;
+                    tot[a][b][e] = 0.f;
+                }
 
         {   // epilogue operands of this centre group: one element per thread, read back from LDS later
             const int k = kbase + tid;
@@ -213,6 +218,18 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv1[m], acc[1][1], 0, 0, 0);
                 }
             }
+            if ((c & 7) == 7 || c + 1 == nchunks) {  // end of a 256-column segment: tot = (first) ? acc : tot + acc
+                const bool first = c < 8;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            tot[a][b][e] = first ? acc[a][b][e] : tot[a][b][e] + acc[a][b][e];
+                            acc[a][b][e] = 0.f;
+                        }
+            }
         }
 
         if (cg == 0) {
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
                     const int kl = (2 * wave + ct) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     const int disc = sDisc[kl];
                     if (disc >= 0) {
-                        const float t = dist_epilogue(acc[ct][rt][e], xn, sCn[kl], disc != 0, r);
+                        const float t = dist_epilogue(tot[ct][rt][e], xn, sCn[kl], disc != 0, r);
                         lexmin(bv, bi, t, kbase + kl);
                     }
                 }
@@ -297,6 +314,65 @@ __device__ __forceinline__ float key_value(unsigned long long key)
     unsigned u = (unsigned)(key >> 32);
     u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
     return __uint_as_float(u);
+}
+
+// Canonical dot over NB resident 256-column blocks (one segment each) of two swizzled LDS rows: NB
+// independent FMA chains per lane, interleaved so the VALU is issue-bound instead of latency-bound;
+// ds_read_b128 pairs software-pipelined two chunks ahead.  Returns fold(tot_in, seg_0, .., seg_NB-1).
+template <int NB>
+__device__ __forceinline__ float dot_blocks(const float *pc, const float *px, int scz, int sxz, float tot, bool first)
+{
+    // chunk tt (4 columns) of a row sits at float offset ((tt ^ s) << 2), s = row & 7: the XOR only touches
+    // the low 3 bits of tt, so 8 per-lane base pointers + compile-time offsets address every chunk
+    const float *pcu[8], *pxu[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        pcu[u] = pc + ((u << 2) ^ scz);
+        pxu[u] = px + ((u << 2) ^ sxz);
+    }
+    float acc[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) acc[q] = 0.f;
+    float4 cA[NB][2], xA[NB][2], cB[NB][2], xB[NB][2];
+#define ACAV_LD_GROUP(Cq, Xq, g)                                                                              \
+    _Pragma("unroll") for (int q = 0; q < NB; ++q) _Pragma("unroll") for (int u = 0; u < 2; ++u) {            \
+        Cq[q][u] = *reinterpret_cast<const float4 *>(pcu[((g) * 2 + u) & 7] + q * 256 + ((((g) * 2 + u) >> 3) << 5)); \
+        Xq[q][u] = *reinterpret_cast<const float4 *>(pxu[((g) * 2 + u) & 7] + q * 256 + ((((g) * 2 + u) >> 3) << 5)); \
+    }
+#define ACAV_FMA_GROUP(Cq, Xq)                                                                                \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                           \
+        _Pragma("unroll") for (int q = 0; q < NB; ++q) acc[q] = __builtin_fmaf(Cq[q][u].x, Xq[q][u].x, acc[q]); \
+        _Pragma("unroll") for (int q = 0; q < NB; ++q) acc[q] = __builtin_fmaf(Cq[q][u].y, Xq[q][u].y, acc[q]); \
+        _Pragma("unroll") for (int q = 0; q < NB; ++q) acc[q] = __builtin_fmaf(Cq[q][u].z, Xq[q][u].z, acc[q]); \
+        _Pragma("unroll") for (int q = 0; q < NB; ++q) acc[q] = __builtin_fmaf(Cq[q][u].w, Xq[q][u].w, acc[q]); \
+    }
+    ACAV_LD_GROUP(cA, xA, 0)
+#pragma unroll
+    for (int g = 0; g < 32; g += 2) {
+        ACAV_LD_GROUP(cB, xB, g + 1)
+        ACAV_FMA_GROUP(cA, xA)
+        if (g + 2 < 32) { ACAV_LD_GROUP(cA, xA, g + 2) }
+        ACAV_FMA_GROUP(cB, xB)
+    }
+#undef ACAV_LD_GROUP
+#undef ACAV_FMA_GROUP
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        tot = first ? acc[q] : tot + acc[q];
+        first = false;
+    }
+    return tot;
+}
+
+__device__ __forceinline__ float dot_blocks_n(int nblk, const float *pc, const float *px, int scz, int sxz, float tot,
+                                              bool first)
+{
+    switch (nblk) {
+        case 1: return dot_blocks<1>(pc, px, scz, sxz, tot, first);
+        case 2: return dot_blocks<2>(pc, px, scz, sxz, tot, first);
+        case 3: return dot_blocks<3>(pc, px, scz, sxz, tot, first);
+        default: return dot_blocks<4>(pc, px, scz, sxz, tot, first);
+    }
 }
 
 // k_step_dist_dma: grid (ceil(K/8), ceil(b/8)), ONE wave per workgroup.  Lane l: centre l>>3, row l&7.
@@ -356,43 +432,8 @@ __global__ __launch_bounds__(64) void k_step_dist_dma(const float *__restrict__ 
                 }
             }
         }
-        const float *pc = sT + kk * SD_DS;
-        const float *px = sT + (SD_NC + ii) * SD_DS;
-        const int sc = kk << 2, sx = ii << 2;
-        for (int blk = 0; blk < nblk; ++blk) {
-            // 16 DMA instructions per block were issued in block order: wait until block `blk` landed
-            const int later = ragged ? 0 : (nblk - 1 - blk);
-            if (later == 3) ACAV_WAIT_VMCNT(48);
-            else if (later == 2) ACAV_WAIT_VMCNT(32);
-            else if (later == 1) ACAV_WAIT_VMCNT(16);
-            else ACAV_WAIT_VMCNT(0);
-            // 64 chunks of 4 columns, software-pipelined in groups of 8: the ds_read_b128 of group g+1
-            // are in flight while the dependent FMA chain consumes group g
-            const float *pcb = pc + blk * 256, *pxb = px + blk * 256;
-            float4 cA[8], xA[8], cB[8], xB[8];
-#define ACAV_LD_GROUP(C, X, g)                                                                 \
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                             \
-        C[u] = *reinterpret_cast<const float4 *>(pcb + ((((g) * 8 + u) << 2) ^ sc));            \
-        X[u] = *reinterpret_cast<const float4 *>(pxb + ((((g) * 8 + u) << 2) ^ sx));            \
-    }
-#define ACAV_FMA_GROUP(C, X)                                  \
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) {            \
-        acc = __builtin_fmaf(C[u].x, X[u].x, acc);             \
-        acc = __builtin_fmaf(C[u].y, X[u].y, acc);             \
-        acc = __builtin_fmaf(C[u].z, X[u].z, acc);             \
-        acc = __builtin_fmaf(C[u].w, X[u].w, acc);             \
-    }
-            ACAV_LD_GROUP(cA, xA, 0)
-#pragma unroll
-            for (int g = 0; g < 8; g += 2) {
-                ACAV_LD_GROUP(cB, xB, g + 1)
-                ACAV_FMA_GROUP(cA, xA)
-                if (g + 2 < 8) { ACAV_LD_GROUP(cA, xA, g + 2) }
-                ACAV_FMA_GROUP(cB, xB)
-            }
-#undef ACAV_LD_GROUP
-#undef ACAV_FMA_GROUP
-        }
+        ACAV_WAIT_VMCNT(0);  // the whole stage has landed (the wave only reads what its own DMA wrote)
+        acc = dot_blocks_n(nblk, sT + kk * SD_DS, sT + (SD_NC + ii) * SD_DS, kk << 2, ii << 2, acc, j0 == 0);
         // the next stage overwrites sT: all ds_reads above have returned (acc depends on them)
     }
     const int k = kbase + kk, row = rbase + ii;
@@ -432,7 +473,7 @@ __global__ __launch_bounds__(256) void k_step_dist_mfma(const float *__restrict_
     const int srow = tid >> 3, sq = tid & 7;  // row 0..31; float4 #sq and #sq+8 of the 64-column stage
     const int nchunks = (d + SD_BK - 1) / SD_BK;
 
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, tot = {0.f, 0.f, 0.f, 0.f};
     float4 xr[2], cr[2];
     auto issue_loads = [&](int c) {
 #pragma unroll
@@ -461,6 +502,13 @@ __global__ __launch_bounds__(256) void k_step_dist_mfma(const float *__restrict_
 #pragma unroll
         for (int t = 0; t < SD_BK / 4; ++t)
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * t], pb[4 * t], acc, 0, 0, 0);
+        if ((c & 3) == 3 || c + 1 == nchunks) {  // end of a 256-column segment
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                tot[e] = c < 4 ? acc[e] : tot[e] + acc[e];
+                acc[e] = 0.f;
+            }
+        }
     }
     // D[i][j]: column j = lane&15 (row of x), row i = 4*(lane>>4) + reg (centre)
     const int row = rbase + rw * 16 + l15;
@@ -471,7 +519,7 @@ __global__ __launch_bounds__(256) void k_step_dist_mfma(const float *__restrict_
         for (int e = 0; e < 4; ++e) {
             const int k = kbase + cw * 16 + 4 * g + e;
             if (k < K) {
-                const unsigned long long kc = pack_key(dist_epilogue(acc[e], xnv, cn[k], counts[k] < thr, r), k);
+                const unsigned long long kc = pack_key(dist_epilogue(tot[e], xnv, cn[k], counts[k] < thr, r), k);
                 key = kc < key ? kc : key;
             }
         }
@@ -612,6 +660,296 @@ __global__ __launch_bounds__(256) void k_step_update(const float *__restrict__ x
     }
 }
 
+// --------------------------------------------------------------------- k_train_persistent
+// Many consecutive add() steps in ONE launch ("owner computes"): workgroup (cg, rg) = one wave that
+// OWNS centres [8cg, 8cg+8) -- resident in LDS for the whole launch, replicated over the row groups --
+// and labels batch rows [8rg, 8rg+8) of every step.  Per step:
+//   1. the step's 8 rows are already in LDS (prefetched by LDS-DMA during the previous step);
+//      issue the DMA of the next step's rows into the other buffer
+//   2. one dependent FMA chain per lane (centre l>>3, row l&7), canonical column order
+//   3. fold (distance, centre) into the step's 64-bit key per row with a device-scope atomicMin, drain
+//      (s_waitcnt vmcnt(0)), arrive on a monotonic device-scope counter, spin (bounded) until all
+//      workgroups arrived, read the 32 final keys with device-scope atomic loads
+//   4. every replica applies the identical in-order update to the centres it owns (rows fetched from
+//      global: read-only data), refreshes ||c||^2 and its usage counts, all in LDS
+// No plain-store data crosses workgroups inside the launch: keys and the counter are device-scope
+// atomics, x is read-only, so no L2 write-back / L1 invalidate is needed (MI355X_MICROARCH.md,
+// inter-workgroup visibility).  All workgroups must be co-resident: the host only takes this path
+// when the grid is well below the CU count, and every spin is bounded (err flag instead of a hang).
+constexpr int TP_NC = 8;
+constexpr int TP_NR = 8;
+constexpr int TP_DS = 1024;
+constexpr int TP_MAXB = 32;
+constexpr unsigned TP_SPIN_LIMIT = 1u << 24;
+
+constexpr int TP_RING = 4;
+struct TrainCtl {
+    unsigned err;          // 1 = a bounded spin gave up
+    unsigned pad[3];
+    unsigned long long prof[8];  // shader-clock cycles per phase, summed over the steps of workgroup (1,0)
+    unsigned long long prof_wg[256][8];  // the same per workgroup (ACAV_PROFILE_STEPS diagnostics)
+    // granules[ring][centre group][batch row]: {tag:16 | local centre:16 | orderable distance:32}, each
+    // written by exactly one workgroup per synced step with ONE 8-byte device-scope store
+    unsigned long long gran[TP_RING][(SU_MAXK / TP_NC)][TP_MAXB];
+};
+
+__device__ __forceinline__ int tp_off(int row, int j)
+{
+    return row * TP_DS + (j & ~255) + (((((j >> 2) & 63) ^ (row & 7))) << 2) + (j & 3);
+}
+
+// DMA of column block `blk` of 8 rows (clamped duplicates for ragged groups are never used)
+__device__ __forceinline__ void tp_dma_block(float *lds, const float *__restrict__ src, int first_row, int nrows_valid,
+                                             int d, int blk, int lane)
+{
+#pragma unroll
+    for (int row = 0; row < 8; ++row) {
+        const int grow = first_row + (row < nrows_valid ? row : 0);
+        const float *g = src + (size_t)grow * d + blk * 256 + ((lane ^ (row & 7)) << 2);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)(lds + row * TP_DS + blk * 256), 16, 0, 0);
+    }
+}
+
+// 4 waves per workgroup; wave w owns column block (= canonical segment) w of every LDS row: it DMAs it,
+// runs the segment's FMA chain for all 64 (centre, row) pairs, and applies the centre update to it.
+// One wave can only issue ~1 ds_read_b128 per 20+ cycles, so the 4 waves quadruple the LDS read rate;
+// the 4 segment sums are folded in order ((s0+s1)+s2)+s3 -- exactly the canonical dot.
+__global__ __launch_bounds__(256) void k_train_persistent(
+    const float *__restrict__ x, const float *__restrict__ xn, int b, int d, int K, float *__restrict__ centers,
+    float *__restrict__ cn, float *__restrict__ counts, const float *__restrict__ thr, double lr0, float r,
+    const int64_t *__restrict__ forced, int need, int T, TrainCtl *__restrict__ ctl, StepScalars *__restrict__ sc,
+    int nwg)
+{
+    __shared__ __attribute__((aligned(16))) float sC[TP_NC * TP_DS];
+    __shared__ __attribute__((aligned(16))) float sX[2][TP_NR * TP_DS];
+    __shared__ float sCn[TP_NC];
+    __shared__ float sCnt[TP_NC];
+    __shared__ float sPart[4][64];
+    __shared__ int sBest[TP_MAXB];
+    __shared__ int sDead;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kk = lane >> 3, ii = lane & 7;
+    const int kbase = blockIdx.x * TP_NC, rbase = blockIdx.y * TP_NR;
+    const int nck = min(TP_NC, K - kbase), nrv = min(TP_NR, b - rbase);
+    const int nblk = d >> 8;
+    const int ncg = gridDim.x;
+    const bool active = wave < nblk;  // this wave has a column block
+
+    if (active) tp_dma_block(sC, centers, kbase, nck, d, wave, lane);
+    if (tid < TP_NC) {
+        const int k = kbase + (tid < nck ? tid : 0);
+        sCn[tid] = cn[k];
+        sCnt[tid] = counts[k];
+    }
+    if (tid == 0) sDead = 0;
+    if (need < T && active) tp_dma_block(sX[need & 1], x + (size_t)need * b * d, rbase, nrv, d, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    unsigned nsync = 0;
+    long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < T; ++t) {
+        const float *xb = x + (size_t)t * b * d;
+        const long long c0 = clock64();
+        if (t < need) {
+            if (tid < b) sBest[tid] = (int)forced[(size_t)t * b + tid];
+            __syncthreads();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my block of step t's rows landed (issued one step ago)
+            float xn_t = 0.f, thr_t = 0.f;
+            if (wave == 0) {  // in flight under the FMA chain
+                xn_t = xn[(size_t)t * b + rbase + (ii < nrv ? ii : 0)];
+                thr_t = thr[t];
+            }
+            if (t + 1 < T && active) tp_dma_block(sX[(t + 1) & 1], x + (size_t)(t + 1) * b * d, rbase, nrv, d, wave, lane);
+            const long long c1 = clock64();
+            pr[0] += c1 - c0;
+            float part = 0.f;
+            if (active)
+                part = dot_blocks<1>(sC + kk * TP_DS + wave * 256, sX[t & 1] + ii * TP_DS + wave * 256, kk << 2, ii << 2,
+                                     0.f, true);
+            sPart[wave][lane] = part;
+            __syncthreads();
+            const long long c2 = clock64();
+            pr[1] += c2 - c1;
+            if (wave == 0) {
+                float acc = sPart[0][lane];
+                for (int w = 1; w < nblk; ++w) acc = acc + sPart[w][lane];  // canonical left fold of the segments
+                const int k = kbase + kk;
+                unsigned long long key = ~0ull;
+                if (kk < nck && ii < nrv) key = pack_key(dist_epilogue(acc, xn_t, sCn[kk], sCnt[kk] < thr_t, r), k);
+                unsigned long long o = __shfl_xor(key, 8);
+                key = o < key ? o : key;
+                o = __shfl_xor(key, 16);
+                key = o < key ? o : key;
+                o = __shfl_xor(key, 32);
+                key = o < key ? o : key;
+                // publish: one tagged granule per (my centre group, my row), a single 8-byte device-scope store
+                const unsigned long long tag = (unsigned long long)((nsync % 65535u) + 1u) << 48;
+                unsigned long long(*ring)[TP_MAXB] = ctl->gran[nsync % TP_RING];
+                if (lane < nrv) {
+                    const unsigned long long local = (key == ~0ull) ? 0xFFFFull : ((key & 0xffffffffull) - (unsigned)kbase);
+                    __hip_atomic_store(&ring[blockIdx.x][rbase + lane], tag | (local << 32) | (key >> 32), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // gather: lane (row = l & 31, half = l >> 5) sweeps the granules of its row from half of the
+                // centre groups until every tag is this step's; then the lexicographic minimum
+                const int srow = lane & 31, half = lane >> 5;
+                unsigned long long bestkey = ~0ull;
+                unsigned ok = 1;
+                constexpr int TP_SW = 16;  // granules per lane per batch of loads (all in flight before the first use)
+                for (unsigned spins = 0;; ++spins) {
+                    bool all = true;
+                    bestkey = ~0ull;
+                    if (srow < b) {
+                        for (int cg0 = half; cg0 < ncg; cg0 += 2 * TP_SW) {
+                            unsigned long long g[TP_SW];
+#pragma unroll
+                            for (int u = 0; u < TP_SW; ++u) {
+                                const int cg = cg0 + 2 * u;
+                                g[u] = __hip_atomic_load(&ring[cg < ncg ? cg : half][srow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+#pragma unroll
+                            for (int u = 0; u < TP_SW; ++u) {
+                                const int cg = cg0 + 2 * u;
+                                if (cg < ncg) {
+                                    all &= (g[u] >> 48) == (tag >> 48);
+                                    const unsigned loc = (unsigned)(g[u] >> 32) & 0xFFFFu;
+                                    const unsigned long long cand =
+                                        loc == 0xFFFFu ? ~0ull : (((g[u] & 0xffffffffull) << 32) | (unsigned)(cg * TP_NC + loc));
+                                    bestkey = cand < bestkey ? cand : bestkey;
+                                }
+                            }
+                        }
+                    }
+                    if (__all(all)) break;
+                    if (spins > TP_SPIN_LIMIT || (spins & 1023) == 1023) {
+                        if (spins > TP_SPIN_LIMIT || __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            if (lane == 0) __hip_atomic_store(&ctl->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = 0;
+                            break;
+                        }
+                    }
+                }
+                o = __shfl_xor(bestkey, 32);
+                bestkey = o < bestkey ? o : bestkey;
+                if (lane < b) sBest[lane] = (int)(bestkey & 0xffffffffull);
+                if (!ok && lane == 0) sDead = 1;
+            }
+            ++nsync;
+            __syncthreads();
+            pr[2] += clock64() - c2;
+            if (sDead) break;  // uniform
+        }
+        // ---- update: every replica of a centre group does the same arithmetic; wave w owns column block w
+        const long long c3 = clock64();
+        const int best = (lane < b) ? sBest[lane] : -1;
+        double lr = lr0;
+        bool fell = false;
+        if ((double)b * lr0 >= 1.0) {  // lr fallback (:116-119) possible at all?  (never at the defaults 32 * 0.01)
+            int cmaxi = 0;
+#pragma unroll
+            for (int i = 0; i < TP_MAXB; ++i) {
+                const int li = __builtin_amdgcn_readlane(best, i);  // scalar; -1 for rows >= b
+                const int c = __popcll(__ballot(lane < b && best == li));
+                cmaxi = (i < b && c > cmaxi) ? c : cmaxi;
+            }
+            if ((double)(float)cmaxi * lr >= 1.0) {
+                lr = 0.5 / (double)(float)cmaxi;
+                fell = true;
+            }
+        }
+        const float lr32 = (float)lr;
+        if (fell && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) sc->fallback += 1;
+        unsigned long long msk[TP_NC];
+        unsigned touched = 0;
+#pragma unroll
+        for (int c8 = 0; c8 < TP_NC; ++c8) {
+            msk[c8] = (c8 < nck) ? __ballot(lane < b && best == kbase + c8) : 0ull;
+            touched |= (msk[c8] ? 1u : 0u) << c8;
+        }
+        if (touched) {  // uniform over the workgroup
+            if (active) {
+                // all row loads of all touched centres are issued before the first use: one round trip
+                float4 dl[TP_NC];
+#pragma unroll
+                for (int c8 = 0; c8 < TP_NC; ++c8) {
+                    unsigned long long m = msk[c8];
+                    bool have = false;
+                    while (m) {  // rows of the batch with this label, ascending (torch_scatter's CPU order)
+                        const int i = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const float4 x4 = *reinterpret_cast<const float4 *>(xb + (size_t)i * d + wave * 256 + (lane << 2));
+                        const float4 v = make_float4(x4.x * lr32, x4.y * lr32, x4.z * lr32, x4.w * lr32);
+                        dl[c8] = have ? make_float4(dl[c8].x + v.x, dl[c8].y + v.y, dl[c8].z + v.z, dl[c8].w + v.w) : v;
+                        have = true;
+                    }
+                }
+#pragma unroll
+                for (int c8 = 0; c8 < TP_NC; ++c8) {
+                    if (msk[c8]) {
+                        const float f = 1.0f - (float)__popcll(msk[c8]) * lr32;
+                        float4 *pc4 = reinterpret_cast<float4 *>(sC + c8 * TP_DS + wave * 256 + ((lane ^ (c8 & 7)) << 2));
+                        const float4 c4 = *pc4;
+                        *pc4 = make_float4(c4.x * f + dl[c8].x, c4.y * f + dl[c8].y, c4.z * f + dl[c8].z, c4.w * f + dl[c8].w);
+                    }
+                }
+            }
+            __syncthreads();
+            pr[6] += clock64() - c3;
+            // ||c||^2 refresh: half-wave (2*wave + lane>>5) takes centre c8 = that index (32 canonical chains)
+            {
+                const int c8 = 2 * wave + (lane >> 5), q = lane & 31;
+                const bool mine = (touched >> c8) & 1u;
+                float p = 0.f;
+                if (mine) {
+#pragma unroll 32
+                    for (int j = q; j < d; j += 32) {
+                        const float v = sC[tp_off(c8, j)];
+                        p = __builtin_fmaf(v, v, p);
+                    }
+                }
+                p = p + __shfl_xor(p, 1);
+                p = p + __shfl_xor(p, 2);
+                p = p + __shfl_xor(p, 4);
+                p = p + __shfl_xor(p, 8);
+                p = p + __shfl_xor(p, 16);
+                if (q == 0 && mine) {
+                    int cnt = 0;
+#pragma unroll
+                    for (int e = 0; e < TP_NC; ++e) cnt = (e == c8) ? __popcll(msk[e]) : cnt;
+                    sCn[c8] = norm2_from_sumsq(p);
+                    sCnt[c8] = sCnt[c8] + (float)cnt;
+                }
+            }
+            __syncthreads();
+        }
+        pr[3] += clock64() - c3;
+        pr[4] += clock64() - c0;
+    }
+    if (tid == 0) {
+        const int w = blockIdx.y * gridDim.x + blockIdx.x;
+        if (w == 1 % (int)(gridDim.x * gridDim.y))
+            for (int q = 0; q < 7; ++q) ctl->prof[q] = (unsigned long long)pr[q];
+        if (w < 256)
+            for (int q = 0; q < 7; ++q) ctl->prof_wg[w][q] = (unsigned long long)pr[q];
+    }
+    // ---- write the owned state back (one replica per centre group)
+    if (blockIdx.y == 0 && !sDead && active) {
+        for (int c8 = 0; c8 < nck; ++c8) {
+            const float4 v = *reinterpret_cast<const float4 *>(sC + c8 * TP_DS + wave * 256 + ((lane ^ (c8 & 7)) << 2));
+            *reinterpret_cast<float4 *>(centers + (size_t)(kbase + c8) * d + wave * 256 + (lane << 2)) = v;
+        }
+    }
+    if (blockIdx.y == 0 && !sDead && tid < nck) {
+        cn[kbase + tid] = sCn[tid];
+        counts[kbase + tid] = sCnt[tid];
+    }
+}
+
 __global__ void k_fill_u64(unsigned long long *p, int n, unsigned long long v)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -628,7 +966,8 @@ struct acav_kmeans {
     double reinit_p = 0.7, reinit_r = 5.0;
     int64_t count = 0;  // python int self.count (deterministic on the host)
     DevBuf centers, cn, counts, scalars;
-    DevBuf stage_x, stage_lab, stage_forced, keys, xn, wg_sum, minval;
+    DevBuf stage_x, stage_lab, stage_forced, keys, xn, wg_sum, minval, thr, ctl;
+    int64_t n_persistent_launches = 0;
     int key_phase = 0;  // which half of `keys` the next step's distance kernel folds into
     int64_t n_assign_launches = 0, n_step_launches = 0;
 
@@ -915,6 +1254,58 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
         hipLaunchKernelGGL(k_row_norm2, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, fx, (int)rows, km->d,
                            km->xn.as<float>());
         ACAV_HIP_TRY(hipGetLastError());
+    }
+    // persistent path: the whole call in one launch, centres resident in LDS (k_train_persistent)
+    const int nwg = ((km->K + TP_NC - 1) / TP_NC) * (int)((b + TP_NR - 1) / TP_NR);
+    const char *nop = getenv("ACAV_NO_PERSISTENT");
+    const bool persistent = steps > 0 && !(nop && nop[0] == '1') && (km->d % 256) == 0 && km->d <= TP_DS &&
+                            b <= TP_MAXB && nwg <= 192 && ((uintptr_t)fx & 15) == 0;
+    if (persistent) {
+        std::vector<float> thr((size_t)steps);
+        for (int64_t t = 0; t < steps; ++t)
+            thr[(size_t)t] = (float)pow((double)(km->count + t * b) / (double)km->K, km->reinit_p);
+        ACAV_TRY(km->thr.ensure(sizeof(float) * (size_t)steps));
+        ACAV_HIP_TRY(hipMemcpyAsync(km->thr.p, thr.data(), sizeof(float) * (size_t)steps, hipMemcpyHostToDevice, st));
+        ACAV_TRY(km->ctl.ensure(sizeof(TrainCtl)));
+        ACAV_HIP_TRY(hipMemsetAsync(km->ctl.p, 0, sizeof(TrainCtl), st));  // err = 0, every granule tag = 0 (never a live tag)
+        hipLaunchKernelGGL(k_train_persistent, dim3((km->K + TP_NC - 1) / TP_NC, (unsigned)((b + TP_NR - 1) / TP_NR)),
+                           dim3(256), 0, st, fx, km->xn.as<float>(), (int)b, km->d, km->K, km->centers.as<float>(),
+                           km->cn.as<float>(), km->counts.as<float>(), km->thr.as<float>(), lr, (float)km->reinit_r,
+                           static_cast<const int64_t *>(dw), (int)need, (int)steps, km->ctl.as<TrainCtl>(),
+                           km->scalars.as<StepScalars>(), nwg);
+        ACAV_HIP_TRY(hipGetLastError());
+        struct { unsigned err, pad[3]; unsigned long long prof[8]; unsigned long long prof_wg[256][8]; } head{};
+        ACAV_HIP_TRY(hipMemcpyAsync(&head, km->ctl.p, sizeof(head), hipMemcpyDeviceToHost, st));
+        ACAV_HIP_TRY(hipStreamSynchronize(st));  // also covers the thr staging vector going out of scope
+        if (getenv("ACAV_PROFILE_STEPS")) {
+            const double den = (double)(steps > need ? steps - need : 1);
+            fprintf(stderr, "[acav] persistent epoch: %lld steps; cycles/step: wait+dma-issue %.0f, fma %.0f, exchange %.0f, "
+                            "update %.0f (hist %.0f, rows+apply %.0f), total %.0f\n", (long long)steps, head.prof[0] / den,
+                    head.prof[1] / den, head.prof[2] / den, head.prof[3] / den, head.prof[5] / den, head.prof[6] / den,
+                    head.prof[4] / den);
+            for (int w = 0; w < nwg && w < 256; w += 1) {
+                if (w % 16 == 0 || w == nwg - 1)
+                    fprintf(stderr, "[acav]   wg %3d: wait %.0f fma %.0f exch %.0f upd %.0f (rows %.0f)\n", w,
+                            head.prof_wg[w][0] / den, head.prof_wg[w][1] / den, head.prof_wg[w][2] / den,
+                            head.prof_wg[w][3] / den, head.prof_wg[w][6] / den);
+            }
+            double mx[4] = {0, 0, 0, 0}, mn[4] = {1e30, 1e30, 1e30, 1e30};
+            for (int w = 0; w < nwg && w < 256; ++w)
+                for (int q = 0; q < 4; ++q) {
+                    const double v = head.prof_wg[w][q] / den;
+                    mx[q] = v > mx[q] ? v : mx[q];
+                    mn[q] = v < mn[q] ? v : mn[q];
+                }
+            fprintf(stderr, "[acav]   over workgroups: wait %.0f..%.0f fma %.0f..%.0f exch %.0f..%.0f upd %.0f..%.0f\n", mn[0],
+                    mx[0], mn[1], mx[1], mn[2], mx[2], mn[3], mx[3]);
+        }
+        ACAV_REQUIRE(head.err == 0, ACAV_EHIP,
+                     "persistent k-means kernel gave up at a grid barrier (not all %d workgroups resident?); "
+                     "set ACAV_NO_PERSISTENT=1 to use the per-step launch path", nwg);
+        km->count += steps * b;
+        km->n_step_launches += steps;
+        km->n_persistent_launches += 1;
+        return ACAV_OK;
     }
     for (int64_t t = 0; t < steps; ++t) {
         const int64_t *f = t < need ? static_cast<const int64_t *>(dw) + t * b : nullptr;

@@ -84,6 +84,40 @@ def test_bulk_train_equals_stepwise_and_oracle(env):
     assert km.count == ref.count == 2 * n
 
 
+@pytest.mark.parametrize("n,d,K,b", [(2048, 256, 40, 32), (4096, 1024, 256, 32), (1536, 512, 20, 24),
+                                     (2048, 768, 64, 32)])
+def test_persistent_epoch_kernel(env, n, d, K, b):
+    """acav_kmeans_train takes the persistent one-launch path for d % 256 == 0, d <= 1024, b <= 32:
+    centres resident in LDS, per-step device-scope key exchange.  Must equal the oracle bit for bit
+    (ragged centre groups K=40/20, ragged row group b=24, warm-up steps inside the launch)."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    x = _mixture(d + K, n, d, K)
+    acav.manual_seed(13)
+    km = KMeans(None, d, K).to("cuda:0")
+    ref = O.KMeans(d, K, O.Rng(13))
+    xt = torch.from_numpy(x).cuda()
+    for e in range(2):
+        km.train_epoch(xt, b, lr=0.01)
+        ref.train_epoch(x, b, lr=0.01)
+        assert np.array_equal(km.centers.numpy(), ref.centers), f"epoch {e}"
+        assert np.array_equal(km.counts.numpy(), ref.counts)
+    assert km.count == ref.count
+    lab, _ = km.calc_best(xt)
+    assert np.array_equal(lab.cpu().numpy(), ref.calc_best(x)[0])
+    # the lr fallback inside the persistent kernel
+    km2 = KMeans(None, d, K).to("cuda:0")
+    ref2 = O.KMeans(d, K, O.Rng(13))
+    km2.centers, km2.counts, km2.count = ref2.centers, ref2.counts, 0
+    acav.manual_seed(14)
+    rng2 = O.Rng(14)
+    ref2.rng = rng2
+    km2.train_epoch(xt, b, lr=0.3)
+    ref2.train_epoch(x, b, lr=0.3)
+    assert km2.fallback == ref2.fallback and km2.fallback > 0
+    assert np.array_equal(km2.centers.numpy(), ref2.centers)
+
+
 @pytest.mark.parametrize("n,d,K", [(1000, 88, 32), (777, 130, 70), (513, 64, 300), (4096, 1024, 256),
                                    (300, 2304, 32), (64, 8, 3), (1, 32, 5)])
 def test_assign_matches_oracle(env, n, d, K):

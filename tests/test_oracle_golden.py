@@ -144,13 +144,16 @@ def test_mi_free_running_invariants():
 def test_canonical_arithmetic_definitions():
     """the oracle's canonical dot / sumsq are what their header says (pure-Python restatement)"""
     rs = np.random.RandomState(1)
-    for d in (1, 31, 32, 33, 200, 1024):
+    for d in (1, 31, 32, 33, 200, 256, 257, 1024, 1300):
         v = rs.randn(d).astype(np.float32)
         w = rs.randn(d).astype(np.float32)
-        acc = np.float32(0)
-        for j in range(d):  # one sequential FMA chain: exact product in float64, one rounding
-            acc = np.float32(np.float64(v[j]) * np.float64(w[j]) + np.float64(acc))
-        assert O.dot(v, w) == float(acc)
+        tot = None
+        for j0 in range(0, d, 256):  # 256-column segments, each ONE sequential FMA chain, folded left to right
+            acc = np.float32(0)
+            for j in range(j0, min(d, j0 + 256)):  # exact product in float64, one rounding
+                acc = np.float32(np.float64(v[j]) * np.float64(w[j]) + np.float64(acc))
+            tot = acc if tot is None else np.float32(tot + acc)
+        assert O.dot(v, w) == float(tot)
         p = np.zeros(32, np.float32)
         for j in range(d):
             p[j & 31] = np.float32(np.float64(v[j]) * np.float64(v[j]) + np.float64(p[j & 31]))
