@@ -190,55 +190,48 @@ __device__ __forceinline__ unsigned mt_temper(unsigned y)
 }
 __device__ __forceinline__ unsigned mt_twist(unsigned y) { return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
 
+// The refill loop of mt19937 is the uniform recurrence over the concatenated blocks
+//     X[m] = X[m-227] ^ twist((X[m-624] & UPPER) | (X[m-623] & LOWER)),   m >= 624
+// (the "new mt[0]" the last word of a block pairs with is simply X[m-623]).  One workgroup walks it in
+// steps of 227 consecutive words -- the widest step whose inputs all come from earlier steps -- with
+// exactly one barrier per step, through a 2048-word circular LDS window.  Draws [idx, idx+n) of the
+// stream are tempered and written out; the state is left exactly as the sequential generator would
+// leave it (block holding the last drawn word, idx in 1..624).  The chain of n/227 dependent LDS round
+// trips is what bounds a single stream; throughput comes from running independent chunks concurrently.
 __global__ __launch_bounds__(256) void k_mt_generate(unsigned *__restrict__ mt_state, unsigned *__restrict__ out,
-                                                     long long n)
+                                                    long long n)
 {
-    __shared__ unsigned mt[624];
-    const int tid = threadIdx.x;
-    for (int k = tid; k < 624; k += 256) mt[k] = mt_state[k];
-    int idx = (int)mt_state[624];
+    constexpr unsigned W = 2048;
+    __shared__ unsigned X[W];
+    const unsigned tid = threadIdx.x;
+    if (n <= 0) return;
+    const long long p = (long long)mt_state[624];  // first draw = X[p], 0 <= p <= 624
+    for (unsigned k = tid; k < 624; k += 256) X[k] = mt_state[k];
+    const long long q = p + n;                      // one past the last draw
+    const long long base = 624 * ((q - 1) / 624);   // block the sequential generator would hold
+    const long long need = base + 624;              // generate at least up to here
     __syncthreads();
-    long long produced = 0;
-    while (produced < n) {
-        if (idx >= 624) {
-            // the sequential refill reads mt[k], mt[k+1] BEFORE they are rewritten and mt[k+397 mod 624]
-            // already rewritten for k >= 227; each phase therefore reads, barriers, then writes.
-            unsigned v = 0;
-            if (tid < 227) {  // phase 1: k in [0,227)
-                const unsigned y = (mt[tid] & 0x80000000u) | (mt[tid + 1] & 0x7fffffffu);
-                v = mt[tid + 397] ^ mt_twist(y);
-            }
-            __syncthreads();
-            if (tid < 227) mt[tid] = v;
-            __syncthreads();
-            if (tid < 227) {  // phase 2: k in [227,454), mt[k-227] is new
-                const int k = tid + 227;
-                const unsigned y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu);
-                v = mt[k - 227] ^ mt_twist(y);
-            }
-            __syncthreads();
-            if (tid < 227) mt[tid + 227] = v;
-            __syncthreads();
-            if (tid < 170) {  // phase 3: k in [454,624); k = 623 pairs with the NEW mt[0]
-                const int k = tid + 454;
-                const unsigned nxt = (k == 623) ? mt[0] : mt[k + 1];
-                const unsigned y = (mt[k] & 0x80000000u) | (nxt & 0x7fffffffu);
-                v = mt[k - 227] ^ mt_twist(y);
-            }
-            __syncthreads();
-            if (tid < 170) mt[tid + 454] = v;
-            __syncthreads();
-            idx = 0;
+    for (long long m = p + tid; m < 624 && m < q; m += 256) out[m - p] = mt_temper(X[m]);  // draws left in the block
+    const long long steps = (need - 624 + 226) / 227;
+    unsigned *outp = out + (624 - p);               // out index of stream word 624
+    const long long lim = q - 624;                  // words 624 .. q-1 are draws
+    unsigned w = 624 + tid;                         // window index of this thread's word (mod W)
+    long long rel = tid;                            // stream index minus 624
+    for (long long st = 0; st < steps; ++st) {
+        if (tid < 227) {
+            const unsigned a = X[(w - 624) & (W - 1)], b2 = X[(w - 623) & (W - 1)], c = X[(w - 227) & (W - 1)];
+            const unsigned v = c ^ mt_twist((a & 0x80000000u) | (b2 & 0x7fffffffu));
+            X[w & (W - 1)] = v;
+            if (rel < lim) outp[rel] = mt_temper(v);
         }
-        const long long left = n - produced;
-        const int m = (624 - idx) < left ? (624 - idx) : (int)left;
-        for (int t = tid; t < m; t += 256) out[produced + t] = mt_temper(mt[idx + t]);
-        produced += m;
-        idx += m;
+        w += 227;
+        rel += 227;
+        __syncthreads();
     }
-    __syncthreads();
-    for (int k = tid; k < 624; k += 256) mt_state[k] = mt[k];
-    if (tid == 0) mt_state[624] = (unsigned)idx;
+    // words [base, base+624) are inside the window: at most 226 words were generated past `need`
+    const unsigned wb = (unsigned)(base & (W - 1));
+    for (unsigned k = tid; k < 624; k += 256) mt_state[k] = X[(wb + k) & (W - 1)];
+    if (tid == 0) mt_state[624] = (unsigned)(q - base);
 }
 
 // ------------------------------------------------------------------- parallel Fisher-Yates
@@ -276,10 +269,13 @@ __global__ __launch_bounds__(256) void k_fy_build(const unsigned *__restrict__ d
 __global__ __launch_bounds__(256) void k_fy_apply(const int *__restrict__ A, int L, int B,
                                                   const int *__restrict__ h, const int *__restrict__ head,
                                                   const int *__restrict__ next, const int *__restrict__ g,
-                                                  int *__restrict__ batch_out, int *__restrict__ A_new)
+                                                  int *__restrict__ batch_out, int *__restrict__ A_new,
+                                                  int *__restrict__ head_next, int *__restrict__ g_next)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L) return;
+    head_next[i] = -1;  // the list heads of the NEXT iteration (the other buffer pair; L only shrinks)
+    g_next[i] = -1;
     const int p = h[i];
     int j;
     if (p == i) {
@@ -320,7 +316,11 @@ struct acav_mi {
     DevBuf asg, pairs, Nc, ac, bc, SN, Sa, Sb, phi, scalars;
     DevBuf stage, ids32, scores;
     // greedy buffers
-    DevBuf A0, A1, draws, h, head, next, g, mt, batch, S, G, tr_pos, tr_ids, tr_sc, forced;
+    DevBuf A0, A1, draws, draws2, h, head, head2, next, g, g2, mt, batch, S, G, tr_pos, tr_ids, tr_sc, forced;
+    // the mt19937 stream does not depend on the selection state: it is generated one iteration ahead on
+    // its own stream (double-buffered draws), overlapping the Fisher-Yates / select kernels
+    hipStream_t st_mt = nullptr;
+    hipEvent_t ev_mt[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
 };
 
 struct acav_rng;  // state access through the C ABI below
@@ -401,6 +401,16 @@ ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignm
         return ACAV_OK;
     };
     rc = body();
+    if (rc == ACAV_OK) {
+        bool ok = hipStreamCreateWithFlags(&mi->st_mt, hipStreamNonBlocking) == hipSuccess;
+        for (int q = 0; q < 2 && ok; ++q)
+            ok = hipEventCreateWithFlags(&mi->ev_mt[q], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&mi->ev_used[q], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            set_error("could not create the MT stream / events");
+            rc = ACAV_EHIP;
+        }
+    }
     if (rc != ACAV_OK) {
         mi->ctx.fini();
         delete mi;
@@ -415,6 +425,14 @@ ACAV_EXPORT int acav_mi_destroy(acav_mi *mi)
     if (!mi) return ACAV_OK;
     (void)hipSetDevice(mi->ctx.device);
     (void)hipStreamSynchronize(mi->ctx.stream);
+    if (mi->st_mt) {
+        (void)hipStreamSynchronize(mi->st_mt);
+        (void)hipStreamDestroy(mi->st_mt);
+    }
+    for (int q = 0; q < 2; ++q) {
+        if (mi->ev_mt[q]) (void)hipEventDestroy(mi->ev_mt[q]);
+        if (mi->ev_used[q]) (void)hipEventDestroy(mi->ev_used[q]);
+    }
     mi->ctx.fini();
     delete mi;
     return ACAV_OK;
@@ -529,10 +547,15 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
     ACAV_TRY(ids_to_device32(mi, candidates, L, mi->stage, mi->A0));
     ACAV_TRY(mi->A1.ensure(sizeof(int) * (size_t)(L + B)));
     ACAV_TRY(mi->draws.ensure(sizeof(unsigned) * (size_t)L));
+    ACAV_TRY(mi->draws2.ensure(sizeof(unsigned) * (size_t)L));
     ACAV_TRY(mi->h.ensure(sizeof(int) * (size_t)L));
     ACAV_TRY(mi->head.ensure(sizeof(int) * (size_t)L));
     ACAV_TRY(mi->next.ensure(sizeof(int) * (size_t)L));
     ACAV_TRY(mi->g.ensure(sizeof(int) * (size_t)L));
+    ACAV_TRY(mi->head2.ensure(sizeof(int) * (size_t)L));
+    ACAV_TRY(mi->g2.ensure(sizeof(int) * (size_t)L));
+    ACAV_HIP_TRY(hipMemsetAsync(mi->head.p, 0xFF, sizeof(int) * (size_t)L, st));
+    ACAV_HIP_TRY(hipMemsetAsync(mi->g.p, 0xFF, sizeof(int) * (size_t)L, st));
     ACAV_TRY(mi->mt.ensure(sizeof(unsigned) * 625));
     ACAV_TRY(mi->batch.ensure(sizeof(int) * SEL_MAXB));
     ACAV_TRY(mi->S.ensure(sizeof(long long) * (size_t)cap));
@@ -555,19 +578,37 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
 
     int *Acur = mi->A0.as<int>(), *Anew = mi->A1.as<int>();
     int64_t l = L;
+    hipStream_t smt = mi->st_mt;
+    unsigned *dbuf[2] = {mi->draws.as<unsigned>(), mi->draws2.as<unsigned>()};
+    // everything queued so far on the main stream (state upload) happens before the first MT launch
+    ACAV_HIP_TRY(hipEventRecord(mi->ev_used[0], st));
+    ACAV_HIP_TRY(hipStreamWaitEvent(smt, mi->ev_used[0], 0));
+    auto launch_mt = [&](int64_t it_, int64_t l_) -> int {
+        const int cur_ = (int)(it_ & 1);
+        if (it_ >= 2) ACAV_HIP_TRY(hipStreamWaitEvent(smt, mi->ev_used[cur_], 0));  // its last reader (build it_-2) is done
+        if (l_ > 1)
+            hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(256), 0, smt, mi->mt.as<unsigned>(), dbuf[cur_],
+                               (long long)(l_ - 1));
+        ACAV_HIP_TRY(hipEventRecord(mi->ev_mt[cur_], smt));
+        return ACAV_OK;
+    };
+    if (iters > 0) ACAV_TRY(launch_mt(0, l));
     for (int64_t it = 0; it < iters; ++it) {
         const int Li = (int)l;
+        const int cur = (int)(it & 1);
         const unsigned grid = (unsigned)((Li + 255) / 256);
-        if (Li > 1) {
-            hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(256), 0, st, mi->mt.as<unsigned>(),
-                               mi->draws.as<unsigned>(), (long long)(Li - 1));
-        }
-        ACAV_HIP_TRY(hipMemsetAsync(mi->head.p, 0xFF, sizeof(int) * (size_t)Li, st));
-        ACAV_HIP_TRY(hipMemsetAsync(mi->g.p, 0xFF, sizeof(int) * (size_t)Li, st));
-        hipLaunchKernelGGL(k_fy_build, dim3(grid), dim3(256), 0, st, mi->draws.as<unsigned>(), Li, mi->h.as<int>(),
-                           mi->head.as<int>(), mi->next.as<int>(), mi->g.as<int>());
-        hipLaunchKernelGGL(k_fy_apply, dim3(grid), dim3(256), 0, st, Acur, Li, B, mi->h.as<int>(), mi->head.as<int>(),
-                           mi->next.as<int>(), mi->g.as<int>(), mi->batch.as<int>(), Anew);
+        const int64_t l_next = l - B + (keep_unselected ? B - k : 0);
+        if (it + 1 < iters) ACAV_TRY(launch_mt(it + 1, l_next));  // one iteration ahead, on its own stream
+        ACAV_HIP_TRY(hipStreamWaitEvent(st, mi->ev_mt[cur], 0));
+        int *hd = (it & 1) ? mi->head2.as<int>() : mi->head.as<int>();
+        int *gg = (it & 1) ? mi->g2.as<int>() : mi->g.as<int>();
+        int *hd_n = (it & 1) ? mi->head.as<int>() : mi->head2.as<int>();
+        int *gg_n = (it & 1) ? mi->g.as<int>() : mi->g2.as<int>();
+        hipLaunchKernelGGL(k_fy_build, dim3(grid), dim3(256), 0, st, dbuf[cur], Li, mi->h.as<int>(), hd,
+                           mi->next.as<int>(), gg);
+        ACAV_HIP_TRY(hipEventRecord(mi->ev_used[cur], st));
+        hipLaunchKernelGGL(k_fy_apply, dim3(grid), dim3(256), 0, st, Acur, Li, B, mi->h.as<int>(), hd,
+                           mi->next.as<int>(), gg, mi->batch.as<int>(), Anew, hd_n, gg_n);
         ACAV_HIP_TRY(hipGetLastError());
         ACAV_TRY(launch_select(mi, mi->batch.as<int>(), B, k, nullptr, mi->S.as<long long>() + it * k,
                                mi->G.as<double>() + it * k, forced_pos ? mi->forced.as<int>() + it * k : nullptr,
@@ -588,6 +629,7 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
         if (trace_ids) ACAV_HIP_TRY(hipMemcpyAsync(trace_ids, mi->tr_ids.p, sizeof(long long) * (size_t)(iters * B), hipMemcpyDeviceToHost, st));
         if (trace_scores) ACAV_HIP_TRY(hipMemcpyAsync(trace_scores, mi->tr_sc.p, sizeof(double) * (size_t)(iters * B), hipMemcpyDeviceToHost, st));
     }
+    ACAV_HIP_TRY(hipStreamSynchronize(smt));
     ACAV_HIP_TRY(hipMemcpyAsync(mtbuf, mi->mt.p, sizeof(mtbuf), hipMemcpyDeviceToHost, st));
     ACAV_HIP_TRY(hipStreamSynchronize(st));
     ACAV_TRY(acav_rng_set_state(rng, mtbuf, (int)mtbuf[624]));  // the stream continues on the host
