@@ -144,7 +144,7 @@ def assign_clusters(args, table, resident, cl, shard_names):
     print("extracting clustering for views: {}".format([v[1:] for v in cl]))
     labels = OrderedDict()
     for v, km in cl.items():
-        best, _ = km.calc_best(resident[v])
+        best, _ = km.calc_best(resident[v], need_mean=False)
         labels[v] = best.cpu().numpy()
     saved = []
     for shard in shard_names:

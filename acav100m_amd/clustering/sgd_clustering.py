@@ -210,8 +210,10 @@ class KMeans:
             self.to(f"cuda:{st['_device']}")
 
     # ---------------------------------------------------------------------- compute
-    def calc_best(self, batch):
-        """sgd_clustering.py:63-79 -> (best LongTensor[b], mean of the minima)."""
+    def calc_best(self, batch, need_mean=True):
+        """sgd_clustering.py:63-79 -> (best LongTensor[b], mean of the minima).
+        need_mean=False (bulk assign): the library may take its HBM-bound bf16-filter + exact-re-check path
+        (bit-identical labels); the second return value is then None."""
         import torch
         h = self._require_handle()
         k = self._shape[0]
@@ -221,9 +223,19 @@ class KMeans:
             out = torch.from_numpy(best)
             return (out.cuda(self._device) if on_gpu else out), mean
         labels = torch.empty(b, dtype=torch.long, device=(batch.device if on_gpu else "cpu"))
+        if not need_mean:
+            _lib.check(_lib._lib.acav_kmeans_assign(h, xp, b, _lib.ptr(labels), None))
+            _lib.check(_lib._lib.acav_kmeans_sync(h))
+            return labels, None
         mean = C.c_float(0)
         _lib.check(_lib._lib.acav_kmeans_assign(h, xp, b, _lib.ptr(labels), C.byref(mean)))
         return labels, mean.value
+
+    def filter_stats(self):
+        """(filter launches, rows of the last one, rows that needed the exact re-check)"""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib._lib.acav_kmeans_filter_stats(self._require_handle(), C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     @property
     def is_distributed(self):

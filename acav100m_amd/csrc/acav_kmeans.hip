@@ -113,8 +113,15 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
                                                        const float *__restrict__ counts, int K, float thr,
                                                        float r, int64_t *__restrict__ labels,
                                                        float *__restrict__ minval_out,
-                                                       double *__restrict__ wg_sum)
+                                                       double *__restrict__ wg_sum,
+                                                       const int *__restrict__ row_idx,
+                                                       const unsigned *__restrict__ row_cnt)
 {
+    // row_idx != NULL: exact re-check pass of the bf16 filter -- the rows to label are x[row_idx[0 .. *row_cnt)]
+    if (row_idx) {
+        n = (int64_t)*row_cnt;
+        if ((int64_t)blockIdx.x * AS_ROWS >= n) return;  // uniform
+    }
     __shared__ __attribute__((aligned(16))) float sC[AS_CG * AS_LD];
     __shared__ __attribute__((aligned(16))) float sX[AS_ROWS * AS_LD];
     __shared__ float sXn[AS_ROWS];
@@ -165,10 +172,13 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int64_t gr = row0 + srow + 32 * m;
-                if (GUARD)
+                if (GUARD) {
                     xr[m] = ld4_guard(x + (size_t)gr * d, j, d, gr < n, vec_ok);
-                else
-                    xr[m] = *reinterpret_cast<const float4 *>(x + (size_t)(gr < n ? gr : n - 1) * d + j);
+                } else {
+                    int64_t src = gr < n ? gr : n - 1;
+                    if (row_idx) src = row_idx[src];
+                    xr[m] = *reinterpret_cast<const float4 *>(x + (size_t)src * d + j);
+                }
             }
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
@@ -282,8 +292,9 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
     if (tid < AS_ROWS) {  // wave 0
         const bool ok = row0 + tid < n;
         if (ok) {
-            labels[row0 + tid] = (int64_t)gbi;
-            if (minval_out) minval_out[row0 + tid] = gbv;
+            const int64_t dst = row_idx ? (int64_t)row_idx[row0 + tid] : row0 + tid;
+            labels[dst] = (int64_t)gbi;
+            if (minval_out) minval_out[dst] = gbv;
         }
         double s = ok ? (double)gbv : 0.0;
         s += __shfl_xor(s, 1);
@@ -293,6 +304,251 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
         if (tid == 0) wg_sum[blockIdx.x] = s;
+    }
+}
+
+// --------------------------------------------------------------------------- k_assign_bf16
+// HBM-bound calc_best: a bf16-MFMA FILTER followed by an exact fp32 re-check of the ambiguous rows.
+//   1. distances with centres and rows rounded to bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate), the
+//      same fused epilogue; per row the best (d1, k1) and the runner-up value d2 are tracked
+//   2. |D~ - D| <= E_i for every centre (E_i: rigorous bound, see below), so d2 - d1 > 2 E_i proves that k1
+//      is the argmin of the canonical fp32 distances -- first-index ties included, because the inequality
+//      is strict; such rows are final
+//   3. every other row is appended to a list and re-labelled by the exact kernel (k_assign_f32)
+// The result is therefore bit-identical to the exact kernel for ANY input; only the speed depends on how
+// well separated the clusters are.
+// Error bound (per row i, any centre k):  dot~ uses c~ = c(1+a), x~ = x(1+b), |a|,|b| <= 2^-9 (RNE to 8
+// significant bits), products exact in fp32, accumulation error <= d 2^-24 sum|c~x~|; the canonical dot has
+// error <= d 2^-24 sum|cx|; sum|cx| <= ||c|| ||x||.  Hence |dot~ - dot| <= ||c|| ||x|| (2^-8 (1+2^-10) + 2.02 d 2^-24)
+// and, through -2 dot + ||x||^2 + ||c||^2 (three fp32 roundings of magnitude <= (||x||+||c||)^2):
+//   E_i = 2.02 (2^-8 1.002 + 2.02 d 2^-24) cmax ||x_i|| + 2^-20 (||x_i|| + cmax)^2,   cmax = max_k ||c_k||
+// (the under-use division by r > 1 only shrinks both sides).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FB_ROWS = 128;  // rows per workgroup (4 MFMA row tiles)
+constexpr int FB_CG = 256;    // centres per group (8 MFMA tiles)
+constexpr int FB_BK = 64;     // columns per LDS stage
+constexpr int FB_LD = 72;     // padded LDS row in bf16 (144 B = 9 x 16 B: conflict-free ds_read_b128)
+
+struct CentersAux {
+    unsigned cmax_bits;  // bits of max_k ||c_k||^2 (non-negative floats order like unsigned)
+};
+
+__global__ __launch_bounds__(256) void k_centers_bf16(const float *__restrict__ c, const float *__restrict__ cn, int K,
+                                                      int d, __bf16 *__restrict__ out, CentersAux *__restrict__ aux)
+{
+    const size_t total = (size_t)K * d;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (__bf16)c[i];
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < K; k += blockDim.x) atomicMax(&aux->cmax_bits, __float_as_uint(cn[k]));
+}
+
+struct Top2 {
+    float d1;
+    int k1;
+    float d2;
+};
+__device__ __forceinline__ void top2_push(Top2 &t, float v, int k)
+{
+    if (v < t.d1 || (v == t.d1 && k < t.k1)) {
+        t.d2 = t.d1;
+        t.d1 = v;
+        t.k1 = k;
+    } else if (v < t.d2) {
+        t.d2 = v;  // includes v == d1 with a larger index: margin 0 -> re-check
+    }
+}
+__device__ __forceinline__ Top2 top2_merge(Top2 a, Top2 b)
+{
+    const bool b_wins = b.d1 < a.d1 || (b.d1 == a.d1 && b.k1 < a.k1);
+    Top2 m;
+    m.d1 = b_wins ? b.d1 : a.d1;
+    m.k1 = b_wins ? b.k1 : a.k1;
+    m.d2 = fminf(b_wins ? b.d2 : a.d2, b_wins ? a.d1 : b.d1);
+    return m;
+}
+
+__global__ __launch_bounds__(512, 2) void k_assign_bf16(const float *__restrict__ x, int64_t n, int d,
+                                                      const __bf16 *__restrict__ cb, const float *__restrict__ cn,
+                                                      const float *__restrict__ counts, int K, float thr, float r,
+                                                      const CentersAux *__restrict__ aux, float e1coef, float e2coef,
+                                                      int64_t *__restrict__ labels, int *__restrict__ recheck_list,
+                                                      unsigned *__restrict__ recheck_count)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 sX[FB_ROWS * FB_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 sC[FB_CG * FB_LD];
+    __shared__ float sXn[FB_ROWS];
+    __shared__ float sCn[FB_CG];
+    __shared__ int sDisc[FB_CG];
+    __shared__ float sD1[4][FB_ROWS];
+    __shared__ int sK1[4][FB_ROWS];
+    __shared__ float sD2[4][FB_ROWS];
+
+    // 8 waves: wave (wq, wr) owns centres [64 wq, 64 wq + 64) x rows [64 wr, 64 wr + 64) = 2 x 2 MFMA tiles
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave & 3, wr = wave >> 2;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * FB_ROWS;
+    const int srow = tid >> 3, sq = tid & 7;  // staging: 8 threads per row; x rows srow + 64 m (m < 2), centre rows srow + 64 m (m < 4)
+    const int nchunks = d / FB_BK;
+    const int ngroups = (K + FB_CG - 1) / FB_CG;
+
+    float ssq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    Top2 run = {INFINITY, 0x7fffffff, INFINITY};  // threads < 256: row tid, across centre groups
+
+    for (int cg = 0; cg < ngroups; ++cg) {
+        const int kbase = cg * FB_CG;
+        if (tid < FB_CG) {
+            const int k = kbase + tid;
+            sCn[tid] = k < K ? cn[k] : 0.f;
+            sDisc[tid] = k < K ? (counts[k] < thr ? 1 : 0) : -1;
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        // x rows are prefetched TWO stages ahead (two named register sets, 64 KB in flight per workgroup) so
+        // the HBM stream never drains; the L2-resident bf16 centres one stage ahead.  Plain named registers and
+        // macros on purpose: arrays captured by a lambda end up in scratch and serialise the prefetch.
+        float4 xa00, xa01, xa10, xa11, xb00, xb01, xb10, xb11;
+        uint4 cr0, cr1, cr2, cr3;
+        const int64_t gr0 = row0 + srow, gr1 = row0 + srow + 64;
+        const float *xrow0 = x + (size_t)(gr0 < n ? gr0 : n - 1) * d + sq * 4;
+        const float *xrow1 = x + (size_t)(gr1 < n ? gr1 : n - 1) * d + sq * 4;
+        const __bf16 *crow0, *crow1, *crow2, *crow3;
+        {
+            const int k0 = kbase + srow, k1 = k0 + 64, k2 = k0 + 128, k3 = k0 + 192;
+            crow0 = cb + (size_t)(k0 < K ? k0 : K - 1) * d + sq * 8;
+            crow1 = cb + (size_t)(k1 < K ? k1 : K - 1) * d + sq * 8;
+            crow2 = cb + (size_t)(k2 < K ? k2 : K - 1) * d + sq * 8;
+            crow3 = cb + (size_t)(k3 < K ? k3 : K - 1) * d + sq * 8;
+        }
+#define FB_LOAD_X(c, X00, X01, X10, X11)                                     \
+    {                                                                        \
+        X00 = *reinterpret_cast<const float4 *>(xrow0 + (c) * FB_BK);        \
+        X01 = *reinterpret_cast<const float4 *>(xrow0 + (c) * FB_BK + 32);   \
+        X10 = *reinterpret_cast<const float4 *>(xrow1 + (c) * FB_BK);        \
+        X11 = *reinterpret_cast<const float4 *>(xrow1 + (c) * FB_BK + 32);   \
+    }
+#define FB_LOAD_C(c)                                                         \
+    {                                                                        \
+        cr0 = *reinterpret_cast<const uint4 *>(crow0 + (c) * FB_BK);         \
+        cr1 = *reinterpret_cast<const uint4 *>(crow1 + (c) * FB_BK);         \
+        cr2 = *reinterpret_cast<const uint4 *>(crow2 + (c) * FB_BK);         \
+        cr3 = *reinterpret_cast<const uint4 *>(crow3 + (c) * FB_BK);         \
+    }
+#define FB_PUT_X(V, ROW, U, M)                                                                   \
+    {                                                                                            \
+        const float4 v_ = (V);                                                                   \
+        bf16x4 b4_ = {(__bf16)v_.x, (__bf16)v_.y, (__bf16)v_.z, (__bf16)v_.w};                   \
+        *reinterpret_cast<bf16x4 *>(sX + (ROW) * FB_LD + sq * 4 + 32 * (U)) = b4_;               \
+        if (cg == 0) { /* canonical ||x||^2: classes 4 sq + e, ascending columns */              \
+            ssq[M][0] = __builtin_fmaf(v_.x, v_.x, ssq[M][0]);                                   \
+            ssq[M][1] = __builtin_fmaf(v_.y, v_.y, ssq[M][1]);                                   \
+            ssq[M][2] = __builtin_fmaf(v_.z, v_.z, ssq[M][2]);                                   \
+            ssq[M][3] = __builtin_fmaf(v_.w, v_.w, ssq[M][3]);                                   \
+        }                                                                                        \
+    }
+#define FB_STAGE_COMPUTE(c, X00, X01, X10, X11)                                                            \
+    {                                                                                                      \
+        __syncthreads();                                                                                   \
+        FB_PUT_X(X00, srow, 0, 0)                                                                          \
+        FB_PUT_X(X01, srow, 1, 0)                                                                          \
+        FB_PUT_X(X10, srow + 64, 0, 1)                                                                     \
+        FB_PUT_X(X11, srow + 64, 1, 1)                                                                     \
+        *reinterpret_cast<uint4 *>(sC + (srow) * FB_LD + sq * 8) = cr0;                                    \
+        *reinterpret_cast<uint4 *>(sC + (srow + 64) * FB_LD + sq * 8) = cr1;                               \
+        *reinterpret_cast<uint4 *>(sC + (srow + 128) * FB_LD + sq * 8) = cr2;                              \
+        *reinterpret_cast<uint4 *>(sC + (srow + 192) * FB_LD + sq * 8) = cr3;                              \
+        __syncthreads();                                                                                   \
+        if ((c) + 2 < nchunks) FB_LOAD_X((c) + 2, X00, X01, X10, X11) /* this register set is free again */ \
+        if ((c) + 1 < nchunks) FB_LOAD_C((c) + 1)                                                          \
+        const __bf16 *pa_ = sC + ((wq * 2) * 32 + l31) * FB_LD + h * 8;                                    \
+        const __bf16 *pb_ = sX + ((wr * 2) * 32 + l31) * FB_LD + h * 8;                                    \
+        _Pragma("unroll 2") for (int ks = 0; ks < FB_BK / 16; ++ks) {                                      \
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(pa_ + ks * 16);                            \
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(pa_ + 32 * FB_LD + ks * 16);               \
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(pb_ + ks * 16);                            \
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(pb_ + 32 * FB_LD + ks * 16);               \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);               \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);               \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);               \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);               \
+        }                                                                                                  \
+    }
+        FB_LOAD_X(0, xa00, xa01, xa10, xa11)
+        if (nchunks > 1) FB_LOAD_X(1, xb00, xb01, xb10, xb11)
+        FB_LOAD_C(0)
+        for (int c = 0; c < nchunks; c += 2) {
+            FB_STAGE_COMPUTE(c, xa00, xa01, xa10, xa11)
+            if (c + 1 < nchunks) FB_STAGE_COMPUTE(c + 1, xb00, xb01, xb10, xb11)
+        }
+#undef FB_LOAD_X
+#undef FB_LOAD_C
+#undef FB_PUT_X
+#undef FB_STAGE_COMPUTE
+        if (cg == 0) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                float t = (ssq[m][0] + ssq[m][1]) + (ssq[m][2] + ssq[m][3]);
+                t = t + __shfl_xor(t, 1);
+                t = t + __shfl_xor(t, 2);
+                t = t + __shfl_xor(t, 4);
+                if (sq == 0) sXn[srow + 64 * m] = norm2_from_sumsq(t);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int row = (wr * 2 + rt) * 32 + l31;
+            const float xnv = sXn[row];
+            Top2 t = {INFINITY, 0x7fffffff, INFINITY};
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kl = (wq * 2 + ct) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int disc = sDisc[kl];
+                    if (disc >= 0) top2_push(t, dist_epilogue(acc[ct][rt][e], xnv, sCn[kl], disc != 0, r), kbase + kl);
+                }
+            }
+            Top2 o;
+            o.d1 = __shfl_xor(t.d1, 32);
+            o.k1 = __shfl_xor(t.k1, 32);
+            o.d2 = __shfl_xor(t.d2, 32);
+            t = top2_merge(t, o);
+            if (h == 0) {
+                sD1[wq][row] = t.d1;
+                sK1[wq][row] = t.k1;
+                sD2[wq][row] = t.d2;
+            }
+        }
+        __syncthreads();
+        if (tid < FB_ROWS) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                Top2 o = {sD1[w][tid], sK1[w][tid], sD2[w][tid]};
+                run = top2_merge(run, o);
+            }
+        }
+    }
+    if (tid < FB_ROWS && row0 + tid < n) {
+        const float xnorm = __builtin_sqrtf(sXn[tid]);
+        const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
+        const float s = xnorm + cmax;
+        const float E = e1coef * cmax * xnorm + e2coef * s * s;
+        labels[row0 + tid] = (int64_t)run.k1;
+        if (!((run.d2 - run.d1) > 2.0f * E)) {  // also catches NaN / inf
+            const unsigned slot = atomicAdd(recheck_count, 1u);
+            recheck_list[slot] = (int)(row0 + tid);
+        }
     }
 }
 
@@ -967,6 +1223,10 @@ struct acav_kmeans {
     int64_t count = 0;  // python int self.count (deterministic on the host)
     DevBuf centers, cn, counts, scalars;
     DevBuf stage_x, stage_lab, stage_forced, keys, xn, wg_sum, minval, thr, ctl;
+    DevBuf cb16, caux, recheck_list, recheck_count;
+    bool cb16_valid = false;  // bf16 copy of the centres matches `centers`
+    int64_t n_filter_launches = 0;
+    uint64_t last_recheck = 0, last_rows = 0;
     int64_t n_persistent_launches = 0;
     int key_phase = 0;  // which half of `keys` the next step's distance kernel folds into
     int64_t n_assign_launches = 0, n_step_launches = 0;
@@ -1046,6 +1306,21 @@ ACAV_EXPORT int acav_kmeans_stats(acav_kmeans *km, int64_t *assign_launches, int
     return ACAV_OK;
 }
 
+ACAV_EXPORT int acav_kmeans_filter_stats(acav_kmeans *km, int64_t *filter_launches, int64_t *rows, int64_t *rechecked)
+{
+    ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");
+    unsigned cnt = 0;
+    if (km->recheck_count.p && km->n_filter_launches) {
+        ACAV_HIP_TRY(hipSetDevice(km->ctx.device));
+        ACAV_HIP_TRY(hipMemcpyAsync(&cnt, km->recheck_count.p, sizeof(cnt), hipMemcpyDeviceToHost, km->ctx.stream));
+        ACAV_HIP_TRY(hipStreamSynchronize(km->ctx.stream));
+    }
+    if (filter_launches) *filter_launches = km->n_filter_launches;
+    if (rows) *rows = (int64_t)km->last_rows;
+    if (rechecked) *rechecked = (int64_t)cnt;
+    return ACAV_OK;
+}
+
 ACAV_EXPORT int acav_kmeans_set_hyper(acav_kmeans *km, int initial_rounds, double reinit_p, double reinit_r)
 {
     ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");
@@ -1083,6 +1358,7 @@ ACAV_EXPORT int acav_kmeans_set_state(acav_kmeans *km, const float *centers, con
         ACAV_HIP_TRY(hipMemcpyAsync(km->centers.p, centers, bytes,
                                     is_device_ptr(centers) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         ACAV_TRY(km->refresh_cn());
+        km->cb16_valid = false;
     }
     if (counts) {
         ACAV_HIP_TRY(hipMemcpyAsync(km->counts.p, counts, sizeof(float) * km->K,
@@ -1121,14 +1397,48 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
     ACAV_REQUIRE(grid <= 0x7fffffff, ACAV_EINVAL, "n too large for one launch");
     ACAV_TRY(km->wg_sum.ensure(sizeof(double) * (size_t)grid));
     const bool fast = (km->d % AS_BK) == 0 && ((uintptr_t)dx & 15) == 0;
-    if (fast)
+    // bf16 filter + exact re-check (bit-identical labels, HBM-bound when the clusters are separated): taken when
+    // the caller does not need the mean distance (the filter's distances are approximate)
+    const char *noflt = getenv("ACAV_ASSIGN_EXACT_ONLY");
+    const bool filter = !mean_dist && fast && (km->d % FB_BK) == 0 && km->K >= 2 && n >= FB_ROWS &&
+                        !(noflt && noflt[0] == '1') && n < 0x7fffffff;
+    if (filter) {
+        if (!km->cb16_valid) {
+            ACAV_TRY(km->cb16.ensure(sizeof(unsigned short) * (size_t)km->K * km->d));
+            ACAV_TRY(km->caux.ensure(sizeof(CentersAux)));
+            ACAV_HIP_TRY(hipMemsetAsync(km->caux.p, 0, sizeof(CentersAux), st));
+            hipLaunchKernelGGL(k_centers_bf16, dim3(256), dim3(256), 0, st, km->centers.as<float>(), km->cn.as<float>(), km->K,
+                               km->d, km->cb16.as<__bf16>(), km->caux.as<CentersAux>());
+            ACAV_HIP_TRY(hipGetLastError());
+            km->cb16_valid = true;
+        }
+        ACAV_TRY(km->recheck_list.ensure(sizeof(int) * (size_t)n));
+        ACAV_TRY(km->recheck_count.ensure(sizeof(unsigned)));
+        ACAV_HIP_TRY(hipMemsetAsync(km->recheck_count.p, 0, sizeof(unsigned), st));
+        const double rel = ldexp(1.0, -8) * 1.002 + 2.02 * (double)km->d * ldexp(1.0, -24);
+        const float e1 = (float)(2.02 * rel * 1.001), e2 = (float)ldexp(1.0, -20);
+        hipLaunchKernelGGL(k_assign_bf16, dim3((unsigned)((n + FB_ROWS - 1) / FB_ROWS)), dim3(512), 0, st,
+                           static_cast<const float *>(dx), n, km->d, km->cb16.as<__bf16>(), km->cn.as<float>(),
+                           km->counts.as<float>(), km->K, km->threshold(), (float)km->reinit_r, km->caux.as<CentersAux>(), e1,
+                           e2, dlab, km->recheck_list.as<int>(), km->recheck_count.as<unsigned>());
+        ACAV_HIP_TRY(hipGetLastError());
+        // exact pass over the listed rows; workgroups beyond the list exit at once (no host round trip)
         hipLaunchKernelGGL(k_assign_f32<false>, dim3((unsigned)grid), dim3(256), 0, st, static_cast<const float *>(dx), n,
                            km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
-                           km->threshold(), (float)km->reinit_r, dlab, (float *)nullptr, km->wg_sum.as<double>());
+                           km->threshold(), (float)km->reinit_r, dlab, (float *)nullptr, km->wg_sum.as<double>(),
+                           km->recheck_list.as<int>(), km->recheck_count.as<unsigned>());
+        km->n_filter_launches += 1;
+        km->last_rows = (uint64_t)n;
+    } else if (fast)
+        hipLaunchKernelGGL(k_assign_f32<false>, dim3((unsigned)grid), dim3(256), 0, st, static_cast<const float *>(dx), n,
+                           km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
+                           km->threshold(), (float)km->reinit_r, dlab, (float *)nullptr, km->wg_sum.as<double>(),
+                           (const int *)nullptr, (const unsigned *)nullptr);
     else
         hipLaunchKernelGGL(k_assign_f32<true>, dim3((unsigned)grid), dim3(256), 0, st, static_cast<const float *>(dx), n,
                            km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
-                           km->threshold(), (float)km->reinit_r, dlab, (float *)nullptr, km->wg_sum.as<double>());
+                           km->threshold(), (float)km->reinit_r, dlab, (float *)nullptr, km->wg_sum.as<double>(),
+                           (const int *)nullptr, (const unsigned *)nullptr);
     ACAV_HIP_TRY(hipGetLastError());
     km->n_assign_launches += 1;
     if (!lab_dev) ACAV_HIP_TRY(hipMemcpyAsync(labels, dlab, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -1189,6 +1499,7 @@ static int step_device(acav_kmeans *km, const float *dx, int64_t b, double lr, c
     ACAV_HIP_TRY(hipGetLastError());
     if (!dforced) km->key_phase ^= 1;
     km->count += b;
+    km->cb16_valid = false;
     km->n_step_launches += 1;
     return ACAV_OK;
 }
@@ -1303,6 +1614,7 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
                      "persistent k-means kernel gave up at a grid barrier (not all %d workgroups resident?); "
                      "set ACAV_NO_PERSISTENT=1 to use the per-step launch path", nwg);
         km->count += steps * b;
+        km->cb16_valid = false;
         km->n_step_launches += steps;
         km->n_persistent_launches += 1;
         return ACAV_OK;

@@ -83,6 +83,8 @@ int acav_kmeans_set_hyper(acav_kmeans *km, int initial_rounds, double reinit_p, 
  * initial_rounds*k): labels[n] int64, *mean_dist = mean of the row minima
  * (sgd_clustering.py:63-79; called per batch by process_batch._extract_batch :37-49 and as the
  * first half of add :111).  Labels do not depend on how n is split into batches.
+ * mean_dist == NULL selects the HBM-bound path: bf16-MFMA filter + exact fp32 re-check of the rows whose
+ * top-2 gap is below the proven error bound -- the labels are bit-identical to the exact path.
  * During the warm-up the caller uses acav_rng_warmup_best instead (ACAV_ESTATE here). */
 int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, int64_t *labels, float *mean_dist);
 /* KMeans.add(batch) -- one SGD step on the b rows of x with learning rate lr
@@ -104,6 +106,9 @@ int acav_kmeans_sync(acav_kmeans *km);
 /* HIP-event timing on the handle's stream (bench.py roofline figures). */
 int acav_kmeans_timer_begin(acav_kmeans *km);
 int acav_kmeans_timer_end(acav_kmeans *km, float *ms);
+/* bf16-filter bookkeeping of acav_kmeans_assign (mean_dist == NULL path): number of filter launches, and for
+ * the last one the rows labelled and how many of them needed the exact fp32 re-check. */
+int acav_kmeans_filter_stats(acav_kmeans *km, int64_t *filter_launches, int64_t *rows, int64_t *rechecked);
 /* counters: number of kernel launches of the dominant kernels since create (bench bookkeeping) */
 int acav_kmeans_stats(acav_kmeans *km, int64_t *assign_launches, int64_t *step_launches);
 

@@ -145,6 +145,59 @@ def test_assign_matches_oracle(env, n, d, K):
     assert np.array_equal(lab_h.numpy(), lab_ref)
 
 
+@pytest.mark.parametrize("case", ["clustered", "unstructured", "duplicates", "two_groups", "tiny_gap"])
+def test_bf16_filter_path_is_bit_identical(env, case):
+    """calc_best(need_mean=False) = bf16-MFMA filter + exact re-check of the rows whose top-2 gap is below
+    the proven bound.  Labels must equal the oracle's for ANY data: well separated clusters (no re-check),
+    unstructured data (most rows re-checked), duplicated centres (exact ties -> first index), K > 256,
+    and near-ties far below bf16 resolution."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    rs = np.random.RandomState(7)
+    n, d, K = 3000, 256, 64
+    if case == "clustered":
+        rs2 = np.random.RandomState(11)
+        cen = (4.0 * rs2.randn(K, d)).astype(np.float32)
+        x = (cen[rs2.randint(0, K, n)] + 0.3 * rs2.randn(n, d)).astype(np.float32)
+        centers = (cen + 0.05 * rs2.randn(K, d)).astype(np.float32)
+    elif case == "unstructured":
+        x = rs.randn(n, d).astype(np.float32)
+        centers = rs.randn(K, d).astype(np.float32)
+    elif case == "duplicates":
+        x = _mixture(2, n, d, K // 2)
+        centers = np.stack([x[rs.randint(0, n)] for _ in range(K)]).astype(np.float32)
+        centers[40] = centers[3]
+        centers[41] = centers[3]
+        x[:200] = centers[3] + 0.01 * rs.randn(200, d).astype(np.float32)
+    elif case == "two_groups":
+        K, d = 300, 128
+        x = _mixture(3, n, d, 100)
+        centers = np.stack([x[rs.randint(0, n)] for _ in range(K)]).astype(np.float32)
+    else:  # tiny_gap: pairs of centres 1e-4 apart -- invisible to bf16, decided by the exact pass
+        x = _mixture(4, n, d, K // 2)
+        base = np.stack([x[rs.randint(0, n)] for _ in range(K // 2)]).astype(np.float32)
+        centers = np.concatenate([base, base + (1e-4 * rs.randn(K // 2, d)).astype(np.float32)])
+    counts = rs.randint(0, 80, K).astype(np.float32)  # some centres under the usage threshold -> discount
+    count = 10 * K + 2000
+    km = KMeans(None, d, K)
+    km.centers, km.counts, km.count = centers, counts, count
+    km.to("cuda:0")
+    ref = O.KMeans(d, K, O.Rng(0), centers=centers)
+    ref.set_state(None, counts, count)
+    xt = torch.from_numpy(x).cuda()
+    lab, mean = km.calc_best(xt, need_mean=False)
+    assert mean is None
+    launches, rows, rechecked = km.filter_stats()
+    assert launches == 1 and rows == n
+    lab_ref, _ = ref.calc_best(x)
+    assert np.array_equal(lab.cpu().numpy(), lab_ref), f"{(lab.cpu().numpy() != lab_ref).sum()} labels differ"
+    lab_exact, _ = km.calc_best(xt)  # exact path
+    assert np.array_equal(lab_exact.cpu().numpy(), lab_ref)
+    print(f"{case}: {rechecked}/{n} rows needed the exact re-check")
+    if case in ("unstructured", "tiny_gap"):
+        assert rechecked > n // 2   # the exact pass really decided these
+
+
 def test_exact_ties_take_first_index(env):
     torch, acav, O = env
     from acav100m_amd.clustering import KMeans

@@ -1,6 +1,8 @@
-"""Runs only the assign sweep (k_assign_f32) a few times -- a small target for rocprofv3 --pmc passes."""
+"""Runs only the assign sweep a few times -- a small target for rocprofv3 --pmc passes.
+argv: rows reps mode   (mode: exact | filter)"""
 import os
 import sys
+import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,6 +13,7 @@ from acav100m_amd.clustering import KMeans
 
 n, d, k = int(sys.argv[1]) if len(sys.argv) > 1 else 262144, 1024, 256
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+mode = sys.argv[3] if len(sys.argv) > 3 else "exact"
 gen = torch.Generator(device="cuda").manual_seed(0)
 cen = torch.randn(k, d, device="cuda", generator=gen)
 x = cen[torch.randint(0, k, (n,), device="cuda", generator=gen)] + 0.3 * torch.randn(n, d, device="cuda", generator=gen)
@@ -18,10 +21,10 @@ torch.cuda.synchronize()
 km = KMeans(None, d, k)
 km.centers, km.counts, km.count = cen.cpu().numpy(), np.full(k, 1000, np.float32), 10 * k + n
 km.to("cuda:0")
-import time
 for _ in range(reps):
     t0 = time.perf_counter()
-    lab, _ = km.calc_best(x)
+    lab, _ = km.calc_best(x, need_mean=(mode == "exact"))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-print("assign", n, "rows:", dt * 1e3, "ms ->", 2.0 * n * k * d / dt / 1e12, "TFLOP/s")
+print(mode, "assign", n, "rows:", dt * 1e3, "ms ->", 2.0 * n * k * d / dt / 1e12, "TFLOP/s,", (n * d * 4 + n * 8) / dt / 1e9, "GB/s",
+      km.filter_stats() if mode != "exact" else "")
