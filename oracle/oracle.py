@@ -53,6 +53,7 @@ def lib():
             "orc_kmeans_add": (f32, [vp, vp, i64, f64, vp, vp]),
             "orc_kmeans_train_epoch": (None, [vp, vp, i64, i64, f64, vp]),
             "orc_num_threads": (i32, []),
+            "orc_set_threads": (None, [i32]),
             "orc_mi_create": (vp, [vp, i64, i32, i32, vp, i32]),
             "orc_mi_destroy": (None, [vp]),
             "orc_mi_add_samples": (None, [vp, vp, i64]),
@@ -275,3 +276,7 @@ def topk_desc(scores, k):
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
