@@ -88,6 +88,44 @@ def cpu_baseline(n, d, k, b, seed, budget_s=20.0):
     }
 
 
+def mi_stage(seed, v=100_000, c=256, oracle_iters=100):
+    """Informational (outside the timed region): one chunk of the greedy MI selection -- BASELINE configs[2]'s
+    second stage at the reference's chunk granularity -- on the GPU, and the oracle's loop on the host."""
+    import itertools
+    import acav100m_amd
+    from acav100m_amd.subset_selection import get_measure
+    rs = np.random.RandomState(seed)
+    comp = rs.randint(0, c, v)
+    a = np.stack([np.where(rs.rand(v) < 0.5, comp, rs.randint(0, c, v)) for _ in range(2)], 1).astype(np.int64)
+    a[0] = c - 1
+    pairs = list(itertools.combinations(range(2), 2))
+    cand = [int(i) for i in rs.permutation(v)]
+    subset = round(0.2 * v)
+    acav100m_amd.manual_seed(seed)
+    import contextlib
+    import io
+    m = get_measure("batch_mi")(a, ncentroids=c, batch_size=20, selection_size=4, device="cuda", keep_unselected=True)
+    m.init(pairs, cand[1:])
+    with contextlib.redirect_stdout(io.StringIO()):
+        t0 = time.perf_counter()
+        S, _, _, _ = m.run_greedy(subset, cand[:1], None)
+        dt = time.perf_counter() - t0
+    iters = (subset + 3) // 4
+    out = {"workload": f"one chunk: V={v}, D=2, C={c}, select 20% (B=20, k=4)", "iterations": iters,
+           "us_per_iteration": dt / iters * 1e6, "selected_clips_per_s": len(S) / dt, "curated_clips_per_s": v / dt,
+           "permutation_stream_GBs": sum(16 * (v - 1 - 4 * t) for t in range(iters)) / dt / 1e9}
+    try:
+        from oracle import oracle as O
+        O.set_threads(1)
+        t0 = time.perf_counter()
+        O.BatchMI(a, c, pairs).run_greedy(cand[1:], cand[:1], subset, 20, 4, O.Rng(seed), max_iters=oracle_iters)
+        out["cpu_port_us_per_iteration"] = (time.perf_counter() - t0) / oracle_iters * 1e6
+    except Exception as exc:  # the oracle is optional here
+        out["cpu_port_us_per_iteration"] = None
+        out["cpu_port_error"] = str(exc)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,6 +245,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, d, k, b, 1234)
+            out["mi_stage"] = mi_stage(1234)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
