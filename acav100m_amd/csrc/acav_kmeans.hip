@@ -967,6 +967,31 @@ __device__ __forceinline__ void tp_dma_block(float *lds, const float *__restrict
     }
 }
 
+// ||c||^2 refresh of the centres flagged in `pend`: half-wave (2*wave + lane>>5) takes centre c8 = that index
+// (32 canonical chains + butterfly).  Called by every wave; only reads sC rows, writes sCn[c8].
+__device__ __forceinline__ void tp_refresh_norms(unsigned pend, const float *sC, float *sCn, int wave, int lane, int d)
+{
+    const int c8 = 2 * wave + (lane >> 5), q = lane & 31;
+    const bool mine = (pend >> c8) & 1u;
+    float p = 0.f;
+    if (mine) {
+        // column j = q + 32u of row c8 sits at  c8*DS + (((q>>2) ^ (c8&7)) << 2) + (q&3) + 32u : base + constant stride
+        const float *base = sC + c8 * TP_DS + ((((q >> 2) ^ (c8 & 7))) << 2) + (q & 3);
+        const int nu = d >> 5;
+#pragma unroll 32
+        for (int u = 0; u < nu; ++u) {
+            const float v = base[u * 32];
+            p = __builtin_fmaf(v, v, p);
+        }
+    }
+    p = p + __shfl_xor(p, 1);
+    p = p + __shfl_xor(p, 2);
+    p = p + __shfl_xor(p, 4);
+    p = p + __shfl_xor(p, 8);
+    p = p + __shfl_xor(p, 16);
+    if (q == 0 && mine) sCn[c8] = norm2_from_sumsq(p);
+}
+
 // 4 waves per workgroup; wave w owns column block (= canonical segment) w of every LDS row: it DMAs it,
 // runs the segment's FMA chain for all 64 (centre, row) pairs, and applies the centre update to it.
 // One wave can only issue ~1 ds_read_b128 per 20+ cycles, so the 4 waves quadruple the LDS read rate;
@@ -1006,6 +1031,7 @@ __global__ __launch_bounds__(256) void k_train_persistent(
     __syncthreads();
 
     unsigned nsync = 0;
+    unsigned pend = 0;  // centres whose ||c||^2 is stale: refreshed under the next step's FMA phase
     long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int t = 0; t < T; ++t) {
         const float *xb = x + (size_t)t * b * d;
@@ -1028,6 +1054,10 @@ __global__ __launch_bounds__(256) void k_train_persistent(
                 part = dot_blocks<1>(sC + kk * TP_DS + wave * 256, sX[t & 1] + ii * TP_DS + wave * 256, kk << 2, ii << 2,
                                      0.f, true);
             sPart[wave][lane] = part;
+            if (pend) {  // uniform: the previous update's norm refresh, off the update's critical path
+                tp_refresh_norms(pend, sC, sCn, wave, lane, d);
+                pend = 0;
+            }
             __syncthreads();
             const long long c2 = clock64();
             pr[1] += c2 - c1;
@@ -1056,38 +1086,40 @@ __global__ __launch_bounds__(256) void k_train_persistent(
                 const int srow = lane & 31, half = lane >> 5;
                 unsigned long long bestkey = ~0ull;
                 unsigned ok = 1;
-                constexpr int TP_SW = 16;  // granules per lane per batch of loads (all in flight before the first use)
+                constexpr int TP_SW = 16;  // granules per lane: centre groups half, half+2, ... (ncg <= 32 per sweep set)
+                unsigned long long g[TP_SW];
+                unsigned need = 0;  // bit u: granule u of this lane not yet seen with this step's tag
+#pragma unroll
+                for (int u = 0; u < TP_SW; ++u)
+                    if (srow < b && half + 2 * u < ncg) need |= 1u << u;
                 for (unsigned spins = 0;; ++spins) {
-                    bool all = true;
-                    bestkey = ~0ull;
-                    if (srow < b) {
-                        for (int cg0 = half; cg0 < ncg; cg0 += 2 * TP_SW) {
-                            unsigned long long g[TP_SW];
+                    // only the granules still missing are re-read: later passes are short and load the fabric less
 #pragma unroll
-                            for (int u = 0; u < TP_SW; ++u) {
-                                const int cg = cg0 + 2 * u;
-                                g[u] = __hip_atomic_load(&ring[cg < ncg ? cg : half][srow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
+                    for (int u = 0; u < TP_SW; ++u)
+                        if ((need >> u) & 1u)
+                            g[u] = __hip_atomic_load(&ring[half + 2 * u][srow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                            for (int u = 0; u < TP_SW; ++u) {
-                                const int cg = cg0 + 2 * u;
-                                if (cg < ncg) {
-                                    all &= (g[u] >> 48) == (tag >> 48);
-                                    const unsigned loc = (unsigned)(g[u] >> 32) & 0xFFFFu;
-                                    const unsigned long long cand =
-                                        loc == 0xFFFFu ? ~0ull : (((g[u] & 0xffffffffull) << 32) | (unsigned)(cg * TP_NC + loc));
-                                    bestkey = cand < bestkey ? cand : bestkey;
-                                }
-                            }
-                        }
-                    }
-                    if (__all(all)) break;
+                    for (int u = 0; u < TP_SW; ++u)
+                        if (((need >> u) & 1u) && (g[u] >> 48) == (tag >> 48)) need &= ~(1u << u);
+                    pr[7] += 1;  // sweep passes (diagnostics)
+                    if (__all(need == 0)) break;
                     if (spins > TP_SPIN_LIMIT || (spins & 1023) == 1023) {
                         if (spins > TP_SPIN_LIMIT || __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                             if (lane == 0) __hip_atomic_store(&ctl->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             ok = 0;
                             break;
                         }
+                    }
+                }
+                bestkey = ~0ull;
+#pragma unroll
+                for (int u = 0; u < TP_SW; ++u) {
+                    const int cg = half + 2 * u;
+                    if (srow < b && cg < ncg && ok) {
+                        const unsigned loc = (unsigned)(g[u] >> 32) & 0xFFFFu;
+                        const unsigned long long cand =
+                            loc == 0xFFFFu ? ~0ull : (((g[u] & 0xffffffffull) << 32) | (unsigned)(cg * TP_NC + loc));
+                        bestkey = cand < bestkey ? cand : bestkey;
                     }
                 }
                 o = __shfl_xor(bestkey, 32);
@@ -1156,42 +1188,27 @@ __global__ __launch_bounds__(256) void k_train_persistent(
             }
             __syncthreads();
             pr[6] += clock64() - c3;
-            // ||c||^2 refresh: half-wave (2*wave + lane>>5) takes centre c8 = that index (32 canonical chains)
-            {
-                const int c8 = 2 * wave + (lane >> 5), q = lane & 31;
-                const bool mine = (touched >> c8) & 1u;
-                float p = 0.f;
-                if (mine) {
-#pragma unroll 32
-                    for (int j = q; j < d; j += 32) {
-                        const float v = sC[tp_off(c8, j)];
-                        p = __builtin_fmaf(v, v, p);
-                    }
-                }
-                p = p + __shfl_xor(p, 1);
-                p = p + __shfl_xor(p, 2);
-                p = p + __shfl_xor(p, 4);
-                p = p + __shfl_xor(p, 8);
-                p = p + __shfl_xor(p, 16);
-                if (q == 0 && mine) {
-                    int cnt = 0;
+            if (tid < TP_NC && ((touched >> tid) & 1u)) {
+                int cnt = 0;
 #pragma unroll
-                    for (int e = 0; e < TP_NC; ++e) cnt = (e == c8) ? __popcll(msk[e]) : cnt;
-                    sCn[c8] = norm2_from_sumsq(p);
-                    sCnt[c8] = sCnt[c8] + (float)cnt;
-                }
+                for (int e = 0; e < TP_NC; ++e) cnt = (e == (int)tid) ? __popcll(msk[e]) : cnt;
+                sCnt[tid] = sCnt[tid] + (float)cnt;
             }
-            __syncthreads();
+            pend |= touched;  // ||c||^2 of these centres is refreshed under the next FMA phase (or at the end)
         }
         pr[3] += clock64() - c3;
         pr[4] += clock64() - c0;
     }
+    if (pend) {  // uniform
+        tp_refresh_norms(pend, sC, sCn, wave, lane, d);
+        __syncthreads();
+    }
     if (tid == 0) {
         const int w = blockIdx.y * gridDim.x + blockIdx.x;
         if (w == 1 % (int)(gridDim.x * gridDim.y))
-            for (int q = 0; q < 7; ++q) ctl->prof[q] = (unsigned long long)pr[q];
+            for (int q = 0; q < 8; ++q) ctl->prof[q] = (unsigned long long)pr[q];
         if (w < 256)
-            for (int q = 0; q < 7; ++q) ctl->prof_wg[w][q] = (unsigned long long)pr[q];
+            for (int q = 0; q < 8; ++q) ctl->prof_wg[w][q] = (unsigned long long)pr[q];
     }
     // ---- write the owned state back (one replica per centre group)
     if (blockIdx.y == 0 && !sDead && active) {
@@ -1607,8 +1624,8 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
                     mx[q] = v > mx[q] ? v : mx[q];
                     mn[q] = v < mn[q] ? v : mn[q];
                 }
-            fprintf(stderr, "[acav]   over workgroups: wait %.0f..%.0f fma %.0f..%.0f exch %.0f..%.0f upd %.0f..%.0f\n", mn[0],
-                    mx[0], mn[1], mx[1], mn[2], mx[2], mn[3], mx[3]);
+            fprintf(stderr, "[acav]   over workgroups: wait %.0f..%.0f fma %.0f..%.0f exch %.0f..%.0f upd %.0f..%.0f; sweep passes/step %.2f\n", mn[0],
+                    mx[0], mn[1], mx[1], mn[2], mx[2], mn[3], mx[3], head.prof[7] / den);
         }
         ACAV_REQUIRE(head.err == 0, ACAV_EHIP,
                      "persistent k-means kernel gave up at a grid barrier (not all %d workgroups resident?); "
