@@ -321,15 +321,14 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
 // significant bits), products exact in fp32, accumulation error <= d 2^-24 sum|c~x~|; the canonical dot has
 // error <= d 2^-24 sum|cx|; sum|cx| <= ||c|| ||x||.  Hence |dot~ - dot| <= ||c|| ||x|| (2^-8 (1+2^-10) + 2.02 d 2^-24)
 // and, through -2 dot + ||x||^2 + ||c||^2 (three fp32 roundings of magnitude <= (||x||+||c||)^2):
-//   E_i = 2.02 (2^-8 1.002 + 2.02 d 2^-24) cmax ||x_i|| + 2^-20 (||x_i|| + cmax)^2,   cmax = max_k ||c_k||
-// (the under-use division by r > 1 only shrinks both sides).
+//   E_i = 2.02 (2^-8 1.002 + 2.02 d 2^-24) cmax ||x_i|| + 2^-17 (||x_i|| + cmax)^2,   cmax = max_k ||c_k||
+// The second term also covers what the filter's epilogue does differently from the exact one: it multiplies by
+// fl(1/r) where the exact path divides by r (< 2 ulp), and it overwrites the 5 low mantissa bits of a distance
+// with the centre's position in the lane (< 2^-18 relative) -- together < 2^-17 (||x_i|| + cmax)^2 with room to
+// spare.  (The under-use scaling by 1/r < 1 only shrinks both sides.)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FB_ROWS = 128;  // rows per workgroup (4 MFMA row tiles)
-constexpr int FB_CG = 256;    // centres per group (8 MFMA tiles)
-constexpr int FB_BK = 64;     // columns per LDS stage
-constexpr int FB_LD = 72;     // padded LDS row in bf16 (144 B = 9 x 16 B: conflict-free ds_read_b128)
 
 struct CentersAux {
     unsigned cmax_bits;  // bits of max_k ||c_k||^2 (non-negative floats order like unsigned)
@@ -350,16 +349,6 @@ struct Top2 {
     int k1;
     float d2;
 };
-__device__ __forceinline__ void top2_push(Top2 &t, float v, int k)
-{
-    if (v < t.d1 || (v == t.d1 && k < t.k1)) {
-        t.d2 = t.d1;
-        t.d1 = v;
-        t.k1 = k;
-    } else if (v < t.d2) {
-        t.d2 = v;  // includes v == d1 with a larger index: margin 0 -> re-check
-    }
-}
 __device__ __forceinline__ Top2 top2_merge(Top2 a, Top2 b)
 {
     const bool b_wins = b.d1 < a.d1 || (b.d1 == a.d1 && b.k1 < a.k1);
@@ -370,177 +359,335 @@ __device__ __forceinline__ Top2 top2_merge(Top2 a, Top2 b)
     return m;
 }
 
-__global__ __launch_bounds__(512, 2) void k_assign_bf16(const float *__restrict__ x, int64_t n, int d,
-                                                      const __bf16 *__restrict__ cb, const float *__restrict__ cn,
-                                                      const float *__restrict__ counts, int K, float thr, float r,
-                                                      const CentersAux *__restrict__ aux, float e1coef, float e2coef,
-                                                      int64_t *__restrict__ labels, int *__restrict__ recheck_list,
-                                                      unsigned *__restrict__ recheck_count)
-{
-    __shared__ __attribute__((aligned(16))) __bf16 sX[FB_ROWS * FB_LD];
-    __shared__ __attribute__((aligned(16))) __bf16 sC[FB_CG * FB_LD];
-    __shared__ float sXn[FB_ROWS];
-    __shared__ float sCn[FB_CG];
-    __shared__ int sDisc[FB_CG];
-    __shared__ float sD1[4][FB_ROWS];
-    __shared__ int sK1[4][FB_ROWS];
-    __shared__ float sD2[4][FB_ROWS];
+// The filter kernel.  Built so the HBM stream never drains: the raw fp32 rows and the bf16 centres both arrive by
+// LDS-DMA (global_load_lds_dwordx4) into rings -- no staging VGPRs -- and the fp32 -> bf16 rounding happens when a
+// wave reads its B fragment.
+//   * 4 "fat" waves (256 threads, 256 VGPRs), 128 rows x 256 centres per workgroup, TWO workgroups per CU (80 KB of
+//     LDS each): one workgroup's epilogue / ring fill hides under the other's main loop.  Wave w owns centres
+//     64 w .. 64 w + 63 against all 128 rows (2 x 4 accumulator tiles of 32x32).
+//   * 32 columns per stage (2 MFMA k-steps); rows ring of 3 stages, centres ring of 2.  Every wave issues a quarter
+//     of both: per stage 4 centre DMAs (stage c+1) THEN 4 row DMAs (stage c+2), so that the in-order
+//     `s_waitcnt vmcnt(4)` at the top of a stage retires rows c and centres c and leaves rows c+1 in flight.
+//   * one raw s_barrier per stage: after it every wave may read stage c, and the slots of stage c-1 are free for
+//     the next DMA (a __syncthreads() would drain the DMA queue: vmcnt(0)).
+//   * the DMAs are issued from inline asm: hipcc cannot prove that a ds_read does not alias an in-flight builtin
+//     LDS-DMA and would put `s_waitcnt vmcnt(0)` in front of the first fragment read of every stage (measured:
+//     the ring then never holds more than one stage).
+//   * rows: 128-B row chunks, 16-B slots XOR-swizzled by ((row >> 1) & 7); centres: 64-B row chunks, slots
+//     XOR-swizzled by ((row >> 2) & 3) -- both applied to the DMA source address, the LDS image stays
+//     lane-linear; with ds_read_b128's 16-lane groups {0-3,12-15,20-27}/{4-11,16-19,28-31} both fragment reads
+//     are conflict-free.
+//   * canonical ||x||^2: wave w accumulates the 16 classes per lane of row tile w (both k-steps).
+//   * the epilogue scratch aliases the row ring; it multiplies by 1/r where the exact path divides by r (inside
+//     the e2 term of the acceptance bound).
+constexpr int FD_BK = 32;
+constexpr int FD_DX = 3;  // row ring depth (2 stages = 32 KB in flight per workgroup, two workgroups per CU)
+constexpr int FD_DC = 2;  // centre ring depth (1 stage in flight: an L2 round trip is shorter than a stage)
+constexpr int FD_SLOT = 16384;  // bytes per ring slot: 128 rows x 32 fp32 == 256 centres x 32 bf16
+constexpr int FD_SMEM = (FD_DX + FD_DC) * FD_SLOT;  // 80 KB: two workgroups fill the CU's 160 KB
 
-    // 8 waves: wave (wq, wr) owns centres [64 wq, 64 wq + 64) x rows [64 wr, 64 wr + 64) = 2 x 2 MFMA tiles
+// LDS byte address of a __shared__ pointer (wave-uniform) and a 16-byte-per-lane LDS-DMA issued from inline asm:
+// lane l's 16 bytes at gbase + voff(l) land at lds + 16 l.  The compiler does not see the pending LDS write, so the
+// caller owns the ordering: counted `s_waitcnt vmcnt(N)` + barrier before any read of the destination.
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return __builtin_amdgcn_readfirstlane(
+        (unsigned)(__SIZE_TYPE__)(const __attribute__((address_space(3))) void *)(p));
+}
+__device__ __forceinline__ void dma16_asm(const void *gbase_uniform, unsigned voff, unsigned lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gbase_uniform), "s"(lds)
+                 : "memory", "m0");
+}
+
+__device__ __forceinline__ bf16x8 cvt_bf16x8(float4 lo, float4 hi)
+{
+    bf16x8 r = {(__bf16)lo.x, (__bf16)lo.y, (__bf16)lo.z, (__bf16)lo.w, (__bf16)hi.x, (__bf16)hi.y, (__bf16)hi.z, (__bf16)hi.w};
+    return r;
+}
+
+#ifdef ACAV_FD_PROF
+__device__ unsigned long long g_fd_prof[20];
+#define FD_T(v) const long long v = clock64()
+#else
+#define FD_T(v)
+#endif
+
+__global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict__ x, int64_t n, int d,
+                                                            const __bf16 *__restrict__ cb, const float *__restrict__ cn,
+                                                            const float *__restrict__ counts, int K, float thr, float r,
+                                                            const CentersAux *__restrict__ aux, float e1coef, float e2coef,
+                                                            int64_t *__restrict__ labels, int *__restrict__ recheck_list,
+                                                            unsigned *__restrict__ recheck_count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
+    float *sXr = reinterpret_cast<float *>(fd_smem);                        // [FD_DX][128][32] fp32
+    __bf16 *sCb = reinterpret_cast<__bf16 *>(fd_smem + FD_DX * FD_SLOT);    // [FD_DC][256][32] bf16
+    // epilogue scratch ALIASES the row ring (the rings are idle between the last stage and the next group's first DMA)
+    float *sXn = reinterpret_cast<float *>(fd_smem);  // [128]
+    float *sCn = sXn + 128;                           // [256]
+    float *sSc = sCn + 256;                           // [256] 1, or 1/r for a discounted centre
+    float *sD1 = sSc + 256;                           // [4][128]
+    int *sK1 = reinterpret_cast<int *>(sD1 + 512);    // [4][128]
+    float *sD2 = reinterpret_cast<float *>(sK1 + 512);  // [4][128]
+
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wq = wave & 3, wr = wave >> 2;
+    const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = centre quarter (64 centres)
     const int l31 = lane & 31, h = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * FB_ROWS;
-    const int srow = tid >> 3, sq = tid & 7;  // staging: 8 threads per row; x rows srow + 64 m (m < 2), centre rows srow + 64 m (m < 4)
-    const int nchunks = d / FB_BK;
-    const int ngroups = (K + FB_CG - 1) / FB_CG;
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    const int nchunks = d / FD_BK;
+    const int ngroups = (K + 255) / 256;
+    const float inv_r = 1.0f / r;
 
-    float ssq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    Top2 run = {INFINITY, 0x7fffffff, INFINITY};  // threads < 256: row tid, across centre groups
+    // DMA share of this wave: instructions 4 wq .. 4 wq + 3 of the 16 per slot, for rows and for centres.
+    // Source = uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset; destination = slot + (4 wq + q) KB.
+    unsigned voffx[4], voffc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rr = (wq * 4 + q) * 8 + (lane >> 3);
+        const int rc = row0 + rr < n ? rr : (int)(n - 1 - row0);  // ragged tail: re-read the last row
+        voffx[q] = (unsigned)rc * (unsigned)d * 4u + (((lane & 7) ^ ((rr >> 1) & 7)) << 4);
+    }
+    const unsigned xring = lds_addr(sXr) + wq * 4096, cring = lds_addr(sCb) + wq * 4096;
+
+    float ssq[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ssq[e] = 0.f;
+    Top2 run = {INFINITY, 0x7fffffff, INFINITY};
+    float my_xn = 0.f;                         // ||x||^2 of row tid (tid < 128), kept across centre groups
+    float xn_rt[4] = {0.f, 0.f, 0.f, 0.f};     // ... and of this lane's four fragment rows
+#ifdef ACAV_FD_PROF
+    long long fdp0 = 0, fdp1 = 0, fdp2 = 0, fdp3 = 0, fdp4 = 0, fdp5 = 0, fdp6 = 0;
+    const long long fd_tstart = clock64(), fd_wstart = wall_clock64();
+#endif
 
     for (int cg = 0; cg < ngroups; ++cg) {
-        const int kbase = cg * FB_CG;
-        if (tid < FB_CG) {
-            const int k = kbase + tid;
-            sCn[tid] = k < K ? cn[k] : 0.f;
-            sDisc[tid] = k < K ? (counts[k] < thr ? 1 : 0) : -1;
+        const int kbase = cg * 256;
+#ifdef ACAV_FD_PROF
+        const long long fd_tgrp = clock64();
+#endif
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = (wq * 4 + q) * 16 + (lane >> 2);
+            const int rc = kbase + rr < K ? rr : K - 1 - kbase;
+            voffc[q] = (unsigned)rc * (unsigned)d * 2u + (((lane & 3) ^ ((rr >> 2) & 3)) << 4);
         }
-        f32x16 acc[2][2];
+        const char *gx = reinterpret_cast<const char *>(x + (size_t)row0 * d);
+        const char *gc = reinterpret_cast<const char *>(cb + (size_t)kbase * d);
+        int wx = 0, wc = 0;  // ring slots the next issue fills
+        auto issue_x = [&]() {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dma16_asm(gx, voffx[q], xring + wx * FD_SLOT + q * 1024);
+            gx += FD_BK * 4;
+            wx = wx + 1 == FD_DX ? 0 : wx + 1;
+        };
+        auto issue_c = [&]() {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dma16_asm(gc, voffc[q], cring + wc * FD_SLOT + q * 1024);
+            gc += FD_BK * 2;
+            wc = wc + 1 == FD_DC ? 0 : wc + 1;
+        };
+
+        f32x16 acc[2][4];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-        // x rows are prefetched TWO stages ahead (two named register sets, 64 KB in flight per workgroup) so
-        // the HBM stream never drains; the L2-resident bf16 centres one stage ahead.  Plain named registers and
-        // macros on purpose: arrays captured by a lambda end up in scratch and serialise the prefetch.
-        float4 xa00, xa01, xa10, xa11, xb00, xb01, xb10, xb11;
-        uint4 cr0, cr1, cr2, cr3;
-        const int64_t gr0 = row0 + srow, gr1 = row0 + srow + 64;
-        const float *xrow0 = x + (size_t)(gr0 < n ? gr0 : n - 1) * d + sq * 4;
-        const float *xrow1 = x + (size_t)(gr1 < n ? gr1 : n - 1) * d + sq * 4;
-        const __bf16 *crow0, *crow1, *crow2, *crow3;
-        {
-            const int k0 = kbase + srow, k1 = k0 + 64, k2 = k0 + 128, k3 = k0 + 192;
-            crow0 = cb + (size_t)(k0 < K ? k0 : K - 1) * d + sq * 8;
-            crow1 = cb + (size_t)(k1 < K ? k1 : K - 1) * d + sq * 8;
-            crow2 = cb + (size_t)(k2 < K ? k2 : K - 1) * d + sq * 8;
-            crow3 = cb + (size_t)(k3 < K ? k3 : K - 1) * d + sq * 8;
-        }
-#define FB_LOAD_X(c, X00, X01, X10, X11)                                     \
-    {                                                                        \
-        X00 = *reinterpret_cast<const float4 *>(xrow0 + (c) * FB_BK);        \
-        X01 = *reinterpret_cast<const float4 *>(xrow0 + (c) * FB_BK + 32);   \
-        X10 = *reinterpret_cast<const float4 *>(xrow1 + (c) * FB_BK);        \
-        X11 = *reinterpret_cast<const float4 *>(xrow1 + (c) * FB_BK + 32);   \
-    }
-#define FB_LOAD_C(c)                                                         \
-    {                                                                        \
-        cr0 = *reinterpret_cast<const uint4 *>(crow0 + (c) * FB_BK);         \
-        cr1 = *reinterpret_cast<const uint4 *>(crow1 + (c) * FB_BK);         \
-        cr2 = *reinterpret_cast<const uint4 *>(crow2 + (c) * FB_BK);         \
-        cr3 = *reinterpret_cast<const uint4 *>(crow3 + (c) * FB_BK);         \
-    }
-#define FB_PUT_X(V, ROW, U, M)                                                                   \
-    {                                                                                            \
-        const float4 v_ = (V);                                                                   \
-        bf16x4 b4_ = {(__bf16)v_.x, (__bf16)v_.y, (__bf16)v_.z, (__bf16)v_.w};                   \
-        *reinterpret_cast<bf16x4 *>(sX + (ROW) * FB_LD + sq * 4 + 32 * (U)) = b4_;               \
-        if (cg == 0) { /* canonical ||x||^2: classes 4 sq + e, ascending columns */              \
-            ssq[M][0] = __builtin_fmaf(v_.x, v_.x, ssq[M][0]);                                   \
-            ssq[M][1] = __builtin_fmaf(v_.y, v_.y, ssq[M][1]);                                   \
-            ssq[M][2] = __builtin_fmaf(v_.z, v_.z, ssq[M][2]);                                   \
-            ssq[M][3] = __builtin_fmaf(v_.w, v_.w, ssq[M][3]);                                   \
-        }                                                                                        \
-    }
-#define FB_STAGE_COMPUTE(c, X00, X01, X10, X11)                                                            \
-    {                                                                                                      \
-        __syncthreads();                                                                                   \
-        FB_PUT_X(X00, srow, 0, 0)                                                                          \
-        FB_PUT_X(X01, srow, 1, 0)                                                                          \
-        FB_PUT_X(X10, srow + 64, 0, 1)                                                                     \
-        FB_PUT_X(X11, srow + 64, 1, 1)                                                                     \
-        *reinterpret_cast<uint4 *>(sC + (srow) * FB_LD + sq * 8) = cr0;                                    \
-        *reinterpret_cast<uint4 *>(sC + (srow + 64) * FB_LD + sq * 8) = cr1;                               \
-        *reinterpret_cast<uint4 *>(sC + (srow + 128) * FB_LD + sq * 8) = cr2;                              \
-        *reinterpret_cast<uint4 *>(sC + (srow + 192) * FB_LD + sq * 8) = cr3;                              \
-        __syncthreads();                                                                                   \
-        if ((c) + 2 < nchunks) FB_LOAD_X((c) + 2, X00, X01, X10, X11) /* this register set is free again */ \
-        if ((c) + 1 < nchunks) FB_LOAD_C((c) + 1)                                                          \
-        const __bf16 *pa_ = sC + ((wq * 2) * 32 + l31) * FB_LD + h * 8;                                    \
-        const __bf16 *pb_ = sX + ((wr * 2) * 32 + l31) * FB_LD + h * 8;                                    \
-        _Pragma("unroll 2") for (int ks = 0; ks < FB_BK / 16; ++ks) {                                      \
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(pa_ + ks * 16);                            \
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(pa_ + 32 * FB_LD + ks * 16);               \
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(pb_ + ks * 16);                            \
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(pb_ + 32 * FB_LD + ks * 16);               \
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);               \
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);               \
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);               \
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);               \
-        }                                                                                                  \
-    }
-        FB_LOAD_X(0, xa00, xa01, xa10, xa11)
-        if (nchunks > 1) FB_LOAD_X(1, xb00, xb01, xb10, xb11)
-        FB_LOAD_C(0)
-        for (int c = 0; c < nchunks; c += 2) {
-            FB_STAGE_COMPUTE(c, xa00, xa01, xa10, xa11)
-            if (c + 1 < nchunks) FB_STAGE_COMPUTE(c + 1, xb00, xb01, xb10, xb11)
-        }
-#undef FB_LOAD_X
-#undef FB_LOAD_C
-#undef FB_PUT_X
-#undef FB_STAGE_COMPUTE
-        if (cg == 0) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                float t = (ssq[m][0] + ssq[m][1]) + (ssq[m][2] + ssq[m][3]);
-                t = t + __shfl_xor(t, 1);
-                t = t + __shfl_xor(t, 2);
-                t = t + __shfl_xor(t, 4);
-                if (sq == 0) sXn[srow + 64 * m] = norm2_from_sumsq(t);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const int row = (wr * 2 + rt) * 32 + l31;
-            const float xnv = sXn[row];
-            Top2 t = {INFINITY, 0x7fffffff, INFINITY};
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int kl = (wq * 2 + ct) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const int disc = sDisc[kl];
-                    if (disc >= 0) top2_push(t, dist_epilogue(acc[ct][rt][e], xnv, sCn[kl], disc != 0, r), kbase + kl);
+
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave is done with the previous centre group's epilogue scratch
+        issue_x();                     // rows 0, centres 0, rows 1: the steady-state order (centres c+1, rows c+2)
+        issue_c();
+        if (nchunks > 1) issue_x();
+        int rx = 0, rcs = 0;  // ring slots stage c is read from
+#ifdef ACAV_FD_PROF
+        const long long fd_tloop0 = clock64();
+#endif
+        for (int c = 0; c < nchunks; ++c) {
+            FD_T(t0);
+            // retire rows c and centres c; rows c+1 (the 4 newest loads) may stay in flight
+            if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FD_T(t1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            FD_T(t2);
+            const float *px = sXr + rx * (128 * 32);
+            const __bf16 *pc = sCb + rcs * (256 * 32);
+            rx = rx + 1 == FD_DX ? 0 : rx + 1;
+            rcs = rcs + 1 == FD_DC ? 0 : rcs + 1;
+            const int swz = (l31 >> 1) & 7;  // ((rowX >> 1) & 7) for every row tile (32 rows = 2 swizzle periods)
+            const float *pxl = px + l31 * 32;
+            const __bf16 *pcl = pc + (wq * 64 + l31) * 32;
+            const int swa = (l31 >> 2) & 3;  // ((rowA >> 2) & 3), likewise
+#define FD_LOAD_A(ks, A)                                                                          \
+    A[0] = *reinterpret_cast<const bf16x8 *>(pcl + (((2 * (ks) + h) ^ swa) << 3));                \
+    A[1] = *reinterpret_cast<const bf16x8 *>(pcl + 32 * 32 + (((2 * (ks) + h) ^ swa) << 3));
+#define FD_LOAD_X(ks, rt, F0, F1)                                                                                 \
+    const float4 F0 = *reinterpret_cast<const float4 *>(pxl + (rt) * 1024 + (((4 * (ks) + 2 * h) ^ swz) << 2));   \
+    const float4 F1 = *reinterpret_cast<const float4 *>(pxl + (rt) * 1024 + (((4 * (ks) + 2 * h + 1) ^ swz) << 2));
+#define FD_SSQ(ks, F0, F1)                                           \
+    ssq[8 * (ks) + 0] = __builtin_fmaf(F0.x, F0.x, ssq[8 * (ks) + 0]); \
+    ssq[8 * (ks) + 1] = __builtin_fmaf(F0.y, F0.y, ssq[8 * (ks) + 1]); \
+    ssq[8 * (ks) + 2] = __builtin_fmaf(F0.z, F0.z, ssq[8 * (ks) + 2]); \
+    ssq[8 * (ks) + 3] = __builtin_fmaf(F0.w, F0.w, ssq[8 * (ks) + 3]); \
+    ssq[8 * (ks) + 4] = __builtin_fmaf(F1.x, F1.x, ssq[8 * (ks) + 4]); \
+    ssq[8 * (ks) + 5] = __builtin_fmaf(F1.y, F1.y, ssq[8 * (ks) + 5]); \
+    ssq[8 * (ks) + 6] = __builtin_fmaf(F1.z, F1.z, ssq[8 * (ks) + 6]); \
+    ssq[8 * (ks) + 7] = __builtin_fmaf(F1.w, F1.w, ssq[8 * (ks) + 7]);
+#define FD_MMA(A, rt, B)                                                                            \
+    acc[0][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B, acc[0][rt], 0, 0, 0);              \
+    acc[1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B, acc[1][rt], 0, 0, 0);
+            // k-step 0 operands of the first two row tiles are read BEFORE the DMA issue: the issue stalls while the
+            // memory pipe accepts 8 KB, which hides this LDS latency
+            bf16x8 a0[2], a1[2];
+            FD_LOAD_A(0, a0)
+            FD_LOAD_X(0, 0, p00, p01)
+            FD_LOAD_X(0, 1, p10, p11)
+            if (c + 1 < nchunks) issue_c();  // into the slots stage c-1 just vacated
+            if (c + 2 < nchunks) issue_x();
+            FD_T(t3);
+            {
+                const bf16x8 b0 = cvt_bf16x8(p00, p01), b1 = cvt_bf16x8(p10, p11);
+                FD_LOAD_X(0, 2, p20, p21)
+                FD_LOAD_X(0, 3, p30, p31)
+                FD_MMA(a0, 0, b0)
+                FD_MMA(a0, 1, b1)
+                const bf16x8 b2 = cvt_bf16x8(p20, p21), b3 = cvt_bf16x8(p30, p31);
+                FD_LOAD_A(1, a1)
+                FD_LOAD_X(1, 0, q00, q01)
+                FD_LOAD_X(1, 1, q10, q11)
+                FD_MMA(a0, 2, b2)
+                FD_MMA(a0, 3, b3)
+                const bf16x8 d0 = cvt_bf16x8(q00, q01), d1 = cvt_bf16x8(q10, q11);
+                FD_LOAD_X(1, 2, q20, q21)
+                FD_LOAD_X(1, 3, q30, q31)
+                FD_MMA(a1, 0, d0)
+                FD_MMA(a1, 1, d1)
+                const bf16x8 d2 = cvt_bf16x8(q20, q21), d3 = cvt_bf16x8(q30, q31);
+                FD_MMA(a1, 2, d2)
+                FD_MMA(a1, 3, d3)
+                if (cg == 0) {  // this wave's share of the canonical ||x||^2: row tile wq, classes 16 ks + 8 h + e
+                    FD_LOAD_X(0, wq, s00, s01)
+                    FD_LOAD_X(1, wq, s10, s11)
+                    FD_SSQ(0, s00, s01)
+                    FD_SSQ(1, s10, s11)
                 }
             }
-            Top2 o;
+#undef FD_LOAD_A
+#undef FD_LOAD_X
+#undef FD_SSQ
+#undef FD_MMA
+#ifdef ACAV_FD_PROF
+            {
+                const long long t4 = clock64();
+                fdp0 += t1 - t0, fdp1 += t2 - t1, fdp2 += t3 - t2, fdp3 += t4 - t3, fdp4 += 1;
+            }
+#endif
+        }
+#ifdef ACAV_FD_PROF
+        const long long fd_tloop1 = clock64();
+        fdp5 += fd_tloop0 - fd_tgrp;
+        fdp6 += fd_tloop1 - fd_tloop0;
+#endif
+        float my_cn = INFINITY, my_sc = 1.0f;  // +inf beyond K: such a centre never wins and never becomes the runner-up
+        if (kbase + tid < K) {
+            my_cn = cn[kbase + tid];
+            my_sc = counts[kbase + tid] < thr ? inv_r : 1.0f;
+        }
+        __syncthreads();  // every wave has read its last fragments: the row ring becomes epilogue scratch
+        sCn[tid] = my_cn;
+        sSc[tid] = my_sc;
+        if (cg == 0) {
+            // lane (i, h) of wave w holds classes 16 ks + 8 h + e of row 32 w + i.  Canonical tree: (p0+p1)+(p2+p3)
+            // per group of 4 classes, then ((g0+g1)+(g2+g3)) + ((g4+g5)+(g6+g7)): g0,g1 = (ks 0, h 0), g2,g3 =
+            // (ks 0, h 1), g4,g5 = (ks 1, h 0), g6,g7 = (ks 1, h 1).
+            float ta = ((ssq[0] + ssq[1]) + (ssq[2] + ssq[3])) + ((ssq[4] + ssq[5]) + (ssq[6] + ssq[7]));
+            float tb = ((ssq[8] + ssq[9]) + (ssq[10] + ssq[11])) + ((ssq[12] + ssq[13]) + (ssq[14] + ssq[15]));
+            ta = ta + __shfl_xor(ta, 32);
+            tb = tb + __shfl_xor(tb, 32);
+            if (h == 0) sXn[wq * 32 + l31] = norm2_from_sumsq(ta + tb);
+        }
+        __syncthreads();
+        if (cg == 0) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) xn_rt[rt] = sXn[rt * 32 + l31];
+            if (tid < 128) my_xn = sXn[tid];
+        }
+        // Scan of this lane's 4 x 32 distances without a single compare: the low 5 mantissa bits of every distance
+        // are replaced by its position (ct, g, j) in the lane, so min() carries the argmin along and
+        // d2 = min(d2, max(d1, v)) tracks the runner-up.  The perturbation (< 2^-18 relative) is part of the e2
+        // term of the acceptance bound; exact ties, NaNs and infinities end in a zero / NaN margin -> re-check.
+        float s1[4], s2[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) s1[rt] = INFINITY, s2[rt] = INFINITY;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int kl = wq * 64 + ct * 32 + 4 * h + 8 * g;
+                const float4 cnv = *reinterpret_cast<const float4 *>(sCn + kl);
+                const float4 scv = *reinterpret_cast<const float4 *>(sSc + kl);
+                const float cn4[4] = {cnv.x, cnv.y, cnv.z, cnv.w};
+                const float sc4[4] = {scv.x, scv.y, scv.z, scv.w};
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = __builtin_fmaf(-2.0f, acc[ct][rt][4 * g + j], xn_rt[rt]);  // == (-2 dot) + xn
+                        v = v + cn4[j];
+                        v = v * sc4[j];  // * (1/r) where the exact path divides by r
+                        v = __uint_as_float((__float_as_uint(v) & 0xFFFFFFE0u) | (unsigned)(ct * 16 + g * 4 + j));
+                        s2[rt] = fminf(s2[rt], fmaxf(s1[rt], v));
+                        s1[rt] = fminf(s1[rt], v);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const int row = rt * 32 + l31;
+            const unsigned c5 = __float_as_uint(s1[rt]) & 31u;  // (ct, g, j) of the lane's minimum
+            Top2 t = {s1[rt], kbase + wq * 64 + 4 * h + (int)((c5 >> 4) * 32 + ((c5 >> 2) & 3) * 8 + (c5 & 3)), s2[rt]}, o;
             o.d1 = __shfl_xor(t.d1, 32);
             o.k1 = __shfl_xor(t.k1, 32);
             o.d2 = __shfl_xor(t.d2, 32);
             t = top2_merge(t, o);
             if (h == 0) {
-                sD1[wq][row] = t.d1;
-                sK1[wq][row] = t.k1;
-                sD2[wq][row] = t.d2;
+                sD1[wq * 128 + row] = t.d1;
+                sK1[wq * 128 + row] = t.k1;
+                sD2[wq * 128 + row] = t.d2;
             }
         }
         __syncthreads();
-        if (tid < FB_ROWS) {
+        if (tid < 128) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                Top2 o = {sD1[w][tid], sK1[w][tid], sD2[w][tid]};
+                Top2 o = {sD1[w * 128 + tid], sK1[w * 128 + tid], sD2[w * 128 + tid]};
                 run = top2_merge(run, o);
             }
         }
     }
-    if (tid < FB_ROWS && row0 + tid < n) {
-        const float xnorm = __builtin_sqrtf(sXn[tid]);
+#ifdef ACAV_FD_PROF
+    if (lane == 0 && (blockIdx.x & 31) == 0 && (wq == 0 || wq == 3)) {
+        const int o = wq == 0 ? 0 : 8;
+        atomicAdd(&g_fd_prof[o + 0], (unsigned long long)fdp0);
+        atomicAdd(&g_fd_prof[o + 1], (unsigned long long)fdp1);
+        atomicAdd(&g_fd_prof[o + 2], (unsigned long long)fdp2);
+        atomicAdd(&g_fd_prof[o + 3], (unsigned long long)fdp3);
+        atomicAdd(&g_fd_prof[o + 4], (unsigned long long)fdp4);
+        atomicAdd(&g_fd_prof[o + 5], (unsigned long long)(clock64() - fd_tstart));
+        atomicAdd(&g_fd_prof[o + 6], (unsigned long long)(wall_clock64() - fd_wstart));
+        atomicAdd(&g_fd_prof[o + 7], 1ull);
+        atomicAdd(&g_fd_prof[16 + o / 8 * 2], (unsigned long long)fdp5);
+        atomicAdd(&g_fd_prof[17 + o / 8 * 2], (unsigned long long)fdp6);
+    }
+#endif
+    if (tid < 128 && row0 + tid < n) {
+        const float xnorm = __builtin_sqrtf(my_xn);
         const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
         const float s = xnorm + cmax;
         const float E = e1coef * cmax * xnorm + e2coef * s * s;
@@ -1417,7 +1564,7 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
     // bf16 filter + exact re-check (bit-identical labels, HBM-bound when the clusters are separated): taken when
     // the caller does not need the mean distance (the filter's distances are approximate)
     const char *noflt = getenv("ACAV_ASSIGN_EXACT_ONLY");
-    const bool filter = !mean_dist && fast && (km->d % FB_BK) == 0 && km->K >= 2 && n >= FB_ROWS &&
+    const bool filter = !mean_dist && fast && (km->d % FD_BK) == 0 && km->K >= 2 && n >= FB_ROWS &&
                         !(noflt && noflt[0] == '1') && n < 0x7fffffff;
     if (filter) {
         if (!km->cb16_valid) {
@@ -1433,12 +1580,30 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         ACAV_TRY(km->recheck_count.ensure(sizeof(unsigned)));
         ACAV_HIP_TRY(hipMemsetAsync(km->recheck_count.p, 0, sizeof(unsigned), st));
         const double rel = ldexp(1.0, -8) * 1.002 + 2.02 * (double)km->d * ldexp(1.0, -24);
-        const float e1 = (float)(2.02 * rel * 1.001), e2 = (float)ldexp(1.0, -20);
-        hipLaunchKernelGGL(k_assign_bf16, dim3((unsigned)((n + FB_ROWS - 1) / FB_ROWS)), dim3(512), 0, st,
+        const float e1 = (float)(2.02 * rel * 1.001), e2 = (float)ldexp(1.0, -17);
+        ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_assign_bf16),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, FD_SMEM));
+        hipLaunchKernelGGL(k_assign_bf16, dim3((unsigned)((n + FB_ROWS - 1) / FB_ROWS)), dim3(256), FD_SMEM, st,
                            static_cast<const float *>(dx), n, km->d, km->cb16.as<__bf16>(), km->cn.as<float>(),
                            km->counts.as<float>(), km->K, km->threshold(), (float)km->reinit_r, km->caux.as<CentersAux>(), e1,
                            e2, dlab, km->recheck_list.as<int>(), km->recheck_count.as<unsigned>());
         ACAV_HIP_TRY(hipGetLastError());
+#ifdef ACAV_FD_PROF
+        {
+            unsigned long long hp[20];
+            hipStreamSynchronize(st);
+            hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_fd_prof), sizeof(hp));
+            for (int o = 0; o < 16; o += 8)
+                fprintf(stderr, "fd_prof wave%d: stages %llu  vmwait %.0f  barrier %.0f  issue %.0f  compute %.0f cycles/stage\n",
+                        o ? 3 : 0, hp[o + 4], (double)hp[o] / hp[o + 4], (double)hp[o + 1] / hp[o + 4],
+                        (double)hp[o + 2] / hp[o + 4], (double)hp[o + 3] / hp[o + 4]),
+                fprintf(stderr, "   prologue %.0f loop %.0f cycles per WG\n", (double)hp[16 + o / 8 * 2] / hp[o + 7], (double)hp[17 + o / 8 * 2] / hp[o + 7]),
+                fprintf(stderr, "   per WG: %.0f cycles, %.2f us (100 MHz wall clock) -> %.2f GHz\n", (double)hp[o + 5] / hp[o + 7],
+                        (double)hp[o + 6] / hp[o + 7] / 100.0, (double)hp[o + 5] / hp[o + 6] * 0.1);
+            memset(hp, 0, sizeof(hp));
+            hipMemcpyToSymbol(HIP_SYMBOL(g_fd_prof), hp, sizeof(hp));
+        }
+#endif
         // exact pass over the listed rows; workgroups beyond the list exit at once (no host round trip)
         hipLaunchKernelGGL(k_assign_f32<false>, dim3((unsigned)grid), dim3(256), 0, st, static_cast<const float *>(dx), n,
                            km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
