@@ -1,0 +1,43 @@
+"""Fold the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py into <prefix>_pmc_assign.json:
+HBM bytes per launch of the assign filter kernel, corrected as MI355X_MICROARCH.md (HBM section) prescribes."""
+import csv
+import json
+import re
+import sys
+
+out, prefix = sys.argv[1], sys.argv[2]
+N, D, K = 1_000_000, 1024, 256
+
+
+def per_kernel(path):
+    acc = {}
+    try:
+        rows = list(csv.DictReader(open(path)))
+    except OSError:
+        return acc
+    for r in rows:
+        m = re.search(r"k_[a-z0-9_]+", r["Kernel_Name"])
+        if not m:
+            continue
+        acc.setdefault(m.group(0), []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}  # mean per launch
+
+
+fetch = per_kernel(f"{out}/{prefix}_pmc_fetch_counter_collection.csv")
+write = per_kernel(f"{out}/{prefix}_pmc_write_counter_collection.csv")
+fk = fetch.get("k_assign_bf16", 0.0)
+wk = write.get("k_assign_bf16", 0.0)
+traffic = (2.0 * fk + wk + 2.0 * fetch.get("k_assign_f32", 0.0) + write.get("k_assign_f32", 0.0)) * 1024.0
+alg = N * D * 4 + N * 8
+json.dump({
+    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-include-regex k_assign -- python bench.py --steps 2 "
+               "--warmup 1 --no-cpu-baseline (separate passes; tools/collect_profiles.sh)",
+    "kernel": "k_assign_bf16 + k_assign_f32 (exact re-check pass, empty list on this data)",
+    "rows": N, "d": D, "K": K,
+    "FETCH_SIZE_raw_KB": fetch, "WRITE_SIZE_raw_KB": write,
+    "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads "
+                  "on gfx950 -> x2; units are KB; mean per launch",
+    "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg,
+    "traffic_over_algorithmic": traffic / alg if alg else None,
+}, open(f"{out}/{prefix}_pmc_assign.json", "w"), indent=1)
+print(open(f"{out}/{prefix}_pmc_assign.json").read())
