@@ -191,46 +191,85 @@ __device__ __forceinline__ unsigned mt_temper(unsigned y)
 __device__ __forceinline__ unsigned mt_twist(unsigned y) { return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
 
 // The refill loop of mt19937 is the uniform recurrence over the concatenated blocks
-//     X[m] = X[m-227] ^ twist((X[m-624] & UPPER) | (X[m-623] & LOWER)),   m >= 624
-// (the "new mt[0]" the last word of a block pairs with is simply X[m-623]).  One workgroup walks it in
-// steps of 227 consecutive words -- the widest step whose inputs all come from earlier steps -- with
-// exactly one barrier per step, through a 2048-word circular LDS window.  Draws [idx, idx+n) of the
-// stream are tempered and written out; the state is left exactly as the sequential generator would
-// leave it (block holding the last drawn word, idx in 1..624).  The chain of n/227 dependent LDS round
-// trips is what bounds a single stream; throughput comes from running independent chunks concurrently.
-__global__ __launch_bounds__(256) void k_mt_generate(unsigned *__restrict__ mt_state, unsigned *__restrict__ out,
-                                                    long long n)
+//     X[m] = X[m-227] ^ T(m-624),   T(j) = twist(U(j)),  U(j) = (X[j] & UPPER) | (X[j+1] & LOWER),   m >= 624
+// (the "new mt[0]" the last word of a block pairs with is simply X[m-623]).  twist and U are GF(2)-linear, so the
+// recurrence can be substituted into itself and the three twists folded into one:
+//     X[m] = X[m-681] ^ twist(U(m-1078) ^ U(m-851) ^ U(m-624)),   m >= 1078
+// whose newest operand is X[m-623]: 623 consecutive words are independent of each other.  One workgroup walks
+// the stream in steps of 623 words (the first 454 words past the state in two plain 227-word steps), one barrier
+// per step.  The window is LINEAR in LDS (all seven operands at constant offsets from one address register) and is
+// slid back every MT_EPOCH steps.  The loop is VALU-issue bound (10 waves on 4 SIMDs), hence the folding, and hence
+// the words are stored RAW: the consumer (k_fy_build) applies the tempering.  `out` must hold n + MT_PAD words.
+// The state is left exactly as the sequential generator would leave it (block holding the last drawn word,
+// idx in 1..624).
+constexpr int MT_THREADS = 640;
+constexpr int MT_WIDE = 623;
+constexpr int MT_BACK = 1078;
+constexpr int MT_EPOCH = 24;                              // wide steps between two slides of the window
+constexpr int MT_WIN = MT_BACK + MT_WIDE * MT_EPOCH;      // 16030 words = 62.6 KB of LDS
+constexpr int MT_PAD = 1280;  // the generator completes the 624-word block of the last draw (+ up to 622 words of the last step)
+__global__ __launch_bounds__(MT_THREADS) void k_mt_generate(unsigned *__restrict__ mt_state, unsigned *__restrict__ out,
+                                                           long long n)
 {
-    constexpr unsigned W = 2048;
-    __shared__ unsigned X[W];
+    __shared__ unsigned X[MT_WIN];
     const unsigned tid = threadIdx.x;
     if (n <= 0) return;
     const long long p = (long long)mt_state[624];  // first draw = X[p], 0 <= p <= 624
-    for (unsigned k = tid; k < 624; k += 256) X[k] = mt_state[k];
+    for (unsigned k = tid; k < 624; k += MT_THREADS) X[k] = mt_state[k];
     const long long q = p + n;                      // one past the last draw
     const long long base = 624 * ((q - 1) / 624);   // block the sequential generator would hold
     const long long need = base + 624;              // generate at least up to here
     __syncthreads();
-    for (long long m = p + tid; m < 624 && m < q; m += 256) out[m - p] = mt_temper(X[m]);  // draws left in the block
-    const long long steps = (need - 624 + 226) / 227;
-    unsigned *outp = out + (624 - p);               // out index of stream word 624
-    const long long lim = q - 624;                  // words 624 .. q-1 are draws
-    unsigned w = 624 + tid;                         // window index of this thread's word (mod W)
-    long long rel = tid;                            // stream index minus 624
-    for (long long st = 0; st < steps; ++st) {
+    for (long long m = p + tid; m < 624 && m < q; m += MT_THREADS) out[m - p] = X[m];  // draws left in the block
+    unsigned *outp = out + (624 - p);  // raw word of stream index m goes to outp[m - 624] (beyond q: padding)
+    long long m0 = 624;     // stream index of the next word to generate
+    long long shift = 0;    // stream index of X[0]
+    for (; m0 < need && m0 < MT_BACK; m0 += 227) {  // two plain steps: 624..850, 851..1077
         if (tid < 227) {
-            const unsigned a = X[(w - 624) & (W - 1)], b2 = X[(w - 623) & (W - 1)], c = X[(w - 227) & (W - 1)];
-            const unsigned v = c ^ mt_twist((a & 0x80000000u) | (b2 & 0x7fffffffu));
-            X[w & (W - 1)] = v;
-            if (rel < lim) outp[rel] = mt_temper(v);
+            const unsigned w = (unsigned)m0 + tid;
+            const unsigned v = X[w - 227] ^ mt_twist((X[w - 624] & 0x80000000u) | (X[w - 623] & 0x7fffffffu));
+            X[w] = v;
+            outp[w - 624] = v;
         }
-        w += 227;
-        rel += 227;
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
-    // words [base, base+624) are inside the window: at most 226 words were generated past `need`
-    const unsigned wb = (unsigned)(base & (W - 1));
-    for (unsigned k = tid; k < 624; k += 256) mt_state[k] = X[(wb + k) & (W - 1)];
+    unsigned bi = (unsigned)(m0 - shift) + tid;  // window index of this thread's word
+    unsigned oi = (unsigned)(m0 - 624) + tid;    // its index in outp (n < 2^31 on this path)
+    int left = MT_EPOCH;
+    while (m0 < need) {
+        if (left == 0) {  // slide: the last MT_BACK words move to the front of the window (disjoint ranges)
+            unsigned keep[2];
+            const unsigned src = (unsigned)(m0 - shift) - MT_BACK;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) keep[u] = tid + u * MT_THREADS < MT_BACK ? X[src + tid + u * MT_THREADS] : 0u;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (tid + u * MT_THREADS < MT_BACK) X[tid + u * MT_THREADS] = keep[u];
+            __syncthreads();
+            shift = m0 - MT_BACK;
+            bi = MT_BACK + tid;
+            left = MT_EPOCH;
+        }
+        if (tid < MT_WIDE) {
+            const unsigned *x = X + (bi - MT_BACK);  // operands at constant offsets: 0,1 | 227,228 | 454,455 | 397
+            const unsigned a = x[0] ^ x[227] ^ x[454], b2 = x[1] ^ x[228] ^ x[455];
+            const unsigned v = x[MT_BACK - 681] ^ mt_twist((a & 0x80000000u) | (b2 & 0x7fffffffu));
+            X[bi] = v;
+            outp[oi] = v;
+        }
+        bi += MT_WIDE;
+        oi += MT_WIDE;
+        m0 += MT_WIDE;
+        --left;
+        // LDS ordering only: a __syncthreads() would also wait for the global stores above to be acknowledged
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    __syncthreads();
+    // words [base, base+624) are inside the window: at most 622 words were generated past `need`
+    const unsigned wb = (unsigned)(base - shift);
+    for (unsigned k = tid; k < 624; k += MT_THREADS) mt_state[k] = X[wb + k];
     if (tid == 0) mt_state[624] = (unsigned)(q - base);
 }
 
@@ -256,7 +295,7 @@ __global__ __launch_bounds__(256) void k_fy_build(const unsigned *__restrict__ d
         next[i] = -1;
         return;
     }
-    const int hh = i + (int)(draws[i] % (unsigned)(L - i));
+    const int hh = i + (int)(mt_temper(draws[i]) % (unsigned)(L - i));  // k_mt_generate stores raw words
     h[i] = hh;
     if (hh != i) {
         next[i] = atomicExch(&head[hh], i);
@@ -546,8 +585,8 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
     ACAV_TRY(mi->A0.ensure(sizeof(int) * (size_t)(L + B)));  // before the conversion: ensure() does not copy
     ACAV_TRY(ids_to_device32(mi, candidates, L, mi->stage, mi->A0));
     ACAV_TRY(mi->A1.ensure(sizeof(int) * (size_t)(L + B)));
-    ACAV_TRY(mi->draws.ensure(sizeof(unsigned) * (size_t)L));
-    ACAV_TRY(mi->draws2.ensure(sizeof(unsigned) * (size_t)L));
+    ACAV_TRY(mi->draws.ensure(sizeof(unsigned) * (size_t)(L + MT_PAD)));
+    ACAV_TRY(mi->draws2.ensure(sizeof(unsigned) * (size_t)(L + MT_PAD)));
     ACAV_TRY(mi->h.ensure(sizeof(int) * (size_t)L));
     ACAV_TRY(mi->head.ensure(sizeof(int) * (size_t)L));
     ACAV_TRY(mi->next.ensure(sizeof(int) * (size_t)L));
@@ -587,7 +626,7 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
         const int cur_ = (int)(it_ & 1);
         if (it_ >= 2) ACAV_HIP_TRY(hipStreamWaitEvent(smt, mi->ev_used[cur_], 0));  // its last reader (build it_-2) is done
         if (l_ > 1)
-            hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(256), 0, smt, mi->mt.as<unsigned>(), dbuf[cur_],
+            hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(MT_THREADS), 0, smt, mi->mt.as<unsigned>(), dbuf[cur_],
                                (long long)(l_ - 1));
         ACAV_HIP_TRY(hipEventRecord(mi->ev_mt[cur_], smt));
         return ACAV_OK;
