@@ -81,6 +81,20 @@ constexpr int SEL_MAXBP = 8192;
 // (descending, ties -> lower batch position), commit them, emit S/GAIN, and append the
 // unselected ids in ascending order to the new candidate array (batch.py:132-171).
 // ids == batch_in when called for plain scoring (k = 0: nothing committed).
+// The kernel sits on the critical path of every iteration and is pure latency, so every phase issues all of its
+// independent loads before the first use: scoring is 4 dependent load levels (id -> row -> counts -> phi), the
+// top-k is k wave-wide argmax reductions, the commit of k <= SEL_FASTK picks is 3 levels per pair.
+constexpr int SEL_FASTK = 8;
+
+__device__ __forceinline__ void sel_argmax_step(double &s, int &w, int lane_delta)
+{
+    const double so = __shfl_xor(s, lane_delta);
+    const int wo = __shfl_xor(w, lane_delta);
+    const bool take = so > s || (so == s && wo < w);  // NaN scores never win; ties -> lower batch position
+    s = take ? so : s;
+    w = take ? wo : w;
+}
+
 __global__ __launch_bounds__(256) void k_mi_select(
     const int *__restrict__ asg, int D, int C, int P, const int *__restrict__ pairs,
     const int *__restrict__ batch, int B, int k, int *__restrict__ Nc, int *__restrict__ ac,
@@ -93,64 +107,76 @@ __global__ __launch_bounds__(256) void k_mi_select(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double *sS = reinterpret_cast<double *>(smem_raw);  // [B*P]
     __shared__ double sScore[SEL_MAXB];
+    __shared__ int sId[SEL_MAXB];
     __shared__ int sPos[SEL_MAXB];
     __shared__ int sPick[SEL_MAXB];
+    __shared__ unsigned long long sUsed;
     const int tid = threadIdx.x;
     const long long nc = sc->nc;
+    if (tid < B) sId[tid] = batch[tid];
+    __syncthreads();
     for (int t = tid; t < B * P; t += blockDim.x) {
         const int w = t / P, p = t - w * P;
-        sS[t] = mi_pair_score(asg, D, C, p, pairs, batch[w], Nc, ac, bc, SN, Sa, Sb, phi, nc);
+        sS[t] = mi_pair_score(asg, D, C, p, pairs, sId[w], Nc, ac, bc, SN, Sa, Sb, phi, nc);
     }
     __syncthreads();
-    if (tid < B) {
-        double tot = 0.0;
-        for (int p = 0; p < P; ++p) tot = tot + sS[tid * P + p];
-        const double s = tot / (double)P;
-        sScore[tid] = s;
-        if (scores_out) scores_out[tid] = s;
-        if (trace_scores) trace_scores[tid] = s;
-        if (trace_ids) trace_ids[tid] = batch[tid];
+    if (tid < 64) {  // wave 0: means, then k argmax rounds over the B <= 64 lanes
+        double s = -INFINITY;
+        if (tid < B) {
+            double tot = 0.0;
+            for (int p = 0; p < P; ++p) tot = tot + sS[tid * P + p];
+            s = tot / (double)P;
+            sScore[tid] = s;
+            if (scores_out) scores_out[tid] = s;
+            if (trace_scores) trace_scores[tid] = s;
+            if (trace_ids) trace_ids[tid] = sId[tid];
+        }
+        if (k > 0) {
+            unsigned long long used = 0ull;
+            const bool nan_or_out = !(s == s) || tid >= B;
+            for (int r = 0; r < k; ++r) {
+                // candidates still in play; a NaN score compares false with everything: the serial scan this
+                // replaces would keep the first unused position in that case, so do the same
+                double sr = (nan_or_out || (used >> tid & 1ull)) ? -INFINITY : s;
+                int wr = tid < B && !(used >> tid & 1ull) ? tid : 0x7fffffff;
+                sel_argmax_step(sr, wr, 1);
+                sel_argmax_step(sr, wr, 2);
+                sel_argmax_step(sr, wr, 4);
+                sel_argmax_step(sr, wr, 8);
+                sel_argmax_step(sr, wr, 16);
+                sel_argmax_step(sr, wr, 32);
+                used |= 1ull << wr;
+                if (tid == 0) {
+                    sPos[r] = wr;
+                    if (trace_pos) trace_pos[r] = wr;
+                }
+            }
+            if (forced_pos) {
+                used = 0ull;
+                for (int r = 0; r < k; ++r) used |= 1ull << forced_pos[r];
+                if (tid < k) sPos[tid] = forced_pos[tid];
+            }
+            if (tid == 0) sUsed = used;
+        }
     }
     __syncthreads();
     if (k == 0) return;
-    if (tid == 0) {
-        unsigned long long used = 0ull;
-        for (int r = 0; r < k; ++r) {
-            int bi = -1;
+    if (tid < k) {
+        const int pos = sPos[tid];
+        sPick[tid] = sId[pos];
+        S_out[tid] = (long long)sId[pos];
+        G_out[tid] = sScore[pos];
+    }
+    if (keep_unselected && tid < B) {  // get_unselected: torch.unique -> ascending ids (batch.py:167-171)
+        const unsigned long long used = sUsed;
+        if (!(used >> tid & 1ull)) {
+            const int v = sId[tid];
+            int rank = 0;
             for (int w = 0; w < B; ++w) {
-                if (used >> w & 1ull) continue;
-                if (bi < 0 || sScore[w] > sScore[bi]) bi = w;
+                const int o = sId[w];
+                rank += (!(used >> w & 1ull) && (o < v || (o == v && w < tid))) ? 1 : 0;
             }
-            used |= 1ull << bi;
-            if (trace_pos) trace_pos[r] = bi;
-            sPos[r] = bi;
-        }
-        if (forced_pos) {
-            used = 0ull;
-            for (int r = 0; r < k; ++r) {
-                sPos[r] = forced_pos[r];
-                used |= 1ull << forced_pos[r];
-            }
-        }
-        for (int r = 0; r < k; ++r) {
-            sPick[r] = batch[sPos[r]];
-            S_out[r] = (long long)sPick[r];
-            G_out[r] = sScore[sPos[r]];
-        }
-        if (keep_unselected) {  // get_unselected: torch.unique -> ascending ids (batch.py:167-171)
-            int u[SEL_MAXB];
-            int nu = 0;
-            for (int w = 0; w < B; ++w) {
-                if (used >> w & 1ull) continue;
-                const int v = batch[w];
-                int q = nu++;
-                while (q > 0 && u[q - 1] > v) {
-                    u[q] = u[q - 1];
-                    --q;
-                }
-                u[q] = v;
-            }
-            for (int q = 0; q < nu; ++q) requeue_out[q] = u[q];
+            requeue_out[rank] = v;
         }
     }
     __syncthreads();
@@ -158,17 +184,64 @@ __global__ __launch_bounds__(256) void k_mi_select(
     for (int p = tid; p < P; p += blockDim.x) {
         const int d0 = pairs[2 * p], d1 = pairs[2 * p + 1];
         double sN = SN[p], sa = Sa[p], sb = Sb[p];
-        for (int r = 0; r < k; ++r) {
-            const int *row = asg + (size_t)sPick[r] * D;
-            const int i = row[d0], j = row[d1];
-            const size_t cell = ((size_t)p * C + i) * C + j;
-            const int cN = Nc[cell], ca = ac[(size_t)p * C + j], cb = bc[(size_t)p * C + i];
-            Nc[cell] = cN + 1;
-            ac[(size_t)p * C + j] = ca + 1;
-            bc[(size_t)p * C + i] = cb + 1;
-            sN = sN - phi[cN] + phi[cN + 1];
-            sa = sa - phi[ca] + phi[ca + 1];
-            sb = sb - phi[cb] + phi[cb + 1];
+        if (k <= SEL_FASTK) {
+            int ci[SEL_FASTK], cj[SEL_FASTK], cN[SEL_FASTK], ca[SEL_FASTK], cb[SEL_FASTK];
+#pragma unroll
+            for (int r = 0; r < SEL_FASTK; ++r)
+                if (r < k) {
+                    const int *row = asg + (size_t)sPick[r] * D;
+                    ci[r] = row[d0];
+                    cj[r] = row[d1];
+                }
+#pragma unroll
+            for (int r = 0; r < SEL_FASTK; ++r)
+                if (r < k) {
+                    cN[r] = Nc[((size_t)p * C + ci[r]) * C + cj[r]];
+                    ca[r] = ac[(size_t)p * C + cj[r]];
+                    cb[r] = bc[(size_t)p * C + ci[r]];
+                }
+#pragma unroll
+            for (int r = 0; r < SEL_FASTK; ++r)  // counts as pick r sees them: earlier picks of this iteration included
+                if (r < k) {
+#pragma unroll
+                    for (int e = 0; e < SEL_FASTK; ++e)
+                        if (e < r) {
+                            cN[r] += (ci[e] == ci[r] && cj[e] == cj[r]) ? 1 : 0;
+                            ca[r] += (cj[e] == cj[r]) ? 1 : 0;
+                            cb[r] += (ci[e] == ci[r]) ? 1 : 0;
+                        }
+                }
+            double f[SEL_FASTK][6];
+#pragma unroll
+            for (int r = 0; r < SEL_FASTK; ++r)
+                if (r < k) {
+                    f[r][0] = phi[cN[r]], f[r][1] = phi[cN[r] + 1];
+                    f[r][2] = phi[ca[r]], f[r][3] = phi[ca[r] + 1];
+                    f[r][4] = phi[cb[r]], f[r][5] = phi[cb[r] + 1];
+                }
+#pragma unroll
+            for (int r = 0; r < SEL_FASTK; ++r)
+                if (r < k) {
+                    Nc[((size_t)p * C + ci[r]) * C + cj[r]] = cN[r] + 1;  // same-thread stores: the last pick's count stays
+                    ac[(size_t)p * C + cj[r]] = ca[r] + 1;
+                    bc[(size_t)p * C + ci[r]] = cb[r] + 1;
+                    sN = sN - f[r][0] + f[r][1];
+                    sa = sa - f[r][2] + f[r][3];
+                    sb = sb - f[r][4] + f[r][5];
+                }
+        } else {
+            for (int r = 0; r < k; ++r) {
+                const int *row = asg + (size_t)sPick[r] * D;
+                const int i = row[d0], j = row[d1];
+                const size_t cell = ((size_t)p * C + i) * C + j;
+                const int cN = Nc[cell], ca = ac[(size_t)p * C + j], cb = bc[(size_t)p * C + i];
+                Nc[cell] = cN + 1;
+                ac[(size_t)p * C + j] = ca + 1;
+                bc[(size_t)p * C + i] = cb + 1;
+                sN = sN - phi[cN] + phi[cN + 1];
+                sa = sa - phi[ca] + phi[ca + 1];
+                sb = sb - phi[cb] + phi[cb + 1];
+            }
         }
         SN[p] = sN;
         Sa[p] = sa;
@@ -207,6 +280,7 @@ constexpr int MT_WIDE = 623;
 constexpr int MT_BACK = 1078;
 constexpr int MT_EPOCH = 24;                              // wide steps between two slides of the window
 constexpr int MT_WIN = MT_BACK + MT_WIDE * MT_EPOCH;      // 16030 words = 62.6 KB of LDS
+constexpr int MT_GROUP = 8;   // greedy iterations whose draws one launch generates
 constexpr int MT_PAD = 1280;  // the generator completes the 624-word block of the last draw (+ up to 622 words of the last step)
 __global__ __launch_bounds__(MT_THREADS) void k_mt_generate(unsigned *__restrict__ mt_state, unsigned *__restrict__ out,
                                                            long long n)
@@ -585,8 +659,8 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
     ACAV_TRY(mi->A0.ensure(sizeof(int) * (size_t)(L + B)));  // before the conversion: ensure() does not copy
     ACAV_TRY(ids_to_device32(mi, candidates, L, mi->stage, mi->A0));
     ACAV_TRY(mi->A1.ensure(sizeof(int) * (size_t)(L + B)));
-    ACAV_TRY(mi->draws.ensure(sizeof(unsigned) * (size_t)(L + MT_PAD)));
-    ACAV_TRY(mi->draws2.ensure(sizeof(unsigned) * (size_t)(L + MT_PAD)));
+    ACAV_TRY(mi->draws.ensure(sizeof(unsigned) * ((size_t)L * MT_GROUP + MT_PAD)));
+    ACAV_TRY(mi->draws2.ensure(sizeof(unsigned) * ((size_t)L * MT_GROUP + MT_PAD)));
     ACAV_TRY(mi->h.ensure(sizeof(int) * (size_t)L));
     ACAV_TRY(mi->head.ensure(sizeof(int) * (size_t)L));
     ACAV_TRY(mi->next.ensure(sizeof(int) * (size_t)L));
@@ -622,30 +696,49 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
     // everything queued so far on the main stream (state upload) happens before the first MT launch
     ACAV_HIP_TRY(hipEventRecord(mi->ev_used[0], st));
     ACAV_HIP_TRY(hipStreamWaitEvent(smt, mi->ev_used[0], 0));
-    auto launch_mt = [&](int64_t it_, int64_t l_) -> int {
-        const int cur_ = (int)(it_ & 1);
-        if (it_ >= 2) ACAV_HIP_TRY(hipStreamWaitEvent(smt, mi->ev_used[cur_], 0));  // its last reader (build it_-2) is done
-        if (l_ > 1)
+    // The draws do not depend on what gets selected (L shrinks by a fixed amount per iteration), so the generator
+    // runs a whole GROUP of iterations ahead on its own stream: one launch and two event operations per MT_GROUP
+    // iterations instead of per iteration (the loop is host-launch bound otherwise).
+    const int64_t dl = B - (keep_unselected ? B - k : 0);  // candidates consumed per iteration
+    const int64_t ngroups = (iters + MT_GROUP - 1) / MT_GROUP;
+    auto group_draws = [&](int64_t g_) -> int64_t {  // draws of group g_ = sum over its iterations of (L_t - 1)
+        int64_t tot = 0;
+        for (int64_t t = g_ * MT_GROUP; t < iters && t < (g_ + 1) * MT_GROUP; ++t) {
+            const int64_t lt = L - t * dl;
+            tot += lt > 1 ? lt - 1 : 0;
+        }
+        return tot;
+    };
+    auto launch_mt = [&](int64_t g_) -> int {
+        const int cur_ = (int)(g_ & 1);
+        if (g_ >= 2) ACAV_HIP_TRY(hipStreamWaitEvent(smt, mi->ev_used[cur_], 0));  // its last reader (group g_-2) is done
+        const int64_t nd = group_draws(g_);
+        if (nd > 0)
             hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(MT_THREADS), 0, smt, mi->mt.as<unsigned>(), dbuf[cur_],
-                               (long long)(l_ - 1));
+                               (long long)nd);
         ACAV_HIP_TRY(hipEventRecord(mi->ev_mt[cur_], smt));
         return ACAV_OK;
     };
-    if (iters > 0) ACAV_TRY(launch_mt(0, l));
+    if (iters > 0) ACAV_TRY(launch_mt(0));
+    int64_t draw_off = 0;  // offset of this iteration's draws inside its group's buffer
     for (int64_t it = 0; it < iters; ++it) {
         const int Li = (int)l;
-        const int cur = (int)(it & 1);
+        const int64_t grp = it / MT_GROUP;
+        const int cur = (int)(grp & 1);
         const unsigned grid = (unsigned)((Li + 255) / 256);
-        const int64_t l_next = l - B + (keep_unselected ? B - k : 0);
-        if (it + 1 < iters) ACAV_TRY(launch_mt(it + 1, l_next));  // one iteration ahead, on its own stream
-        ACAV_HIP_TRY(hipStreamWaitEvent(st, mi->ev_mt[cur], 0));
+        if (it % MT_GROUP == 0) {
+            if (grp + 1 < ngroups) ACAV_TRY(launch_mt(grp + 1));  // one group ahead, on its own stream
+            ACAV_HIP_TRY(hipStreamWaitEvent(st, mi->ev_mt[cur], 0));
+            draw_off = 0;
+        }
         int *hd = (it & 1) ? mi->head2.as<int>() : mi->head.as<int>();
         int *gg = (it & 1) ? mi->g2.as<int>() : mi->g.as<int>();
         int *hd_n = (it & 1) ? mi->head.as<int>() : mi->head2.as<int>();
         int *gg_n = (it & 1) ? mi->g.as<int>() : mi->g2.as<int>();
-        hipLaunchKernelGGL(k_fy_build, dim3(grid), dim3(256), 0, st, dbuf[cur], Li, mi->h.as<int>(), hd,
+        hipLaunchKernelGGL(k_fy_build, dim3(grid), dim3(256), 0, st, dbuf[cur] + draw_off, Li, mi->h.as<int>(), hd,
                            mi->next.as<int>(), gg);
-        ACAV_HIP_TRY(hipEventRecord(mi->ev_used[cur], st));
+        draw_off += Li > 1 ? Li - 1 : 0;
+        if (it % MT_GROUP == MT_GROUP - 1 || it + 1 == iters) ACAV_HIP_TRY(hipEventRecord(mi->ev_used[cur], st));
         hipLaunchKernelGGL(k_fy_apply, dim3(grid), dim3(256), 0, st, Acur, Li, B, mi->h.as<int>(), hd,
                            mi->next.as<int>(), gg, mi->batch.as<int>(), Anew, hd_n, gg_n);
         ACAV_HIP_TRY(hipGetLastError());
