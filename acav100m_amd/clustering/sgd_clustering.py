@@ -319,6 +319,12 @@ class KMeans:
         _lib.check(_lib._lib.acav_kmeans_train(h, xp, n, int(batch_size), float(lr),
                                                _lib.ptr(warm) if need else None, need))
 
+    def train_epoch_distributed(self, x_local, batch_size, lr=None, chunk_steps=1024):
+        """One epoch of the reference's multi-GPU add() loop (global batch = world * batch_size rows, rank-major)
+        without a collective per step: see acav100m_amd/parallel/kmeans_dp.py:train_epoch_dp."""
+        from ..parallel import train_epoch_dp
+        train_epoch_dp(self, x_local, int(batch_size), self.lr if lr is None else lr, chunk_steps=chunk_steps)
+
     def get_attrs_plain(self):
         """get_attrs() without the args object (what the checkpoint files hold)"""
         dt = self.get_attrs()

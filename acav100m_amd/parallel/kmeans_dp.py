@@ -39,6 +39,63 @@ def distributed_add(engine, batch, lr):
     return mean
 
 
+def train_epoch_dp(engine, x_local, b_local, lr, chunk_steps=1024, force_collective=False):
+    """One training epoch with the reference's DDP semantics (sgd_clustering.py:94-129 under is_distributed):
+    step t's global batch is the rank-major concatenation of every rank's rows [t*b_local, (t+1)*b_local), and
+    every rank applies the same update.
+
+    The SGD chain is latency-bound (each step needs the centres of the previous one), so a per-step collective
+    would cost more than the step itself.  But the ROWS of future steps do not depend on the state: they are
+    all-gathered in bulk, `chunk_steps` steps at a time (one large collective over xGMI, overlapped with the
+    training of the previous chunk), and every rank then runs the identical device-resident epoch over the global
+    batches (engine.train_epoch, b = world * b_local) -- no collective on the step path, bit-identical state on all
+    ranks, equal to distributed_add() step by step.  Only the warm-up labels (drawn from each rank's own
+    generator) travel separately: a few KB, once.
+
+    `engine`: train_epoch(x, b, lr, warm_best=), warmup_steps(b, steps), draw_warmup(b), synchronize().
+    force_collective: take the gather path even with one rank (single-GPU test of the plumbing)."""
+    rank, w = world()
+    x_local = _as_tensor(x_local)
+    n_local, d = x_local.shape
+    steps = n_local // b_local
+    if w == 1 and not force_collective:
+        engine.train_epoch(x_local, b_local, lr)
+        return
+    bg = w * b_local
+    # warm-up labels: rank r draws the labels of ITS rows; everybody needs all of them
+    need = engine.warmup_steps(bg, steps)
+    warm = None
+    if need:
+        mine = torch.stack([_as_tensor(engine.draw_warmup(b_local)).to(torch.long) for _ in range(need)])
+        mine = mine.to(x_local.device).contiguous()
+        allw = torch.empty((w * need, b_local), dtype=torch.long, device=x_local.device)  # rank-major concatenation
+        dist.all_gather_into_tensor(allw, mine)
+        warm = allw.view(w, need, b_local).permute(1, 0, 2).reshape(need, bg).cpu().numpy()  # [step, rank-major rows]
+
+    def gather(c0, s):
+        loc = x_local[c0 * b_local:(c0 + s) * b_local].contiguous()
+        g = torch.empty((w * s * b_local, d), dtype=loc.dtype, device=loc.device)  # rank-major concatenation
+        dist.all_gather_into_tensor(g, loc)
+        # [rank, step, row] -> [step, rank, row]: the global batches, contiguous
+        return g.view(w, s, b_local, d).permute(1, 0, 2, 3).reshape(s * bg, d).contiguous()
+
+    done_warm = 0
+    nxt = gather(0, min(chunk_steps, steps)) if steps else None
+    for c0 in range(0, steps, chunk_steps):
+        s = min(chunk_steps, steps - c0)
+        cur = nxt
+        engine.synchronize()  # the chunk trained before `cur` is finished: its buffer may be recycled
+        wb = None
+        nw = min(max(need - done_warm, 0), s)
+        if need:
+            wb = warm[done_warm:done_warm + nw]
+            done_warm += nw
+        engine.train_epoch(cur, bg, lr, warm_best=wb if need else None)  # asynchronous on the engine's stream
+        if c0 + s < steps:  # gather the next chunk while this one trains
+            nxt = gather(c0 + s, min(chunk_steps, steps - c0 - s))
+    engine.synchronize()
+
+
 def average_state(centers, counts):
     """KMeans.initialize(): all_reduce(SUM) then * 1/world (mps/distributed.py:139-155)."""
     rank, w = world()

@@ -183,10 +183,8 @@ def main():
         # --- update: one epoch of add() at b=32
         if world == 1:
             km.train_epoch(x, b, lr=0.01)
-        else:
-            km.lr = 0.01
-            for t in range(n // b):
-                km.add(x[t * b:(t + 1) * b])
+        else:  # reference DDP semantics: global batch = world * b rows per step; rows all-gathered in bulk
+            km.train_epoch_distributed(x, b, lr=0.01)
         # --- assign sweep, timed with HIP events on the library's own stream
         _lib.check(lib.acav_kmeans_timer_begin(km._h))
         _lib.check(lib.acav_kmeans_assign(km._h, _lib.ptr(x), n, _lib.ptr(labels), None))

@@ -34,6 +34,28 @@ class _Engine:
     def apply_update(self, x, best, lr):
         self.km.apply_update(x.numpy(), best.numpy(), lr)
 
+    # bulk surface used by train_epoch_dp
+    def warmup_steps(self, b, steps):
+        c, cnt, count, fb = self.km.get_state()
+        lim = 10 * c.shape[0]
+        return 0 if count >= lim else min(int(steps), -(-(lim - count) // int(b)))
+
+    def draw_warmup(self, b):
+        return torch.from_numpy(self.rng_labels.pop(0)[:b].copy())
+
+    def train_epoch(self, x, b, lr, warm_best=None):
+        x = x.numpy()
+        nw = 0 if warm_best is None else len(warm_best)
+        for t in range(len(x) // b):
+            xb = x[t * b:(t + 1) * b]
+            if t < nw:
+                self.km.apply_update(xb, np.asarray(warm_best[t], np.int64), lr)
+            else:
+                self.km.add(xb, lr)
+
+    def synchronize(self):
+        pass
+
 
 def _worker(rank, world, port, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -66,6 +88,17 @@ def _worker(rank, world, port, tmp):
                 ref.km.add(x[t * world * b_local:(t + 1) * world * b_local])
             rc, rcnt, rcount, _ = ref.km.get_state()
             np.savez(os.path.join(tmp, "single.npz"), c=rc, cnt=rcnt, count=rcount)
+        # bulk-gathered epoch (train_epoch_dp) == the per-step path above == single process, warm-up included
+        from acav100m_amd.parallel import train_epoch_dp
+        steps2, bl = 9, 8
+        xl = (cen[rs.randint(0, k, steps2 * bl)] + 0.3 * np.random.RandomState(100 + rank).randn(steps2 * bl, d)).astype(np.float32)
+        lab_rs = np.random.RandomState(7 + rank)
+        eng2 = _Engine(O, d, k, cen, np.zeros(k, np.float32), 0)       # count 0: the first steps are warm-up
+        eng2.rng_labels = [lab_rs.randint(0, k, bl).astype(np.int64) for _ in range(steps2)]
+        my_labels = [a.copy() for a in eng2.rng_labels]
+        train_epoch_dp(eng2, torch.from_numpy(xl), bl, 0.01, chunk_steps=4)
+        c2, cnt2, count2, _ = eng2.km.get_state()
+        np.savez(os.path.join(tmp, f"dp_rank{rank}.npz"), c=c2, cnt=cnt2, count=count2, x=xl, lab=np.stack(my_labels))
         assert list(shard_slice(7)) == list(range(rank, 7, world))
         dist.barrier()
     finally:
@@ -78,4 +111,23 @@ def test_distributed_add_two_ranks(tmp_path):
     r0, r1, s = (np.load(tmp_path / f) for f in ("rank0.npz", "rank1.npz", "single.npz"))
     assert np.array_equal(r0["c"], r1["c"]) and np.array_equal(r0["cnt"], r1["cnt"])      # ranks identical
     assert np.array_equal(r0["c"], s["c"]) and np.array_equal(r0["cnt"], s["cnt"])        # == single process
+    # train_epoch_dp: ranks identical, and equal to one process fed the rank-major global batches
+    from oracle import oracle as O
+    d0, d1 = (np.load(tmp_path / f) for f in ("dp_rank0.npz", "dp_rank1.npz"))
+    assert np.array_equal(d0["c"], d1["c"]) and np.array_equal(d0["cnt"], d1["cnt"]) and d0["count"] == d1["count"]
+    k, dd = d0["c"].shape
+    rs = np.random.RandomState(0)
+    cen = rs.randn(k, dd).astype(np.float32)
+    ref = O.KMeans(dd, k, O.Rng(0), centers=cen)
+    ref.set_state(None, np.zeros(k, np.float32), 0)
+    steps2, bl = d0["lab"].shape
+    for t in range(steps2):
+        xb = np.concatenate([d0["x"][t * bl:(t + 1) * bl], d1["x"][t * bl:(t + 1) * bl]])
+        c, cnt, count, _ = ref.get_state()
+        if count < 10 * k:
+            ref.apply_update(xb, np.concatenate([d0["lab"][t], d1["lab"][t]]), 0.01)
+        else:
+            ref.add(xb, 0.01)
+    rc, rcnt, rcount, _ = ref.get_state()
+    assert np.array_equal(d0["c"], rc) and np.array_equal(d0["cnt"], rcnt) and int(d0["count"]) == rcount
     assert int(r0["count"]) == int(s["count"])

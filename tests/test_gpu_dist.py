@@ -43,5 +43,17 @@ def test_distributed_add_world1_rccl():
             assert abs(m - m_ref) <= 1e-5 * abs(m_ref) + 1e-30
         assert np.array_equal(km.centers.numpy(), ref.centers)
         assert np.array_equal(km.counts.numpy(), ref.counts) and km.count == ref.count
+        # the bulk-gathered epoch (what bench.py --gpus N runs): all_gather_into_tensor of row chunks + warm-up
+        # labels over RCCL, then the device-resident epoch over the global batches; with one rank == plain epoch
+        from acav100m_amd.parallel import train_epoch_dp
+        d2, k2, b2, steps2 = 256, 40, 32, 100
+        x2 = (rs.randn(k2, d2)[rs.randint(0, k2, steps2 * b2)] * 3 + rs.randn(steps2 * b2, d2)).astype(np.float32)
+        acav100m_amd.manual_seed(9)
+        km2 = KMeans(args, d2, k2).to("cuda:0")
+        train_epoch_dp(km2, torch.from_numpy(x2).cuda(), b2, 0.01, chunk_steps=16, force_collective=True)
+        ref2 = O.KMeans(d2, k2, O.Rng(9))
+        ref2.train_epoch(x2, b2, 0.01)
+        assert np.array_equal(km2.centers.numpy(), ref2.centers)
+        assert np.array_equal(km2.counts.numpy(), ref2.counts) and km2.count == ref2.count
     finally:
         dist.destroy_process_group()
