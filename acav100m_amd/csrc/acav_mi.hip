@@ -15,6 +15,7 @@
 #include <cmath>
 
 #include "acav_common.h"
+#include <vector>
 
 using namespace acav;
 
@@ -250,6 +251,115 @@ __global__ __launch_bounds__(256) void k_mi_select(
     if (tid == 0) sc->nc = nc + k;
 }
 
+// ------------------------------------------------------------------- exact greedy (mi / mem_mi)
+// EfficientMI.run_greedy (mi.py:150-192): every iteration scores ALL remaining candidates and commits the
+// first maximum.  One launch per iteration: each workgroup scores 256 candidates and reduces them to one
+// (score, position) pair, ordered by (score descending, position ascending) -- removal keeps the order of the
+// rest, so "first among the remaining" is "smallest original position".  The last workgroup to arrive
+// (device-scope ticket) reduces the block results, commits the winner to the tables, marks it removed and emits
+// S / GAIN.  forced: commit this original position instead (teacher forcing).
+struct ExactBest {
+    double s;
+    int pos;
+    int pad;
+};
+__device__ __forceinline__ bool exact_better(double s, int p, double so, int po)
+{
+    return so > s || (so == s && po < p);  // candidate (so, po) beats (s, p)
+}
+
+__global__ __launch_bounds__(256) void k_mi_exact_iter(
+    const int *__restrict__ asg, int D, int C, int P, const int *__restrict__ pairs, const int *__restrict__ A, int L,
+    unsigned char *__restrict__ removed, int *__restrict__ Nc, int *__restrict__ ac, int *__restrict__ bc,
+    double *__restrict__ SN, double *__restrict__ Sa, double *__restrict__ Sb, const double *__restrict__ phi,
+    MiScalars *__restrict__ sc, ExactBest *__restrict__ blockbest, unsigned *__restrict__ ticket,
+    long long *__restrict__ S_out, double *__restrict__ G_out, const int *__restrict__ forced,
+    double *__restrict__ trace_scores, int *__restrict__ trace_argmax)
+{
+    __shared__ double sS[4];
+    __shared__ int sP[4];
+    __shared__ int sLast;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = blockIdx.x * 256 + tid;
+    const long long nc = sc->nc;
+    double s = -INFINITY;
+    int pos = 0x7fffffff;
+    if (w < L && !removed[w]) {
+        const int id = A[w];
+        double tot = 0.0;
+        for (int p = 0; p < P; ++p) tot = tot + mi_pair_score(asg, D, C, p, pairs, id, Nc, ac, bc, SN, Sa, Sb, phi, nc);
+        s = tot / (double)P;
+        pos = w;
+    }
+    if (trace_scores && w < L) trace_scores[w] = pos == w ? s : (double)NAN;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const double so = __shfl_xor(s, dlt);
+        const int po = __shfl_xor(pos, dlt);
+        if (exact_better(s, pos, so, po)) s = so, pos = po;
+    }
+    if (lane == 0) sS[wave] = s, sP[wave] = pos;
+    __syncthreads();
+    if (tid == 0) {
+        for (int q = 1; q < 4; ++q)
+            if (exact_better(s, pos, sS[q], sP[q])) s = sS[q], pos = sP[q];
+        blockbest[blockIdx.x].s = s;
+        blockbest[blockIdx.x].pos = pos;
+        __threadfence();  // the result is visible device-wide before the ticket is taken
+        const unsigned t = atomicAdd(ticket, 1u);
+        sLast = (t == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!sLast) return;  // uniform
+    __threadfence();
+    s = -INFINITY, pos = 0x7fffffff;
+    for (int q = tid; q < (int)gridDim.x; q += 256) {
+        const double so = __hip_atomic_load(&blockbest[q].s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int po = __hip_atomic_load(&blockbest[q].pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (exact_better(s, pos, so, po)) s = so, pos = po;
+    }
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const double so = __shfl_xor(s, dlt);
+        const int po = __shfl_xor(pos, dlt);
+        if (exact_better(s, pos, so, po)) s = so, pos = po;
+    }
+    if (lane == 0) sS[wave] = s, sP[wave] = pos;
+    __syncthreads();
+    if (tid == 0) {
+        for (int q = 1; q < 4; ++q)
+            if (exact_better(s, pos, sS[q], sP[q])) s = sS[q], pos = sP[q];
+        if (trace_argmax) *trace_argmax = pos;
+        if (forced) {
+            pos = *forced;
+            double tot = 0.0;
+            for (int p = 0; p < P; ++p)
+                tot = tot + mi_pair_score(asg, D, C, p, pairs, A[pos], Nc, ac, bc, SN, Sa, Sb, phi, nc);
+            s = tot / (double)P;
+        }
+        sP[0] = pos;
+        *S_out = (long long)A[pos];
+        *G_out = s;
+        removed[pos] = 1;
+        *ticket = 0u;
+        sc->nc = nc + 1;
+    }
+    __syncthreads();
+    const int id = A[sP[0]];
+    for (int p = tid; p < P; p += 256) {  // update_cache: one pick
+        const int *row = asg + (size_t)id * D;
+        const int i = row[pairs[2 * p]], j = row[pairs[2 * p + 1]];
+        const size_t cell = ((size_t)p * C + i) * C + j;
+        const int cN = Nc[cell], ca = ac[(size_t)p * C + j], cb = bc[(size_t)p * C + i];
+        Nc[cell] = cN + 1;
+        ac[(size_t)p * C + j] = ca + 1;
+        bc[(size_t)p * C + i] = cb + 1;
+        SN[p] = SN[p] - phi[cN] + phi[cN + 1];
+        Sa[p] = Sa[p] - phi[ca] + phi[ca + 1];
+        Sb[p] = Sb[p] - phi[cb] + phi[cb + 1];
+    }
+}
+
 // ------------------------------------------------------------------------------ MT19937
 // Continues torch's CPU generator stream on the device: mt[624] + idx in global memory, one
 // workgroup.  A block of 624 words is regenerated in three dependent phases (k<227, <454, <624).
@@ -430,6 +540,7 @@ struct acav_mi {
     DevBuf stage, ids32, scores;
     // greedy buffers
     DevBuf A0, A1, draws, draws2, h, head, head2, next, g, g2, mt, batch, S, G, tr_pos, tr_ids, tr_sc, forced;
+    DevBuf removed, blockbest, ticket, tr_am;  // exact greedy
     // the mt19937 stream does not depend on the selection state: it is generated one iteration ahead on
     // its own stream (double-buffered draws), overlapping the Fisher-Yates / select kernels
     hipStream_t st_mt = nullptr;
@@ -550,6 +661,71 @@ ACAV_EXPORT int acav_mi_destroy(acav_mi *mi)
     delete mi;
     return ACAV_OK;
 }
+ACAV_EXPORT int acav_mi_run_exact(acav_mi *mi, const int64_t *candidates, int64_t L, int ns, int64_t subset,
+                                  int64_t *S_out, double *GAIN_out, int64_t *n_selected, const int64_t *forced_pos,
+                                  double *trace_scores, int64_t *trace_argmax)
+{
+    ACAV_REQUIRE(mi && candidates && S_out && GAIN_out && n_selected, ACAV_EINVAL, "NULL argument");
+    ACAV_REQUIRE(L > 0 && L < 0x7fffffff && ns >= 0, ACAV_EINVAL, "bad candidate count %lld", (long long)L);
+    ACAV_HIP_TRY(hipSetDevice(mi->ctx.device));
+    hipStream_t st = mi->ctx.stream;
+    int64_t iters = subset - 1 - ns;  // range(len(start_indices), subset_size - 1)   (mi.py:161)
+    if (iters < 0) iters = 0;
+    if (iters > L) iters = L;
+    *n_selected = iters;
+    if (iters == 0) return ACAV_OK;
+    for (int64_t i = 0; i < L; ++i)
+        ACAV_REQUIRE(candidates[i] >= 0 && candidates[i] < mi->V, ACAV_EINVAL, "candidate id %lld outside [0, %lld)",
+                     (long long)candidates[i], (long long)mi->V);
+    if (forced_pos)
+        for (int64_t i = 0; i < iters; ++i)
+            ACAV_REQUIRE(forced_pos[i] >= 0 && forced_pos[i] < L, ACAV_EINVAL, "forced position out of range");
+    const unsigned grid = (unsigned)((L + 255) / 256);
+    ACAV_TRY(mi->A0.ensure(sizeof(int) * (size_t)L));
+    ACAV_TRY(ids_to_device32(mi, candidates, L, mi->stage, mi->A0));
+    ACAV_TRY(mi->removed.ensure((size_t)L));
+    ACAV_TRY(mi->blockbest.ensure(sizeof(ExactBest) * grid));
+    ACAV_TRY(mi->ticket.ensure(sizeof(unsigned)));
+    ACAV_TRY(mi->S.ensure(sizeof(long long) * (size_t)iters));
+    ACAV_TRY(mi->G.ensure(sizeof(double) * (size_t)iters));
+    ACAV_HIP_TRY(hipMemsetAsync(mi->removed.p, 0, (size_t)L, st));
+    ACAV_HIP_TRY(hipMemsetAsync(mi->ticket.p, 0, sizeof(unsigned), st));
+    if (forced_pos) {
+        std::vector<int> f32((size_t)iters);
+        for (int64_t i = 0; i < iters; ++i) f32[(size_t)i] = (int)forced_pos[i];
+        ACAV_TRY(mi->forced.ensure(sizeof(int) * (size_t)iters));
+        ACAV_HIP_TRY(hipMemcpyAsync(mi->forced.p, f32.data(), sizeof(int) * (size_t)iters, hipMemcpyHostToDevice, st));
+        ACAV_HIP_TRY(hipStreamSynchronize(st));  // f32 is a local
+    }
+    if (trace_scores) ACAV_TRY(mi->tr_sc.ensure(sizeof(double) * (size_t)iters * (size_t)L));
+    if (trace_argmax) ACAV_TRY(mi->tr_am.ensure(sizeof(int) * (size_t)iters));
+    for (int64_t it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL(k_mi_exact_iter, dim3(grid), dim3(256), 0, st, mi->asg.as<int>(), mi->D, mi->C, mi->P,
+                           mi->pairs.as<int>(), mi->A0.as<int>(), (int)L, mi->removed.as<unsigned char>(), mi->Nc.as<int>(),
+                           mi->ac.as<int>(), mi->bc.as<int>(), mi->SN.as<double>(), mi->Sa.as<double>(), mi->Sb.as<double>(),
+                           mi->phi.as<double>(), mi->scalars.as<MiScalars>(), mi->blockbest.as<ExactBest>(),
+                           mi->ticket.as<unsigned>(), mi->S.as<long long>() + it, mi->G.as<double>() + it,
+                           forced_pos ? mi->forced.as<int>() + it : nullptr,
+                           trace_scores ? mi->tr_sc.as<double>() + (size_t)it * (size_t)L : nullptr,
+                           trace_argmax ? mi->tr_am.as<int>() + it : nullptr);
+    }
+    ACAV_HIP_TRY(hipGetLastError());
+    ACAV_HIP_TRY(hipMemcpyAsync(S_out, mi->S.p, sizeof(long long) * (size_t)iters, hipMemcpyDeviceToHost, st));
+    ACAV_HIP_TRY(hipMemcpyAsync(GAIN_out, mi->G.p, sizeof(double) * (size_t)iters, hipMemcpyDeviceToHost, st));
+    if (trace_scores)
+        ACAV_HIP_TRY(hipMemcpyAsync(trace_scores, mi->tr_sc.p, sizeof(double) * (size_t)iters * (size_t)L,
+                                    hipMemcpyDeviceToHost, st));
+    std::vector<int> am;
+    if (trace_argmax) {
+        am.resize((size_t)iters);
+        ACAV_HIP_TRY(hipMemcpyAsync(am.data(), mi->tr_am.p, sizeof(int) * (size_t)iters, hipMemcpyDeviceToHost, st));
+    }
+    ACAV_HIP_TRY(hipStreamSynchronize(st));
+    if (trace_argmax)
+        for (int64_t i = 0; i < iters; ++i) trace_argmax[i] = am[(size_t)i];
+    return ACAV_OK;
+}
+
 ACAV_EXPORT int acav_mi_sync(acav_mi *mi)
 {
     ACAV_REQUIRE(mi, ACAV_EINVAL, "handle is NULL");

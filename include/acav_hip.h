@@ -141,6 +141,16 @@ int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64_t L, const 
                        int64_t subset, int B, int k, int keep_unselected, acav_rng *rng, int64_t *S_out,
                        double *GAIN_out, int64_t *n_selected, int64_t *n_iters, int64_t *trace_ids,
                        double *trace_scores, int32_t *trace_pos, const int32_t *forced_pos, int64_t max_iters);
+/* EfficientMI.run_greedy / EfficientMemMI (measures/mi.py:150-192; 'mi' and 'mem_mi' of measures/__init__.py:5-14):
+ * the exact greedy.  Each of the subset - 1 - ns iterations scores ALL remaining candidates (mi.py:108-110),
+ * commits the first maximum (scores.max(dim=0), mi.py:79) and removes it, keeping the order of the rest.  The ns
+ * start indices are NOT added to the tables (mi.py never does; batch.py does) -- they only shorten the loop.
+ * S_out / GAIN_out hold *n_selected = max(0, min(subset - 1 - ns, L)) entries (the picks after the start indices).
+ * Optional (host): forced_pos [iters] = ORIGINAL positions (index into candidates) to commit instead of the argmax;
+ * trace_scores [iters, L] = canonical scores by original position (NaN once removed); trace_argmax [iters]. */
+int acav_mi_run_exact(acav_mi *mi, const int64_t *candidates, int64_t L, int ns, int64_t subset, int64_t *S_out,
+                      double *GAIN_out, int64_t *n_selected, const int64_t *forced_pos, double *trace_scores,
+                      int64_t *trace_argmax);
 int acav_mi_get_counts(acav_mi *mi, int32_t *N, int32_t *a, int32_t *b, int64_t *n);
 int acav_mi_sync(acav_mi *mi);
 int acav_mi_timer_begin(acav_mi *mi);

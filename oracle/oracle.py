@@ -61,6 +61,7 @@ def lib():
             "orc_mi_scores_canon": (None, [vp, vp, i32, vp]),
             "orc_topk_desc": (None, [vp, i32, i32, vp]),
             "orc_mi_run_greedy": (i64, [vp, vp, i64, vp, i32, i64, i32, i32, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp]),
+            "orc_mi_run_exact": (i64, [vp, vp, i64, vp, i32, i64, vp, vp, vp, vp, vp]),
             "orc_mi_get_counts": (None, [vp, vp, vp, vp, vp]),
         }
         for name, (res, args) in sig.items():
@@ -264,6 +265,25 @@ class BatchMI:
         res = dict(S=S[:n].copy(), GAIN=G[:nit * k].copy(), iters=nit)  # S is cut (batch.py:258), GAIN is not
         if trace:
             res.update(ids=t_ids[:nit], scores=t_sc[:nit], pos=t_pos[:nit])
+        return res
+
+
+    def run_exact(self, candidates, start, subset, forced_idx=None, trace=False):
+        """EfficientMI / EfficientMemMI exact greedy (mi.py:150-192): S holds the picks AFTER the start indices."""
+        cand, start = _i64(candidates), _i64(start)
+        niter = max(int(subset) - 1 - len(start), 0)
+        S = np.empty(niter + 1, np.int64)
+        G = np.empty(niter + 1, np.float64)
+        fi = None if forced_idx is None else _i64(forced_idx)
+        if fi is not None:
+            assert len(fi) >= min(niter, len(cand))
+        t_sc = np.empty((niter, len(cand)), np.float64) if trace else None
+        t_am = np.empty(niter + 1, np.int64) if trace else None
+        n = lib().orc_mi_run_exact(self.h, _p(cand), len(cand), _p(start), len(start), int(subset), _p(S), _p(G),
+                                   _p(fi), _p(t_sc), _p(t_am))
+        res = dict(S=S[:n].copy(), GAIN=G[:n].copy(), iters=int(n))
+        if trace:
+            res.update(scores=t_sc[:n], argmax=t_am[:n].copy())
         return res
 
 

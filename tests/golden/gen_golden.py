@@ -7,7 +7,7 @@ this script and the tiny stand-in modules under _stubs/ for the reference's un-v
 imports (torch_scatter, diffdist, wget, braceexpand).
 
     python tests/golden/gen_golden.py            # all three groups
-    python tests/golden/gen_golden.py kmeans|mi|rng|cli
+    python tests/golden/gen_golden.py kmeans|mi|mi_exact|rng|cli
 
 Groups:
   rng.npz     torch.manual_seed/rand/randperm and random.shuffle streams (G6)
@@ -200,6 +200,70 @@ def gen_mi():
         np.savez_compressed(os.path.join(HERE, f"mi_{name}.npz"), **out)
         print(f"mi_{name}.npz written: {len(S)} selected in {len(rec['ids'])} iterations")
 
+# --------------------------------------------------------------------- mi / mem_mi (exact greedy)
+def gen_mi_exact():
+    """reference `mi` (EfficientMI, dense fp32 tensors) and `mem_mi` (EfficientMemMI, running fp32 nlogn sums):
+    every iteration scores ALL remaining candidates and takes the first maximum (mi.py:76-114,150-192)."""
+    sys.path.insert(0, os.path.join(REF, "subset_selection", "code"))
+    import torch
+    import run_greedy as ref_run_greedy  # noqa: E402  (the reference)
+    from measures.mi import EfficientMI  # noqa: E402
+
+    cases = {
+        # name: (seed, V, D, C, subset)
+        "a": (0, 300, 2, 8, 60),
+        "b": (1, 240, 3, 6, 50),
+        "c": (2, 500, 2, 16, 40),
+    }
+    for name, (seed, v, dd, c, subset) in cases.items():
+        rs = np.random.RandomState(300 + seed)
+        comp = rs.randint(0, c, size=v)
+        cols = []
+        for _ in range(dd):
+            indep = rs.randint(0, c, size=v)
+            share = rs.rand(v) < 0.5
+            cols.append(np.where(share, comp, indep))
+        assignments = np.stack(cols, 1).astype(np.int64)
+        assignments[0, :] = c - 1
+        types = [("m%d" % i, "layer_0") for i in range(dd)]
+        out = dict(assignments=assignments, seed=seed, C=c, subset=subset)
+        for measure in ("mi", "mem_mi"):
+            rec = dict(scores=[], idx=[])
+            orig = EfficientMI.calc_score
+
+            def calc_score(self, *a, **k):
+                sc = self._calc_score(*a, **k).mean(dim=-1)
+                score, idx = sc.max(dim=0)
+                rec["scores"].append(sc.cpu().numpy().astype(np.float32).copy())
+                rec["idx"].append(int(idx.item()))
+                return score.item(), idx.item()
+
+            EfficientMI.calc_score = calc_score
+            args = _NS(batch=_NS(batch_size=20, selection_size=4, keep_unselected=True),
+                       computation=_NS(device="cpu"), log_every=10 ** 9, log_times=None,
+                       node_rank=None, parent_pid=None)
+            random.seed(seed)
+            torch.manual_seed(seed)
+            S, GAIN, _ = ref_run_greedy._run_greedy(args, assignments, types, subset, None, measure,
+                                                    "combination", True, False)
+            EfficientMI.calc_score = orig
+            w0 = len(rec["scores"][0])
+            sc = np.full((len(rec["scores"]), w0), np.nan, np.float32)  # iteration t scores the W0 - t remaining
+            for t, row in enumerate(rec["scores"]):
+                sc[t, :len(row)] = row
+            out[f"{measure}_S"] = np.array(S, np.int64)
+            out[f"{measure}_GAIN"] = np.array(GAIN, np.float64)
+            out[f"{measure}_scores"] = sc
+            out[f"{measure}_idx"] = np.array(rec["idx"], np.int64)
+        random.seed(seed)
+        cand = list(range(v))
+        random.shuffle(cand)
+        out["shuffled"] = np.array(cand, np.int64)
+        same = float(np.mean(out["mi_S"] == out["mem_mi_S"]))
+        np.savez_compressed(os.path.join(HERE, f"mi_exact_{name}.npz"), **out)
+        print(f"mi_exact_{name}.npz written: {len(out['mi_S'])} selected; mi vs mem_mi S equivalence {same:.3f}, "
+              f"GAIN diff max {np.abs(out['mi_GAIN'] - out['mem_mi_GAIN']).max():.3e}")
+
 
 # ----------------------------------------------------------------------------- cli
 def gen_cli_clustering(root):
@@ -272,9 +336,9 @@ if __name__ == "__main__":
     if sys.argv[1:2] == ["cli_subset"]:
         gen_cli_subset(sys.argv[2])
         sys.exit(0)
-    which = sys.argv[1:] or ["rng", "kmeans", "mi", "cli"]
+    which = sys.argv[1:] or ["rng", "kmeans", "mi", "mi_exact", "cli"]
     if len(which) > 1:
         for w in which:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
-        {"rng": gen_rng, "kmeans": gen_kmeans, "mi": gen_mi, "cli": gen_cli}[which[0]]()
+        {"rng": gen_rng, "kmeans": gen_kmeans, "mi": gen_mi, "mi_exact": gen_mi_exact, "cli": gen_cli}[which[0]]()

@@ -150,3 +150,97 @@ def test_mi_errors(env):
         bad = a.copy()
         bad[3, 0] = 9
         _measure(bad, 4, [(0, 1)], list(range(1, 50)))
+
+
+# ------------------------------------------------------------------ exact greedy ('mi' / 'mem_mi')
+def _remaining_to_original(idx, L):
+    """positions in the shrinking list (what the reference records) -> positions in the initial list"""
+    alive = list(range(L))
+    return np.array([alive.pop(int(i)) for i in idx], np.int64)
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+@pytest.mark.parametrize("measure", ["mi", "mem_mi"])
+def test_exact_greedy_golden_teacher_forced(env, golden_dir, name, measure):
+    """HIP exact greedy replaying the reference's recorded picks: S / GAIN / per-iteration score vectors equal the
+    oracle's bit for bit, hence (test_oracle_golden) the reference's to 2e-6 with its picks inside exact ties."""
+    torch, acav, O = env
+    from acav100m_amd.subset_selection import get_measure
+    g = np.load(os.path.join(golden_dir, f"mi_exact_{name}.npz"))
+    a, c, subset, cand = g["assignments"], int(g["C"]), int(g["subset"]), g["shuffled"]
+    pairs = list(itertools.combinations(range(a.shape[1]), 2))
+    idx = g[f"{measure}_idx"]
+    L = len(cand) - 1
+    m = get_measure(measure)(a, ncentroids=c, batch_size=20, selection_size=4, device="cuda:0", keep_unselected=True)
+    m.init(pairs, [int(i) for i in cand[1:]])
+    S, GAIN, timelapse, lookups = m.run_greedy(subset, [int(cand[0])], None, record_trace=True,
+                                               forced_pos=_remaining_to_original(idx, L))
+    assert S == g[f"{measure}_S"].tolist() and len(GAIN) == len(timelapse) == len(lookups) == subset - 2
+    ref = O.BatchMI(a, c, pairs).run_exact(cand[1:], cand[:1], subset, forced_idx=idx, trace=True)
+    assert np.array_equal(np.array(GAIN), ref["GAIN"])  # float64, bit for bit
+    alive = list(range(L))
+    for t in range(subset - 2):
+        row = m.trace["scores"][t]
+        assert np.array_equal(row[alive], ref["scores"][t, :len(alive)])
+        dead = np.setdiff1d(np.arange(L), alive)
+        assert np.isnan(row[dead]).all()
+        assert m.trace["argmax"][t] == alive[int(ref["argmax"][t])]
+        alive.pop(int(idx[t]))
+    assert len(m.candidate_ids) == L - (subset - 2)
+
+
+@pytest.mark.parametrize("v,dd,c,subset,pairing", [(3000, 2, 16, 200, "combination"), (1500, 4, 40, 120, "combination"),
+                                                    (5000, 10, 12, 60, "bipartite"), (700, 3, 300, 90, "combination")])
+def test_exact_greedy_free_running_equals_oracle(env, v, dd, c, subset, pairing):
+    """free-running: same picks in the same order, identical float64 gains (first-maximum rule, ties included --
+    many candidates share an assignment row, so exact ties are the norm); D=10 views with the reference's
+    bipartite pairing (P=25) as in the real 5+5-layer pipeline; C > 256."""
+    torch, acav, O = env
+    from acav100m_amd.subset_selection import get_measure
+    from acav100m_amd.subset_selection.pairing import get_cluster_pairing
+    a = _correlated(50 + v, v, dd, c)
+    keys = [("audio" if i < dd // 2 else "video", f"layer_{i}") for i in range(dd)]
+    pairs = get_cluster_pairing(keys, pairing) if pairing != "combination" else list(itertools.combinations(range(dd), 2))
+    rs = np.random.RandomState(v)
+    cand = rs.permutation(v)
+    m = get_measure("mem_mi")(a, ncentroids=c, device="cuda:0")
+    m.init(pairs, [int(i) for i in cand[1:]])
+    S, GAIN, _, _ = m.run_greedy(subset, [int(cand[0])])
+    ref = O.BatchMI(a, c, pairs).run_exact(cand[1:], cand[:1], subset)
+    assert S[0] == cand[0] and S[1:] == ref["S"].tolist() and len(S) == subset - 1
+    assert np.array_equal(np.array(GAIN), ref["GAIN"])
+    assert len(set(S)) == len(S)
+    # the tables hold exactly the picks (the start index is not added: mi.py never does)
+    om = O.BatchMI(a, c, pairs)
+    om.add_samples(np.array(S[1:], np.int64))
+    Nc, ac, bc, nc = om.counts()
+    cache = m.cache
+    assert np.array_equal(cache["N"], Nc) and np.array_equal(cache["a"], ac) and np.array_equal(cache["b"], bc)
+    assert cache["n"] == nc == subset - 2
+
+
+def test_exact_greedy_through_run_greedy(env):
+    """run_greedy._run_greedy(measure_name='mi') end to end, and the edge cases of the loop bounds (mi.py:161)"""
+    torch, acav, O = env
+    import random
+    import importlib
+    rg = importlib.import_module("acav100m_amd.subset_selection.run_greedy")
+    from acav100m_amd.config import Namespace
+    a = _correlated(3, 400, 2, 8)
+    args = Namespace(batch=Namespace(batch_size=20, selection_size=4, keep_unselected=True),
+                     computation=Namespace(device="cuda"), log_every=10 ** 9, log_times=None, node_rank=None,
+                     parent_pid=None)
+    random.seed(5)
+    S, GAIN, _ = rg._run_greedy(args, a, [("m0", "layer_0"), ("m1", "layer_0")], 30, None, "mi", "combination", True, False)
+    random.seed(5)
+    cand = list(range(400))
+    random.shuffle(cand)
+    ref = O.BatchMI(a, 8, [(0, 1)]).run_exact(np.array(cand[1:]), np.array(cand[:1]), 30)
+    assert S == [cand[0]] + ref["S"].tolist() and np.array_equal(np.array(GAIN), ref["GAIN"])
+    from acav100m_amd.subset_selection import get_measure
+    m = get_measure("mi")(a, ncentroids=8, device="cuda:0")
+    m.init([(0, 1)], cand[1:])
+    assert m.run_greedy(2, [cand[0]])[0] == [cand[0]]          # subset - 1 - ns = 0 iterations
+    assert m.run_greedy(1, [cand[0]])[0] == [cand[0]]
+    S_all = m.run_greedy(10 ** 6, [cand[0]])[0]                # more than there are candidates: everything, once
+    assert sorted(S_all) == list(range(400))

@@ -161,3 +161,33 @@ def test_canonical_arithmetic_definitions():
         ss = ((gq[0] + gq[1]) + (gq[2] + gq[3])) + ((gq[4] + gq[5]) + (gq[6] + gq[7]))
         assert O.sumsq(v) == float(ss)
         assert O.norm2(v) == float(np.float32(np.sqrt(np.float32(ss))) ** 2)
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+@pytest.mark.parametrize("measure", ["mi", "mem_mi"])
+def test_mi_exact_greedy_golden(golden_dir, name, measure):
+    """'mi' / 'mem_mi' (measures/mi.py:150-192, 284-412): exact greedy, all remaining candidates scored per
+    iteration, first maximum committed.  The reference's two formulations already disagree with each other on
+    near-ties, so the pin is teacher-forced: replaying the reference's picks, (1) the canonical float64 scores equal
+    its fp32 score vectors to 2e-6 absolute at every iteration, (2) every pick of the reference IS a canonical
+    maximum (gap <= 1e-12: it only ever differs inside exact ties of the canonical score), (3) S and GAIN follow."""
+    g = np.load(os.path.join(golden_dir, f"mi_exact_{name}.npz"))
+    a, c, subset, cand = g["assignments"], int(g["C"]), int(g["subset"]), g["shuffled"]
+    pairs = list(itertools.combinations(range(a.shape[1]), 2))
+    idx, ref_sc = g[f"{measure}_idx"], g[f"{measure}_scores"]
+    r = O.BatchMI(a, c, pairs).run_exact(cand[1:], cand[:1], subset, forced_idx=idx, trace=True)
+    n = subset - 2
+    assert r["iters"] == n == len(idx)
+    assert np.array_equal(r["S"], g[f"{measure}_S"][1:]) and g[f"{measure}_S"][0] == cand[0]
+    assert np.allclose(r["GAIN"], g[f"{measure}_GAIN"], rtol=0, atol=2e-6)
+    for t in range(n):
+        L = ref_sc.shape[1] - t
+        mine = r["scores"][t, :L]
+        assert np.isnan(r["scores"][t, L:]).all() and np.isnan(ref_sc[t, L:]).all()
+        assert np.max(np.abs(mine - ref_sc[t, :L].astype(np.float64))) <= 2e-6
+        assert mine.max() - mine[idx[t]] <= 1e-12 * max(1.0, abs(mine.max()))
+        assert r["argmax"][t] == int(np.argmax(mine))  # first maximum
+    # free-running: the tie-free mem_mi runs are reproduced exactly
+    if measure == "mem_mi" and name in ("a", "b"):
+        free = O.BatchMI(a, c, pairs).run_exact(cand[1:], cand[:1], subset)
+        assert np.array_equal(free["S"], g["mem_mi_S"][1:])
