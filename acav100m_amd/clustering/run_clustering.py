@@ -156,7 +156,10 @@ def assign_clusters(args, table, resident, cl, shard_names):
         size = table.shard_size[ids[0]] if ids else 0
         if len(ids) < round(size * args.data.output.shard_ok_ratio):
             continue  # too incomplete to save (:261-268)
-        io.dump_pickle(io.assignment_rows(table, labels, ids), out_path)
+        rows = io.assignment_rows(table, labels, ids)
+        io.dump_pickle(rows, out_path)
+        if io.sidecar_mode() == 'write':  # columnar twin for our own subset-selection loader (opt-in: extra files)
+            io.write_assignment_sidecar(out_path, rows)
         saved.append(out_path)
     return saved
 

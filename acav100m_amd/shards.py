@@ -116,39 +116,141 @@ class FeatureTable:
         return len(self.filename)
 
 
-def load_feature_shards(paths, model_order=None, audio_models=()):
+# ------------------------------------------------------------------ columnar sidecars
+# The pkl shard (a list of per-row dicts of small numpy vectors) stays THE contract: it is what the upstream
+# feature extractor writes and what the reference reads.  But unpickling + per-row dict walking is the wall-clock
+# floor of a run once the kernels are fast (~45 us per row and view), so a shard can carry a columnar twin next to
+# it:   <stem>.cols/meta.json + v<i>.npy  (one float32 [rows, d] matrix per view, memory-mapped on load).
+# A sidecar is only trusted while the pkl's size and mtime match what meta.json recorded.
+SIDECAR_VERSION = 1
+
+
+def sidecar_mode(mode=None):
+    """'off' (never look), 'auto' (use a valid sidecar, never write: default), 'write' (also build missing ones)."""
+    mode = (mode or os.environ.get('ACAV_SHARD_SIDECAR', 'auto')).lower()
+    if mode not in ('off', 'auto', 'write'):
+        raise ValueError("sidecar mode must be off|auto|write, not {!r}".format(mode))
+    return mode
+
+
+def _source_stamp(path):
+    st = os.stat(path)
+    return {'size': st.st_size, 'mtime_ns': st.st_mtime_ns}
+
+
+def feature_sidecar_dir(path):
+    path = Path(path)
+    return path.with_name(path.stem + '.cols')
+
+
+def _shard_columns_from_rows(rows, stem):
+    """per-row dicts -> {'filename','shard_name','shard_size', 'views': OrderedDict[(kind,mk,layer)] -> [n,d], 'tags'}"""
+    out = {'filename': [], 'shard_name': [], 'shard_size': [], 'views': OrderedDict(), 'tags': OrderedDict()}
+    cols = OrderedDict()
+    for row in rows:
+        out['filename'].append(row['filename'])
+        out['shard_name'].append(row.get('shard_name', stem))
+        out['shard_size'].append(row.get('shard_size', len(rows)))
+        for kind, key in (('audio', 'audio_features'), ('video', 'video_features')):
+            for feat in row.get(key, []):
+                mk = feat['model_key']
+                out['tags'].setdefault((kind, mk), (feat.get('extractor_name'), feat.get('dataset')))
+                for layer, vec in _layers_of(feat['array']):
+                    cols.setdefault((kind, mk, layer), []).append(np.asarray(vec, dtype=np.float32))
+    n = len(out['filename'])
+    for view, vecs in cols.items():
+        if len(vecs) != n:
+            raise ValueError(f"view {view} is missing in {n - len(vecs)} rows of shard {stem}")
+        out['views'][view] = np.stack(vecs, 0) if n else np.zeros((0, 0), np.float32)
+    return out
+
+
+def write_feature_sidecar(path, columns=None):
+    """Build <stem>.cols/ for the pkl shard at `path` (atomically: temp dir + rename).  Returns the directory."""
+    path = Path(path)
+    if columns is None:
+        columns = _shard_columns_from_rows(load_pickle(path), path.stem)
+    final = feature_sidecar_dir(path)
+    tmp = final.with_name(final.name + '.tmp{}'.format(os.getpid()))
+    tmp.mkdir(parents=True, exist_ok=True)
+    views = []
+    for i, (view, mat) in enumerate(columns['views'].items()):
+        np.save(tmp / 'v{}.npy'.format(i), np.ascontiguousarray(mat, np.float32))
+        views.append(list(view) + [int(mat.shape[1]) if mat.ndim == 2 else 0])
+    meta = {'version': SIDECAR_VERSION, 'source': _source_stamp(path), 'rows': len(columns['filename']),
+            'filename': list(columns['filename']), 'shard_name': list(columns['shard_name']),
+            'shard_size': [int(x) for x in columns['shard_size']], 'views': views,
+            'tags': [[k[0], k[1], v[0], v[1]] for k, v in columns['tags'].items()]}
+    dump_json(meta, tmp / 'meta.json')
+    if final.exists():
+        import shutil
+        shutil.rmtree(final)
+    os.rename(tmp, final)
+    return final
+
+
+def read_feature_sidecar(path):
+    """-> columns dict (views memory-mapped) or None when there is no sidecar or it is stale / unreadable."""
+    d = feature_sidecar_dir(path)
+    try:
+        meta = load_json(d / 'meta.json')
+        if meta.get('version') != SIDECAR_VERSION or meta.get('source') != _source_stamp(path):
+            return None
+        out = {'filename': meta['filename'], 'shard_name': meta['shard_name'], 'shard_size': meta['shard_size'],
+               'views': OrderedDict(), 'tags': OrderedDict()}
+        for kind, mk, name, dataset in meta['tags']:
+            out['tags'][(kind, mk)] = (name, dataset)
+        for i, (kind, mk, layer, dim) in enumerate(meta['views']):
+            mat = np.load(d / 'v{}.npy'.format(i), mmap_mode='r')
+            if mat.dtype != np.float32 or mat.shape != (meta['rows'], dim):
+                return None
+            out['views'][(kind, mk, layer)] = mat
+        return out
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def load_feature_shards(paths, model_order=None, audio_models=(), sidecar=None):
     """Read shards in the given order (training order of a single-stream loader: sorted shards,
     rows in file order -- clustering data/clustering.py:153-186 with num_workers=0).
-    Corrupt shards are reported and skipped like the reference does (:167-182)."""
+    Corrupt shards are reported and skipped like the reference does (:167-182).
+    sidecar: see sidecar_mode(); a valid columnar twin of a shard replaces its unpickling."""
+    mode = sidecar_mode(sidecar)
     table = FeatureTable()
-    cols = OrderedDict()
+    parts = OrderedDict()
     for path in paths:
         path = Path(path)
-        try:
-            rows = load_pickle(path)
-        except Exception as exc:  # EOFError and friends
-            print(exc)
-            print('Exception in shard loading: {}'.format(path.stem))
-            continue
-        ids = []
-        for row in rows:
-            ids.append(len(table.filename))
-            table.filename.append(row['filename'])
-            table.shard_name.append(row.get('shard_name', path.stem))
-            table.shard_size.append(row.get('shard_size', len(rows)))
-            for kind, key in (('audio', 'audio_features'), ('video', 'video_features')):
-                for feat in row.get(key, []):
-                    mk = feat['model_key']
-                    table.tags.setdefault((kind, mk), (feat.get('extractor_name'), feat.get('dataset')))
-                    for layer, vec in _layers_of(feat['array']):
-                        cols.setdefault((kind, mk, layer), []).append(np.asarray(vec, dtype=np.float32))
-        table.shard_rows[path.stem] = ids
+        columns = read_feature_sidecar(path) if mode != 'off' else None
+        if columns is None:
+            try:
+                rows = load_pickle(path)
+            except Exception as exc:  # EOFError and friends
+                print(exc)
+                print('Exception in shard loading: {}'.format(path.stem))
+                continue
+            columns = _shard_columns_from_rows(rows, path.stem)
+            if mode == 'write':
+                try:
+                    write_feature_sidecar(path, columns)
+                except OSError as exc:  # read-only data directory: the pkl path still works
+                    print('could not write the sidecar of {}: {}'.format(path.stem, exc))
+        base = len(table.filename)
+        n = len(columns['filename'])
+        table.filename.extend(columns['filename'])
+        table.shard_name.extend(columns['shard_name'])
+        table.shard_size.extend(columns['shard_size'])
+        for key, tag in columns['tags'].items():
+            table.tags.setdefault(key, tag)
+        for view, mat in columns['views'].items():
+            parts.setdefault(view, []).append((base, mat))
+        table.shard_rows[path.stem] = list(range(base, base + n))
     n = len(table)
-    order = sorted(cols, key=lambda v: _view_rank(v, model_order, audio_models))
+    order = sorted(parts, key=lambda v: _view_rank(v, model_order, audio_models))
     for view in order:
-        if len(cols[view]) != n:
-            raise ValueError(f"view {view} is missing in {n - len(cols[view])} rows")
-        table.views[view] = np.stack(cols[view], 0) if n else np.zeros((0, 0), np.float32)
+        have = sum(m.shape[0] for _, m in parts[view])
+        if have != n:
+            raise ValueError(f"view {view} is missing in {n - have} rows")
+        table.views[view] = np.concatenate([m for _, m in parts[view]], 0) if n else np.zeros((0, 0), np.float32)
     return table
 
 
@@ -185,25 +287,90 @@ def assignment_rows(table, labels, row_ids):
 
 
 # --------------------------------------------------------------------------- assignment shards
-def load_assignment_shards(paths):
-    """-> (assignments int64 [V,D], shard_names[V], filenames[V], clustering_types)  --
+def assignment_sidecar_path(path):
+    path = Path(path)
+    return path.with_name(path.stem + '.assign.npz')
+
+
+def write_assignment_sidecar(path, rows=None):
+    """<stem>.assign.npz next to an assignment pkl: labels int64 [rows, D] + types + names (uncompressed)."""
+    path = Path(path)
+    if rows is None:
+        rows = load_pickle(path)
+    per_row, shard_names, filenames = _assignment_rows_to_lists(rows)
+    mat, types = rows_to_matrix(per_row)
+    stamp = _source_stamp(path)
+    tmp = assignment_sidecar_path(path).with_suffix('.tmp{}.npz'.format(os.getpid()))
+    np.savez(tmp, labels=mat, types=np.array(json.dumps([list(t) for t in types])),
+             shard_name=np.array(shard_names), filename=np.array(filenames),
+             source=np.array([SIDECAR_VERSION, stamp['size'], stamp['mtime_ns']], np.int64))
+    os.replace(tmp, assignment_sidecar_path(path))
+    return assignment_sidecar_path(path)
+
+
+def read_assignment_sidecar(path):
+    try:
+        stamp = _source_stamp(path)
+        with np.load(assignment_sidecar_path(path), allow_pickle=False) as z:
+            if z['source'].tolist() != [SIDECAR_VERSION, stamp['size'], stamp['mtime_ns']]:
+                return None
+            types = [tuple(t) for t in json.loads(str(z['types']))]
+            return z['labels'].astype(np.int64), types, z['shard_name'].tolist(), z['filename'].tolist()
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def _assignment_rows_to_lists(rows):
+    per_row, shard_names, filenames = [], [], []
+    for row in rows:
+        res = {}
+        for key in ('audio_assignments', 'video_assignments'):
+            for feat in row.get(key, []):
+                for layer, val in _layers_of(feat['array']):
+                    if layer == 'model':
+                        raise ValueError("scalar assignment arrays are not supported (dataloader.py:27-35)")
+                    res[(feat['model_key'], layer)] = int(val)
+        per_row.append(res)
+        shard_names.append(row['shard_name'])
+        filenames.append(row['filename'])
+    return per_row, shard_names, filenames
+
+
+def load_assignment_shards(paths, sidecar=None):
+    """-> (assignments int64 [V,D], clustering_types, shard_names[V], filenames[V])  --
     dataloader.format_row / format_assignments / preprocess (subset dataloader.py:17-69):
     clustering_types = sorted (model_key, layer) tuples; only dict/list 'array's are supported by the
-    reference (its scalar branch references an undefined name), so is the same here."""
-    per_row, shard_names, filenames = [], [], []
+    reference (its scalar branch references an undefined name), so is the same here.
+    A valid <stem>.assign.npz (written by our clustering stage next to each pkl) replaces the per-row parsing."""
+    mode = sidecar_mode(sidecar)
+    mats, types, shard_names, filenames = [], None, [], []
     for path in paths:
-        for row in load_pickle(path):
-            res = {}
-            for key in ('audio_assignments', 'video_assignments'):
-                for feat in row.get(key, []):
-                    for layer, val in _layers_of(feat['array']):
-                        if layer == 'model':
-                            raise ValueError("scalar assignment arrays are not supported (dataloader.py:27-35)")
-                        res[(feat['model_key'], layer)] = int(val)
-            per_row.append(res)
-            shard_names.append(row['shard_name'])
-            filenames.append(row['filename'])
-    return rows_to_matrix(per_row) + (shard_names, filenames)
+        got = read_assignment_sidecar(path) if mode != 'off' else None
+        if got is None:
+            rows = load_pickle(path)
+            per_row, sn, fn = _assignment_rows_to_lists(rows)
+            mat, ty = rows_to_matrix(per_row)
+            if per_row and any(sorted(r.keys()) != ty for r in per_row):
+                raise KeyError("rows of {} do not share one set of clusterings".format(Path(path).stem))
+            if mode == 'write':
+                try:
+                    write_assignment_sidecar(path, rows)
+                except OSError as exc:
+                    print('could not write the sidecar of {}: {}'.format(Path(path).stem, exc))
+        else:
+            mat, ty, sn, fn = got
+        if len(sn) == 0:
+            continue
+        if types is None:
+            types = ty
+        elif ty != types:
+            raise KeyError("shard {} holds clusterings {} instead of {}".format(Path(path).stem, ty, types))
+        mats.append(mat)
+        shard_names.extend(sn)
+        filenames.extend(fn)
+    types = types or []
+    mat = np.concatenate(mats, 0) if mats else np.zeros((0, len(types)), np.int64)
+    return mat, types, shard_names, filenames
 
 
 def rows_to_matrix(per_row):

@@ -4,6 +4,7 @@ import pickle
 import sys
 
 import numpy as np
+import pytest
 
 from acav100m_amd import shards as io
 from acav100m_amd.config import CLUSTERING_DEFAULTS, SUBSET_DEFAULTS, merge, parse_cli
@@ -76,3 +77,58 @@ def test_partitions_metas_and_output_csv(tmp_path, golden_dir):
     ref_first = open(os.path.join(golden_dir, "cli_output.csv")).readline().strip()
     assert ref_first == 'shard-000000,vid000000000_010.mp4,vid000000000,"[10, 20]"'  # the reference's own line format
     assert [list(b) for b in io.chunked(list(range(5)), 2)] == [[0, 1], [2, 3], [4]]
+
+
+def test_columnar_sidecars_round_trip(tmp_path, golden_dir, monkeypatch):
+    """the columnar twins of feature / assignment shards reproduce the pkl path exactly, are
+    ignored once the pkl changes, and are never written unless asked for."""
+    import sys
+    import time
+    sys.path.insert(0, golden_dir)
+    import synth
+    from acav100m_amd import shards as io
+    glob = synth.write_feature_shards(str(tmp_path), n_shards=3, rows=64, seed=3)
+    paths = io.brace_expand(glob)
+    monkeypatch.delenv("ACAV_SHARD_SIDECAR", raising=False)
+    t0 = time.perf_counter()
+    ref = io.load_feature_shards(paths)                      # 'auto' with no sidecar: plain pkl path, nothing written
+    t_pkl = time.perf_counter() - t0
+    assert not any(io.feature_sidecar_dir(p).exists() for p in paths)
+    built = io.load_feature_shards(paths, sidecar="write")   # builds the twins while loading
+    assert all(io.feature_sidecar_dir(p).is_dir() for p in paths)
+    t0 = time.perf_counter()
+    fast = io.load_feature_shards(paths)                     # 'auto' now memory-maps the columns
+    t_cols = time.perf_counter() - t0
+    for other in (built, fast):
+        assert list(other.views) == list(ref.views) and other.tags == ref.tags
+        assert other.filename == ref.filename and other.shard_name == ref.shard_name and other.shard_size == ref.shard_size
+        assert other.shard_rows == ref.shard_rows
+        for v in ref.views:
+            assert other.views[v].dtype == np.float32 and np.array_equal(other.views[v], ref.views[v])
+    print(f"feature shards: pkl {t_pkl * 1e3:.1f} ms, sidecar {t_cols * 1e3:.1f} ms")
+    # a rewritten pkl invalidates its twin (size / mtime stamp): the loader falls back to the pkl
+    rows = io.load_pickle(paths[0])
+    rows[0]['filename'] = 'changed.mp4'
+    io.dump_pickle(rows, paths[0])
+    assert io.read_feature_sidecar(paths[0]) is None and io.read_feature_sidecar(paths[1]) is not None
+    assert io.load_feature_shards(paths).filename[0] == 'changed.mp4'
+    assert io.load_feature_shards(paths, sidecar="off").filename[0] == 'changed.mp4'
+    # assignment shards
+    table = io.load_feature_shards(paths, sidecar="off")
+    rs = np.random.RandomState(0)
+    labels = {v: rs.randint(0, 32, len(table)).astype(np.int64) for v in table.views}
+    apaths = []
+    for shard, ids in table.shard_rows.items():
+        p = tmp_path / "clusters" / (shard + ".pkl")
+        io.dump_pickle(io.assignment_rows(table, labels, ids), p)
+        apaths.append(p)
+    ref_a = io.load_assignment_shards(apaths)
+    for p in apaths:
+        io.write_assignment_sidecar(p)
+    fast_a = io.load_assignment_shards(apaths)
+    assert np.array_equal(ref_a[0], fast_a[0]) and fast_a[0].dtype == np.int64
+    assert ref_a[1] == fast_a[1] and ref_a[2] == fast_a[2] and ref_a[3] == fast_a[3]
+    io.dump_pickle(io.load_pickle(apaths[0])[:-1], apaths[0])     # stale twin is ignored
+    assert len(io.load_assignment_shards(apaths)[2]) == len(ref_a[2]) - 1
+    with pytest.raises(ValueError):
+        io.sidecar_mode("sometimes")
