@@ -40,13 +40,27 @@ def run_partition(args, shard_paths):
                       shuffle_candidates=args.shuffle_candidates, verbose=args.verbose)
 
 
-def _run(args, path):
+def _load(args, path):
+    """chunk.load_and_preprocess (chunk.py:156-175): everything of a chunk that does not need the GPU."""
     partitions, metas = load_data(path, args.data.meta.path, args.verbose)
+    data = [(k, io.load_assignment_shards(partitions[k])) for k in sorted(partitions)]
+    return data, metas
+
+
+def _select(args, data):
     results = []
-    for k in sorted(partitions):
-        print('running partition {}/{}'.format(k, len(partitions)))
-        results.append(run_partition(args, partitions[k]))
-    return results, metas
+    for k, (assignments, clustering_types, shard_names, filenames) in data:
+        print('running partition {}/{}'.format(k, len(data)))
+        results.append(run_greedy(args, assignments, shard_names, filenames, clustering_types, args.subset.size,
+                                  args.subset.ratio, measure_name=args.measure_name,
+                                  cluster_pairing=args.clustering.pairing, shuffle_candidates=args.shuffle_candidates,
+                                  verbose=args.verbose))
+    return results
+
+
+def _run(args, path):
+    data, metas = _load(args, path)
+    return _select(args, data), metas
 
 
 def run_single(args):
@@ -78,14 +92,29 @@ def run_chunks(args):
     print("running {} chunks in {} gpus".format(num_chunks, gpus))
     chunk_args.node_rank = rank
     written = []
+    # computation.load_async (chunk.py:119-120,197-226): the next chunk's shards are read and parsed by a host
+    # thread while the GPU selects from the current one.  Chunks are still consumed in order, so the cache files
+    # are the same as in the synchronous mode.
+    pool = None
+    if chunk_args.computation.load_async and len(mine) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1)
+    pending = pool.submit(_load, chunk_args, mine[0][1]) if pool else None
     for i, (num, chunk) in enumerate(mine):
         print("running chunk {}".format(num))
-        results, metas = _run(chunk_args, chunk)
+        if pool:
+            data, metas = pending.result()
+            pending = pool.submit(_load, chunk_args, mine[i + 1][1]) if i + 1 < len(mine) else None
+            results = _select(chunk_args, data)
+        else:
+            results, metas = _run(chunk_args, chunk)
         res = results[0] if results else []  # a chunk is assumed to be a single partition (chunk.py:152)
         name = "cache_{}_{}_{}".format(chunk_args.parent_pid, rank, i)
         cache_out = Path(args.data.output.path).parent / 'caches' / Path(args.data.output.path).name
         out_path, _ = io.append_output_csv(res, metas, cache_out, name + '_')
         written.append(out_path)
+    if pool:
+        pool.shutdown()
     return written
 
 

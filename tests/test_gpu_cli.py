@@ -97,3 +97,30 @@ def test_subset_cli_output_csv(workdir, golden_dir):
     assert [r[1] for r in po] == [filenames[s] for s in sorted(res["S"])]
     overlap = len({r[1] for r in po} & {r[1] for r in pr}) / 205.0
     print(f"overlap with the reference's free-running selection: {overlap:.2f}")
+
+
+def test_chunked_run_sync_and_async_prefetch(workdir):
+    """chunk mode (chunk.py:21-53): per-chunk selections into caches/, merged by reduce_csvs; with
+    computation.load_async the next chunk is loaded by a host thread while the GPU works -- same files."""
+    import acav100m_amd
+    from acav100m_amd.subset_selection.cli import Cli
+    root, glob = workdir
+    if not os.path.isfile(os.path.join(root, "clusters", "shard-000000.pkl")):
+        pytest.skip("clustering test did not run")
+    outs = {}
+    for mode in (False, True):
+        out_dir = os.path.join(root, "chunked_async" if mode else "chunked_sync")
+        os.makedirs(out_dir, exist_ok=True)
+        out_csv = os.path.join(out_dir, "output.csv")
+        random.seed(1)
+        acav100m_amd.manual_seed(1)
+        Cli().run(shards_path=os.path.join(root, "clusters", "shard-{000000..000003}.pkl"),
+                  meta_path=os.path.join(root, "videos"), out_path=out_csv, chunk_size=2,
+                  **{"computation.load_async": mode})
+        caches = sorted(os.listdir(os.path.join(out_dir, "caches")))
+        assert len(caches) == 2 and all(c.startswith("cache_") and c.endswith("_output.csv") for c in caches)
+        Cli().reduce_csvs(out_path=out_csv)
+        outs[mode] = open(out_csv).read().splitlines()
+        # each chunk (2 shards = 512 clips) selects round(0.2 * 512) = 102 clips
+        assert len(outs[mode]) == 204
+    assert outs[False] == outs[True]
