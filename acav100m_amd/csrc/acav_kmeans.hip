@@ -399,6 +399,12 @@ __device__ __forceinline__ void dma16_asm(const void *gbase_uniform, unsigned vo
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gbase_uniform), "s"(lds)
                  : "memory", "m0");
 }
+// the same with the non-temporal policy: for data that is read exactly once (the feature rows)
+__device__ __forceinline__ void dma16_asm_nt(const void *gbase_uniform, unsigned voff, unsigned lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(gbase_uniform), "s"(lds)
+                 : "memory", "m0");
+}
 
 __device__ __forceinline__ bf16x8 cvt_bf16x8(float4 lo, float4 hi)
 {
@@ -413,6 +419,7 @@ __device__ unsigned long long g_fd_prof[20];
 #define FD_T(v)
 #endif
 
+template <bool NT>
 __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict__ x, int64_t n, int d,
                                                             const __bf16 *__restrict__ cb, const float *__restrict__ cn,
                                                             const float *__restrict__ counts, int K, float thr, float r,
@@ -478,7 +485,10 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict_
         int wx = 0, wc = 0;  // ring slots the next issue fills
         auto issue_x = [&]() {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dma16_asm(gx, voffx[q], xring + wx * FD_SLOT + q * 1024);
+            for (int q = 0; q < 4; ++q) {
+                if (NT) dma16_asm_nt(gx, voffx[q], xring + wx * FD_SLOT + q * 1024);
+                else dma16_asm(gx, voffx[q], xring + wx * FD_SLOT + q * 1024);
+            }
             gx += FD_BK * 4;
             wx = wx + 1 == FD_DX ? 0 : wx + 1;
         };
@@ -1581,9 +1591,12 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         ACAV_HIP_TRY(hipMemsetAsync(km->recheck_count.p, 0, sizeof(unsigned), st));
         const double rel = ldexp(1.0, -8) * 1.002 + 2.02 * (double)km->d * ldexp(1.0, -24);
         const float e1 = (float)(2.02 * rel * 1.001), e2 = (float)ldexp(1.0, -17);
-        ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_assign_bf16),
+        // rows are read exactly once: non-temporal DMA policy (ACAV_FILTER_NT=0 restores the default policy)
+        const char *vnt = getenv("ACAV_FILTER_NT");
+        auto kern = (vnt && vnt[0] == '0') ? k_assign_bf16<false> : k_assign_bf16<true>;
+        ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, FD_SMEM));
-        hipLaunchKernelGGL(k_assign_bf16, dim3((unsigned)((n + FB_ROWS - 1) / FB_ROWS)), dim3(256), FD_SMEM, st,
+        hipLaunchKernelGGL(kern, dim3((unsigned)((n + FB_ROWS - 1) / FB_ROWS)), dim3(256), FD_SMEM, st,
                            static_cast<const float *>(dx), n, km->d, km->cb16.as<__bf16>(), km->cn.as<float>(),
                            km->counts.as<float>(), km->K, km->threshold(), (float)km->reinit_r, km->caux.as<CentersAux>(), e1,
                            e2, dlab, km->recheck_list.as<int>(), km->recheck_count.as<unsigned>());

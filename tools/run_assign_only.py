@@ -1,5 +1,5 @@
 """Runs only the assign sweep a few times -- a small target for rocprofv3 --pmc passes.
-argv: rows reps mode   (mode: exact | filter)"""
+argv: rows reps mode [d K]   (mode: exact | filter)"""
 import os
 import sys
 import time
@@ -11,7 +11,9 @@ import torch
 import acav100m_amd
 from acav100m_amd.clustering import KMeans
 
-n, d, k = int(sys.argv[1]) if len(sys.argv) > 1 else 262144, 1024, 256
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+d = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+k = int(sys.argv[5]) if len(sys.argv) > 5 else 256
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 mode = sys.argv[3] if len(sys.argv) > 3 else "exact"
 gen = torch.Generator(device="cuda").manual_seed(0)
