@@ -1402,6 +1402,7 @@ struct acav_kmeans {
     int64_t n_filter_launches = 0;
     uint64_t last_recheck = 0, last_rows = 0;
     int64_t n_persistent_launches = 0;
+    int num_cus = 0;  // multiProcessorCount of the handle's device (queried on first use)
     int key_phase = 0;  // which half of `keys` the next step's distance kernel folds into
     int64_t n_assign_launches = 0, n_step_launches = 0;
 
@@ -1764,8 +1765,15 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
     // persistent path: the whole call in one launch, centres resident in LDS (k_train_persistent)
     const int nwg = ((km->K + TP_NC - 1) / TP_NC) * (int)((b + TP_NR - 1) / TP_NR);
     const char *nop = getenv("ACAV_NO_PERSISTENT");
+    // every workgroup of the launch must be resident at once (one per CU: 97 KB of LDS each): keep a quarter of
+    // the device's CUs spare (256 CUs on MI355X -> at most 192 workgroups)
+    if (km->num_cus == 0) {
+        hipDeviceProp_t prop;
+        ACAV_HIP_TRY(hipGetDeviceProperties(&prop, km->ctx.device));
+        km->num_cus = prop.multiProcessorCount;
+    }
     const bool persistent = steps > 0 && !(nop && nop[0] == '1') && (km->d % 256) == 0 && km->d <= TP_DS &&
-                            b <= TP_MAXB && nwg <= 192 && ((uintptr_t)fx & 15) == 0;
+                            b <= TP_MAXB && nwg <= (3 * km->num_cus) / 4 && ((uintptr_t)fx & 15) == 0;
     if (persistent) {
         std::vector<float> thr((size_t)steps);
         for (int64_t t = 0; t < steps; ++t)
