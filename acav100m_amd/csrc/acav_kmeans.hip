@@ -788,13 +788,14 @@ __device__ __forceinline__ float dot_blocks_n(int nblk, const float *pc, const f
     }
 }
 
-// k_step_dist_dma: grid (ceil(K/8), ceil(b/8)), ONE wave per workgroup.  Lane l: centre l>>3, row l&7.
+// k_step_dist_dma: grid (ceil(K/8), ceil(b/8)), 4 waves per workgroup (wave w = column block w of a stage, as in
+// k_train_persistent: a lone wave can only issue ~1 ds_read_b128 per 20+ cycles).  Lane l: centre l>>3, row l&7.
 // The 8 centre rows + 8 batch rows of a stage (up to 1024 columns = 64 KB) are pulled into LDS with
-// direct global->LDS DMA (global_load_lds_dwordx4, no VGPR staging), issued column-block by
-// column-block; the wave then waits with COUNTED s_waitcnt vmcnt(N) for block 0, 1, ... and runs
-// one dependent v_fma_f32 chain per lane over the columns in ascending order while the later blocks
-// are still landing (no barrier: a wave only reads what its own DMA wrote).  The FMA chain is
-// bitwise the f32 MFMA's, at 4-cycle instead of 10-cycle dependent latency per column.
+// direct global->LDS DMA (global_load_lds_dwordx4, no VGPR staging); each wave pulls its own 256-column
+// block, waits for it, and runs one dependent v_fma_f32 chain per lane over the block's columns in ascending
+// order (a wave only reads what its own DMA wrote); wave 0 then folds the per-block sums left to right --
+// the canonical segmented dot.  The FMA chain is bitwise the f32 MFMA's, at 4-cycle instead of 10-cycle
+// dependent latency per column.
 // LDS rows keep their 16-byte chunks XOR-permuted by (row & 7) -- applied to the DMA SOURCE address,
 // the LDS image stays lane-linear -- so the 8 rows one ds_read_b128 touches sit in 8 bank groups.
 constexpr int SD_NC = 8;
@@ -803,34 +804,38 @@ constexpr int SD_DS = 1024;
 
 #define ACAV_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-__global__ __launch_bounds__(64) void k_step_dist_dma(const float *__restrict__ x, int b, int d,
-                                                      const float *__restrict__ centers,
-                                                      const float *__restrict__ cn,
-                                                      const float *__restrict__ counts,
-                                                      const float *__restrict__ xn, int K, float thr, float r,
-                                                      unsigned long long *__restrict__ keys)
+__global__ __launch_bounds__(256) void k_step_dist_dma(const float *__restrict__ x, int b, int d,
+                                                       const float *__restrict__ centers,
+                                                       const float *__restrict__ cn,
+                                                       const float *__restrict__ counts,
+                                                       const float *__restrict__ xn, int K, float thr, float r,
+                                                       unsigned long long *__restrict__ keys)
 {
     __shared__ __attribute__((aligned(16))) float sT[(SD_NC + SD_NR) * SD_DS];
-    const int lane = threadIdx.x;
+    __shared__ float sPart[2][4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // wave w owns column block w of a stage
     const int kk = lane >> 3;
     const int ii = lane & 7;
     const int kbase = blockIdx.x * SD_NC, rbase = blockIdx.y * SD_NR;
     const bool ragged_rows = (kbase + SD_NC > K) || (rbase + SD_NR > b);
 
-    float acc = 0.f;
-    for (int j0 = 0; j0 < d; j0 += SD_DS) {
+    float acc = 0.f;  // wave 0: the canonical left fold of the 256-column segments
+    int par = 0;
+    for (int j0 = 0; j0 < d; j0 += SD_DS, par ^= 1) {
         const int ncols = min(SD_DS, d - j0);
         const int nblk = (ncols + 255) >> 8;
-        const bool ragged = ragged_rows || (ncols & 255);
-        if (ragged) {
-            // slots the DMA will not write must read as 0 (fma(c, 0, acc) == acc)
-            for (int i = lane; i < (SD_NC + SD_NR) * nblk * 64; i += 64) {
-                const int row = i / (nblk * 64), c4 = i - row * (nblk * 64);
-                *reinterpret_cast<float4 *>(sT + row * SD_DS + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wave < nblk) {
+            const int blk = wave;
+            const bool ragged = ragged_rows || (blk == nblk - 1 && (ncols & 255));
+            if (ragged) {
+                // slots the DMA will not write must read as 0 (fma(c, 0, acc) == acc)
+                for (int i = lane; i < (SD_NC + SD_NR) * 64; i += 64) {
+                    const int row = i >> 6, c4 = i & 63;
+                    *reinterpret_cast<float4 *>(sT + row * SD_DS + blk * 256 + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        for (int blk = 0; blk < nblk; ++blk) {
 #pragma unroll
             for (int row = 0; row < SD_NC + SD_NR; ++row) {
                 const bool is_c = row < SD_NC;
@@ -844,11 +849,16 @@ __global__ __launch_bounds__(64) void k_step_dist_dma(const float *__restrict__ 
                         (__attribute__((address_space(3))) void *)(sT + row * SD_DS + blk * 256), 16, 0, 0);
                 }
             }
+            ACAV_WAIT_VMCNT(0);  // this wave's block has landed (a wave only reads what its own DMA wrote)
+            sPart[par][wave][lane] = dot_blocks<1>(sT + kk * SD_DS + blk * 256, sT + (SD_NC + ii) * SD_DS + blk * 256,
+                                                   kk << 2, ii << 2, 0.f, true);
         }
-        ACAV_WAIT_VMCNT(0);  // the whole stage has landed (the wave only reads what its own DMA wrote)
-        acc = dot_blocks_n(nblk, sT + kk * SD_DS, sT + (SD_NC + ii) * SD_DS, kk << 2, ii << 2, acc, j0 == 0);
-        // the next stage overwrites sT: all ds_reads above have returned (acc depends on them)
+        __syncthreads();
+        if (wave == 0)
+            for (int w = 0; w < nblk; ++w) acc = (j0 == 0 && w == 0) ? sPart[par][0][lane] : acc + sPart[par][w][lane];
+        // the next stage writes the other sPart buffer; a wave overwrites only its own block of sT
     }
+    if (wave != 0) return;
     const int k = kbase + kk, row = rbase + ii;
     unsigned long long key = ~0ull;
     if (k < K && row < b) key = pack_key(dist_epilogue(acc, xn[row], cn[k], counts[k] < thr, r), k);
@@ -1016,29 +1026,60 @@ __global__ __launch_bounds__(256) void k_step_update(const float *__restrict__ x
             if (sCnt[k]) counts[k] = counts[k] + (float)sCnt[k];  // exact small integers in fp32
         if (keys_next)
             for (int i = tid; i < b; i += blockDim.x) keys_next[i] = ~0ull;
-        if (tid == 0) {
-            if (fell) sc->fallback += 1;
-            sc->lr_used = lr32;
+        if (tid < 64) {  // mean of the row minima (add()'s return value; float64 sum, order-free to 1e-12)
             double s = 0.0;
-            for (int i = 0; i < b; ++i) s += (double)sMin[i];
-            sc->mean = (float)(s / (double)b);
+            for (int i = tid; i < b; i += 64) s += (double)sMin[i];
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) s += __shfl_xor(s, dlt);
+            if (tid == 0) {
+                if (fell) sc->fallback += 1;
+                sc->lr_used = lr32;
+                sc->mean = (float)(s / (double)b);
+            }
         }
     }
     if (!first) return;  // uniform per block
 
     const float f = 1.0f - (float)cnt_mine * lr32;
     float *crow = centers + (size_t)mine * d;
+    // rows of the batch with this label, ascending (torch_scatter's CPU order): compacted once into sBest's slot
+    // range [0, cnt_mine) of sList so the update loop below can issue its row loads ahead of the ordered adds
+    int *sList = reinterpret_cast<int *>(sMin);  // sMin is dead from here on (block 0 has folded it)
+    __syncthreads();
+    {
+        __shared__ int sWaveCnt[4];
+        int base = 0;
+        for (int i0 = 0; i0 < b; i0 += 256) {  // uniform trip count
+            const int i = i0 + tid;
+            const bool m = i < b && sBest[i] == mine;
+            const unsigned long long bal = __ballot(m);
+            const int lane = tid & 63, wv = tid >> 6;
+            if (lane == 0) sWaveCnt[wv] = __popcll(bal);
+            __syncthreads();
+            int off = base;
+            for (int q = 0; q < wv; ++q) off += sWaveCnt[q];
+            if (m) sList[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+            base += sWaveCnt[0] + sWaveCnt[1] + sWaveCnt[2] + sWaveCnt[3];
+            __syncthreads();
+        }
+    }
     if ((d & 3) == 0) {
         for (int j = tid * 4; j < d; j += blockDim.x * 4) {
             const float4 c4 = *reinterpret_cast<const float4 *>(crow + j);
             float4 dl = make_float4(0.f, 0.f, 0.f, 0.f);
             bool have = false;
-            for (int i = me; i < b; ++i) {
-                if (sBest[i] != mine) continue;
-                const float4 x4 = *reinterpret_cast<const float4 *>(x + (size_t)i * d + j);
-                const float4 v = make_float4(x4.x * lr32, x4.y * lr32, x4.z * lr32, x4.w * lr32);
-                dl = have ? make_float4(dl.x + v.x, dl.y + v.y, dl.z + v.z, dl.w + v.w) : v;
-                have = true;
+            for (int q0 = 0; q0 < cnt_mine; q0 += 4) {
+                float4 xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)  // up to 4 independent row loads in flight, then the ordered adds
+                    if (q0 + u < cnt_mine) xv[u] = *reinterpret_cast<const float4 *>(x + (size_t)sList[q0 + u] * d + j);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (q0 + u < cnt_mine) {
+                        const float4 v = make_float4(xv[u].x * lr32, xv[u].y * lr32, xv[u].z * lr32, xv[u].w * lr32);
+                        dl = have ? make_float4(dl.x + v.x, dl.y + v.y, dl.z + v.z, dl.w + v.w) : v;
+                        have = true;
+                    }
             }
             const float4 nv = make_float4(c4.x * f + dl.x, c4.y * f + dl.y, c4.z * f + dl.z, c4.w * f + dl.w);
             *reinterpret_cast<float4 *>(crow + j) = nv;
@@ -1679,7 +1720,7 @@ static int step_device(acav_kmeans *km, const float *dx, int64_t b, double lr, c
         const bool dma_ok = (km->d & 3) == 0 && ((uintptr_t)dx & 15) == 0;
         if (dma_ok) {
             hipLaunchKernelGGL(k_step_dist_dma, dim3((km->K + SD_NC - 1) / SD_NC, (unsigned)((b + SD_NR - 1) / SD_NR)),
-                               dim3(64), 0, st, dx, (int)b, km->d, km->centers.as<float>(), km->cn.as<float>(),
+                               dim3(256), 0, st, dx, (int)b, km->d, km->centers.as<float>(), km->cn.as<float>(),
                                km->counts.as<float>(), xn_dev, km->K, km->threshold(), (float)km->reinit_r, kcur);
         } else {
             hipLaunchKernelGGL(k_step_dist_mfma, dim3((km->K + 31) / 32, (unsigned)((b + 31) / 32)), dim3(256), 0, st, dx,
