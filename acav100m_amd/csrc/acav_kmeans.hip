@@ -1153,15 +1153,19 @@ __device__ __forceinline__ int tp_off(int row, int j)
 }
 
 // DMA of column block `blk` of 8 rows (clamped duplicates for ragged groups are never used)
+template <bool RAGGED>
 __device__ __forceinline__ void tp_dma_block(float *lds, const float *__restrict__ src, int first_row, int nrows_valid,
                                              int d, int blk, int lane)
 {
 #pragma unroll
     for (int row = 0; row < 8; ++row) {
         const int grow = first_row + (row < nrows_valid ? row : 0);
-        const float *g = src + (size_t)grow * d + blk * 256 + ((lane ^ (row & 7)) << 2);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                         (__attribute__((address_space(3))) void *)(lds + row * TP_DS + blk * 256), 16, 0, 0);
+        const int col = blk * 256 + ((lane ^ (row & 7)) << 2);
+        const float *g = src + (size_t)grow * d + col;
+        // ragged last block (d % 256 != 0): the slots past column d are never written and keep their initial zeros
+        if (!RAGGED || col < d)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)(lds + row * TP_DS + blk * 256), 16, 0, 0);
     }
 }
 
@@ -1175,7 +1179,7 @@ __device__ __forceinline__ void tp_refresh_norms(unsigned pend, const float *sC,
     if (mine) {
         // column j = q + 32u of row c8 sits at  c8*DS + (((q>>2) ^ (c8&7)) << 2) + (q&3) + 32u : base + constant stride
         const float *base = sC + c8 * TP_DS + ((((q >> 2) ^ (c8 & 7))) << 2) + (q & 3);
-        const int nu = d >> 5;
+        const int nu = (d + 31) >> 5;  // columns past d read the zero padding
 #pragma unroll 32
         for (int u = 0; u < nu; ++u) {
             const float v = base[u * 32];
@@ -1194,6 +1198,7 @@ __device__ __forceinline__ void tp_refresh_norms(unsigned pend, const float *sC,
 // runs the segment's FMA chain for all 64 (centre, row) pairs, and applies the centre update to it.
 // One wave can only issue ~1 ds_read_b128 per 20+ cycles, so the 4 waves quadruple the LDS read rate;
 // the 4 segment sums are folded in order ((s0+s1)+s2)+s3 -- exactly the canonical dot.
+template <bool RAGGED>  // RAGGED: d % 256 != 0 (guarded DMA / update lanes, zero-padded last block)
 __global__ __launch_bounds__(256) void k_train_persistent(
     const float *__restrict__ x, const float *__restrict__ xn, int b, int d, int K, float *__restrict__ centers,
     float *__restrict__ cn, float *__restrict__ counts, const float *__restrict__ thr, double lr0, float r,
@@ -1213,18 +1218,27 @@ __global__ __launch_bounds__(256) void k_train_persistent(
     const int kk = lane >> 3, ii = lane & 7;
     const int kbase = blockIdx.x * TP_NC, rbase = blockIdx.y * TP_NR;
     const int nck = min(TP_NC, K - kbase), nrv = min(TP_NR, b - rbase);
-    const int nblk = d >> 8;
+    const int nblk = (d + 255) >> 8;
     const int ncg = gridDim.x;
     const bool active = wave < nblk;  // this wave has a column block
+    const bool col_ok = !RAGGED || wave * 256 + (lane << 2) < d;  // this lane's 4 columns of the block exist (d % 4 == 0)
 
-    if (active) tp_dma_block(sC, centers, kbase, nck, d, wave, lane);
+    if (RAGGED && active) {  // ragged last block: columns d .. 256 nblk - 1 must read as zero for good
+        for (int row = 0; row < TP_NC; ++row) {
+            *reinterpret_cast<float4 *>(sC + row * TP_DS + wave * 256 + (lane << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(sX[0] + row * TP_DS + wave * 256 + (lane << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(sX[1] + row * TP_DS + wave * 256 + (lane << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // before the DMA below writes the same rows
+    }
+    if (active) tp_dma_block<RAGGED>(sC, centers, kbase, nck, d, wave, lane);
     if (tid < TP_NC) {
         const int k = kbase + (tid < nck ? tid : 0);
         sCn[tid] = cn[k];
         sCnt[tid] = counts[k];
     }
     if (tid == 0) sDead = 0;
-    if (need < T && active) tp_dma_block(sX[need & 1], x + (size_t)need * b * d, rbase, nrv, d, wave, lane);
+    if (need < T && active) tp_dma_block<RAGGED>(sX[need & 1], x + (size_t)need * b * d, rbase, nrv, d, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -1244,7 +1258,7 @@ __global__ __launch_bounds__(256) void k_train_persistent(
                 xn_t = xn[(size_t)t * b + rbase + (ii < nrv ? ii : 0)];
                 thr_t = thr[t];
             }
-            if (t + 1 < T && active) tp_dma_block(sX[(t + 1) & 1], x + (size_t)(t + 1) * b * d, rbase, nrv, d, wave, lane);
+            if (t + 1 < T && active) tp_dma_block<RAGGED>(sX[(t + 1) & 1], x + (size_t)(t + 1) * b * d, rbase, nrv, d, wave, lane);
             const long long c1 = clock64();
             pr[0] += c1 - c0;
             float part = 0.f;
@@ -1368,7 +1382,8 @@ __global__ __launch_bounds__(256) void k_train_persistent(
                     while (m) {  // rows of the batch with this label, ascending (torch_scatter's CPU order)
                         const int i = __ffsll((long long)m) - 1;
                         m &= m - 1;
-                        const float4 x4 = *reinterpret_cast<const float4 *>(xb + (size_t)i * d + wave * 256 + (lane << 2));
+                        const float4 x4 = col_ok ? *reinterpret_cast<const float4 *>(xb + (size_t)i * d + wave * 256 + (lane << 2))
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
                         const float4 v = make_float4(x4.x * lr32, x4.y * lr32, x4.z * lr32, x4.w * lr32);
                         dl[c8] = have ? make_float4(dl[c8].x + v.x, dl[c8].y + v.y, dl[c8].z + v.z, dl[c8].w + v.w) : v;
                         have = true;
@@ -1376,7 +1391,7 @@ __global__ __launch_bounds__(256) void k_train_persistent(
                 }
 #pragma unroll
                 for (int c8 = 0; c8 < TP_NC; ++c8) {
-                    if (msk[c8]) {
+                    if (msk[c8] && col_ok) {
                         const float f = 1.0f - (float)__popcll(msk[c8]) * lr32;
                         float4 *pc4 = reinterpret_cast<float4 *>(sC + c8 * TP_DS + wave * 256 + ((lane ^ (c8 & 7)) << 2));
                         const float4 c4 = *pc4;
@@ -1412,7 +1427,7 @@ __global__ __launch_bounds__(256) void k_train_persistent(
     if (blockIdx.y == 0 && !sDead && active) {
         for (int c8 = 0; c8 < nck; ++c8) {
             const float4 v = *reinterpret_cast<const float4 *>(sC + c8 * TP_DS + wave * 256 + ((lane ^ (c8 & 7)) << 2));
-            *reinterpret_cast<float4 *>(centers + (size_t)(kbase + c8) * d + wave * 256 + (lane << 2)) = v;
+            if (col_ok) *reinterpret_cast<float4 *>(centers + (size_t)(kbase + c8) * d + wave * 256 + (lane << 2)) = v;
         }
     }
     if (blockIdx.y == 0 && !sDead && tid < nck) {
@@ -1813,7 +1828,7 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
         ACAV_HIP_TRY(hipGetDeviceProperties(&prop, km->ctx.device));
         km->num_cus = prop.multiProcessorCount;
     }
-    const bool persistent = steps > 0 && !(nop && nop[0] == '1') && (km->d % 256) == 0 && km->d <= TP_DS &&
+    const bool persistent = steps > 0 && !(nop && nop[0] == '1') && (km->d % 4) == 0 && km->d <= TP_DS &&
                             b <= TP_MAXB && nwg <= (3 * km->num_cus) / 4 && ((uintptr_t)fx & 15) == 0;
     if (persistent) {
         std::vector<float> thr((size_t)steps);
@@ -1823,7 +1838,8 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
         ACAV_HIP_TRY(hipMemcpyAsync(km->thr.p, thr.data(), sizeof(float) * (size_t)steps, hipMemcpyHostToDevice, st));
         ACAV_TRY(km->ctl.ensure(sizeof(TrainCtl)));
         ACAV_HIP_TRY(hipMemsetAsync(km->ctl.p, 0, sizeof(TrainCtl), st));  // err = 0, every granule tag = 0 (never a live tag)
-        hipLaunchKernelGGL(k_train_persistent, dim3((km->K + TP_NC - 1) / TP_NC, (unsigned)((b + TP_NR - 1) / TP_NR)),
+        auto tkern = (km->d & 255) ? k_train_persistent<true> : k_train_persistent<false>;
+        hipLaunchKernelGGL(tkern, dim3((km->K + TP_NC - 1) / TP_NC, (unsigned)((b + TP_NR - 1) / TP_NR)),
                            dim3(256), 0, st, fx, km->xn.as<float>(), (int)b, km->d, km->K, km->centers.as<float>(),
                            km->cn.as<float>(), km->counts.as<float>(), km->thr.as<float>(), lr, (float)km->reinit_r,
                            static_cast<const int64_t *>(dw), (int)need, (int)steps, km->ctl.as<TrainCtl>(),
