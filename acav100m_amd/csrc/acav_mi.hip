@@ -418,8 +418,11 @@ __global__ __launch_bounds__(MT_THREADS) void k_mt_generate(unsigned *__restrict
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    unsigned bi = (unsigned)(m0 - shift) + tid;  // window index of this thread's word
-    unsigned oi = (unsigned)(m0 - 624) + tid;    // its index in outp (n < 2^31 on this path)
+    // loop-carried: ONE LDS address (all seven operands and the result at constant offsets from it) and one
+    // byte offset into `out` (SGPR base + 32-bit VGPR offset store): the loop is VALU-issue bound
+    const unsigned *xw = X + ((unsigned)(m0 - shift) + tid - MT_BACK);  // &X[bi - MT_BACK]
+    unsigned ob = ((unsigned)(m0 - p) + tid) * 4u;                      // byte offset of out[m - p]  (n < 2^29 here)
+    const char *outb = reinterpret_cast<const char *>(out);
     int left = MT_EPOCH;
     while (m0 < need) {
         if (left == 0) {  // slide: the last MT_BACK words move to the front of the window (disjoint ranges)
@@ -432,18 +435,18 @@ __global__ __launch_bounds__(MT_THREADS) void k_mt_generate(unsigned *__restrict
                 if (tid + u * MT_THREADS < MT_BACK) X[tid + u * MT_THREADS] = keep[u];
             __syncthreads();
             shift = m0 - MT_BACK;
-            bi = MT_BACK + tid;
+            xw = X + tid;
             left = MT_EPOCH;
         }
         if (tid < MT_WIDE) {
-            const unsigned *x = X + (bi - MT_BACK);  // operands at constant offsets: 0,1 | 227,228 | 454,455 | 397
-            const unsigned a = x[0] ^ x[227] ^ x[454], b2 = x[1] ^ x[228] ^ x[455];
-            const unsigned v = x[MT_BACK - 681] ^ mt_twist((a & 0x80000000u) | (b2 & 0x7fffffffu));
-            X[bi] = v;
-            outp[oi] = v;
+            // operands at constant offsets: 0,1 | 227,228 | 454,455 | 397; result at MT_BACK
+            const unsigned a = xw[0] ^ xw[227] ^ xw[454], b2 = xw[1] ^ xw[228] ^ xw[455];
+            const unsigned v = xw[MT_BACK - 681] ^ mt_twist((a & 0x80000000u) | (b2 & 0x7fffffffu));
+            const_cast<unsigned *>(xw)[MT_BACK] = v;
+            *reinterpret_cast<unsigned *>(const_cast<char *>(outb) + ob) = v;
         }
-        bi += MT_WIDE;
-        oi += MT_WIDE;
+        xw += MT_WIDE;
+        ob += MT_WIDE * 4u;
         m0 += MT_WIDE;
         --left;
         // LDS ordering only: a __syncthreads() would also wait for the global stores above to be acknowledged
