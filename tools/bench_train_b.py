@@ -1,4 +1,5 @@
-"""us per SGD step of acav_kmeans_train at several batch sizes (the multi-GPU path trains on global batches of 32 W rows)."""
+"""us per SGD step of acav_kmeans_train at several batch sizes (the multi-GPU path trains on global batches of 32 W rows).
+argv: batch sizes; BENCH_D / BENCH_K select the shape."""
 import os
 import sys
 import time
@@ -9,7 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import acav100m_amd
 from acav100m_amd.clustering import KMeans
 
-n, d, k = 262144, 1024, 256
+n = 262144
+d = int(os.environ.get("BENCH_D", "1024"))
+k = int(os.environ.get("BENCH_K", "256"))
 g = torch.Generator(device="cuda").manual_seed(0)
 cen = torch.randn(k, d, device="cuda", generator=g) * 4
 x = cen[torch.randint(0, k, (n,), device="cuda", generator=g)] + 0.3 * torch.randn(n, d, device="cuda", generator=g)
