@@ -73,7 +73,7 @@ class KMeans:
 
     def _release(self):
         h, self._h = getattr(self, "_h", None), None
-        if h and _lib._lib is not None:
+        if h and _lib is not None and _lib._lib is not None:  # module globals die first at interpreter exit
             _lib._lib.acav_kmeans_destroy(h)
 
     def _require_handle(self):

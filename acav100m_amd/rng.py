@@ -24,7 +24,7 @@ class Generator:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h and _lib._lib is not None:
+        if h and _lib is not None and _lib._lib is not None:  # module globals die first at interpreter exit
             _lib._lib.acav_rng_destroy(h)
 
     @property

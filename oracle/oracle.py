@@ -91,7 +91,7 @@ class Rng:
         self.h = lib().orc_rng_create(int(seed) & 0xFFFFFFFF)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:  # module globals die first at interpreter exit
             lib().orc_rng_destroy(self.h)
             self.h = None
 
@@ -146,7 +146,7 @@ class KMeans:
         self.h = lib().orc_kmeans_create(k, d, _p(c0), rng.h)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:  # module globals die first at interpreter exit
             lib().orc_kmeans_destroy(self.h)
             self.h = None
 
@@ -215,7 +215,7 @@ class BatchMI:
         self.h = lib().orc_mi_create(_p(a), self.V, self.D, self.C, _p(self.pairs), self.P)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:  # module globals die first at interpreter exit
             lib().orc_mi_destroy(self.h)
             self.h = None
 
