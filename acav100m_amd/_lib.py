@@ -46,6 +46,7 @@ SIGNATURES = {
     "acav_mi_score_batch": [vp, vp, i32, vp],
     "acav_mi_run_greedy": [vp, vp, i64, vp, i32, i64, i32, i32, i32, vp, vp, vp, C.POINTER(i64),
                            C.POINTER(i64), vp, vp, vp, vp, i64],
+    "acav_mi_run_greedy_multi": [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "acav_mi_run_exact": [vp, vp, i64, i32, i64, vp, vp, C.POINTER(i64), vp, vp, vp],
     "acav_mi_get_counts": [vp, vp, vp, vp, C.POINTER(i64)],
     "acav_mi_sync": [vp],

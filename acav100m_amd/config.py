@@ -117,6 +117,7 @@ SUBSET_DEFAULTS = {
         'dist_backend': 'nccl',
         'dist_init_method': 'tcp://localhost:9967',
         'load_async': False,
+        'concurrent_chunks': 1,  # ours: > 1 selects from that many chunks in lockstep on one GPU (own RNG stream each)
     },
     'subset': {'ratio': 0.2, 'size': None},
     'clustering': {'pairing': 'combination'},

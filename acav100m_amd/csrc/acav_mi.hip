@@ -96,7 +96,7 @@ __device__ __forceinline__ void sel_argmax_step(double &s, int &w, int lane_delt
     w = take ? wo : w;
 }
 
-__global__ __launch_bounds__(256) void k_mi_select(
+__device__ __forceinline__ void mi_select_body(
     const int *__restrict__ asg, int D, int C, int P, const int *__restrict__ pairs,
     const int *__restrict__ batch, int B, int k, int *__restrict__ Nc, int *__restrict__ ac,
     int *__restrict__ bc, double *__restrict__ SN, double *__restrict__ Sa, double *__restrict__ Sb,
@@ -251,6 +251,19 @@ __global__ __launch_bounds__(256) void k_mi_select(
     if (tid == 0) sc->nc = nc + k;
 }
 
+__global__ __launch_bounds__(256) void k_mi_select(
+    const int *__restrict__ asg, int D, int C, int P, const int *__restrict__ pairs,
+    const int *__restrict__ batch, int B, int k, int *__restrict__ Nc, int *__restrict__ ac,
+    int *__restrict__ bc, double *__restrict__ SN, double *__restrict__ Sa, double *__restrict__ Sb,
+    const double *__restrict__ phi, MiScalars *__restrict__ sc, double *__restrict__ scores_out,
+    long long *__restrict__ S_out, double *__restrict__ G_out, const int *__restrict__ forced_pos,
+    int *__restrict__ trace_pos, long long *__restrict__ trace_ids, double *__restrict__ trace_scores,
+    int keep_unselected, int *__restrict__ requeue_out)
+{
+    mi_select_body(asg, D, C, P, pairs, batch, B, k, Nc, ac, bc, SN, Sa, Sb, phi, sc, scores_out, S_out, G_out, forced_pos,
+                   trace_pos, trace_ids, trace_scores, keep_unselected, requeue_out);
+}
+
 // ------------------------------------------------------------------- exact greedy (mi / mem_mi)
 // EfficientMI.run_greedy (mi.py:150-192): every iteration scores ALL remaining candidates and commits the
 // first maximum.  One launch per iteration: each workgroup scores 256 candidates and reduces them to one
@@ -392,8 +405,7 @@ constexpr int MT_EPOCH = 24;                              // wide steps between 
 constexpr int MT_WIN = MT_BACK + MT_WIDE * MT_EPOCH;      // 16030 words = 62.6 KB of LDS
 constexpr int MT_GROUP = 8;   // greedy iterations whose draws one launch generates
 constexpr int MT_PAD = 1280;  // the generator completes the 624-word block of the last draw (+ up to 622 words of the last step)
-__global__ __launch_bounds__(MT_THREADS) void k_mt_generate(unsigned *__restrict__ mt_state, unsigned *__restrict__ out,
-                                                           long long n)
+__device__ __forceinline__ void mt_generate_body(unsigned *__restrict__ mt_state, unsigned *__restrict__ out, long long n)
 {
     __shared__ unsigned X[MT_WIN];
     const unsigned tid = threadIdx.x;
@@ -460,6 +472,12 @@ __global__ __launch_bounds__(MT_THREADS) void k_mt_generate(unsigned *__restrict
     if (tid == 0) mt_state[624] = (unsigned)(q - base);
 }
 
+__global__ __launch_bounds__(MT_THREADS) void k_mt_generate(unsigned *__restrict__ mt_state, unsigned *__restrict__ out,
+                                                           long long n)
+{
+    mt_generate_body(mt_state, out, n);
+}
+
 // ------------------------------------------------------------------- parallel Fisher-Yates
 // Sequential semantics (torch.randperm + index_select == in-place):  for i in 0..L-2:
 //   swap(A[i], A[h_i]),  h_i = i + draw_i % (L - i).
@@ -471,11 +489,9 @@ __global__ __launch_bounds__(MT_THREADS) void k_mt_generate(unsigned *__restrict
 //   pred = max{ j in list(h_i) : j < i } exists  -> A[f(pred)]
 //   otherwise                                     -> A[h_i]
 // and position L-1 ends with A[f(L-1)].
-__global__ __launch_bounds__(256) void k_fy_build(const unsigned *__restrict__ draws, int L, int *__restrict__ h,
-                                                  int *__restrict__ head, int *__restrict__ next,
-                                                  int *__restrict__ g)
+__device__ __forceinline__ void fy_build_body(const unsigned *__restrict__ draws, int L, int *__restrict__ h,
+                                              int *__restrict__ head, int *__restrict__ next, int *__restrict__ g, int i)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L) return;
     if (i == L - 1) {
         h[i] = i;
@@ -492,13 +508,19 @@ __global__ __launch_bounds__(256) void k_fy_build(const unsigned *__restrict__ d
     }
 }
 
-__global__ __launch_bounds__(256) void k_fy_apply(const int *__restrict__ A, int L, int B,
-                                                  const int *__restrict__ h, const int *__restrict__ head,
-                                                  const int *__restrict__ next, const int *__restrict__ g,
-                                                  int *__restrict__ batch_out, int *__restrict__ A_new,
-                                                  int *__restrict__ head_next, int *__restrict__ g_next)
+__global__ __launch_bounds__(256) void k_fy_build(const unsigned *__restrict__ draws, int L, int *__restrict__ h,
+                                                  int *__restrict__ head, int *__restrict__ next,
+                                                  int *__restrict__ g)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    fy_build_body(draws, L, h, head, next, g, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+}
+
+__device__ __forceinline__ void fy_apply_body(const int *__restrict__ A, int L, int B, const int *__restrict__ h,
+                                              const int *__restrict__ head, const int *__restrict__ next,
+                                              const int *__restrict__ g, int *__restrict__ batch_out,
+                                              int *__restrict__ A_new, int *__restrict__ head_next,
+                                              int *__restrict__ g_next, int i)
+{
     if (i >= L) return;
     head_next[i] = -1;  // the list heads of the NEXT iteration (the other buffer pair; L only shrinks)
     g_next[i] = -1;
@@ -526,6 +548,83 @@ __global__ __launch_bounds__(256) void k_fy_apply(const int *__restrict__ A, int
         A_new[i - B] = v;
 }
 
+__global__ __launch_bounds__(256) void k_fy_apply(const int *__restrict__ A, int L, int B,
+                                                  const int *__restrict__ h, const int *__restrict__ head,
+                                                  const int *__restrict__ next, const int *__restrict__ g,
+                                                  int *__restrict__ batch_out, int *__restrict__ A_new,
+                                                  int *__restrict__ head_next, int *__restrict__ g_next)
+{
+    fy_apply_body(A, L, B, h, head, next, g, batch_out, A_new, head_next, g_next, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+}
+
+// ------------------------------------------------------------------ several chunks in lockstep
+// The greedy loop of ONE chunk is a chain of small dependent kernels: most of the GPU idles, and several chunks
+// driven from several host threads do not overlap (the HIP runtime serialises the launches).  Chunks are
+// independent (chunk.py:21-53), so the same three launches per iteration (+ one generator launch per group) can
+// serve a whole batch of them: blockIdx.y (or .x for the one-workgroup kernels) picks the chunk, every per-chunk
+// pointer and size comes from a descriptor array in device memory, and everything that changes per iteration is a
+// function of the iteration number (L_t = L0 - t * dl, buffer parities, offsets).  Same device functions as the
+// single-chunk kernels, hence the same results.
+struct ChunkDesc {
+    const int *asg, *pairs;
+    int *Nc, *ac, *bc;
+    double *SN, *Sa, *Sb;
+    const double *phi;
+    MiScalars *sc;
+    int *A[2];
+    unsigned *draws[2];
+    int *h, *next, *head[2], *g[2];
+    unsigned *mt;
+    int *batch;
+    long long *S;
+    double *G;
+    int D, C, P, L0, iters, pad;
+};
+
+__device__ __forceinline__ long long chunk_draws(const ChunkDesc &c, int t0, int t1, int dl)
+{  // draws of iterations [t0, t1) of the chunk: sum of (L_t - 1)
+    long long tot = 0;
+    for (int t = t0; t < t1 && t < c.iters; ++t) {
+        const int lt = c.L0 - t * dl;
+        tot += lt > 1 ? lt - 1 : 0;
+    }
+    return tot;
+}
+
+__global__ __launch_bounds__(MT_THREADS) void k_mt_generate_multi(const ChunkDesc *__restrict__ cd, int group, int dl)
+{
+    const ChunkDesc c = cd[blockIdx.x];
+    const long long n = chunk_draws(c, group * MT_GROUP, (group + 1) * MT_GROUP, dl);
+    if (n > 0) mt_generate_body(c.mt, c.draws[group & 1], n);
+}
+
+__global__ __launch_bounds__(256) void k_fy_build_multi(const ChunkDesc *__restrict__ cd, int it, int dl)
+{
+    const ChunkDesc c = cd[blockIdx.y];
+    if (it >= c.iters) return;
+    const int group = it / MT_GROUP;
+    const unsigned *draws = c.draws[group & 1] + chunk_draws(c, group * MT_GROUP, it, dl);
+    fy_build_body(draws, c.L0 - it * dl, c.h, c.head[it & 1], c.next, c.g[it & 1], (int)(blockIdx.x * blockDim.x + threadIdx.x));
+}
+
+__global__ __launch_bounds__(256) void k_fy_apply_multi(const ChunkDesc *__restrict__ cd, int it, int dl, int B)
+{
+    const ChunkDesc c = cd[blockIdx.y];
+    if (it >= c.iters) return;
+    fy_apply_body(c.A[it & 1], c.L0 - it * dl, B, c.h, c.head[it & 1], c.next, c.g[it & 1], c.batch, c.A[(it + 1) & 1],
+                  c.head[(it + 1) & 1], c.g[(it + 1) & 1], (int)(blockIdx.x * blockDim.x + threadIdx.x));
+}
+
+__global__ __launch_bounds__(256) void k_mi_select_multi(const ChunkDesc *__restrict__ cd, int it, int dl, int B, int k,
+                                                         int keep_unselected)
+{
+    const ChunkDesc c = cd[blockIdx.x];
+    if (it >= c.iters) return;
+    mi_select_body(c.asg, c.D, c.C, c.P, c.pairs, c.batch, B, k, c.Nc, c.ac, c.bc, c.SN, c.Sa, c.Sb, c.phi, c.sc, nullptr,
+                   c.S + (size_t)it * k, c.G + (size_t)it * k, nullptr, nullptr, nullptr, nullptr, keep_unselected,
+                   c.A[(it + 1) & 1] + (c.L0 - it * dl - B));
+}
+
 __global__ void k_i64_to_i32(const long long *__restrict__ in, int *__restrict__ out, long long n)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -544,6 +643,7 @@ struct acav_mi {
     // greedy buffers
     DevBuf A0, A1, draws, draws2, h, head, head2, next, g, g2, mt, batch, S, G, tr_pos, tr_ids, tr_sc, forced;
     DevBuf removed, blockbest, ticket, tr_am;  // exact greedy
+    DevBuf chunk_desc;                         // descriptor array of a multi-chunk run (lead handle)
     // the mt19937 stream does not depend on the selection state: it is generated one iteration ahead on
     // its own stream (double-buffered draws), overlapping the Fisher-Yates / select kernels
     hipStream_t st_mt = nullptr;
@@ -664,6 +764,142 @@ ACAV_EXPORT int acav_mi_destroy(acav_mi *mi)
     delete mi;
     return ACAV_OK;
 }
+// Several independent chunks (one handle, candidate list, start set, subset size and generator each) selected in
+// lockstep: the same kernels as acav_mi_run_greedy, one launch serving every chunk (see ChunkDesc).  All handles
+// must live on the same device; the first handle's streams carry the work.  Results per chunk are exactly those
+// of acav_mi_run_greedy called with that chunk's arguments and generator.
+ACAV_EXPORT int acav_mi_run_greedy_multi(acav_mi **mis, int nchunks, const int64_t *const *candidates, const int64_t *L,
+                                         const int64_t *const *start, const int *ns, const int64_t *subset, int B, int k,
+                                         int keep_unselected, acav_rng **rngs, int64_t *const *S_out,
+                                         double *const *GAIN_out, int64_t *n_selected, int64_t *n_iters)
+{
+    ACAV_REQUIRE(mis && nchunks > 0 && candidates && L && ns && subset && rngs && S_out && GAIN_out, ACAV_EINVAL,
+                 "NULL argument");
+    ACAV_REQUIRE(B > 0 && B <= SEL_MAXB && k > 0 && k <= B, ACAV_EINVAL, "batch_size %d / selection_size %d out of range", B,
+                 k);
+    acav_mi *lead = mis[0];
+    ACAV_REQUIRE(lead, ACAV_EINVAL, "handle is NULL");
+    ACAV_HIP_TRY(hipSetDevice(lead->ctx.device));
+    hipStream_t st = lead->ctx.stream, smt = lead->st_mt;
+    const int64_t dl = B - (keep_unselected ? B - k : 0);
+    std::vector<ChunkDesc> desc((size_t)nchunks);
+    std::vector<int64_t> iters((size_t)nchunks, 0);
+    int64_t iters_max = 0, lmax = 0;
+    int pmax = 1;
+    for (int c = 0; c < nchunks; ++c) {
+        acav_mi *mi = mis[c];
+        ACAV_REQUIRE(mi && candidates[c] && rngs[c] && S_out[c] && GAIN_out[c], ACAV_EINVAL, "chunk %d: NULL argument", c);
+        ACAV_REQUIRE(mi->ctx.device == lead->ctx.device, ACAV_EINVAL, "chunk %d lives on another device", c);
+        ACAV_REQUIRE(L[c] > 0 && L[c] <= mi->V && ns[c] >= 0 && (ns[c] == 0 || (start && start[c])) && subset[c] >= 0,
+                     ACAV_EINVAL, "chunk %d: bad sizes", c);
+        ACAV_REQUIRE((int64_t)B * mi->P <= SEL_MAXBP, ACAV_EINVAL, "chunk %d: B*P exceeds %d", c, SEL_MAXBP);
+        for (int e = 0; e < c; ++e) ACAV_REQUIRE(mis[e] != mi && rngs[e] != rngs[c], ACAV_EINVAL, "chunks must not share a handle or a generator");
+        ACAV_HIP_TRY(hipStreamSynchronize(mi->ctx.stream));  // whatever the handle was doing on its own stream is over
+        if (ns[c]) ACAV_TRY(acav_mi_add_samples(mi, start[c], ns[c]));
+        int64_t nS = 0, l = L[c], itc = 0;
+        while (nS < subset[c]) {
+            ACAV_REQUIRE(l >= B, ACAV_ERANGE, "chunk %d: %lld candidates left < batch_size %d (batch.py:143-150)", c,
+                         (long long)l, B);
+            nS += k;
+            l -= dl;
+            ++itc;
+        }
+        iters[(size_t)c] = itc;
+        iters_max = itc > iters_max ? itc : iters_max;
+        lmax = L[c] > lmax ? L[c] : lmax;
+        pmax = mi->P > pmax ? mi->P : pmax;
+        const size_t Lc = (size_t)L[c];
+        hipStream_t sc = mi->ctx.stream;
+        ACAV_TRY(mi->A0.ensure(sizeof(int) * (Lc + B)));
+        ACAV_TRY(ids_to_device32(mi, candidates[c], L[c], mi->stage, mi->A0));
+        ACAV_TRY(mi->A1.ensure(sizeof(int) * (Lc + B)));
+        ACAV_TRY(mi->draws.ensure(sizeof(unsigned) * (Lc * MT_GROUP + MT_PAD)));
+        ACAV_TRY(mi->draws2.ensure(sizeof(unsigned) * (Lc * MT_GROUP + MT_PAD)));
+        ACAV_TRY(mi->h.ensure(sizeof(int) * Lc));
+        ACAV_TRY(mi->head.ensure(sizeof(int) * Lc));
+        ACAV_TRY(mi->next.ensure(sizeof(int) * Lc));
+        ACAV_TRY(mi->g.ensure(sizeof(int) * Lc));
+        ACAV_TRY(mi->head2.ensure(sizeof(int) * Lc));
+        ACAV_TRY(mi->g2.ensure(sizeof(int) * Lc));
+        ACAV_HIP_TRY(hipMemsetAsync(mi->head.p, 0xFF, sizeof(int) * Lc, sc));
+        ACAV_HIP_TRY(hipMemsetAsync(mi->g.p, 0xFF, sizeof(int) * Lc, sc));
+        ACAV_TRY(mi->mt.ensure(sizeof(unsigned) * 625));
+        ACAV_TRY(mi->batch.ensure(sizeof(int) * SEL_MAXB));
+        ACAV_TRY(mi->S.ensure(sizeof(long long) * (size_t)(itc * k + 1)));
+        ACAV_TRY(mi->G.ensure(sizeof(double) * (size_t)(itc * k + 1)));
+        unsigned mtbuf[625];
+        int idx = 0;
+        ACAV_TRY(acav_rng_get_state(rngs[c], mtbuf, &idx));
+        mtbuf[624] = (unsigned)idx;
+        ACAV_HIP_TRY(hipMemcpyAsync(mi->mt.p, mtbuf, sizeof(mtbuf), hipMemcpyHostToDevice, sc));
+        ACAV_HIP_TRY(hipStreamSynchronize(sc));  // mtbuf is a local; the lead's streams take over from here
+        ChunkDesc &d = desc[(size_t)c];
+        d.asg = mi->asg.as<int>(), d.pairs = mi->pairs.as<int>();
+        d.Nc = mi->Nc.as<int>(), d.ac = mi->ac.as<int>(), d.bc = mi->bc.as<int>();
+        d.SN = mi->SN.as<double>(), d.Sa = mi->Sa.as<double>(), d.Sb = mi->Sb.as<double>();
+        d.phi = mi->phi.as<double>(), d.sc = mi->scalars.as<MiScalars>();
+        d.A[0] = mi->A0.as<int>(), d.A[1] = mi->A1.as<int>();
+        d.draws[0] = mi->draws.as<unsigned>(), d.draws[1] = mi->draws2.as<unsigned>();
+        d.h = mi->h.as<int>(), d.next = mi->next.as<int>();
+        d.head[0] = mi->head.as<int>(), d.head[1] = mi->head2.as<int>();
+        d.g[0] = mi->g.as<int>(), d.g[1] = mi->g2.as<int>();
+        d.mt = mi->mt.as<unsigned>(), d.batch = mi->batch.as<int>();
+        d.S = mi->S.as<long long>(), d.G = mi->G.as<double>();
+        d.D = mi->D, d.C = mi->C, d.P = mi->P, d.L0 = (int)L[c], d.iters = (int)itc, d.pad = 0;
+    }
+    ACAV_TRY(lead->chunk_desc.ensure(sizeof(ChunkDesc) * (size_t)nchunks));
+    ACAV_HIP_TRY(hipMemcpyAsync(lead->chunk_desc.p, desc.data(), sizeof(ChunkDesc) * (size_t)nchunks, hipMemcpyHostToDevice, st));
+    ACAV_HIP_TRY(hipStreamSynchronize(st));  // desc is a local
+    const ChunkDesc *dcd = lead->chunk_desc.as<ChunkDesc>();
+    const int64_t ngroups = (iters_max + MT_GROUP - 1) / MT_GROUP;
+    ACAV_HIP_TRY(hipEventRecord(lead->ev_used[0], st));
+    ACAV_HIP_TRY(hipStreamWaitEvent(smt, lead->ev_used[0], 0));
+    auto launch_mt = [&](int64_t g_) -> int {
+        const int cur_ = (int)(g_ & 1);
+        if (g_ >= 2) ACAV_HIP_TRY(hipStreamWaitEvent(smt, lead->ev_used[cur_], 0));  // the readers of group g_-2 are done
+        hipLaunchKernelGGL(k_mt_generate_multi, dim3((unsigned)nchunks), dim3(MT_THREADS), 0, smt, dcd, (int)g_, (int)dl);
+        ACAV_HIP_TRY(hipEventRecord(lead->ev_mt[cur_], smt));
+        return ACAV_OK;
+    };
+    if (iters_max > 0) ACAV_TRY(launch_mt(0));
+    const size_t smem = sizeof(double) * (size_t)B * (size_t)pmax;
+    for (int64_t it = 0; it < iters_max; ++it) {
+        const int64_t grp = it / MT_GROUP;
+        const int cur = (int)(grp & 1);
+        if (it % MT_GROUP == 0) {
+            if (grp + 1 < ngroups) ACAV_TRY(launch_mt(grp + 1));
+            ACAV_HIP_TRY(hipStreamWaitEvent(st, lead->ev_mt[cur], 0));
+        }
+        const int64_t lt = lmax - it * dl;  // the longest list still in play bounds the grid
+        const dim3 grid((unsigned)((lt + 255) / 256), (unsigned)nchunks);
+        hipLaunchKernelGGL(k_fy_build_multi, grid, dim3(256), 0, st, dcd, (int)it, (int)dl);
+        if (it % MT_GROUP == MT_GROUP - 1 || it + 1 == iters_max) ACAV_HIP_TRY(hipEventRecord(lead->ev_used[cur], st));
+        hipLaunchKernelGGL(k_fy_apply_multi, grid, dim3(256), 0, st, dcd, (int)it, (int)dl, B);
+        hipLaunchKernelGGL(k_mi_select_multi, dim3((unsigned)nchunks), dim3(256), smem, st, dcd, (int)it, (int)dl, B, k,
+                           keep_unselected);
+    }
+    ACAV_HIP_TRY(hipGetLastError());
+    ACAV_HIP_TRY(hipStreamSynchronize(smt));
+    for (int c = 0; c < nchunks; ++c) {
+        acav_mi *mi = mis[c];
+        const int64_t itc = iters[(size_t)c];
+        const int64_t nsel = itc * k < subset[c] ? itc * k : subset[c];
+        if (itc > 0) {
+            ACAV_HIP_TRY(hipMemcpyAsync(S_out[c], mi->S.p, sizeof(long long) * (size_t)nsel, hipMemcpyDeviceToHost, st));
+            ACAV_HIP_TRY(hipMemcpyAsync(GAIN_out[c], mi->G.p, sizeof(double) * (size_t)(itc * k), hipMemcpyDeviceToHost, st));
+        }
+        if (n_selected) n_selected[c] = nsel;
+        if (n_iters) n_iters[c] = itc;
+    }
+    ACAV_HIP_TRY(hipStreamSynchronize(st));
+    for (int c = 0; c < nchunks; ++c) {  // every generator continues on the host where its chunk stopped drawing
+        unsigned mtbuf[625];
+        ACAV_HIP_TRY(hipMemcpy(mtbuf, mis[c]->mt.p, sizeof(mtbuf), hipMemcpyDeviceToHost));
+        ACAV_TRY(acav_rng_set_state(rngs[c], mtbuf, (int)mtbuf[624]));
+    }
+    return ACAV_OK;
+}
+
 ACAV_EXPORT int acav_mi_run_exact(acav_mi *mi, const int64_t *candidates, int64_t L, int ns, int64_t subset,
                                   int64_t *S_out, double *GAIN_out, int64_t *n_selected, const int64_t *forced_pos,
                                   double *trace_scores, int64_t *trace_argmax)

@@ -148,3 +148,53 @@ class EfficientBatchMI:
             print(msg)
         print("Time Consumed: {} seconds".format(elapsed))
         return (S_list, GAIN, timelapse, LOOKUPS)
+
+
+    # ------------------------------------------------------------ several chunks in lockstep
+    @staticmethod
+    def run_greedy_multi(measures, subset_sizes, start_indices_list, verbose=False):
+        """run_greedy for several independent measures (one per chunk, chunk.py:21-53) with ONE set of kernel
+        launches per iteration (acav_mi_run_greedy_multi).  Every measure needs its own generator and must share
+        batch_size / selection_size / keep_unselected; element i of the result is what
+        measures[i].run_greedy(subset_sizes[i], start_indices_list[i]) returns."""
+        n = len(measures)
+        assert n > 0 and len(subset_sizes) == n and len(start_indices_list) == n
+        m0 = measures[0]
+        for m, sub in zip(measures, subset_sizes):
+            m.k = m.modify_k(sub)
+        B, k = int(m0.B), int(m0.k)
+        assert all(int(m.B) == B and int(m.k) == k and bool(m.keep_unselected) == bool(m0.keep_unselected)
+                   for m in measures), "chunks run in lockstep must share batch_size / selection_size / keep_unselected"
+        assert len({id(m._generator) for m in measures}) == n, "every chunk needs its own generator"
+        cands = [m.candidate_ids for m in measures]
+        starts = [np.ascontiguousarray(s, dtype=np.int64) for s in start_indices_list]
+        niters = [math.ceil(int(s) / k) for s in subset_sizes]
+        S = [np.empty(it * k + k, np.int64) for it in niters]
+        G = [np.empty(it * k + k, np.float64) for it in niters]
+
+        def parr(ptrs):
+            return (C.c_void_p * n)(*[p.value if isinstance(p, C.c_void_p) else p for p in ptrs])
+
+        h_arr = parr([m._h for m in measures])
+        c_arr = parr([_lib.ptr(c) for c in cands])
+        s_arr = parr([_lib.ptr(s) if len(s) else None for s in starts])
+        r_arr = parr([m._generator.handle for m in measures])
+        S_arr = parr([_lib.ptr(a) for a in S])
+        G_arr = parr([_lib.ptr(a) for a in G])
+        L = np.array([len(c) for c in cands], np.int64)
+        ns = np.array([len(s) for s in starts], np.int32)
+        sub = np.array([int(s) for s in subset_sizes], np.int64)
+        nsel = np.zeros(n, np.int64)
+        nit = np.zeros(n, np.int64)
+        t0 = time.time()
+        _lib.check(_lib._lib.acav_mi_run_greedy_multi(h_arr, n, c_arr, _lib.ptr(L), s_arr, _lib.ptr(ns), _lib.ptr(sub), B, k,
+                                                      int(bool(m0.keep_unselected)), r_arr, S_arr, G_arr, _lib.ptr(nsel),
+                                                      _lib.ptr(nit)))
+        elapsed = time.time() - t0
+        if verbose:
+            print("Time Consumed: {} seconds for {} chunks in lockstep".format(elapsed, n))
+        out = []
+        for i in range(n):
+            it = int(nit[i])
+            out.append((S[i][:int(nsel[i])].tolist(), G[i][:it * k].tolist(), [elapsed / max(it, 1)] * it, [1] * it))
+        return out

@@ -13,7 +13,7 @@ from pathlib import Path
 
 from .. import shards as io
 from ..parallel import world
-from .run_greedy import run_greedy
+from .run_greedy import _prepare, run_greedy
 
 
 def load_data(shard_paths, metas_path, verbose=False):
@@ -91,6 +91,9 @@ def run_chunks(args):
     mine = chunks[rank * per:(rank + 1) * per] if rank < gpus else []
     print("running {} chunks in {} gpus".format(num_chunks, gpus))
     chunk_args.node_rank = rank
+    width = int(chunk_args.computation.concurrent_chunks or 1)
+    if width > 1:
+        return _run_chunks_lockstep(args, chunk_args, mine, rank, width)
     written = []
     # computation.load_async (chunk.py:119-120,197-226): the next chunk's shards are read and parsed by a host
     # thread while the GPU selects from the current one.  Chunks are still consumed in order, so the cache files
@@ -115,6 +118,52 @@ def run_chunks(args):
         written.append(out_path)
     if pool:
         pool.shutdown()
+    return written
+
+
+def _run_chunks_lockstep(args, chunk_args, mine, rank, width):
+    """computation.concurrent_chunks = width > 1: `width` chunks at a time share ONE set of kernel launches per
+    greedy iteration (acav_mi_run_greedy_multi) -- the loop of a single chunk is a chain of small dependent kernels
+    and leaves most of the GPU idle.  The reference runs a process's chunks one after the other on one RNG
+    stream (chunk.py:115-131); chunks in flight together need a stream each: chunk number `num` draws from
+    Generator(computation.random_seed + 1 + num), whichever rank or group it lands in."""
+    from ..rng import Generator
+    from .measures.batch import EfficientBatchMI
+    assert chunk_args.measure_name == 'batch_mi', "lockstep chunks are implemented for the batch_mi measure"
+    base_seed = int(chunk_args.computation.random_seed or 0)
+    written = []
+    for g0 in range(0, len(mine), width):
+        group = mine[g0:g0 + width]
+        prepared = []
+        for num, chunk in group:
+            print("loading chunk {}".format(num))
+            data, metas = _load(chunk_args, chunk)
+            if not data:
+                prepared.append(None)
+                continue
+            k, (assignments, clustering_types, shard_names, filenames) = data[0]  # single partition (chunk.py:152)
+            measure, start, subset = _prepare(chunk_args, assignments, clustering_types, chunk_args.subset.size,
+                                              chunk_args.subset.ratio, chunk_args.measure_name,
+                                              chunk_args.clustering.pairing, chunk_args.shuffle_candidates,
+                                              chunk_args.verbose, generator=Generator(base_seed + 1 + num))
+            prepared.append((measure, start, subset, shard_names, filenames, metas))
+        live = [p for p in prepared if p is not None]
+        print("running chunks {} in lockstep".format([num for num, _ in group]))
+        results = EfficientBatchMI.run_greedy_multi([p[0] for p in live], [p[2] for p in live], [p[1] for p in live],
+                                                    verbose=chunk_args.verbose) if live else []
+        ri = 0
+        for j, (num, chunk) in enumerate(group):
+            i = g0 + j
+            res, metas = [], {}
+            if prepared[j] is not None:
+                S = sorted(results[ri][0])
+                ri += 1
+                _, _, _, shard_names, filenames, metas = prepared[j]
+                res = [{'filename': filenames[s], 'shard_name': shard_names[s]} for s in S]
+            name = "cache_{}_{}_{}".format(chunk_args.parent_pid, rank, i)
+            cache_out = Path(args.data.output.path).parent / 'caches' / Path(args.data.output.path).name
+            out_path, _ = io.append_output_csv(res, metas, cache_out, name + '_')
+            written.append(out_path)
     return written
 
 

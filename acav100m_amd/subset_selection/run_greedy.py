@@ -5,8 +5,10 @@ from .measures import get_measure
 from .pairing import get_cluster_pairing
 
 
-def _run_greedy(args, assignments, clustering_types, subset_size, subset_ratio, measure_name='mi',
-                cluster_pairing='combination', shuffle_candidates=True, verbose=False):
+def _prepare(args, assignments, clustering_types, subset_size, subset_ratio, measure_name='mi',
+             cluster_pairing='combination', shuffle_candidates=True, verbose=False, generator=None):
+    """Everything of _run_greedy (run_greedy.py:9-48) up to the measure's run_greedy call:
+    -> (measure, start_indices, subset_size)."""
     ncentroids = int(assignments.max()) + 1  # C = max label + 1, not K (run_greedy.py:20)
     dataset_size = assignments.shape[0]
     if subset_size is None:
@@ -18,9 +20,10 @@ def _run_greedy(args, assignments, clustering_types, subset_size, subset_ratio, 
     batch_size = min(args.batch.batch_size, dataset_size - 1)
     selection_size = min(args.batch.selection_size, batch_size)
 
+    extra = {} if generator is None else {'generator': generator}
     measure = get_measure(measure_name)(assignments, ncentroids=ncentroids, batch_size=batch_size,
                                         selection_size=selection_size, device=args.computation.device,
-                                        keep_unselected=args.batch.keep_unselected)
+                                        keep_unselected=args.batch.keep_unselected, **extra)
 
     candidates = list(range(dataset_size))
     if shuffle_candidates:
@@ -32,6 +35,13 @@ def _run_greedy(args, assignments, clustering_types, subset_size, subset_ratio, 
     candidates = candidates[1:]
 
     measure.init(clustering_combinations, candidates)
+    return measure, start_indices, subset_size
+
+
+def _run_greedy(args, assignments, clustering_types, subset_size, subset_ratio, measure_name='mi',
+                cluster_pairing='combination', shuffle_candidates=True, verbose=False):
+    measure, start_indices, subset_size = _prepare(args, assignments, clustering_types, subset_size, subset_ratio,
+                                                   measure_name, cluster_pairing, shuffle_candidates, verbose)
     S, GAIN, timelapse, LOOKUPS = measure.run_greedy(
         subset_size, start_indices, None, verbose=verbose, log_every=args.log_every, log_times=args.log_times,
         node_rank=args.node_rank, pid=args.parent_pid)

@@ -141,6 +141,17 @@ int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64_t L, const 
                        int64_t subset, int B, int k, int keep_unselected, acav_rng *rng, int64_t *S_out,
                        double *GAIN_out, int64_t *n_selected, int64_t *n_iters, int64_t *trace_ids,
                        double *trace_scores, int32_t *trace_pos, const int32_t *forced_pos, int64_t max_iters);
+/* nchunks independent selections (chunk.py:21-53: one EfficientBatchMI + run_greedy per chunk) driven in lockstep
+ * by ONE set of kernel launches per iteration -- the greedy loop of a single chunk is a chain of small dependent
+ * kernels that leaves the GPU mostly idle.  Arrays are indexed by chunk; B, k and keep_unselected are shared.
+ * Chunk c yields exactly what acav_mi_run_greedy(mis[c], candidates[c], L[c], start[c], ns[c], subset[c], B, k,
+ * keep_unselected, rngs[c], ...) yields, and leaves rngs[c] where that call would.  All handles on one device, no
+ * handle or generator twice.  (The reference runs the chunks of a process one after the other on ONE generator;
+ * chunks in flight together need a generator each -- see subset_selection/run.py.) */
+int acav_mi_run_greedy_multi(acav_mi **mis, int nchunks, const int64_t *const *candidates, const int64_t *L,
+                             const int64_t *const *start, const int *ns, const int64_t *subset, int B, int k,
+                             int keep_unselected, acav_rng **rngs, int64_t *const *S_out, double *const *GAIN_out,
+                             int64_t *n_selected, int64_t *n_iters);
 /* EfficientMI.run_greedy / EfficientMemMI (measures/mi.py:150-192; 'mi' and 'mem_mi' of measures/__init__.py:5-14):
  * the exact greedy.  Each of the subset - 1 - ns iterations scores ALL remaining candidates (mi.py:108-110),
  * commits the first maximum (scores.max(dim=0), mi.py:79) and removes it, keeping the order of the rest.  The ns

@@ -124,3 +124,40 @@ def test_chunked_run_sync_and_async_prefetch(workdir):
         # each chunk (2 shards = 512 clips) selects round(0.2 * 512) = 102 clips
         assert len(outs[mode]) == 204
     assert outs[False] == outs[True]
+
+
+def test_chunked_run_lockstep_chunks(workdir):
+    """computation.concurrent_chunks=2: both chunks selected in lockstep by one set of launches; every chunk gets
+    its own generator (random_seed + 1 + chunk number), so the result equals running that chunk alone with it."""
+    import acav100m_amd
+    from acav100m_amd.rng import Generator
+    from acav100m_amd.subset_selection.cli import Cli
+    from acav100m_amd import shards as io
+    from oracle import oracle as O
+    root, glob = workdir
+    if not os.path.isfile(os.path.join(root, "clusters", "shard-000000.pkl")):
+        pytest.skip("clustering test did not run")
+    out_dir = os.path.join(root, "chunked_lockstep")
+    os.makedirs(out_dir, exist_ok=True)
+    out_csv = os.path.join(out_dir, "output.csv")
+    random.seed(1)
+    Cli().run(shards_path=os.path.join(root, "clusters", "shard-{000000..000003}.pkl"),
+              meta_path=os.path.join(root, "videos"), out_path=out_csv, chunk_size=2,
+              **{"computation.concurrent_chunks": 2, "computation.random_seed": 7})
+    Cli().reduce_csvs(out_path=out_csv)
+    lines = open(out_csv).read().splitlines()
+    assert len(lines) == 204
+    # expected: each chunk alone, oracle, same Python shuffle order (chunk 0 then chunk 1) and generator seeds 8, 9
+    random.seed(1)
+    want = []
+    for num in range(2):
+        paths = [os.path.join(root, "clusters", "shard-%06d.pkl" % s) for s in (2 * num, 2 * num + 1)]
+        a, types, shard_names, filenames = io.load_assignment_shards(paths)
+        cand = list(range(len(a)))
+        random.shuffle(cand)
+        pairs = list(itertools.combinations(range(len(types)), 2))
+        res = O.BatchMI(a, int(a.max()) + 1, pairs).run_greedy(cand[1:], cand[:1], round(0.2 * len(a)), 20, 4,
+                                                               O.Rng(7 + 1 + num))
+        want += [filenames[s] for s in sorted(res["S"])]
+    got = [r[1] for r in csv.reader(_io.StringIO("\n".join(lines)))]
+    assert got == want

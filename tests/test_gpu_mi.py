@@ -244,3 +244,49 @@ def test_exact_greedy_through_run_greedy(env):
     assert m.run_greedy(1, [cand[0]])[0] == [cand[0]]
     S_all = m.run_greedy(10 ** 6, [cand[0]])[0]                # more than there are candidates: everything, once
     assert sorted(S_all) == list(range(400))
+
+
+def test_lockstep_chunks_equal_individual_runs(env):
+    """acav_mi_run_greedy_multi: several chunks (different sizes, different D / P / C tables, own generators) driven
+    by one set of launches per iteration give exactly what each chunk gives alone -- and hence the oracle's result;
+    every generator ends where its own run would have left it."""
+    torch, acav, O = env
+    from acav100m_amd.rng import Generator
+    from acav100m_amd.subset_selection import get_measure
+    from acav100m_amd.subset_selection.measures.batch import EfficientBatchMI
+    specs = [(3000, 2, 16, 300), (1200, 3, 40, 100), (5000, 2, 256, 37), (800, 4, 8, 160), (2500, 2, 64, 1)]
+    data = []
+    for i, (v, dd, c, subset) in enumerate(specs):
+        a = _correlated(900 + i, v, dd, c)
+        cand = np.random.RandomState(i).permutation(v)
+        data.append((a, c, list(itertools.combinations(range(dd), 2)), cand, subset))
+
+    def build(i, seed):
+        a, c, pairs, cand, subset = data[i]
+        m = get_measure("batch_mi")(a, ncentroids=c, batch_size=20, selection_size=4, device="cuda:0",
+                                    keep_unselected=True, generator=Generator(seed))
+        m.init(pairs, [int(j) for j in cand[1:]])
+        return m
+
+    for keep in (True,):
+        alone, tails = [], []
+        for i in range(len(specs)):
+            m = build(i, 50 + i)
+            alone.append(m.run_greedy(data[i][4], [int(data[i][3][0])], None))
+            tails.append(m._generator.u32())
+        ms = [build(i, 50 + i) for i in range(len(specs))]
+        multi = EfficientBatchMI.run_greedy_multi(ms, [d[4] for d in data], [[int(d[3][0])] for d in data])
+        for i in range(len(specs)):
+            assert multi[i][0] == alone[i][0] and multi[i][1] == alone[i][1], f"chunk {i}"
+            assert ms[i]._generator.u32() == tails[i]
+            a, c, pairs, cand, subset = data[i]
+            r = O.BatchMI(a, c, pairs).run_greedy(cand[1:], cand[:1], subset, 20, 4, O.Rng(50 + i))
+            assert multi[i][0] == r["S"].tolist()
+            cache = ms[i].cache
+            Nc, ac, bc, nc = O.BatchMI(a, c, pairs).counts()
+            assert cache["n"] == 1 + len(multi[i][1])
+    with pytest.raises(AssertionError):
+        g = Generator(1)
+        m1, m2 = build(0, 1), build(1, 2)
+        m1._generator = m2._generator = g
+        EfficientBatchMI.run_greedy_multi([m1, m2], [10, 10], [[0], [0]])
