@@ -114,6 +114,24 @@ def mi_stage(seed, v=100_000, c=256, oracle_iters=100):
     out = {"workload": f"one chunk: V={v}, D=2, C={c}, select 20% (B=20, k=4)", "iterations": iters,
            "us_per_iteration": dt / iters * 1e6, "selected_clips_per_s": len(S) / dt, "curated_clips_per_s": v / dt,
            "permutation_stream_GBs": sum(16 * (v - 1 - 4 * t) for t in range(iters)) / dt / 1e9}
+    # the same chunk size with 8 chunks in lockstep (computation.concurrent_chunks): aggregate per chunk-iteration
+    try:
+        from acav100m_amd.rng import Generator
+        from acav100m_amd.subset_selection.measures.batch import EfficientBatchMI
+        ms = []
+        for i in range(8):
+            mi = get_measure("batch_mi")(a, ncentroids=c, batch_size=20, selection_size=4, device="cuda",
+                                         keep_unselected=True, generator=Generator(seed + 1 + i))
+            mi.init(pairs, cand[1:])
+            ms.append(mi)
+        with contextlib.redirect_stdout(io.StringIO()):
+            t0 = time.perf_counter()
+            EfficientBatchMI.run_greedy_multi(ms, [subset] * 8, [cand[:1]] * 8)
+            dt8 = time.perf_counter() - t0
+        out["lockstep_8_chunks"] = {"us_per_chunk_iteration": dt8 / (8 * iters) * 1e6, "curated_clips_per_s": 8 * v / dt8}
+        del ms
+    except Exception as exc:
+        out["lockstep_8_chunks"] = {"error": str(exc)}
     try:
         from oracle import oracle as O
         O.set_threads(1)
