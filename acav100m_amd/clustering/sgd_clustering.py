@@ -15,8 +15,11 @@ from .. import _lib
 from ..rng import default_generator
 
 
-def _as_f32_2d(batch):
-    """-> (object keeping the memory alive, void*, rows, is_torch_cuda)"""
+def _as_f32_2d(batch, width=None):
+    """-> (object keeping the memory alive, void*, rows, is_torch_cuda); width: the d the library will stride by"""
+    shape = tuple(batch.shape) if hasattr(batch, "shape") else np.shape(batch)
+    if len(shape) != 2 or (width is not None and shape[1] != width):
+        raise ValueError("expected a [rows, {}] feature matrix, got shape {}".format(width if width is not None else "d", shape))
     if hasattr(batch, "data_ptr"):  # torch tensor (cpu or cuda)
         import torch
         t = batch.detach()
@@ -217,7 +220,7 @@ class KMeans:
         import torch
         h = self._require_handle()
         k = self._shape[0]
-        keep, xp, b, on_gpu = _as_f32_2d(batch)
+        keep, xp, b, on_gpu = _as_f32_2d(batch, self._shape[1])
         if self.count < self.initial_rounds * k:
             best, mean = self._generator.warmup_best(k, b)
             out = torch.from_numpy(best)
@@ -264,7 +267,7 @@ class KMeans:
             raise NotImplementedError("the reference's slow `sequential` branch is never enabled (sequential=False)")
         k = self._shape[0]
         lr = self.lr(self.count) if callable(self.lr) else self.lr
-        keep, xp, b, on_gpu = _as_f32_2d(batch)
+        keep, xp, b, on_gpu = _as_f32_2d(batch, self._shape[1])
         if self.is_distributed:
             return self._add_distributed(batch, lr)
         mean = C.c_float(0)
@@ -282,7 +285,7 @@ class KMeans:
 
     def apply_update(self, x, best, lr):
         """The update half of add() on an already-labelled global batch (sgd_clustering.py:113-128)."""
-        keep, xp, b, _ = _as_f32_2d(x)
+        keep, xp, b, _ = _as_f32_2d(x, self._shape[1])
         if hasattr(best, "data_ptr"):
             import torch
             lab = best.detach().to(torch.long).contiguous()
@@ -307,7 +310,7 @@ class KMeans:
         and must consume it batch by batch); drawn here otherwise."""
         h = self._require_handle()
         lr = self.lr if lr is None else lr
-        keep, xp, n, _ = _as_f32_2d(x)
+        keep, xp, n, _ = _as_f32_2d(x, self._shape[1])
         need = self.warmup_steps(batch_size, n // batch_size)
         if warm_best is None:
             warm = np.empty((need, batch_size), np.int64)

@@ -1605,8 +1605,9 @@ ACAV_EXPORT int acav_kmeans_set_state(acav_kmeans *km, const float *centers, con
 
 ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, int64_t *labels, float *mean_dist)
 {
-    ACAV_REQUIRE(km && x && labels, ACAV_EINVAL, "NULL argument");
+    ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");
     ACAV_REQUIRE(n >= 0, ACAV_EINVAL, "n must be >= 0");
+    ACAV_REQUIRE(n == 0 || (x && labels), ACAV_EINVAL, "NULL argument");  // an empty tensor has no storage
     ACAV_REQUIRE(!km->warm(), ACAV_ESTATE,
                  "count=%lld < initial_rounds*k=%lld: labels come from the warm-up rng (acav_rng_warmup_best)",
                  (long long)km->count, (long long)km->initial_rounds * km->K);
@@ -1791,8 +1792,11 @@ ACAV_EXPORT int acav_kmeans_apply_update(acav_kmeans *km, const float *x, int64_
 ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, int64_t b, double lr,
                                   const int64_t *warm_best, int64_t n_warm)
 {
-    ACAV_REQUIRE(km && x, ACAV_EINVAL, "NULL argument");
+    ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");
     ACAV_REQUIRE(n >= 0 && b > 0 && n_warm >= 0, ACAV_EINVAL, "bad sizes");
+    ACAV_REQUIRE(b <= SU_MAXB, ACAV_EINVAL, "batch size %lld above the supported %d", (long long)b, SU_MAXB);
+    if (n / b == 0) return ACAV_OK;  // drop_last: not even one full batch (run_clustering.py:204)
+    ACAV_REQUIRE(x, ACAV_EINVAL, "NULL argument");
     ACAV_HIP_TRY(hipSetDevice(km->ctx.device));
     hipStream_t st = km->ctx.stream;
     const int64_t steps = n / b;  // drop_last=True (run_clustering.py:204)

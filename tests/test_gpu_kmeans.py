@@ -285,3 +285,38 @@ def test_errors_are_loud(env):
         km.add(np.zeros((4, 8), np.float32))  # not on a GPU
     with pytest.raises(acav.AcavError):
         km.to("cpu")
+
+
+def test_edge_cases_empty_single_and_limits(env):
+    """empty inputs, single rows / single centre-adjacent sizes, and the documented limits fail cleanly (no crash,
+    no hang): the C ABI reports ACAV_EINVAL -> ValueError like the reference's asserts."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    d, K = 16, 5
+    acav.manual_seed(3)
+    km = KMeans(None, d, K).to("cuda:0")
+    ref = O.KMeans(d, K, O.Rng(3))
+    x = _mixture(1, 200, d, K)
+    xt = torch.from_numpy(x).cuda()
+    km.train_epoch(xt, 32, lr=0.01)
+    ref.train_epoch(x, 32, lr=0.01)
+    # empty batch: no labels, state untouched
+    empty = torch.empty((0, d), dtype=torch.float32, device="cuda")
+    lab, _ = km.calc_best(empty, need_mean=False)
+    assert lab.numel() == 0
+    km.train_epoch(empty, 32, lr=0.01)             # floor(0 / 32) = 0 steps
+    km.train_epoch(xt[:31], 32, lr=0.01)           # fewer rows than one batch: drop_last -> 0 steps
+    assert np.array_equal(km.centers.numpy(), ref.centers) and km.count == ref.count
+    # one row, one step of one row
+    one, _ = km.calc_best(xt[:1])
+    assert one.cpu().numpy().tolist() == ref.calc_best(x[:1])[0].tolist()
+    km.train_epoch(xt[:3], 1, lr=0.01)
+    ref.train_epoch(x[:3], 1, lr=0.01)
+    assert np.array_equal(km.centers.numpy(), ref.centers) and km.count == ref.count
+    # limits
+    with pytest.raises(ValueError):
+        km.train_epoch(xt, 2048, lr=0.01)          # batch above the supported 1024
+    with pytest.raises((ValueError, acav.AcavError)):
+        km.calc_best(torch.zeros((4, d + 1), device="cuda"))  # wrong feature width
+    with pytest.raises((ValueError, acav.AcavError)):
+        KMeans(None, d, 0).to("cuda:0")            # the handle is created on the move to the device
