@@ -254,6 +254,14 @@ def main():
                          "launch_ms": a_ms, "algorithmic_bytes": bytes_per_launch,
                          "algorithmic_flops": flops_per_launch, "effective_TFLOPs": tfs,
                          "rows_rechecked_exact": frecheck, "rows": frows},
+            # the kernel that dominates the wall clock is NOT throughput-bound: n/b dependent SGD steps (each needs
+            # the centres the previous one wrote); its bytes against the HBM roof are reported for completeness
+            "train_kernel": {"kernel": "k_train_persistent" if world == 1 else "k_step_dist_dma + k_step_update (global batch %d)" % (b * world),
+                             "bound": "latency (dependent chain of %d steps)" % (n // b),
+                             "us_per_step": (ms_per_step - a_ms) * 1e3 / (n // b),
+                             "algorithmic_bytes_per_epoch": n * d * 4 * world,
+                             "achieved_GBs": n * d * 4 * world / ((ms_per_step - a_ms) * 1e-3) / 1e9,
+                             "frac_of_hbm_peak": n * d * 4 * world / ((ms_per_step - a_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "stages": {"assign_ms": a_ms, "assign_clips_per_s": n / (a_ms * 1e-3),
                        "train_epoch_ms": ms_per_step - a_ms,
                        "train_clips_per_s": n / ((ms_per_step - a_ms) * 1e-3),
