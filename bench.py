@@ -162,12 +162,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("ACAV_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device(dev))
+        backend = os.environ.get("ACAV_BENCH_BACKEND", "nccl")  # "gloo": several ranks on ONE GPU (plumbing check)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import acav100m_amd
     from acav100m_amd import _lib

@@ -57,3 +57,66 @@ def test_distributed_add_world1_rccl():
         assert np.array_equal(km2.counts.numpy(), ref2.counts) and km2.count == ref2.count
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share cuda:0; gloo moves the bytes
+    try:
+        import acav100m_amd
+        from acav100m_amd.clustering import KMeans
+
+        class NS:
+            pass
+        args = NS()
+        args.computation = NS()
+        args.computation.device = "cuda"
+        args.computation.num_gpus = world
+        d, k, b, steps = 256, 24, 16, 40
+        rs = np.random.RandomState(100 + rank)
+        x = (np.random.RandomState(5).randn(k, d)[rs.randint(0, k, steps * b)] * 3 + rs.randn(steps * b, d)).astype(np.float32)
+        acav100m_amd.manual_seed(11 + rank)           # every rank draws ITS warm-up labels from its own stream
+        km = KMeans(args, d, k).to("cuda:0")
+        km.centers = np.random.RandomState(5).randn(k, d).astype(np.float32) * 1e-5   # same start on all ranks
+        km.initialize()
+        km.train_epoch_distributed(torch.from_numpy(x).cuda(), b, lr=0.01, chunk_steps=16)
+        np.savez(os.path.join(tmp, f"r{rank}.npz"), c=km.centers.numpy(), n=km.counts.numpy(), count=km.count, x=x)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_bulk_gathered_epoch(tmp_path):
+    """The multi-GPU epoch end to end with TWO processes and real GPU engines (both on cuda:0, gloo carrying the
+    collectives): identical state on both ranks, equal to one process fed the rank-major global batches -- warm-up
+    labels of each rank's own generator included."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    assert np.array_equal(r0["c"], r1["c"]) and np.array_equal(r0["n"], r1["n"]) and r0["count"] == r1["count"]
+    from oracle import oracle as O
+    d, k, b, steps = 256, 24, 16, 40
+    ref = O.KMeans(d, k, O.Rng(0), centers=np.random.RandomState(5).randn(k, d).astype(np.float32) * 1e-5)
+    g0, g1 = O.Rng(11), O.Rng(12)
+    # the product draws torch.rand(k, d) * 1e-5 at construction from each rank's generator before the warm-up labels
+    g0.rand(k * d), g1.rand(k * d)
+    for t in range(steps):
+        xb = np.concatenate([r0["x"][t * b:(t + 1) * b], r1["x"][t * b:(t + 1) * b]])
+        c, cnt, count, _ = ref.get_state()
+        if count < 10 * k:
+            lab = np.concatenate([g0.rand(k, b).argmin(0), g1.rand(k, b).argmin(0)]).astype(np.int64)  # sgd_clustering.py:67-68,78
+            ref.apply_update(xb, lab, 0.01)
+        else:
+            ref.add(xb, 0.01)
+    rc, rcnt, rcount, _ = ref.get_state()
+    assert np.array_equal(r0["c"], rc) and np.array_equal(r0["n"], rcnt) and int(r0["count"]) == rcount
