@@ -322,6 +322,14 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
 // error <= d 2^-24 sum|cx|; sum|cx| <= ||c|| ||x||.  Hence |dot~ - dot| <= ||c|| ||x|| (2^-8 (1+2^-10) + 2.02 d 2^-24)
 // and, through -2 dot + ||x||^2 + ||c||^2 (three fp32 roundings of magnitude <= (||x||+||c||)^2):
 //   E_i = 2.02 (2^-8 1.002 + 2.02 d 2^-24) cmax ||x_i|| + 2^-17 (||x_i|| + cmax)^2,   cmax = max_k ||c_k||
+// CENTRED CENTRES.  With c = c' + mu for ANY common vector mu, -2 x.c = -2 x.c' - 2 x.mu and the last term is the
+// same for every centre of a row: it moves d1 and d2 alike.  The filter therefore multiplies by c' = fl(c - mu)
+// (mu = the mean centre) and its bf16 error scales with cmax' = max_k ||c'_k|| -- the SPREAD of the centres -- instead
+// of their norm; embeddings with a large common component (post-ReLU features) would otherwise send almost every
+// row to the exact re-check.  Only the accumulation error of the canonical dot keeps the raw norm:
+//   E_i = 2.02 [ (2^-8 1.002 + 1.01 d 2^-24) cmax' + (1.01 d 2^-24 + 2^-24) cmax ] ||x_i|| + 2^-17 (||x_i|| + cmax)^2
+// (2^-24 ||x|| cmax' covers the rounding of c - mu; mu = 0 gives back the formula above).  A row constant does not
+// survive the under-use division by r, so the centres are only centred when no centre is under-used.
 // The second term also covers what the filter's epilogue does differently from the exact one: it multiplies by
 // fl(1/r) where the exact path divides by r (< 2 ulp), and it overwrites the 5 low mantissa bits of a distance
 // with the centre's position in the lane (< 2^-18 relative) -- together < 2^-17 (||x_i|| + cmax)^2 with room to
@@ -331,17 +339,60 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int FB_ROWS = 128;  // rows per workgroup (4 MFMA row tiles)
 
 struct CentersAux {
-    unsigned cmax_bits;  // bits of max_k ||c_k||^2 (non-negative floats order like unsigned)
+    unsigned cmax_bits;   // bits of max_k ||c_k||^2 (non-negative floats order like unsigned)
+    unsigned cmaxc_bits;  // bits of (an upper bound of) max_k ||c'_k||^2 of the copy the filter multiplies by
+    unsigned any_disc;    // some centre is under-used (distance / r): no centring
+    unsigned pad;
 };
 
-__global__ __launch_bounds__(256) void k_centers_bf16(const float *__restrict__ c, const float *__restrict__ cn, int K,
-                                                      int d, __bf16 *__restrict__ out, CentersAux *__restrict__ aux)
+// mu[j] = mean over the centres of column j (any vector would do, see the bound): 32 columns x 8 centre lanes per block
+// Block 0 also scans the per-centre scalars: max ||c_k||^2 and whether any centre is under-used.
+__global__ __launch_bounds__(256) void k_centers_mu(const float *__restrict__ c, const float *__restrict__ cn,
+                                                    const float *__restrict__ counts, int K, int d, float thr,
+                                                    float *__restrict__ mu, CentersAux *__restrict__ aux)
 {
-    const size_t total = (size_t)K * d;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = (__bf16)c[i];
+    __shared__ float sp[8][32];
     if (blockIdx.x == 0)
-        for (int k = threadIdx.x; k < K; k += blockDim.x) atomicMax(&aux->cmax_bits, __float_as_uint(cn[k]));
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            atomicMax(&aux->cmax_bits, __float_as_uint(cn[k]));
+            if (counts[k] < thr) atomicOr(&aux->any_disc, 1u);
+        }
+    const int cj = threadIdx.x & 31, ky = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + cj;
+    float s = 0.f;
+    if (j < d)
+        for (int k = ky; k < K; k += 8) s = s + c[(size_t)k * d + j];
+    sp[ky][cj] = s;
+    __syncthreads();
+    if (ky == 0 && j < d) {
+        float t = sp[0][cj];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t = t + sp[q][cj];
+        mu[j] = t / (float)K;
+    }
+}
+
+// one block per centre: the bf16 copy of c_k (or of c_k - mu) and the largest squared norm of what was rounded
+__global__ __launch_bounds__(256) void k_centers_bf16(const float *__restrict__ c, const float *__restrict__ mu, int d,
+                                                      __bf16 *__restrict__ out, CentersAux *__restrict__ aux)
+{
+    __shared__ float sred[4];
+    const bool centred = aux->any_disc == 0u;
+    const size_t base = (size_t)blockIdx.x * d;
+    float ss = 0.f;
+    for (int j = threadIdx.x; j < d; j += blockDim.x) {
+        const float v = centred ? c[base + j] - mu[j] : c[base + j];
+        out[base + j] = (__bf16)v;
+        ss = __builtin_fmaf(v, v, ss);
+    }
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) ss = ss + __shfl_xor(ss, dlt);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = ((sred[0] + sred[1]) + (sred[2] + sred[3])) * (1.0f + 2.0f * (float)d * 5.9604645e-8f);  // >= exact
+        atomicMax(&aux->cmaxc_bits, __float_as_uint(tot));
+    }
 }
 
 struct Top2 {
@@ -423,7 +474,7 @@ template <bool NT>
 __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict__ x, int64_t n, int d,
                                                             const __bf16 *__restrict__ cb, const float *__restrict__ cn,
                                                             const float *__restrict__ counts, int K, float thr, float r,
-                                                            const CentersAux *__restrict__ aux, float e1coef, float e2coef,
+                                                            const CentersAux *__restrict__ aux, float e1c, float e1r, float e2coef,
                                                             int64_t *__restrict__ labels, int *__restrict__ recheck_list,
                                                             unsigned *__restrict__ recheck_count)
 {
@@ -699,8 +750,9 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict_
     if (tid < 128 && row0 + tid < n) {
         const float xnorm = __builtin_sqrtf(my_xn);
         const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
+        const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
         const float s = xnorm + cmax;
-        const float E = e1coef * cmax * xnorm + e2coef * s * s;
+        const float E = (e1c * cmaxc + e1r * cmax) * xnorm + e2coef * s * s;
         labels[row0 + tid] = (int64_t)run.k1;
         if (!((run.d2 - run.d1) > 2.0f * E)) {  // also catches NaN / inf
             const unsigned slot = atomicAdd(recheck_count, 1u);
@@ -1453,7 +1505,7 @@ struct acav_kmeans {
     int64_t count = 0;  // python int self.count (deterministic on the host)
     DevBuf centers, cn, counts, scalars;
     DevBuf stage_x, stage_lab, stage_forced, keys, xn, wg_sum, minval, thr, ctl;
-    DevBuf cb16, caux, recheck_list, recheck_count;
+    DevBuf cb16, caux, cmu, recheck_list, recheck_count;
     bool cb16_valid = false;  // bf16 copy of the centres matches `centers`
     int64_t n_filter_launches = 0;
     uint64_t last_recheck = 0, last_rows = 0;
@@ -1639,16 +1691,22 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
             ACAV_TRY(km->cb16.ensure(sizeof(unsigned short) * (size_t)km->K * km->d));
             ACAV_TRY(km->caux.ensure(sizeof(CentersAux)));
             ACAV_HIP_TRY(hipMemsetAsync(km->caux.p, 0, sizeof(CentersAux), st));
-            hipLaunchKernelGGL(k_centers_bf16, dim3(256), dim3(256), 0, st, km->centers.as<float>(), km->cn.as<float>(), km->K,
-                               km->d, km->cb16.as<__bf16>(), km->caux.as<CentersAux>());
+            ACAV_TRY(km->cmu.ensure(sizeof(float) * (size_t)km->d));
+            hipLaunchKernelGGL(k_centers_mu, dim3((unsigned)((km->d + 31) / 32)), dim3(256), 0, st, km->centers.as<float>(),
+                               km->cn.as<float>(), km->counts.as<float>(), km->K, km->d, km->threshold(), km->cmu.as<float>(),
+                               km->caux.as<CentersAux>());
+            hipLaunchKernelGGL(k_centers_bf16, dim3((unsigned)km->K), dim3(256), 0, st, km->centers.as<float>(),
+                               km->cmu.as<float>(), km->d, km->cb16.as<__bf16>(), km->caux.as<CentersAux>());
             ACAV_HIP_TRY(hipGetLastError());
             km->cb16_valid = true;
         }
         ACAV_TRY(km->recheck_list.ensure(sizeof(int) * (size_t)n));
         ACAV_TRY(km->recheck_count.ensure(sizeof(unsigned)));
         ACAV_HIP_TRY(hipMemsetAsync(km->recheck_count.p, 0, sizeof(unsigned), st));
-        const double rel = ldexp(1.0, -8) * 1.002 + 2.02 * (double)km->d * ldexp(1.0, -24);
-        const float e1 = (float)(2.02 * rel * 1.001), e2 = (float)ldexp(1.0, -17);
+        const double acc = 1.01 * (double)km->d * ldexp(1.0, -24);  // accumulation error of one fp32 dot, relative
+        const float e1c = (float)(2.02 * (ldexp(1.0, -8) * 1.002 + acc) * 1.001);   // x ||c'|| ||x||: bf16 roundings + filter dot
+        const float e1r = (float)(2.02 * (acc + ldexp(1.0, -24)) * 1.001);           // x ||c|| ||x||: canonical dot, c - mu
+        const float e2 = (float)ldexp(1.0, -17);
         // rows are read exactly once: non-temporal DMA policy (ACAV_FILTER_NT=0 restores the default policy)
         const char *vnt = getenv("ACAV_FILTER_NT");
         auto kern = (vnt && vnt[0] == '0') ? k_assign_bf16<false> : k_assign_bf16<true>;
@@ -1656,8 +1714,8 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
                                          hipFuncAttributeMaxDynamicSharedMemorySize, FD_SMEM));
         hipLaunchKernelGGL(kern, dim3((unsigned)((n + FB_ROWS - 1) / FB_ROWS)), dim3(256), FD_SMEM, st,
                            static_cast<const float *>(dx), n, km->d, km->cb16.as<__bf16>(), km->cn.as<float>(),
-                           km->counts.as<float>(), km->K, km->threshold(), (float)km->reinit_r, km->caux.as<CentersAux>(), e1,
-                           e2, dlab, km->recheck_list.as<int>(), km->recheck_count.as<unsigned>());
+                           km->counts.as<float>(), km->K, km->threshold(), (float)km->reinit_r, km->caux.as<CentersAux>(), e1c,
+                           e1r, e2, dlab, km->recheck_list.as<int>(), km->recheck_count.as<unsigned>());
         ACAV_HIP_TRY(hipGetLastError());
 #ifdef ACAV_FD_PROF
         {

@@ -149,12 +149,16 @@ def test_assign_matches_oracle(env, n, d, K):
     assert np.array_equal(lab_h.numpy(), lab_ref)
 
 
-@pytest.mark.parametrize("case", ["clustered", "unstructured", "duplicates", "two_groups", "tiny_gap"])
+@pytest.mark.parametrize("case", ["clustered", "unstructured", "duplicates", "two_groups", "tiny_gap",
+                                  "offset", "offset_unstructured", "offset_tiny_gap", "offset_discounted"])
 def test_bf16_filter_path_is_bit_identical(env, case):
     """calc_best(need_mean=False) = bf16-MFMA filter + exact re-check of the rows whose top-2 gap is below
     the proven bound.  Labels must equal the oracle's for ANY data: well separated clusters (no re-check),
     unstructured data (most rows re-checked), duplicated centres (exact ties -> first index), K > 256,
-    and near-ties far below bf16 resolution."""
+    near-ties far below bf16 resolution, and embeddings with a large common component ("offset": every feature
+    shifted by +25, norms 25x the cluster spread) -- there the filter multiplies by the CENTRED centres, whose
+    bound scales with the spread of the centres, unless a centre is under-used (the row constant does not survive
+    the division by r: "offset_discounted" takes the raw filter and re-checks nearly everything)."""
     torch, acav, O = env
     from acav100m_amd.clustering import KMeans
     rs = np.random.RandomState(7)
@@ -177,11 +181,25 @@ def test_bf16_filter_path_is_bit_identical(env, case):
         K, d = 300, 128
         x = _mixture(3, n, d, 100)
         centers = np.stack([x[rs.randint(0, n)] for _ in range(K)]).astype(np.float32)
+    elif case in ("offset", "offset_discounted"):
+        rs2 = np.random.RandomState(12)
+        cen = (1.0 * rs2.randn(K, d)).astype(np.float32)
+        x = (cen[rs2.randint(0, K, n)] + 0.1 * rs2.randn(n, d) + 25.0).astype(np.float32)
+        centers = (cen + 0.02 * rs2.randn(K, d) + 25.0).astype(np.float32)
+    elif case == "offset_unstructured":
+        x = (rs.randn(n, d) + 25.0).astype(np.float32)
+        centers = (rs.randn(K, d) + 25.0).astype(np.float32)
+    elif case == "offset_tiny_gap":
+        x = (_mixture(4, n, d, K // 2) + 25.0).astype(np.float32)
+        base = np.stack([x[rs.randint(0, n)] for _ in range(K // 2)]).astype(np.float32)
+        centers = np.concatenate([base, base + (1e-4 * rs.randn(K // 2, d)).astype(np.float32)])
     else:  # tiny_gap: pairs of centres 1e-4 apart -- invisible to bf16, decided by the exact pass
         x = _mixture(4, n, d, K // 2)
         base = np.stack([x[rs.randint(0, n)] for _ in range(K // 2)]).astype(np.float32)
         centers = np.concatenate([base, base + (1e-4 * rs.randn(K // 2, d)).astype(np.float32)])
     counts = rs.randint(0, 80, K).astype(np.float32)  # some centres under the usage threshold -> discount
+    if case in ("offset", "offset_unstructured", "offset_tiny_gap"):
+        counts = np.full(K, 1000, np.float32)          # nobody under-used: the centred filter applies
     count = 10 * K + 2000
     km = KMeans(None, d, K)
     km.centers, km.counts, km.count = centers, counts, count
@@ -198,8 +216,10 @@ def test_bf16_filter_path_is_bit_identical(env, case):
     lab_exact, _ = km.calc_best(xt)  # exact path
     assert np.array_equal(lab_exact.cpu().numpy(), lab_ref)
     print(f"{case}: {rechecked}/{n} rows needed the exact re-check")
-    if case in ("unstructured", "tiny_gap"):
+    if case in ("unstructured", "tiny_gap", "offset_tiny_gap", "offset_discounted"):
         assert rechecked > n // 2   # the exact pass really decided these
+    if case == "offset":
+        assert rechecked < n // 20  # centred centres: the common component costs nothing
 
 
 def test_exact_ties_take_first_index(env):

@@ -34,12 +34,14 @@ while time.time() < t_end:
         k = int(rs.choice([2, 3, 17, 64, 255, 256, 257, 300, 600]))
         n = int(rs.choice([1, 63, 128, 129, 1000, 4097, 20000]))
         x = mixture(n, d, k, float(rs.choice([0.05, 1.0, 4.0])))
+        offset = float(rs.choice([0.0, 0.0, 3.0, 40.0]))  # a large common component: the centred filter's case
+        x = (x + offset).astype(np.float32)
         s = int(rs.randint(1 << 30))
         acav100m_amd.manual_seed(s)
         km = KMeans(None, d, k).to("cuda:0")
         ref = O.KMeans(d, k, O.Rng(s))
-        cen = mixture(k, d, k, 1.0)
-        cnts = rs.randint(0, 50, k).astype(np.float32)
+        cen = (mixture(k, d, k, 1.0) + offset).astype(np.float32)
+        cnts = rs.randint(0, 50, k).astype(np.float32) if rs.rand() < 0.5 else np.full(k, 500, np.float32)
         km.centers, km.counts, km.count = cen, cnts, 10 * k + int(cnts.sum())
         ref.set_state(cen, cnts, 10 * k + int(cnts.sum()))
         xt = torch.from_numpy(x).cuda()
