@@ -587,9 +587,13 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict_
 #define FD_LOAD_A(ks, A)                                                                          \
     A[0] = *reinterpret_cast<const bf16x8 *>(pcl + (((2 * (ks) + h) ^ swa) << 3));                \
     A[1] = *reinterpret_cast<const bf16x8 *>(pcl + 32 * 32 + (((2 * (ks) + h) ^ swa) << 3));
-#define FD_LOAD_X(ks, rt, F0, F1)                                                                                 \
-    const float4 F0 = *reinterpret_cast<const float4 *>(pxl + (rt) * 1024 + (((4 * (ks) + 2 * h) ^ swz) << 2));   \
-    const float4 F1 = *reinterpret_cast<const float4 *>(pxl + (rt) * 1024 + (((4 * (ks) + 2 * h + 1) ^ swz) << 2));
+            // accumulator slot j of this wave holds row tile (j + wq) & 3: slot 0 is always the wave's OWN tile, the
+            // one whose canonical ||x||^2 it accumulates -- from the fragments it reads anyway, no branch, no re-read
+            const float *pxj[4] = {pxl + ((0 + wq) & 3) * 1024, pxl + ((1 + wq) & 3) * 1024, pxl + ((2 + wq) & 3) * 1024,
+                                   pxl + ((3 + wq) & 3) * 1024};
+#define FD_LOAD_X(ks, j, F0, F1)                                                                               \
+    const float4 F0 = *reinterpret_cast<const float4 *>(pxj[j] + (((4 * (ks) + 2 * h) ^ swz) << 2));          \
+    const float4 F1 = *reinterpret_cast<const float4 *>(pxj[j] + (((4 * (ks) + 2 * h + 1) ^ swz) << 2));
 #define FD_SSQ(ks, F0, F1)                                           \
     ssq[8 * (ks) + 0] = __builtin_fmaf(F0.x, F0.x, ssq[8 * (ks) + 0]); \
     ssq[8 * (ks) + 1] = __builtin_fmaf(F0.y, F0.y, ssq[8 * (ks) + 1]); \
@@ -631,11 +635,9 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict_
                 const bf16x8 d2 = cvt_bf16x8(q20, q21), d3 = cvt_bf16x8(q30, q31);
                 FD_MMA(a1, 2, d2)
                 FD_MMA(a1, 3, d3)
-                if (cg == 0) {  // this wave's share of the canonical ||x||^2: row tile wq, classes 16 ks + 8 h + e
-                    FD_LOAD_X(0, wq, s00, s01)
-                    FD_LOAD_X(1, wq, s10, s11)
-                    FD_SSQ(0, s00, s01)
-                    FD_SSQ(1, s10, s11)
+                if (cg == 0) {  // uniform: this wave's share of the canonical ||x||^2 (row tile wq, classes 16 ks + 8 h + e)
+                    FD_SSQ(0, p00, p01)
+                    FD_SSQ(1, q00, q01)
                 }
             }
 #undef FD_LOAD_A
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict_
         __syncthreads();
         if (cg == 0) {
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) xn_rt[rt] = sXn[rt * 32 + l31];
+            for (int rt = 0; rt < 4; ++rt) xn_rt[rt] = sXn[((rt + wq) & 3) * 32 + l31];  // slot rt = row tile (rt + wq) & 3
             if (tid < 128) my_xn = sXn[tid];
         }
         // Scan of this lane's 4 x 32 distances without a single compare: the low 5 mantissa bits of every distance
@@ -710,7 +712,7 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict_
         }
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-            const int row = rt * 32 + l31;
+            const int row = ((rt + wq) & 3) * 32 + l31;
             const unsigned c5 = __float_as_uint(s1[rt]) & 31u;  // (ct, g, j) of the lane's minimum
             Top2 t = {s1[rt], kbase + wq * 64 + 4 * h + (int)((c5 >> 4) * 32 + ((c5 >> 2) & 3) * 8 + (c5 & 3)), s2[rt]}, o;
             o.d1 = __shfl_xor(t.d1, 32);
