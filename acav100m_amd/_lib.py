@@ -40,6 +40,7 @@ SIGNATURES = {
     "acav_kmeans_timer_end": [vp, C.POINTER(f32)],
     "acav_kmeans_stats": [vp, C.POINTER(i64), C.POINTER(i64)],
     "acav_kmeans_filter_stats": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
+    "acav_kmeans_filter_time": [vp, C.POINTER(f32)],
     "acav_mi_create": [pp, i32, vp, i64, i32, i32, vp, i32, vp],
     "acav_mi_destroy": [vp],
     "acav_mi_add_samples": [vp, vp, i64],

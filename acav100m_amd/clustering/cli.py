@@ -41,7 +41,22 @@ class Cli:
 
 
 def main(argv=None):
-    command, kwargs = parse_cli(sys.argv[1:] if argv is None else argv)
+    """One process per GPU like the reference (script.py:52-65): started plainly with computation.num_gpus > 1
+    (default: every visible GPU) the CLI re-executes itself once per GPU; started by torchrun -- or as one of those
+    children -- it binds to its GPU (LOCAL_RANK) and joins the process group before anything else."""
+    argv = sys.argv[1:] if argv is None else list(argv)
+    command, kwargs = parse_cli(argv)
+    from ..parallel import launch
+    if launch.env_world() is None:
+        want = kwargs.get('computation.num_gpus')
+        if want is None:
+            import torch
+            want = torch.cuda.device_count()
+        if int(want) > 1:
+            launch.spawn_per_gpu('acav100m_amd.clustering.cli', argv, int(want))
+            return None
+    else:
+        launch.init_process_group(kwargs.get('computation.dist_backend', 'nccl'))
     return getattr(Cli(), command)(**kwargs)
 
 

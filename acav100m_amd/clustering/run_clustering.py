@@ -57,15 +57,19 @@ def load_clusterings(args, table):
         if not path.is_file() and args.clustering.load_cache_from_shard_subset:
             path = _subset_cache(args, epoch)
         if path is not None and path.is_file():
-            with open(path, 'rb') as f:
-                saved = pickle.load(f)
-            if set(saved.keys()) >= set(table.views.keys()):
+            saved = _read_cache(path)
+            if saved is not None:  # a reference-written file does not name the modality: match on (model_key, layer)
+                by_name = {k[1:]: v for k, v in saved.items()}
+                saved = {v: saved.get(v, by_name.get(v[1:])) for v in table.views}
+                saved = saved if all(x is not None for x in saved.values()) else {}
+            if saved is not None and set(saved.keys()) >= set(table.views.keys()):
                 print("loading from clustering cache: {}".format(path))
                 cl = OrderedDict((v, KMeans.load(saved[v])) for v in table.views)
                 for km in cl.values():
                     km.args = args
                 return _to_device(args, cl), True
-            print("clustering cache features does not match with the given models")
+            if saved is not None:
+                print("clustering cache features does not match with the given models")
         print("no clustering cache found.")
     return init_clusterings(args, table), False
 
@@ -80,12 +84,67 @@ def _subset_cache(args, epoch):
     return None if best is None else best[1]
 
 
+def _attrs_of(obj):
+    """attrs dict of one cached clustering: ours (a dict), or a pickled KMeans object (the reference's default
+    scheme, run_clustering.py:110-116, readable when its class is importable)"""
+    if isinstance(obj, dict):
+        dt = dict(obj)
+    elif hasattr(obj, 'get_attrs'):
+        dt = dict(obj.get_attrs())
+    else:
+        dt = dict(vars(obj))
+    for key in ('centers', 'counts'):
+        v = dt[key]
+        if hasattr(v, 'detach'):
+            v = v.detach().cpu().numpy()
+        dt[key] = np.ascontiguousarray(v, np.float32)
+    return dt
+
+
+def _read_cache(path):
+    """-> {(kind, model_key, layer): attrs} or None.  The file is the reference's nested
+    {model_key: {'layer_i' | 'model': KMeans | attrs}} written by torch.save (run_clustering.py:110-116); the flat
+    pickle of round 1 is still accepted.  An unreadable file is reported and treated as absent."""
+    import torch
+    saved = None
+    for reader in (lambda f: torch.load(f, map_location='cpu', weights_only=False), pickle.load):
+        try:
+            with open(path, 'rb') as f:
+                saved = reader(f)
+            break
+        except Exception as exc:  # zip vs pickle stream, missing classes, truncated file ...
+            err = exc
+    if saved is None:
+        print("clustering cache {} is not loadable: {}".format(path, err))
+        return None
+    try:
+        flat = OrderedDict()
+        for key, val in saved.items():
+            if isinstance(key, tuple):  # round-1 layout: {(kind, model_key, layer): attrs}
+                flat[key] = _attrs_of(val)
+                continue
+            for layer, obj in val.items():
+                dt = _attrs_of(obj)
+                flat[(dt.pop('_kind', None), key, layer)] = dt
+        return flat
+    except Exception as exc:
+        print("clustering cache {} has an unknown layout: {}".format(path, exc))
+        return None
+
+
 def save_clusterings(args, epoch, cl):
+    """torch.save of {model_key: {layer: attrs}} -- the reference's file and layout (its save_scheme_ver2 form,
+    run_clustering.py:110-116: plain attrs instead of pickled objects, so either side can read it)."""
+    import torch
     path = _cache_path(args, epoch)
     print("saving clustering cache to: {}".format(path))
     path.parent.mkdir(parents=True, exist_ok=True)
-    with open(path, 'wb') as f:
-        pickle.dump(OrderedDict((v, km.get_attrs_plain()) for v, km in cl.items()), f)
+    nested = OrderedDict()
+    for (kind, mk, layer), km in cl.items():
+        dt = km.get_attrs_plain()
+        dt['_kind'] = kind
+        nested.setdefault(mk, OrderedDict())[layer] = dt
+    torch.save(nested, str(path))
 
 
 def train_clusters(args, table, resident):
@@ -94,7 +153,10 @@ def train_clusters(args, table, resident):
         return cl
     pre = args.clustering.cached_epoch if loaded else 0
     rank, w = world()
-    epochs = math.ceil(args.clustering.epochs / max(1, args.computation.num_gpus or 1))
+    # The reference divides the epochs by the number of GPUs because its DDP step consumes num_gpus batches
+    # (run_clustering.py:146); here several GPUs split the CLUSTERINGS, every one of which still sees every batch
+    # of every epoch -- the N-GPU run produces the files of the one-GPU run.
+    epochs = int(args.clustering.epochs)
     b = int(args.data.batch_size)
     n = len(table)
     steps = n // b  # drop_last (run_clustering.py:139)
@@ -111,30 +173,23 @@ def train_clusters(args, table, resident):
         gen = next(iter(cl.values()))._generator
         gen.u32()
         gen.u32()
-        if w > 1:
-            _train_epoch_distributed(cl, resident, b, steps, rank, w)
+        # warm-up labels, drawn batch by batch across the clusterings like the reference loop (every rank draws
+        # all of them from the same stream, so the generators stay in step whoever trains which clustering)
+        need = {v: km.warmup_steps(b, steps) for v, km in cl.items()}
+        warm = {v: np.empty((need[v], b), np.int64) for v in cl}
+        for t in range(max(need.values(), default=0)):
+            for v, km in cl.items():
+                if t < need[v]:
+                    warm[v][t] = km.draw_warmup(b)
+        if w > 1:  # the clusterings are dealt out over the GPUs; state identical to the one-GPU run on every rank
+            from ..parallel import train_epoch_view_parallel
+            train_epoch_view_parallel(cl, resident, b, lr, warm)
         else:
-            # warm-up labels, drawn batch by batch across the clusterings like the reference loop
-            need = {v: km.warmup_steps(b, steps) for v, km in cl.items()}
-            warm = {v: np.empty((need[v], b), np.int64) for v in cl}
-            for t in range(max(need.values(), default=0)):
-                for v, km in cl.items():
-                    if t < need[v]:
-                        warm[v][t] = km.draw_warmup(b)
             for v, km in cl.items():
                 km.train_epoch(resident[v], b, lr=lr, warm_best=warm[v])
-        save_clusterings(args, epoch, cl)
+        if rank == 0:
+            save_clusterings(args, epoch, cl)
     return cl
-
-
-def _train_epoch_distributed(cl, resident, b, steps, rank, w):
-    """row-striped global batches: rank r labels rows [r*b/w, (r+1)*b/w) of each batch, so the result is
-    the single-process result (acav100m_amd/parallel/kmeans_dp.py)."""
-    lb = b // w
-    for t in range(steps):
-        for v, km in cl.items():
-            x = resident[v]
-            km.add(x[t * b + rank * lb: t * b + (rank + 1) * lb])
 
 
 def assign_clusters(args, table, resident, cl, shard_names):
@@ -152,8 +207,10 @@ def assign_clusters(args, table, resident, cl, shard_names):
         plain = out_dir / (shard + '.pkl')
         if plain.is_file():  # already processed (run_clustering.py:248-250)
             continue
-        ids = table.shard_rows[shard]
-        size = table.shard_size[ids[0]] if ids else 0
+        ids = table.shard_rows.get(shard)
+        if not ids:  # unreadable (reported and skipped by the loader) or empty shard: nothing to write
+            continue
+        size = table.shard_size[ids[0]]
         if len(ids) < round(size * args.data.output.shard_ok_ratio):
             continue  # too incomplete to save (:261-268)
         rows = io.assignment_rows(table, labels, ids)

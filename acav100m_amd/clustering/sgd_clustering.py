@@ -110,6 +110,15 @@ class KMeans:
                                                    C.byref(fb)))
         return centers, counts, count.value, fb.value
 
+    def _scalars(self):
+        """(count, fallback) without moving the centres: `count` is host state of the handle, `fallback` one
+        16-byte read -- add() / calc_best() / warmup_steps() look at them every step"""
+        if self._h is None:
+            return self._count0, self._fallback0
+        count, fb = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib._lib.acav_kmeans_get_state(self._h, None, None, C.byref(count), C.byref(fb)))
+        return count.value, fb.value
+
     @property
     def _shape(self):
         return self._centers0.shape
@@ -126,8 +135,8 @@ class KMeans:
         if self._h is None:
             self._centers0 = v
         else:
-            c = self._host_state()
-            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, _lib.ptr(v), None, c[2], c[3]))
+            c = self._scalars()
+            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, _lib.ptr(v), None, c[0], c[1]))
 
     @property
     def counts(self):
@@ -140,32 +149,34 @@ class KMeans:
         if self._h is None:
             self._counts0 = v
         else:
-            c = self._host_state()
-            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, None, _lib.ptr(v), c[2], c[3]))
+            c = self._scalars()
+            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, None, _lib.ptr(v), c[0], c[1]))
 
     @property
     def count(self):
-        return self._host_state()[2]
+        if self._h is None:
+            return self._count0
+        count = C.c_int64(0)  # host-side integer of the handle: no stream synchronisation
+        _lib.check(_lib._lib.acav_kmeans_get_state(self._h, None, None, C.byref(count), None))
+        return count.value
 
     @count.setter
     def count(self, value):
         if self._h is None:
             self._count0 = int(value)
         else:
-            c = self._host_state()
-            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, None, None, int(value), c[3]))
+            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, None, None, int(value), self._scalars()[1]))
 
     @property
     def fallback(self):
-        return self._host_state()[3]
+        return self._scalars()[1]
 
     @fallback.setter
     def fallback(self, value):
         if self._h is None:
             self._fallback0 = int(value)
         else:
-            c = self._host_state()
-            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, None, None, c[2], int(value)))
+            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, None, None, self._scalars()[0], int(value)))
 
     # ------------------------------------------------------------------- save / load
     def get_attrs(self):
@@ -327,6 +338,21 @@ class KMeans:
         without a collective per step: see acav100m_amd/parallel/kmeans_dp.py:train_epoch_dp."""
         from ..parallel import train_epoch_dp
         train_epoch_dp(self, x_local, int(batch_size), self.lr if lr is None else lr, chunk_steps=chunk_steps)
+
+    # ------------------------------------------------- state exchange (parallel/kmeans_dp.py:broadcast_state)
+    def state_arrays(self):
+        return self._host_state()
+
+    def load_state_arrays(self, centers, counts, count, fallback):
+        c = np.ascontiguousarray(centers, np.float32)
+        n = np.ascontiguousarray(counts, np.float32)
+        if self._h is None:
+            self._centers0, self._counts0, self._count0, self._fallback0 = c, n, int(count), int(fallback)
+        else:
+            _lib.check(_lib._lib.acav_kmeans_set_state(self._h, _lib.ptr(c), _lib.ptr(n), int(count), int(fallback)))
+
+    def skip_epoch(self, rows):
+        """another rank trains this clustering over `rows` rows this epoch; its state arrives by broadcast"""
 
     def get_attrs_plain(self):
         """get_attrs() without the args object (what the checkpoint files hold)"""

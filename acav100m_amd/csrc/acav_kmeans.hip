@@ -117,11 +117,11 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
                                                        const int *__restrict__ row_idx,
                                                        const unsigned *__restrict__ row_cnt)
 {
-    // row_idx != NULL: exact re-check pass of the bf16 filter -- the rows to label are x[row_idx[0 .. *row_cnt)]
-    if (row_idx) {
-        n = (int64_t)*row_cnt;
-        if ((int64_t)blockIdx.x * AS_ROWS >= n) return;  // uniform
-    }
+    // row_idx != NULL: exact re-check pass of the bf16 filter -- the rows to label are x[row_idx[0 .. *row_cnt)].
+    // The list length is only known on the device: that pass is launched with a small fixed grid whose workgroups
+    // stride over the row tiles (an empty list costs one tiny launch, not a worst-case grid of early exits).
+    if (row_idx) n = (int64_t)*row_cnt;
+    const int64_t ntiles = (n + AS_ROWS - 1) / AS_ROWS;
     __shared__ __attribute__((aligned(16))) float sC[AS_CG * AS_LD];
     __shared__ __attribute__((aligned(16))) float sX[AS_ROWS * AS_LD];
     __shared__ float sXn[AS_ROWS];
@@ -135,7 +135,6 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int h = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * AS_ROWS;
     const bool vec_ok = (d & 3) == 0;
 
     // staging roles: 8 threads per row (q = float4 index inside the 32-column stage)
@@ -144,6 +143,8 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
     const int nchunks = (d + AS_BK - 1) / AS_BK;
     const int ngroups = (K + AS_CG - 1) / AS_CG;
 
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // one trip except in the re-check pass
+    const int64_t row0 = tile * AS_ROWS;
     float ssq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float gbv = INFINITY;  // running best of row (tid) across centre groups, threads 0..63
     int gbi = 0x7fffffff;
@@ -303,8 +304,10 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
         s += __shfl_xor(s, 8);
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        if (tid == 0) wg_sum[blockIdx.x] = s;
+        if (tid == 0) wg_sum[tile] = s;
     }
+    __syncthreads();  // the next tile rewrites the epilogue scratch
+  }
 }
 
 // --------------------------------------------------------------------------- k_assign_bf16
@@ -1169,21 +1172,26 @@ __global__ __launch_bounds__(256) void k_step_update(const float *__restrict__ x
 }
 
 // --------------------------------------------------------------------- k_train_persistent
-// Many consecutive add() steps in ONE launch ("owner computes"): workgroup (cg, rg) = one wave that
-// OWNS centres [8cg, 8cg+8) -- resident in LDS for the whole launch, replicated over the row groups --
-// and labels batch rows [8rg, 8rg+8) of every step.  Per step:
+// Many consecutive add() steps in ONE launch ("owner computes"): workgroup (cg, rg) = 4 waves that
+// OWN centres [8cg, 8cg+8) -- resident in LDS for the whole launch, replicated over the row groups --
+// and label batch rows [8rg, 8rg+8) of every step.  Per step:
 //   1. the step's 8 rows are already in LDS (prefetched by LDS-DMA during the previous step);
 //      issue the DMA of the next step's rows into the other buffer
-//   2. one dependent FMA chain per lane (centre l>>3, row l&7), canonical column order
-//   3. fold (distance, centre) into the step's 64-bit key per row with a device-scope atomicMin, drain
-//      (s_waitcnt vmcnt(0)), arrive on a monotonic device-scope counter, spin (bounded) until all
-//      workgroups arrived, read the 32 final keys with device-scope atomic loads
+//   2. wave w runs the canonical FMA chain of column block (= segment) w for all 64 (centre, row) pairs;
+//      wave 0 folds the four partial sums left to right
+//   3. exchange: wave 0 publishes ONE tagged 8-byte granule per (own centre group, own row) -- {step tag,
+//      local centre, orderable distance} -- with a single device-scope store into a ring of TP_RING steps, then
+//      sweeps the granules of all centre groups for the 32 rows with device-scope loads until every tag is this
+//      step's (bounded; err flag instead of a hang) and takes the lexicographic (distance, centre) minimum
 //   4. every replica applies the identical in-order update to the centres it owns (rows fetched from
-//      global: read-only data), refreshes ||c||^2 and its usage counts, all in LDS
-// No plain-store data crosses workgroups inside the launch: keys and the counter are device-scope
-// atomics, x is read-only, so no L2 write-back / L1 invalidate is needed (MI355X_MICROARCH.md,
-// inter-workgroup visibility).  All workgroups must be co-resident: the host only takes this path
-// when the grid is well below the CU count, and every spin is bounded (err flag instead of a hang).
+//      global: read-only data), refreshes ||c||^2 (deferred under the next step's FMA phase) and its usage
+//      counts, all in LDS
+// No plain-store data crosses workgroups inside the launch: the granules are device-scope atomics (one writer
+// each, tag and payload in the same 8 bytes), x is read-only, so no L2 write-back / L1 invalidate is needed
+// (MI355X_MICROARCH.md, inter-workgroup visibility).  All workgroups must be co-resident: the host checks the
+// grid against hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs, every spin is bounded, and on `err` the host
+// re-runs the call on the per-step launch path from the saved state.
+// PROF (ACAV_PROFILE_STEPS=1): per-phase shader-clock timers; compiled out of the default kernel.
 constexpr int TP_NC = 8;
 constexpr int TP_NR = 8;
 constexpr int TP_DS = 1024;
@@ -1252,7 +1260,7 @@ __device__ __forceinline__ void tp_refresh_norms(unsigned pend, const float *sC,
 // runs the segment's FMA chain for all 64 (centre, row) pairs, and applies the centre update to it.
 // One wave can only issue ~1 ds_read_b128 per 20+ cycles, so the 4 waves quadruple the LDS read rate;
 // the 4 segment sums are folded in order ((s0+s1)+s2)+s3 -- exactly the canonical dot.
-template <bool RAGGED>  // RAGGED: d % 256 != 0 (guarded DMA / update lanes, zero-padded last block)
+template <bool RAGGED, bool PROF>  // RAGGED: d % 256 != 0 (guarded DMA / update lanes, zero-padded last block)
 __global__ __launch_bounds__(256) void k_train_persistent(
     const float *__restrict__ x, const float *__restrict__ xn, int b, int d, int K, float *__restrict__ centers,
     float *__restrict__ cn, float *__restrict__ counts, const float *__restrict__ thr, double lr0, float r,
@@ -1298,10 +1306,11 @@ __global__ __launch_bounds__(256) void k_train_persistent(
 
     unsigned nsync = 0;
     unsigned pend = 0;  // centres whose ||c||^2 is stale: refreshed under the next step's FMA phase
+#define TP_CLK() (PROF ? (long long)clock64() : 0ll)
     long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int t = 0; t < T; ++t) {
         const float *xb = x + (size_t)t * b * d;
-        const long long c0 = clock64();
+        const long long c0 = TP_CLK();
         if (t < need) {
             if (tid < b) sBest[tid] = (int)forced[(size_t)t * b + tid];
             __syncthreads();
@@ -1313,7 +1322,7 @@ __global__ __launch_bounds__(256) void k_train_persistent(
                 thr_t = thr[t];
             }
             if (t + 1 < T && active) tp_dma_block<RAGGED>(sX[(t + 1) & 1], x + (size_t)(t + 1) * b * d, rbase, nrv, d, wave, lane);
-            const long long c1 = clock64();
+            const long long c1 = TP_CLK();
             pr[0] += c1 - c0;
             float part = 0.f;
             if (active)
@@ -1325,7 +1334,7 @@ __global__ __launch_bounds__(256) void k_train_persistent(
                 pend = 0;
             }
             __syncthreads();
-            const long long c2 = clock64();
+            const long long c2 = TP_CLK();
             pr[1] += c2 - c1;
             if (wave == 0) {
                 float acc = sPart[0][lane];
@@ -1367,7 +1376,7 @@ __global__ __launch_bounds__(256) void k_train_persistent(
 #pragma unroll
                     for (int u = 0; u < TP_SW; ++u)
                         if (((need >> u) & 1u) && (g[u] >> 48) == (tag >> 48)) need &= ~(1u << u);
-                    pr[7] += 1;  // sweep passes (diagnostics)
+                    if (PROF) pr[7] += 1;  // sweep passes (diagnostics)
                     if (__all(need == 0)) break;
                     if (spins > TP_SPIN_LIMIT || (spins & 1023) == 1023) {
                         if (spins > TP_SPIN_LIMIT || __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -1395,11 +1404,11 @@ __global__ __launch_bounds__(256) void k_train_persistent(
             }
             ++nsync;
             __syncthreads();
-            pr[2] += clock64() - c2;
+            pr[2] += TP_CLK() - c2;
             if (sDead) break;  // uniform
         }
         // ---- update: every replica of a centre group does the same arithmetic; wave w owns column block w
-        const long long c3 = clock64();
+        const long long c3 = TP_CLK();
         const int best = (lane < b) ? sBest[lane] : -1;
         double lr = lr0;
         bool fell = false;
@@ -1454,7 +1463,7 @@ __global__ __launch_bounds__(256) void k_train_persistent(
                 }
             }
             __syncthreads();
-            pr[6] += clock64() - c3;
+            pr[6] += TP_CLK() - c3;
             if (tid < TP_NC && ((touched >> tid) & 1u)) {
                 int cnt = 0;
 #pragma unroll
@@ -1463,14 +1472,15 @@ __global__ __launch_bounds__(256) void k_train_persistent(
             }
             pend |= touched;  // ||c||^2 of these centres is refreshed under the next FMA phase (or at the end)
         }
-        pr[3] += clock64() - c3;
-        pr[4] += clock64() - c0;
+        pr[3] += TP_CLK() - c3;
+        pr[4] += TP_CLK() - c0;
     }
     if (pend) {  // uniform
         tp_refresh_norms(pend, sC, sCn, wave, lane, d);
         __syncthreads();
     }
-    if (tid == 0) {
+#undef TP_CLK
+    if (PROF && tid == 0) {
         const int w = blockIdx.y * gridDim.x + blockIdx.x;
         if (w == 1 % (int)(gridDim.x * gridDim.y))
             for (int q = 0; q < 8; ++q) ctl->prof[q] = (unsigned long long)pr[q];
@@ -1507,11 +1517,12 @@ struct acav_kmeans {
     int64_t count = 0;  // python int self.count (deterministic on the host)
     DevBuf centers, cn, counts, scalars;
     DevBuf stage_x, stage_lab, stage_forced, keys, xn, wg_sum, minval, thr, ctl;
-    DevBuf cb16, caux, cmu, recheck_list, recheck_count;
+    DevBuf cb16, caux, cmu, recheck_list, recheck_count, backup;
+    hipEvent_t ev_f0 = nullptr, ev_f1 = nullptr;  // around the last k_assign_bf16 launch (acav_kmeans_filter_time)
     bool cb16_valid = false;  // bf16 copy of the centres matches `centers`
     int64_t n_filter_launches = 0;
     uint64_t last_recheck = 0, last_rows = 0;
-    int64_t n_persistent_launches = 0;
+    int64_t n_persistent_launches = 0, n_persistent_fallbacks = 0;
     int num_cus = 0;  // multiProcessorCount of the handle's device (queried on first use)
     int key_phase = 0;  // which half of `keys` the next step's distance kernel folds into
     int64_t n_assign_launches = 0, n_step_launches = 0;
@@ -1562,6 +1573,8 @@ ACAV_EXPORT int acav_kmeans_destroy(acav_kmeans *km)
     if (!km) return ACAV_OK;
     (void)hipSetDevice(km->ctx.device);
     (void)hipStreamSynchronize(km->ctx.stream);
+    if (km->ev_f0) (void)hipEventDestroy(km->ev_f0);
+    if (km->ev_f1) (void)hipEventDestroy(km->ev_f1);
     km->ctx.fini();
     delete km;
     return ACAV_OK;
@@ -1606,6 +1619,16 @@ ACAV_EXPORT int acav_kmeans_filter_stats(acav_kmeans *km, int64_t *filter_launch
     return ACAV_OK;
 }
 
+ACAV_EXPORT int acav_kmeans_filter_time(acav_kmeans *km, float *ms)
+{
+    ACAV_REQUIRE(km && ms, ACAV_EINVAL, "NULL argument");
+    ACAV_REQUIRE(km->ev_f0 && km->n_filter_launches > 0, ACAV_ESTATE, "no filter launch yet");
+    ACAV_HIP_TRY(hipSetDevice(km->ctx.device));
+    ACAV_HIP_TRY(hipEventSynchronize(km->ev_f1));
+    ACAV_HIP_TRY(hipEventElapsedTime(ms, km->ev_f0, km->ev_f1));
+    return ACAV_OK;
+}
+
 ACAV_EXPORT int acav_kmeans_set_hyper(acav_kmeans *km, int initial_rounds, double reinit_p, double reinit_r)
 {
     ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");
@@ -1620,6 +1643,10 @@ ACAV_EXPORT int acav_kmeans_get_state(acav_kmeans *km, float *centers, float *co
                                       int64_t *fallback)
 {
     ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");
+    if (!centers && !counts && !fallback) {  // `count` alone is host state: no device round trip, no synchronisation
+        if (count) *count = km->count;
+        return ACAV_OK;
+    }
     ACAV_HIP_TRY(hipSetDevice(km->ctx.device));
     if (centers) ACAV_TRY(from_device(centers, km->centers.p, sizeof(float) * (size_t)km->K * km->d, km->ctx.stream));
     if (counts) ACAV_TRY(from_device(counts, km->counts.p, sizeof(float) * km->K, km->ctx.stream));
@@ -1714,11 +1741,17 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         auto kern = (vnt && vnt[0] == '0') ? k_assign_bf16<false> : k_assign_bf16<true>;
         ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, FD_SMEM));
+        if (!km->ev_f0) {
+            ACAV_HIP_TRY(hipEventCreate(&km->ev_f0));
+            ACAV_HIP_TRY(hipEventCreate(&km->ev_f1));
+        }
+        ACAV_HIP_TRY(hipEventRecord(km->ev_f0, st));
         hipLaunchKernelGGL(kern, dim3((unsigned)((n + FB_ROWS - 1) / FB_ROWS)), dim3(256), FD_SMEM, st,
                            static_cast<const float *>(dx), n, km->d, km->cb16.as<__bf16>(), km->cn.as<float>(),
                            km->counts.as<float>(), km->K, km->threshold(), (float)km->reinit_r, km->caux.as<CentersAux>(), e1c,
                            e1r, e2, dlab, km->recheck_list.as<int>(), km->recheck_count.as<unsigned>());
         ACAV_HIP_TRY(hipGetLastError());
+        ACAV_HIP_TRY(hipEventRecord(km->ev_f1, st));
 #ifdef ACAV_FD_PROF
         {
             unsigned long long hp[20];
@@ -1735,8 +1768,15 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
             hipMemcpyToSymbol(HIP_SYMBOL(g_fd_prof), hp, sizeof(hp));
         }
 #endif
-        // exact pass over the listed rows; workgroups beyond the list exit at once (no host round trip)
-        hipLaunchKernelGGL(k_assign_f32<false>, dim3((unsigned)grid), dim3(256), 0, st, static_cast<const float *>(dx), n,
+        // exact pass over the listed rows (no host round trip): a fixed grid of 2 workgroups per CU strides over
+        // however many row tiles the list turns out to hold
+        if (km->num_cus == 0) {
+            hipDeviceProp_t prop;
+            ACAV_HIP_TRY(hipGetDeviceProperties(&prop, km->ctx.device));
+            km->num_cus = prop.multiProcessorCount;
+        }
+        const int64_t rgrid = grid < 2 * (int64_t)km->num_cus ? grid : 2 * (int64_t)km->num_cus;
+        hipLaunchKernelGGL(k_assign_f32<false>, dim3((unsigned)rgrid), dim3(256), 0, st, static_cast<const float *>(dx), n,
                            km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
                            km->threshold(), (float)km->reinit_r, dlab, (float *)nullptr, km->wg_sum.as<double>(),
                            km->recheck_list.as<int>(), km->recheck_count.as<unsigned>());
@@ -1885,15 +1925,22 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
     // persistent path: the whole call in one launch, centres resident in LDS (k_train_persistent)
     const int nwg = ((km->K + TP_NC - 1) / TP_NC) * (int)((b + TP_NR - 1) / TP_NR);
     const char *nop = getenv("ACAV_NO_PERSISTENT");
-    // every workgroup of the launch must be resident at once (one per CU: 97 KB of LDS each): keep a quarter of
-    // the device's CUs spare (256 CUs on MI355X -> at most 192 workgroups)
+    const bool prof = getenv("ACAV_PROFILE_STEPS") != nullptr;
+    const bool ragged = (km->d & 255) != 0;
+    auto tkern = ragged ? (prof ? k_train_persistent<true, true> : k_train_persistent<true, false>)
+                        : (prof ? k_train_persistent<false, true> : k_train_persistent<false, false>);
+    // every workgroup of the launch must be resident at once: the occupancy query gives the workgroups one CU can
+    // hold (1: 97 KB of LDS each), times the CUs of the device.  Other streams may still hold CUs: the kernel's spins
+    // are bounded and a launch that gave up is re-run below on the per-step path from the saved state.
     if (km->num_cus == 0) {
         hipDeviceProp_t prop;
         ACAV_HIP_TRY(hipGetDeviceProperties(&prop, km->ctx.device));
         km->num_cus = prop.multiProcessorCount;
     }
+    int occ = 0;
+    ACAV_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(tkern), 256, 0));
     const bool persistent = steps > 0 && !(nop && nop[0] == '1') && (km->d % 4) == 0 && km->d <= TP_DS &&
-                            b <= TP_MAXB && nwg <= (3 * km->num_cus) / 4 && ((uintptr_t)fx & 15) == 0;
+                            b <= TP_MAXB && nwg <= occ * km->num_cus && ((uintptr_t)fx & 15) == 0;
     if (persistent) {
         std::vector<float> thr((size_t)steps);
         for (int64_t t = 0; t < steps; ++t)
@@ -1902,7 +1949,14 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
         ACAV_HIP_TRY(hipMemcpyAsync(km->thr.p, thr.data(), sizeof(float) * (size_t)steps, hipMemcpyHostToDevice, st));
         ACAV_TRY(km->ctl.ensure(sizeof(TrainCtl)));
         ACAV_HIP_TRY(hipMemsetAsync(km->ctl.p, 0, sizeof(TrainCtl), st));  // err = 0, every granule tag = 0 (never a live tag)
-        auto tkern = (km->d & 255) ? k_train_persistent<true> : k_train_persistent<false>;
+        // the state as it is now, in case the launch gives up (1 MB at K=256, d=1024: a few microseconds)
+        const size_t cbytes = sizeof(float) * (size_t)km->K * km->d, kbytes = sizeof(float) * (size_t)km->K;
+        ACAV_TRY(km->backup.ensure(cbytes + 2 * kbytes + sizeof(StepScalars)));
+        char *bk = km->backup.as<char>();
+        ACAV_HIP_TRY(hipMemcpyAsync(bk, km->centers.p, cbytes, hipMemcpyDeviceToDevice, st));
+        ACAV_HIP_TRY(hipMemcpyAsync(bk + cbytes, km->cn.p, kbytes, hipMemcpyDeviceToDevice, st));
+        ACAV_HIP_TRY(hipMemcpyAsync(bk + cbytes + kbytes, km->counts.p, kbytes, hipMemcpyDeviceToDevice, st));
+        ACAV_HIP_TRY(hipMemcpyAsync(bk + cbytes + 2 * kbytes, km->scalars.p, sizeof(StepScalars), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(tkern, dim3((km->K + TP_NC - 1) / TP_NC, (unsigned)((b + TP_NR - 1) / TP_NR)),
                            dim3(256), 0, st, fx, km->xn.as<float>(), (int)b, km->d, km->K, km->centers.as<float>(),
                            km->cn.as<float>(), km->counts.as<float>(), km->thr.as<float>(), lr, (float)km->reinit_r,
@@ -1910,9 +1964,9 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
                            km->scalars.as<StepScalars>(), nwg);
         ACAV_HIP_TRY(hipGetLastError());
         struct { unsigned err, pad[3]; unsigned long long prof[8]; unsigned long long prof_wg[256][8]; } head{};
-        ACAV_HIP_TRY(hipMemcpyAsync(&head, km->ctl.p, sizeof(head), hipMemcpyDeviceToHost, st));
+        ACAV_HIP_TRY(hipMemcpyAsync(&head, km->ctl.p, prof ? sizeof(head) : 16, hipMemcpyDeviceToHost, st));
         ACAV_HIP_TRY(hipStreamSynchronize(st));  // also covers the thr staging vector going out of scope
-        if (getenv("ACAV_PROFILE_STEPS")) {
+        if (prof) {
             const double den = (double)(steps > need ? steps - need : 1);
             fprintf(stderr, "[acav] persistent epoch: %lld steps; cycles/step: wait+dma-issue %.0f, fma %.0f, exchange %.0f, "
                             "update %.0f (hist %.0f, rows+apply %.0f), total %.0f\n", (long long)steps, head.prof[0] / den,
@@ -1934,14 +1988,20 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
             fprintf(stderr, "[acav]   over workgroups: wait %.0f..%.0f fma %.0f..%.0f exch %.0f..%.0f upd %.0f..%.0f; sweep passes/step %.2f\n", mn[0],
                     mx[0], mn[1], mx[1], mn[2], mx[2], mn[3], mx[3], head.prof[7] / den);
         }
-        ACAV_REQUIRE(head.err == 0, ACAV_EHIP,
-                     "persistent k-means kernel gave up at a grid barrier (not all %d workgroups resident?); "
-                     "set ACAV_NO_PERSISTENT=1 to use the per-step launch path", nwg);
-        km->count += steps * b;
-        km->cb16_valid = false;
-        km->n_step_launches += steps;
-        km->n_persistent_launches += 1;
-        return ACAV_OK;
+        if (head.err == 0) {
+            km->count += steps * b;
+            km->cb16_valid = false;
+            km->n_step_launches += steps;
+            km->n_persistent_launches += 1;
+            return ACAV_OK;
+        }
+        // the launch gave up at an exchange (not all workgroups resident: the GPU is shared): restore the state it
+        // started from and take the per-step launch path for this call
+        km->n_persistent_fallbacks += 1;
+        ACAV_HIP_TRY(hipMemcpyAsync(km->centers.p, bk, cbytes, hipMemcpyDeviceToDevice, st));
+        ACAV_HIP_TRY(hipMemcpyAsync(km->cn.p, bk + cbytes, kbytes, hipMemcpyDeviceToDevice, st));
+        ACAV_HIP_TRY(hipMemcpyAsync(km->counts.p, bk + cbytes + kbytes, kbytes, hipMemcpyDeviceToDevice, st));
+        ACAV_HIP_TRY(hipMemcpyAsync(km->scalars.p, bk + cbytes + 2 * kbytes, sizeof(StepScalars), hipMemcpyDeviceToDevice, st));
     }
     for (int64_t t = 0; t < steps; ++t) {
         const int64_t *f = t < need ? static_cast<const int64_t *>(dw) + t * b : nullptr;

@@ -3,9 +3,13 @@ import torch.distributed as dist
 
 
 def world():
-    """(rank, world_size) -- (0, 1) when torch.distributed is not initialised."""
+    """(rank, world_size): the process group when there is one, else the launcher environment (the selection
+    stage's per-GPU processes never communicate and do not form a group), else (0, 1)."""
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
+    import os
+    if os.environ.get("ACAV_NO_GROUP") == "1" and "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        return int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     return 0, 1
 
 

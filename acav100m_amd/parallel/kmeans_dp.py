@@ -106,3 +106,52 @@ def average_state(centers, counts):
     buf = buf * (1.0 / w)
     n = centers.numel()
     return buf[:n].reshape(centers.shape), buf[n:].reshape(counts.shape)
+
+
+def broadcast_state(engine, src):
+    """Every rank ends up with rank `src`'s clustering state (centres, usage counts, count, fallback): two small
+    broadcasts (K*d*4 + K*4 bytes, 16 bytes).  `engine`: state_arrays() -> (centers f32 [K,d], counts f32 [K], count,
+    fallback) and load_state_arrays(centers, counts, count, fallback)."""
+    rank, w = world()
+    if w == 1:
+        return
+    centers, counts, count, fallback = engine.state_arrays()
+    dev = _collective_device()
+    flat = torch.cat([torch.as_tensor(centers).reshape(-1), torch.as_tensor(counts).reshape(-1)]).to(dev)
+    ints = torch.tensor([int(count), int(fallback)], dtype=torch.int64, device=dev)
+    dist.broadcast(flat, src)
+    dist.broadcast(ints, src)
+    if rank != src:
+        n = centers.size
+        host = flat.cpu().numpy()
+        engine.load_state_arrays(host[:n].reshape(centers.shape), host[n:], int(ints[0].item()), int(ints[1].item()))
+
+
+def _collective_device():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def train_epoch_view_parallel(engines, rows, b, lr, warm):
+    """One epoch of every clustering with the clusterings dealt out over the ranks (view i -> rank i % world).
+
+    What several GPUs are FOR in this stage: the SGD chain of ONE clustering is a sequence of n/b dependent steps
+    of a few microseconds each -- any per-step exchange between GPUs costs more than the step -- but the reference
+    trains SEVERAL clusterings over the same rows (audio + visual, 5 + 5 layers in the real pipeline,
+    run_clustering.py:32-44) and those chains are independent of each other.  Each rank runs its share of them at
+    full single-GPU speed with the single-process arithmetic, then the owners broadcast their state: the result on
+    every rank is bit-identical to a one-GPU run, with no collective on any step path.
+
+    engines / rows / warm: same-order mappings view -> engine, resident rows, pre-drawn warm-up labels (drawn by
+    every rank from the same stream, so the generators stay in step)."""
+    rank, w = world()
+    views = list(engines)
+    for i, v in enumerate(views):
+        if i % w == rank:
+            engines[v].train_epoch(rows[v], b, lr=lr, warm_best=warm[v])
+    for i, v in enumerate(views):
+        if i % w == rank:
+            engines[v].synchronize()
+        else:
+            engines[v].skip_epoch(rows[v].shape[0] // b * b)  # keeps `count` (and hence the next warm-up plan) in step
+    for i, v in enumerate(views):
+        broadcast_state(engines[v], i % w)

@@ -66,7 +66,25 @@ class Cli:
 
 
 def main(argv=None):
-    command, kwargs = parse_cli(sys.argv[1:] if argv is None else argv)
+    """Chunked runs use one process per GPU like the reference (chunk.py:28,53: spawn(nprocs=num_gpus)): started
+    plainly on a multi-GPU node with a chunk_size, `run` re-executes itself once per GPU; every process takes its
+    block of chunks and never talks to the others (no process group).  Under torchrun the environment is already
+    there."""
+    argv = sys.argv[1:] if argv is None else list(argv)
+    command, kwargs = parse_cli(argv)
+    from ..parallel import launch
+    if launch.env_world() is None:
+        if command == 'run' and kwargs.get('chunk_size') is not None:
+            import torch
+            want = kwargs.get('computation.num_gpus')
+            want = torch.cuda.device_count() if want is None else min(int(want), torch.cuda.device_count())
+            if want > 1:
+                launch.spawn_per_gpu('acav100m_amd.subset_selection.cli', argv, want, {'ACAV_NO_GROUP': '1'})
+                return None
+    else:
+        import os
+        os.environ.setdefault('ACAV_NO_GROUP', '1')
+        launch.bind_device()
     return getattr(Cli(), command)(**kwargs)
 
 

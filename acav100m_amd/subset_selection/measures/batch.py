@@ -64,7 +64,13 @@ class EfficientBatchMI:
         if self._h is not None:
             lib.acav_mi_destroy(self._h)
             self._h = None
-        pairs = np.ascontiguousarray(self.combinations, dtype=np.int32).reshape(-1, 2)
+        # the reference only ever uses columns 0 and 1 of a combination (pair_ids[:, 0], pair_ids[:, 1], batch.py:47-48):
+        # bipartite pairing over three or more model groups yields longer tuples
+        combos = [tuple(c) for c in self.combinations]
+        if not combos or any(len(c) < 2 for c in combos):
+            raise ValueError("every clustering combination needs at least two clustering indices, got {}".format(combos[:4]))
+        pairs = np.ascontiguousarray([c[:2] for c in combos], dtype=np.int32)
+        self._npairs = len(pairs)
         v, d = self.assignments.shape
         h = C.c_void_p()
         _lib.check(lib.acav_mi_create(C.byref(h), _device_index(self.device), _lib.ptr(self.assignments), v, d,
@@ -77,7 +83,7 @@ class EfficientBatchMI:
     @property
     def cache(self):
         """{'N','a','b','n'} integer contingency tables (the reference holds them as fp32 + eps)."""
-        p, c = len(self.combinations), self.ncentroids
+        p, c = self._npairs, self.ncentroids
         N = np.empty((p, c, c), np.int32)
         a = np.empty((p, c), np.int32)
         b = np.empty((p, c), np.int32)

@@ -78,7 +78,7 @@ def run_single(args):
 
 def run_chunks(args):
     """chunk.py:21-53 + run_chunks_node :115-131 for THIS process's rank (one process per GPU)."""
-    args.parent_pid = str(args.parent_pid or os.getpid())
+    args.parent_pid = str(args.parent_pid or os.environ.get('ACAV_PARENT_PID') or os.getpid())  # chunk.py:22
     paths = [p for p in sorted(io.brace_expand(args.data.path)) if Path(p).is_file()]
     chunks = list(enumerate(io.chunked(paths, int(args.chunk_size))))
     num_chunks = len(chunks)

@@ -1,32 +1,45 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json metric on MI355X: clips/sec curated by the k-means hot path.
+"""bench.py -- BASELINE.json metric on MI355X: clips/sec curated = N / (t_kmeans_train + t_kmeans_assign + t_MI).
 
-Workload (config.workload): BASELINE.json configs[1] -- 1M clips, 1024-d features, K=256,
-k-means only (update + assign), one GPU.  One bench "step" = one k-means pass over the resident
-feature matrix exactly as the reference runs it: one training epoch of KMeans.add at the
-reference's batch size b=32 (floor(N/32) sequentially dependent SGD steps,
-run_clustering.py:229-241) followed by one assign sweep (KMeans.calc_best over all N rows,
-run_clustering.py:290-296).  value = N * n_gpus * steps / time, inputs resident in HBM.
+Workload (config.workload): BASELINE.json configs[2] -- 1M clips, two 1024-d views (audio + visual), K=256,
+select 20 % by greedy batch-MI, one GPU, end to end.  One bench "step" is one pass of the whole hot path over the
+resident synthetic features, exactly as the reference's two CLIs run it back to back:
+
+  k-means   per view: KMeans(args, 1024, 256), `clustering.epochs` = 2 epochs of KMeans.add at the reference's batch
+            size b=32 (2 x 31 250 sequentially dependent SGD steps, run_clustering.py:132-177) and one
+            KMeans.calc_best sweep over all rows (run_clustering.py:180-272)
+  hand-off  labels -> assignments [V, 2] int64 (host, the assignment-shard contract of dataloader.py:17-69)
+  MI        run_greedy._run_greedy (run_greedy.py:9-54): C = max+1, python shuffle of the candidates, start index,
+            EfficientBatchMI(B=20, k=4, keep_unselected) greedy selection of round(0.2 V) = 200 000 clips in ONE
+            chunk -- the reference's default (`chunk_size: None`, subset_selection/code/config.py) -- 50 000
+            iterations, each a full torch.randperm of the ~10^6 remaining candidates (batch.py:29-32).
+
+value = N * n_gpus * steps / time with the features resident in HBM when the timed region starts.
 
     python bench.py                      # 1 GPU, defaults
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
            --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1 (weak scaling): every rank holds its own N-row shard; assign is embarrassingly parallel;
-training uses the distributed add() (per step: local labels for 32 local rows, one RCCL
-all-gather of rows+labels, identical global update on every rank -- i.e. the reference run with
---data.batch_size=32*W).
+N > 1 (weak scaling): every rank holds its own 1M-clip partition.  k-means training is one global clustering with the
+reference's DDP semantics (global batch = 32 N rows per step, rows all-gathered in bulk ahead of the SGD chain, no
+collective on the step path); assign is local; the MI selection runs per rank on its own partition -- the reference's
+chunked mode with one chunk per GPU (chunk.py:21-53) -- no exchange.
 
 The JSON line also carries
-  roofline      for the assign sweep = k_assign_bf16 (bf16-MFMA filter over all rows) + k_assign_f32 (exact
-                fp32 re-check of the rows whose top-2 gap is below the proven error bound; labels are
-                bit-identical to the all-exact path): algorithmic bytes N*d*4 + N*8 per sweep over the
-                sweep duration measured with HIP events on the library's stream; bound = HBM.
-  cpu_baseline  the oracle (oracle/libacav_oracle.so, a C port of the reference algorithm) timed on
-                this box's host cores on a bounded sample of the same workload.
+  roofline      k_assign_bf16, the HBM-bound kernel of the path: algorithmic bytes N*d*4 + N*8 per launch over the
+                kernel's duration measured with HIP events on the library's stream around that launch alone
+                (`sweep_*` keys: the whole calc_best sweep incl. centre preparation and the exact re-check pass)
+  roofline_mi   the candidate-permutation stream of the greedy loop (16 L bytes per iteration) vs HBM
+  variants      the same pipeline with the selection chunked (chunk_size = 100 shards = 100k clips, 10 chunks in
+                lockstep, computation.concurrent_chunks) -- a different, equally legal reference configuration
+  cpu_baseline  the oracle (oracle/libacav_oracle.so, a C port of the reference algorithm incl. its dense
+                [B,P,C,C] scoring and per-iteration randperm) timed on this box's host cores on a bounded sample.
 """
 import argparse
+import contextlib
 import ctypes as C
+import io
+import itertools
 import json
 import os
 import sys
@@ -38,30 +51,47 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_F32_PEAK_TF = 157.3   # f32-input MFMA = fp32 vector peak
+EPOCHS = 2                 # clustering/code/config.py: clustering.epochs
+RATIO, BATCH_B, SELECT_K = 0.2, 20, 4   # subset_selection/code/config.py: subset.ratio, batch.*
 
 
-def synth_features(torch, n, d, k, seed, device):
-    """SURVEY 8(d) generator: K Gaussian components, centre ~ N(0,1)^d, row = centre + 0.3 N(0,1)."""
+def synth_views(torch, n, d, k, seed, device, views=2, rho=0.5):
+    """SURVEY 8(d) generator: K Gaussian components per view, component centres ~ N(0,1)^d, row = centre + 0.3 N(0,1);
+    the views share the component id with probability rho, else draw their own (gives the MI selection a signal)."""
     gen = torch.Generator(device=device).manual_seed(seed)
-    cen = torch.randn(k, d, device=device, generator=gen)
-    comp = torch.randint(0, k, (n,), device=device, generator=gen)
-    x = torch.empty(n, d, device=device, dtype=torch.float32)
-    step = 65536
-    for s in range(0, n, step):
-        e = min(n, s + step)
-        x[s:e] = cen[comp[s:e]] + 0.3 * torch.randn(e - s, d, device=device, generator=gen)
-    return x
+    shared = torch.randint(0, k, (n,), device=device, generator=gen)
+    out = []
+    for v in range(views):
+        cen = torch.randn(k, d, device=device, generator=gen)
+        own = torch.randint(0, k, (n,), device=device, generator=gen)
+        comp = torch.where(torch.rand(n, device=device, generator=gen) < rho, shared, own)
+        x = torch.empty(n, d, device=device, dtype=torch.float32)
+        step = 65536
+        for s in range(0, n, step):
+            e = min(n, s + step)
+            x[s:e] = cen[comp[s:e]] + 0.3 * torch.randn(e - s, d, device=device, generator=gen)
+        out.append(x)
+    return out
 
 
-def cpu_baseline(n, d, k, b, seed, budget_s=20.0):
-    """Oracle on the host cores, bounded sample: SGD steps (after the warm-up) + an assign slice.
-    add() is row-parallel over only b=32 rows, so it runs on min(cores, 16) threads (more threads only
-    add fork/join overhead); the assign slice uses every core.  Best of 3 repetitions each."""
+class _NS(dict):
+    __getattr__ = dict.get
+
+
+def select_args(seed=0):
+    return _NS(batch=_NS(batch_size=BATCH_B, selection_size=SELECT_K, keep_unselected=True),
+               computation=_NS(device="cuda", random_seed=seed), log_every=1000, log_times=10,
+               node_rank=None, parent_pid=None)
+
+
+def cpu_baseline(n, d, k, b, views, seed):
+    """Oracle on the host cores, bounded sample of the same pipeline: SGD steps (after the warm-up) + an assign slice
+    per view, and greedy iterations at V = n with the reference's dense scoring.  add() is row-parallel over only
+    b=32 rows: min(cores, 16) threads; assign uses every core; the greedy loop is serial.  Best of 3 for k-means."""
     from oracle import oracle as O
     rs = np.random.RandomState(seed)
     cen = rs.randn(k, d).astype(np.float32)
-    n_steps, n_assign_rows = 48, 16384
+    n_steps, n_assign_rows, mi_iters = 48, 16384, 150
     xs = (cen[rs.randint(0, k, n_steps * b + n_assign_rows)] +
           0.3 * rs.randn(n_steps * b + n_assign_rows, d)).astype(np.float32)
     cores = os.cpu_count() or 1
@@ -74,74 +104,32 @@ def cpu_baseline(n, d, k, b, seed, budget_s=20.0):
         t0 = time.perf_counter()
         for t in range(n_steps):
             km.add(xs[t * b:(t + 1) * b])
-        t_train = min(t_train, (time.perf_counter() - t0) / (n_steps * b))   # s per clip
+        t_train = min(t_train, (time.perf_counter() - t0) / (n_steps * b))   # s per clip and epoch
         O.set_threads(cores)
         t0 = time.perf_counter()
         km.calc_best(xs[n_steps * b:])
         t_assign = min(t_assign, (time.perf_counter() - t0) / n_assign_rows)  # s per clip
+    comp = rs.randint(0, k, n)
+    a = np.stack([np.where(rs.rand(n) < 0.5, comp, rs.randint(0, k, n)) for _ in range(views)], 1).astype(np.int64)
+    a[0] = k - 1
+    pairs = list(itertools.combinations(range(views), 2))
+    cand = [int(i) for i in rs.permutation(n)]
+    O.set_threads(1)
+    t0 = time.perf_counter()
+    O.BatchMI(a, k, pairs).run_greedy(cand[1:], cand[:1], round(RATIO * n), BATCH_B, SELECT_K, O.Rng(seed), dense=True,
+                                      max_iters=mi_iters)
+    t_iter = (time.perf_counter() - t0) / mi_iters
+    iters = -(-round(RATIO * n) // SELECT_K)
+    t_clip = views * (EPOCHS * t_train + t_assign) + iters * t_iter / n
     return {
-        "value": 1.0 / (t_train + t_assign), "unit": "clips/s", "cores": cores, "kind": "port",
-        "sample": f"best of 3: {n_steps} add() steps of b={b} on {train_threads} threads + calc_best over "
-                  f"{n_assign_rows} rows on {cores} threads, d={d}, K={k} (oracle C port, OpenMP over rows); "
-                  f"per-clip times summed and inverted",
-        "train_clips_per_s": 1.0 / t_train, "assign_clips_per_s": 1.0 / t_assign,
+        "value": 1.0 / t_clip, "unit": "clips/s", "cores": cores, "kind": "port",
+        "sample": f"k-means, best of 3: {n_steps} add() steps of b={b} on {train_threads} threads + calc_best over "
+                  f"{n_assign_rows} rows on {cores} threads (d={d}, K={k}), scaled to {views} views x ({EPOCHS} epochs + 1 "
+                  f"sweep); MI: {mi_iters} greedy iterations at V={n} (dense [B,P,C,C] scoring + full randperm per "
+                  f"iteration, 1 thread) scaled to {iters} iterations; oracle C port, per-clip times summed and inverted",
+        "train_clips_per_s_per_epoch": 1.0 / t_train, "assign_clips_per_s": 1.0 / t_assign,
+        "mi_ms_per_iteration": t_iter * 1e3,
     }
-
-
-def mi_stage(seed, v=100_000, c=256, oracle_iters=100):
-    """Informational (outside the timed region): one chunk of the greedy MI selection -- BASELINE configs[2]'s
-    second stage at the reference's chunk granularity -- on the GPU, and the oracle's loop on the host."""
-    import itertools
-    import acav100m_amd
-    from acav100m_amd.subset_selection import get_measure
-    rs = np.random.RandomState(seed)
-    comp = rs.randint(0, c, v)
-    a = np.stack([np.where(rs.rand(v) < 0.5, comp, rs.randint(0, c, v)) for _ in range(2)], 1).astype(np.int64)
-    a[0] = c - 1
-    pairs = list(itertools.combinations(range(2), 2))
-    cand = [int(i) for i in rs.permutation(v)]
-    subset = round(0.2 * v)
-    acav100m_amd.manual_seed(seed)
-    import contextlib
-    import io
-    m = get_measure("batch_mi")(a, ncentroids=c, batch_size=20, selection_size=4, device="cuda", keep_unselected=True)
-    m.init(pairs, cand[1:])
-    with contextlib.redirect_stdout(io.StringIO()):
-        t0 = time.perf_counter()
-        S, _, _, _ = m.run_greedy(subset, cand[:1], None)
-        dt = time.perf_counter() - t0
-    iters = (subset + 3) // 4
-    out = {"workload": f"one chunk: V={v}, D=2, C={c}, select 20% (B=20, k=4)", "iterations": iters,
-           "us_per_iteration": dt / iters * 1e6, "selected_clips_per_s": len(S) / dt, "curated_clips_per_s": v / dt,
-           "permutation_stream_GBs": sum(16 * (v - 1 - 4 * t) for t in range(iters)) / dt / 1e9}
-    # the same chunk size with 8 chunks in lockstep (computation.concurrent_chunks): aggregate per chunk-iteration
-    try:
-        from acav100m_amd.rng import Generator
-        from acav100m_amd.subset_selection.measures.batch import EfficientBatchMI
-        ms = []
-        for i in range(8):
-            mi = get_measure("batch_mi")(a, ncentroids=c, batch_size=20, selection_size=4, device="cuda",
-                                         keep_unselected=True, generator=Generator(seed + 1 + i))
-            mi.init(pairs, cand[1:])
-            ms.append(mi)
-        with contextlib.redirect_stdout(io.StringIO()):
-            t0 = time.perf_counter()
-            EfficientBatchMI.run_greedy_multi(ms, [subset] * 8, [cand[:1]] * 8)
-            dt8 = time.perf_counter() - t0
-        out["lockstep_8_chunks"] = {"us_per_chunk_iteration": dt8 / (8 * iters) * 1e6, "curated_clips_per_s": 8 * v / dt8}
-        del ms
-    except Exception as exc:
-        out["lockstep_8_chunks"] = {"error": str(exc)}
-    try:
-        from oracle import oracle as O
-        O.set_threads(1)
-        t0 = time.perf_counter()
-        O.BatchMI(a, c, pairs).run_greedy(cand[1:], cand[:1], subset, 20, 4, O.Rng(seed), max_iters=oracle_iters)
-        out["cpu_port_us_per_iteration"] = (time.perf_counter() - t0) / oracle_iters * 1e6
-    except Exception as exc:  # the oracle is optional here
-        out["cpu_port_us_per_iteration"] = None
-        out["cpu_port_error"] = str(exc)
-    return out
 
 
 def main():
@@ -154,6 +142,7 @@ def main():
     ap.add_argument("--k", type=int, default=256)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -174,24 +163,22 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    import random
     import acav100m_amd
     from acav100m_amd import _lib
     from acav100m_amd.clustering import KMeans
+    from acav100m_amd.subset_selection.run_greedy import _run_greedy
     lib = acav100m_amd.load_library()
 
-    n, d, k, b = args.n, args.d, args.k, args.batch
-    x = synth_features(torch, n, d, k, 1234 + rank, dev)
+    n, d, k, b, nviews = args.n, args.d, args.k, args.batch, 2
+    xs = synth_views(torch, n, d, k, 1234 + rank, dev, nviews)
     torch.cuda.synchronize()
-    acav100m_amd.manual_seed(0)
 
-    class _A:  # the reference's args.computation view
-        pass
-    cargs = _A()
-    cargs.computation = _A()
-    cargs.computation.device = "cuda"
-    cargs.computation.num_gpus = world
-    km = KMeans(cargs, d, k).to(dev)
-    km.initialize()
+    cargs = _NS(computation=_NS(device="cuda", num_gpus=world))
+    sargs = select_args()
+    types = [("audio_model", "layer_0"), ("visual_model", "layer_0")]
+    subset = round(RATIO * n)
+    iters = -(-subset // SELECT_K)
 
     def barrier():
         torch.cuda.synchronize()
@@ -199,22 +186,53 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    labels = torch.empty(n, dtype=torch.long, device=dev)
-    assign_ms = []
+    labels = [torch.empty(n, dtype=torch.long, device=dev) for _ in range(nviews)]
+    stage = {"train": [], "assign": [], "handoff": [], "mi": []}
+    filt_ms, sweep_ms, filt_stats = [], [], []
+    last = {}
 
     def one_pass(timed):
-        # --- update: one epoch of add() at b=32
-        if world == 1:
-            km.train_epoch(x, b, lr=0.01)
-        else:  # reference DDP semantics: global batch = world * b rows per step; rows all-gathered in bulk
-            km.train_epoch_distributed(x, b, lr=0.01)
-        # --- assign sweep, timed with HIP events on the library's own stream
-        _lib.check(lib.acav_kmeans_timer_begin(km._h))
-        _lib.check(lib.acav_kmeans_assign(km._h, _lib.ptr(x), n, _lib.ptr(labels), None))
-        ms = C.c_float(0)
-        _lib.check(lib.acav_kmeans_timer_end(km._h, C.byref(ms)))
+        acav100m_amd.manual_seed(0)
+        random.seed(0)
+        kms = [KMeans(cargs, d, k).to(dev) for _ in range(nviews)]
+        for km in kms:
+            km.initialize()
+        t0 = time.perf_counter()
+        for epoch in range(EPOCHS):
+            lr = 0.1 ** (2 + epoch // 5)
+            for km, x in zip(kms, xs):
+                if world == 1:
+                    km.train_epoch(x, b, lr=lr)
+                else:  # reference DDP semantics: global batch = world * b rows per step; rows all-gathered in bulk
+                    km.train_epoch_distributed(x, b, lr=lr)
+        for km in kms:
+            km.synchronize()
+        t1 = time.perf_counter()
+        for km, x, lab in zip(kms, xs, labels):  # assign sweep, timed with HIP events on the library's own stream
+            _lib.check(lib.acav_kmeans_timer_begin(km._h))
+            _lib.check(lib.acav_kmeans_assign(km._h, _lib.ptr(x), n, _lib.ptr(lab), None))
+            ms = C.c_float(0)
+            _lib.check(lib.acav_kmeans_timer_end(km._h, C.byref(ms)))
+            fm = C.c_float(0)
+            _lib.check(lib.acav_kmeans_filter_time(km._h, C.byref(fm)))
+            if timed:
+                sweep_ms.append(ms.value)
+                filt_ms.append(fm.value)
+                filt_stats.append(km.filter_stats())
+        t2 = time.perf_counter()
+        a = torch.stack(labels, 1).cpu().numpy()  # the k-means -> MI hand-off (assignment shards in the CLI flow)
+        t3 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            S, GAIN, _ = _run_greedy(sargs, a, types, None, RATIO, "batch_mi", "combination", True, False)
+        t4 = time.perf_counter()
+        assert len(S) == subset and len(set(S)) == subset
+        last["S"], last["a"] = S, a
         if timed:
-            assign_ms.append(ms.value)
+            stage["train"].append(t1 - t0)
+            stage["assign"].append(t2 - t1)
+            stage["handoff"].append(t3 - t2)
+            stage["mi"].append(t4 - t3)
+        del kms
 
     for _ in range(args.warmup):
         one_pass(False)
@@ -232,52 +250,95 @@ def main():
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = n * world * args.steps / elapsed
-        a_ms = float(np.mean(assign_ms))
+        st = {key: float(np.mean(v)) for key, v in stage.items()}
+        f_ms, s_ms = float(np.mean(filt_ms)), float(np.mean(sweep_ms))
         bytes_per_launch = n * d * 4 + n * 8
         flops_per_launch = 2.0 * n * k * d
-        gbs = bytes_per_launch / (a_ms * 1e-3) / 1e9
-        tfs = flops_per_launch / (a_ms * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-            if name.endswith("_pmc_assign.json"):  # summary of the separate rocprofv3 --pmc passes of this command
-                pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+        gbs = bytes_per_launch / (f_ms * 1e-3) / 1e9
+        traffic_profile = None
+        pdir = os.path.join(ROOT, "profiles")
+        for name in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
+            if name.endswith("_pmc_assign.json"):  # summary of the separate rocprofv3 --pmc passes (tools/collect_profiles.sh)
+                pm = json.load(open(os.path.join(pdir, name)))
                 if (pm.get("rows"), pm.get("d"), pm.get("K")) == (n, d, k) and pm.get("kernel", "").startswith("k_assign_bf16"):
-                    traffic, traffic_src = pm["traffic_bytes_per_launch"], "profiles/" + name
+                    traffic_profile = {"file": "profiles/" + name, "bytes_per_launch": pm["traffic_bytes_per_launch"]}
                     break
-        fl, frows, frecheck = km.filter_stats()
+        train_steps = EPOCHS * nviews * (n // b)
+        perm_bytes = sum(16 * (n - 1 - (BATCH_B - (BATCH_B - SELECT_K)) * t) for t in range(iters))
         out = {
-            "metric": "clips/sec curated (k-means update epoch at b=32 + assign sweep)",
+            "metric": "clips/sec curated (k-means train + assign, 2 views) + MI greedy selection of 20 %",
             "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {n} clips x {d}-d, K={k}, k-means only "
-                                   f"(1 training epoch at b={b} = {n // b} SGD steps + 1 assign sweep per step)",
-                       "global_batch": b * world, "rows_per_gpu": n},
-            "roofline": {"kernel": "k_assign_bf16 (+ k_assign_f32 exact re-check pass)", "bound": "hbm",
-                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "launch_ms": a_ms, "algorithmic_bytes": bytes_per_launch,
-                         "algorithmic_flops": flops_per_launch, "effective_TFLOPs": tfs,
-                         "rows_rechecked_exact": frecheck, "rows": frows},
-            # the kernel that dominates the wall clock is NOT throughput-bound: n/b dependent SGD steps (each needs
-            # the centres the previous one wrote); its bytes against the HBM roof are reported for completeness
-            "train_kernel": {"kernel": "k_train_persistent" if world == 1 else "k_step_dist_dma + k_step_update (global batch %d)" % (b * world),
-                             "bound": "latency (dependent chain of %d steps)" % (n // b),
-                             "us_per_step": (ms_per_step - a_ms) * 1e3 / (n // b),
-                             "algorithmic_bytes_per_epoch": n * d * 4 * world,
-                             "achieved_GBs": n * d * 4 * world / ((ms_per_step - a_ms) * 1e-3) / 1e9,
-                             "frac_of_hbm_peak": n * d * 4 * world / ((ms_per_step - a_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "stages": {"assign_ms": a_ms, "assign_clips_per_s": n / (a_ms * 1e-3),
-                       "train_epoch_ms": ms_per_step - a_ms,
-                       "train_clips_per_s": n / ((ms_per_step - a_ms) * 1e-3),
-                       "train_us_per_sgd_step": (ms_per_step - a_ms) * 1e3 / (n // b)},
+            "config": {"workload": f"BASELINE configs[2]: {n} clips x 2 views of {d}-d, K={k}: per view {EPOCHS} training "
+                                   f"epochs at b={b} ({n // b} SGD steps each) + 1 assign sweep, then ONE-chunk greedy "
+                                   f"batch-MI selection of {subset} clips (B={BATCH_B}, k={SELECT_K}, {iters} iterations; "
+                                   f"the reference's default chunk_size=None), end to end on 1 GPU per partition",
+                       "global_batch": b * world, "rows_per_gpu": n, "views": nviews, "epochs": EPOCHS,
+                       "select": subset, "mi_chunks": 1},
+            "stages": {"train_s": st["train"], "assign_s": st["assign"], "handoff_s": st["handoff"], "mi_s": st["mi"],
+                       "train_us_per_sgd_step": st["train"] * 1e6 / train_steps,
+                       "assign_sweep_ms": s_ms, "mi_us_per_iteration": st["mi"] * 1e6 / iters,
+                       "train_clips_per_s": n / st["train"], "assign_clips_per_s": n / st["assign"],
+                       "mi_clips_per_s": n / st["mi"]},
+            "roofline": {"kernel": "k_assign_bf16", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "traffic_from_committed_profile": traffic_profile,
+                         "launch_ms": f_ms, "algorithmic_bytes": bytes_per_launch,
+                         "algorithmic_flops": flops_per_launch, "effective_TFLOPs": flops_per_launch / (f_ms * 1e-3) / 1e12,
+                         "sweep_ms": s_ms, "sweep_GBs": bytes_per_launch / (s_ms * 1e-3) / 1e9,
+                         "sweep_frac": bytes_per_launch / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "rows_rechecked_exact": [int(f[2]) for f in filt_stats[-nviews:]], "rows": n},
+            "roofline_mi": {"kernel": "k_mt_* + k_fy_build + k_fy_apply + k_mi_select (one greedy iteration)",
+                            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                            "algorithmic_bytes": perm_bytes, "achieved": perm_bytes / st["mi"] / 1e9,
+                            "frac": perm_bytes / st["mi"] / 1e9 / HBM_PEAK_GBS,
+                            "note": "16 L bytes per iteration (int64 candidate permutation read + write, SURVEY 8(d)) over "
+                                    "the whole selection incl. its host part (python shuffle, table set-up)"},
+            "train_kernel": {"kernel": "k_train_persistent" if world == 1 else
+                             "k_step_dist_dma + k_step_update (global batch %d)" % (b * world),
+                             "bound": "latency (dependent chain of %d steps per epoch and view)" % (n // b),
+                             "us_per_step": st["train"] * 1e6 / train_steps},
         }
+        if not args.no_variants and world == 1:
+            out["variants"] = {"chunked_lockstep": chunked_variant(last["a"], types, n, st)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n, d, k, b, 1234)
-            out["mi_stage"] = mi_stage(1234)
+            out["cpu_baseline"] = cpu_baseline(n, d, k, b, nviews, 1234)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def chunked_variant(a, types, n, st, chunk=100_000, width=10):
+    """The same selection chunked: chunk_size = 100 shards of 1000 clips (SURVEY 8(d)'s suggestion for cfg5), every
+    chunk selects 20 % of its clips (chunk.py:21-53), `width` chunks in lockstep on one GPU
+    (computation.concurrent_chunks).  Measured once, outside the driver's timed region; combined with the timed
+    k-means stages of this run."""
+    try:
+        from acav100m_amd.rng import Generator
+        from acav100m_amd.subset_selection.measures.batch import EfficientBatchMI
+        from acav100m_amd.subset_selection.run_greedy import _prepare
+        import random
+        random.seed(0)
+        sargs = select_args()
+        t0 = time.perf_counter()
+        total = 0
+        with contextlib.redirect_stdout(io.StringIO()):
+            for g0 in range(0, n, chunk * width):
+                prepared = []
+                for i, c0 in enumerate(range(g0, min(n, g0 + chunk * width), chunk)):
+                    prepared.append(_prepare(sargs, a[c0:c0 + chunk], types, None, RATIO, "batch_mi", "combination", True, False,
+                                             generator=Generator(1 + g0 // chunk + i)))
+                res = EfficientBatchMI.run_greedy_multi([p[0] for p in prepared], [p[2] for p in prepared],
+                                                        [p[1] for p in prepared])
+                total += sum(len(r[0]) for r in res)
+        t_mi = time.perf_counter() - t0
+        t_all = st["train"] + st["assign"] + st["handoff"] + t_mi
+        return {"workload": f"{n // chunk} chunks of {chunk} clips, {width} in lockstep, each selects 20 %",
+                "mi_s": t_mi, "selected": total, "clips_per_s": n / t_all,
+                "note": "k-means stages as timed above; this selection measured once after the timed region"}
+    except Exception as exc:  # informational leg: never takes the driver line down
+        return {"error": repr(exc)}
 
 
 if __name__ == "__main__":

@@ -109,6 +109,9 @@ int acav_kmeans_timer_end(acav_kmeans *km, float *ms);
 /* bf16-filter bookkeeping of acav_kmeans_assign (mean_dist == NULL path): number of filter launches, and for
  * the last one the rows labelled and how many of them needed the exact fp32 re-check. */
 int acav_kmeans_filter_stats(acav_kmeans *km, int64_t *filter_launches, int64_t *rows, int64_t *rechecked);
+/* duration (HIP events on the handle's stream) of the last k_assign_bf16 launch alone -- the kernel bench.py's
+ * roofline is quoted on; blocks until that launch has finished. */
+int acav_kmeans_filter_time(acav_kmeans *km, float *ms);
 /* counters: number of kernel launches of the dominant kernels since create (bench bookkeeping) */
 int acav_kmeans_stats(acav_kmeans *km, int64_t *assign_launches, int64_t *step_launches);
 

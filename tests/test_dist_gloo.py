@@ -56,6 +56,16 @@ class _Engine:
     def synchronize(self):
         pass
 
+    # state exchange surface used by broadcast_state / train_epoch_view_parallel
+    def state_arrays(self):
+        return self.km.get_state()
+
+    def load_state_arrays(self, centers, counts, count, fallback):
+        self.km.set_state(np.ascontiguousarray(centers, np.float32), np.ascontiguousarray(counts, np.float32), int(count))
+
+    def skip_epoch(self, rows):
+        pass
+
 
 def _worker(rank, world, port, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -100,6 +110,25 @@ def _worker(rank, world, port, tmp):
         c2, cnt2, count2, _ = eng2.km.get_state()
         np.savez(os.path.join(tmp, f"dp_rank{rank}.npz"), c=c2, cnt=cnt2, count=count2, x=xl, lab=np.stack(my_labels))
         assert list(shard_slice(7)) == list(range(rank, 7, world))
+        # view-parallel epochs (the CLI's multi-GPU mode): 3 clusterings dealt out over 2 ranks, 2 epochs; every rank
+        # must end with the state a single process reaches for every clustering
+        from acav100m_amd.parallel import train_epoch_view_parallel
+        nv, bv, nrows = 3, 8, 96
+        rsv = np.random.RandomState(5)
+        rows = {v: torch.from_numpy((cen[rsv.randint(0, k, nrows)] + 0.3 * rsv.randn(nrows, d)).astype(np.float32)) for v in range(nv)}
+        warm_all = {v: rsv.randint(0, k, (2, nrows // bv, bv)).astype(np.int64) for v in range(nv)}
+        engs = {v: _Engine(O, d, k, cen + np.float32(0.01 * v), np.zeros(k, np.float32), 0) for v in range(nv)}
+        refs = {v: _Engine(O, d, k, cen + np.float32(0.01 * v), np.zeros(k, np.float32), 0) for v in range(nv)}
+        for epoch in range(2):
+            need = {v: engs[v].warmup_steps(bv, nrows // bv) for v in range(nv)}
+            warm = {v: warm_all[v][epoch][:need[v]] for v in range(nv)}
+            train_epoch_view_parallel(engs, rows, bv, 0.01, warm)
+            for v in range(nv):
+                assert refs[v].warmup_steps(bv, nrows // bv) == need[v]
+                refs[v].train_epoch(rows[v], bv, 0.01, warm_best=warm[v])
+        for v in range(nv):
+            a, b2 = engs[v].km.get_state(), refs[v].km.get_state()
+            assert np.array_equal(a[0], b2[0]) and np.array_equal(a[1], b2[1]) and a[2] == b2[2], f"view {v} rank {rank}"
         dist.barrier()
     finally:
         dist.destroy_process_group()

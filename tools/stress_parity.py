@@ -1,102 +1,105 @@
 """Randomised parity stress (GPU vs oracle, bit-exact): random shapes for assign (both paths), bulk training
-(persistent + per-step kernels), MI batch greedy and exact greedy.  usage: stress_parity.py [seconds] [seed]"""
+(persistent + per-step kernels), MI batch greedy and exact greedy.  usage: stress_parity.py [seconds] [seed]
+tests/test_gpu_configs.py runs a fixed-seed slice of it (stress(seed, budget, max_cases)) inside `pytest -m gpu`."""
 import itertools
 import os
 import sys
 import time
 
 import numpy as np
-import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import acav100m_amd
-from acav100m_amd.clustering import KMeans
-from acav100m_amd.rng import Generator
-from acav100m_amd.subset_selection import get_measure
-from oracle import oracle as O
-
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-rs = np.random.RandomState(seed)
-t_end = time.time() + budget
-counts = dict(assign=0, train=0, mi=0, exact=0)
 
 
-def mixture(n, d, k, spread):
-    cen = rs.randn(k, d).astype(np.float32) * spread
-    return (cen[rs.randint(0, k, n)] + rs.randn(n, d).astype(np.float32)).astype(np.float32)
+def stress(seed=0, budget=60.0, max_cases=None):
+    import torch
+    import acav100m_amd
+    from acav100m_amd.clustering import KMeans
+    from acav100m_amd.rng import Generator
+    from acav100m_amd.subset_selection import get_measure
+    from oracle import oracle as O
+    rs = np.random.RandomState(seed)
+    t_end = time.time() + budget
+    counts = dict(assign=0, train=0, mi=0, exact=0)
 
+    def mixture(n, d, k, spread):
+        cen = rs.randn(k, d).astype(np.float32) * spread
+        return (cen[rs.randint(0, k, n)] + rs.randn(n, d).astype(np.float32)).astype(np.float32)
 
-while time.time() < t_end:
-    which = rs.randint(0, 4)
-    if which == 0:  # assign, filter and exact paths
-        d = int(rs.choice([8, 32, 64, 88, 96, 128, 160, 352, 512, 704, 1024, 1056, 2304]))
-        k = int(rs.choice([2, 3, 17, 64, 255, 256, 257, 300, 600]))
-        n = int(rs.choice([1, 63, 128, 129, 1000, 4097, 20000]))
-        x = mixture(n, d, k, float(rs.choice([0.05, 1.0, 4.0])))
-        offset = float(rs.choice([0.0, 0.0, 3.0, 40.0]))  # a large common component: the centred filter's case
-        x = (x + offset).astype(np.float32)
-        s = int(rs.randint(1 << 30))
-        acav100m_amd.manual_seed(s)
-        km = KMeans(None, d, k).to("cuda:0")
-        ref = O.KMeans(d, k, O.Rng(s))
-        cen = (mixture(k, d, k, 1.0) + offset).astype(np.float32)
-        cnts = rs.randint(0, 50, k).astype(np.float32) if rs.rand() < 0.5 else np.full(k, 500, np.float32)
-        km.centers, km.counts, km.count = cen, cnts, 10 * k + int(cnts.sum())
-        ref.set_state(cen, cnts, 10 * k + int(cnts.sum()))
-        xt = torch.from_numpy(x).cuda()
-        want = ref.calc_best(x)[0]
-        a, _ = km.calc_best(xt, need_mean=False)
-        b, _ = km.calc_best(xt, need_mean=True)
-        assert np.array_equal(a.cpu().numpy(), want) and np.array_equal(b.cpu().numpy(), want), ("assign", n, d, k, s)
-        counts["assign"] += 1
-    elif which == 1:  # bulk training
-        d = int(rs.choice([8, 64, 88, 128, 256, 352, 704, 1000, 1024, 1408]))
-        k = int(rs.choice([3, 16, 40, 64, 100, 256]))
-        b = int(rs.choice([7, 16, 24, 32, 48, 64, 128]))
-        steps = int(rs.randint(3, 60))
-        lr = float(rs.choice([0.01, 0.01, 0.3]))
-        x = mixture(steps * b + int(rs.randint(0, b)), d, k, 3.0)
-        s = int(rs.randint(1 << 30))
-        acav100m_amd.manual_seed(s)
-        km = KMeans(None, d, k).to("cuda:0")
-        ref = O.KMeans(d, k, O.Rng(s))
-        xt = torch.from_numpy(x).cuda()
-        for _ in range(2):
-            km.train_epoch(xt, b, lr=lr)
-            ref.train_epoch(x, b, lr=lr)
-        assert np.array_equal(km.centers.numpy(), ref.centers) and np.array_equal(km.counts.numpy(), ref.counts), ("train", d, k, b, steps, lr, s)
-        assert km.count == ref.count and km.fallback == ref.fallback
-        counts["train"] += 1
-    else:
-        v = int(rs.choice([60, 300, 1000, 5000]))
-        dd = int(rs.choice([2, 3, 5, 10]))
-        c = int(rs.choice([2, 8, 40, 256]))
-        comp = rs.randint(0, c, v)
-        a = np.stack([np.where(rs.rand(v) < 0.5, comp, rs.randint(0, c, v)) for _ in range(dd)], 1).astype(np.int64)
-        a[0] = c - 1
-        pairs = list(itertools.combinations(range(dd), 2))
-        cand = rs.permutation(v)
-        if which == 2:
-            B = int(rs.choice([4, 20, 33])); kk = int(rs.randint(1, B + 1)); keep = bool(rs.randint(0, 2))
-            B = min(B, v - 1); kk = min(kk, B)
-            subset = int(rs.randint(1, max(2, v // 5)))
-            if not keep and (subset + kk - 1) // kk * B > v - 1:
-                continue
+    while time.time() < t_end and (max_cases is None or sum(counts.values()) < max_cases):
+        which = rs.randint(0, 4)
+        if which == 0:  # assign, filter and exact paths
+            d = int(rs.choice([8, 32, 64, 88, 96, 128, 160, 352, 512, 704, 1024, 1056, 2304]))
+            k = int(rs.choice([2, 3, 17, 64, 255, 256, 257, 300, 600]))
+            n = int(rs.choice([1, 63, 128, 129, 1000, 4097, 20000]))
+            x = mixture(n, d, k, float(rs.choice([0.05, 1.0, 4.0])))
+            offset = float(rs.choice([0.0, 0.0, 3.0, 40.0]))  # a large common component: the centred filter's case
+            x = (x + offset).astype(np.float32)
             s = int(rs.randint(1 << 30))
-            m = get_measure("batch_mi")(a, ncentroids=c, batch_size=B, selection_size=kk, device="cuda:0",
-                                        keep_unselected=keep, generator=Generator(s))
-            m.init(pairs, [int(i) for i in cand[1:]])
-            S, G, _, _ = m.run_greedy(subset, [int(cand[0])], None)
-            r = O.BatchMI(a, c, pairs).run_greedy(cand[1:], cand[:1], subset, B, m.k, O.Rng(s), keep_unselected=keep)
-            assert S == r["S"].tolist() and np.array_equal(np.array(G), r["GAIN"]), ("mi", v, dd, c, B, kk, keep, subset, s)
-            counts["mi"] += 1
+            acav100m_amd.manual_seed(s)
+            km = KMeans(None, d, k).to("cuda:0")
+            ref = O.KMeans(d, k, O.Rng(s))
+            cen = (mixture(k, d, k, 1.0) + offset).astype(np.float32)
+            cnts = rs.randint(0, 50, k).astype(np.float32) if rs.rand() < 0.5 else np.full(k, 500, np.float32)
+            km.centers, km.counts, km.count = cen, cnts, 10 * k + int(cnts.sum())
+            ref.set_state(cen, cnts, 10 * k + int(cnts.sum()))
+            xt = torch.from_numpy(x).cuda()
+            want = ref.calc_best(x)[0]
+            a, _ = km.calc_best(xt, need_mean=False)
+            b, _ = km.calc_best(xt, need_mean=True)
+            assert np.array_equal(a.cpu().numpy(), want) and np.array_equal(b.cpu().numpy(), want), ("assign", n, d, k, s)
+            counts["assign"] += 1
+        elif which == 1:  # bulk training
+            d = int(rs.choice([8, 64, 88, 128, 256, 352, 704, 1000, 1024, 1408]))
+            k = int(rs.choice([3, 16, 40, 64, 100, 256]))
+            b = int(rs.choice([7, 16, 24, 32, 48, 64, 128]))
+            steps = int(rs.randint(3, 60))
+            lr = float(rs.choice([0.01, 0.01, 0.3]))
+            x = mixture(steps * b + int(rs.randint(0, b)), d, k, 3.0)
+            s = int(rs.randint(1 << 30))
+            acav100m_amd.manual_seed(s)
+            km = KMeans(None, d, k).to("cuda:0")
+            ref = O.KMeans(d, k, O.Rng(s))
+            xt = torch.from_numpy(x).cuda()
+            for _ in range(2):
+                km.train_epoch(xt, b, lr=lr)
+                ref.train_epoch(x, b, lr=lr)
+            assert np.array_equal(km.centers.numpy(), ref.centers) and np.array_equal(km.counts.numpy(), ref.counts), ("train", d, k, b, steps, lr, s)
+            assert km.count == ref.count and km.fallback == ref.fallback
+            counts["train"] += 1
         else:
-            subset = int(rs.randint(2, max(3, v // 4)))
-            m = get_measure("mi")(a, ncentroids=c, device="cuda:0")
-            m.init(pairs, [int(i) for i in cand[1:]])
-            S, G, _, _ = m.run_greedy(subset, [int(cand[0])])
-            r = O.BatchMI(a, c, pairs).run_exact(cand[1:], cand[:1], subset)
-            assert S[1:] == r["S"].tolist() and np.array_equal(np.array(G), r["GAIN"]), ("exact", v, dd, c, subset)
-            counts["exact"] += 1
-print("stress ok", counts)
+            v = int(rs.choice([60, 300, 1000, 5000]))
+            dd = int(rs.choice([2, 3, 5, 10]))
+            c = int(rs.choice([2, 8, 40, 256]))
+            comp = rs.randint(0, c, v)
+            a = np.stack([np.where(rs.rand(v) < 0.5, comp, rs.randint(0, c, v)) for _ in range(dd)], 1).astype(np.int64)
+            a[0] = c - 1
+            pairs = list(itertools.combinations(range(dd), 2))
+            cand = rs.permutation(v)
+            if which == 2:
+                B = int(rs.choice([4, 20, 33])); kk = int(rs.randint(1, B + 1)); keep = bool(rs.randint(0, 2))
+                B = min(B, v - 1); kk = min(kk, B)
+                subset = int(rs.randint(1, max(2, v // 5)))
+                if not keep and (subset + kk - 1) // kk * B > v - 1:
+                    continue
+                s = int(rs.randint(1 << 30))
+                m = get_measure("batch_mi")(a, ncentroids=c, batch_size=B, selection_size=kk, device="cuda:0",
+                                            keep_unselected=keep, generator=Generator(s))
+                m.init(pairs, [int(i) for i in cand[1:]])
+                S, G, _, _ = m.run_greedy(subset, [int(cand[0])], None)
+                r = O.BatchMI(a, c, pairs).run_greedy(cand[1:], cand[:1], subset, B, m.k, O.Rng(s), keep_unselected=keep)
+                assert S == r["S"].tolist() and np.array_equal(np.array(G), r["GAIN"]), ("mi", v, dd, c, B, kk, keep, subset, s)
+                counts["mi"] += 1
+            else:
+                subset = int(rs.randint(2, max(3, v // 4)))
+                m = get_measure("mi")(a, ncentroids=c, device="cuda:0")
+                m.init(pairs, [int(i) for i in cand[1:]])
+                S, G, _, _ = m.run_greedy(subset, [int(cand[0])])
+                r = O.BatchMI(a, c, pairs).run_exact(cand[1:], cand[:1], subset)
+                assert S[1:] == r["S"].tolist() and np.array_equal(np.array(G), r["GAIN"]), ("exact", v, dd, c, subset)
+                counts["exact"] += 1
+    return counts
+
+
+if __name__ == "__main__":
+    print("stress ok", stress(int(sys.argv[2]) if len(sys.argv) > 2 else 0, float(sys.argv[1]) if len(sys.argv) > 1 else 60.0))
