@@ -76,6 +76,11 @@ int to_device(const void *src, size_t bytes, DevBuf &stage, hipStream_t stream, 
 // Copies a device result to `dst` (host or device), async on stream.
 int from_device(void *dst, const void *src_dev, size_t bytes, hipStream_t stream);
 
+// acav_mtjump.hip: g(t) = t^J mod phi(t) of MT19937 as 624 words (bit i = coefficient of t^i), cached; and the host
+// evaluation window[0..624) <- stream words J ahead
+const uint32_t *mt_jump_poly(int64_t J);
+int mt_jump_window_host(uint32_t *window, int64_t J);
+
 struct StreamCtx {
     int device = 0;
     hipStream_t stream = nullptr;

@@ -417,7 +417,7 @@ __device__ __forceinline__ void mt_generate_body(unsigned *__restrict__ mt_state
     const long long need = base + 624;              // generate at least up to here
     __syncthreads();
     for (long long m = p + tid; m < 624 && m < q; m += MT_THREADS) out[m - p] = X[m];  // draws left in the block
-    unsigned *outp = out + (624 - p);  // raw word of stream index m goes to outp[m - 624] (beyond q: padding)
+    unsigned *outp = out + (624 - p);  // raw word of stream index m goes to outp[m - 624]; nothing is stored past q
     long long m0 = 624;     // stream index of the next word to generate
     long long shift = 0;    // stream index of X[0]
     for (; m0 < need && m0 < MT_BACK; m0 += 227) {  // two plain steps: 624..850, 851..1077
@@ -425,7 +425,7 @@ __device__ __forceinline__ void mt_generate_body(unsigned *__restrict__ mt_state
             const unsigned w = (unsigned)m0 + tid;
             const unsigned v = X[w - 227] ^ mt_twist((X[w - 624] & 0x80000000u) | (X[w - 623] & 0x7fffffffu));
             X[w] = v;
-            outp[w - 624] = v;
+            if ((long long)w < q) outp[w - 624] = v;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -434,6 +434,7 @@ __device__ __forceinline__ void mt_generate_body(unsigned *__restrict__ mt_state
     // byte offset into `out` (SGPR base + 32-bit VGPR offset store): the loop is VALU-issue bound
     const unsigned *xw = X + ((unsigned)(m0 - shift) + tid - MT_BACK);  // &X[bi - MT_BACK]
     unsigned ob = ((unsigned)(m0 - p) + tid) * 4u;                      // byte offset of out[m - p]  (n < 2^29 here)
+    const unsigned ob_end = (unsigned)n * 4u;                          // lanes write back to back: no word past draw n
     const char *outb = reinterpret_cast<const char *>(out);
     int left = MT_EPOCH;
     while (m0 < need) {
@@ -455,7 +456,7 @@ __device__ __forceinline__ void mt_generate_body(unsigned *__restrict__ mt_state
             const unsigned a = xw[0] ^ xw[227] ^ xw[454], b2 = xw[1] ^ xw[228] ^ xw[455];
             const unsigned v = xw[MT_BACK - 681] ^ mt_twist((a & 0x80000000u) | (b2 & 0x7fffffffu));
             const_cast<unsigned *>(xw)[MT_BACK] = v;
-            *reinterpret_cast<unsigned *>(const_cast<char *>(outb) + ob) = v;
+            if (ob < ob_end) *reinterpret_cast<unsigned *>(const_cast<char *>(outb) + ob) = v;
         }
         xw += MT_WIDE;
         ob += MT_WIDE * 4u;
@@ -476,6 +477,61 @@ __global__ __launch_bounds__(MT_THREADS) void k_mt_generate(unsigned *__restrict
                                                            long long n)
 {
     mt_generate_body(mt_state, out, n);
+}
+
+// ONE stream from several workgroups ("lanes").  The stream past the host state is cut into blocks of `blk` words
+// (a multiple of 624); lane w of W generates blocks w, w + W, w + 2W, ... and hops over the other lanes' blocks with
+// the GF(2) jump polynomial t^((W-1) blk) mod phi (acav_mtjump.hip).  states[lane] = the 624 words preceding the lane's
+// next block + idx (624 = all consumed; lane 0 starts from the host state and first hands out what is left of it).
+__global__ __launch_bounds__(MT_THREADS) void k_mt_generate_lanes(unsigned *__restrict__ states, unsigned *__restrict__ out0,
+                                                                 long long blk, long long head)
+{
+    const long long lane = blockIdx.x;
+    const long long extra = lane == 0 ? head : 0;  // leftover draws of the host block, placed right before block 0
+    mt_generate_body(states + lane * 625, out0 + lane * blk - extra, blk + extra);
+}
+
+// states[dst0 + e] <- the window J words ahead of states[src0 + e] (e = blockIdx.x), J given by its polynomial
+// g(t) = t^J mod phi:  Y[k] = XOR over { i : g_i = 1 } of X[i + k], X = the stream continued from the source window.
+// The workgroup regenerates the 19937 + 623 words it needs in LDS (the same folded 623-wide recurrence as the
+// generator), then thread k accumulates Y[k] branch-free.  ~0.1 ms per jump; a lane block takes ~0.85 ms to generate.
+constexpr int MJ_WORDS = MT_BACK + MT_WIDE * 32;  // 21014 >= 624 + 19937
+__global__ __launch_bounds__(MT_THREADS) void k_mt_jump(unsigned *__restrict__ states, int src0, int dst0,
+                                                       const unsigned *__restrict__ poly)
+{
+    __shared__ unsigned X[MJ_WORDS];
+    const unsigned tid = threadIdx.x;
+    const unsigned *src = states + (size_t)(src0 + blockIdx.x) * 625;
+    unsigned *dst = states + (size_t)(dst0 + blockIdx.x) * 625;
+    for (unsigned k = tid; k < 624; k += MT_THREADS) X[k] = src[k];
+    __syncthreads();
+    for (unsigned m0 = 624; m0 < MT_BACK; m0 += 227) {
+        if (tid < 227) {
+            const unsigned w = m0 + tid;
+            X[w] = X[w - 227] ^ mt_twist((X[w - 624] & 0x80000000u) | (X[w - 623] & 0x7fffffffu));
+        }
+        __syncthreads();
+    }
+    for (unsigned m0 = MT_BACK; m0 < MJ_WORDS; m0 += MT_WIDE) {
+        if (tid < MT_WIDE) {
+            const unsigned *xw = X + (m0 + tid - MT_BACK);
+            const unsigned a = xw[0] ^ xw[227] ^ xw[454], b2 = xw[1] ^ xw[228] ^ xw[455];
+            X[m0 + tid] = xw[MT_BACK - 681] ^ mt_twist((a & 0x80000000u) | (b2 & 0x7fffffffu));
+        }
+        __syncthreads();
+    }
+    if (tid < 624) {
+        unsigned acc = 0u;
+        const unsigned *xk = X + tid;
+        for (int wi = 0; wi < 623; ++wi) {  // 19937 = 623 * 32 + 1 coefficients
+            const unsigned g = poly[wi];  // uniform
+#pragma unroll
+            for (int b = 0; b < 32; ++b) acc ^= xk[wi * 32 + b] & (0u - ((g >> b) & 1u));
+        }
+        acc ^= xk[623 * 32] & (0u - (poly[623] & 1u));
+        dst[tid] = acc;
+    }
+    if (tid == 0) dst[624] = 624u;
 }
 
 // ------------------------------------------------------------------- parallel Fisher-Yates
@@ -644,6 +700,7 @@ struct acav_mi {
     DevBuf A0, A1, draws, draws2, h, head, head2, next, g, g2, mt, batch, S, G, tr_pos, tr_ids, tr_sc, forced;
     DevBuf removed, blockbest, ticket, tr_am;  // exact greedy
     DevBuf chunk_desc;                         // descriptor array of a multi-chunk run (lead handle)
+    DevBuf lane_states, ring, polys;           // MT19937 lanes of the single-chunk greedy (MtStream)
     // the mt19937 stream does not depend on the selection state: it is generated one iteration ahead on
     // its own stream (double-buffered draws), overlapping the Fisher-Yates / select kernels
     hipStream_t st_mt = nullptr;
@@ -651,6 +708,159 @@ struct acav_mi {
 };
 
 struct acav_rng;  // state access through the C ABI below
+
+// Host-side plan of one chunk's draw stream: T draws in all, produced on the generator stream `smt` by W lanes in
+// superblocks of S = W * blk words into a two-slot ring, consumed by the Fisher-Yates kernels on `st` iteration by
+// iteration.  Draw r (0 = the first draw of the run) lives at
+//     r <  head                ring[pad - head + r]                 (what was left of the host state's block)
+//     r >= head, r' = r - head ring[pad + r' mod (NSLOT S)]         (+ a mirror of the first `lmax` words of slot 0
+//                                                                    behind the last slot: an iteration that straddles
+//                                                                    the wrap still reads one contiguous range)
+// Nothing depends on what the greedy selects, so the whole schedule (which superblock an iteration needs, when a slot
+// may be overwritten) is computed on the host; the two streams meet through events only.
+struct MtStream {
+    static constexpr int NSLOT = 2;
+    static constexpr int64_t PAD = 624;
+    static constexpr int64_t BLK_DEFAULT = 624 * 4096;  // 2.5 M words per lane block: ~0.85 ms of generation per hop
+    int64_t T = 0, head = 0, blk = 0, S = 0, nblocks = 0, nsuper = 0, lmax = 0;
+    int p0 = 0, W = 1, logW = 0;
+    bool wraps = false;
+    unsigned *ring = nullptr, *states = nullptr, *polys = nullptr;
+    hipStream_t st = nullptr, smt = nullptr;
+    hipEvent_t ev_mt[NSLOT] = {nullptr, nullptr}, ev_used[NSLOT] = {nullptr, nullptr};
+    int64_t produced = 0;  // superblocks enqueued on smt
+    int64_t waited = -1;   // highest superblock `st` has been told to wait for
+    int64_t freed = 0;     // superblocks [0, freed) are no longer read by any iteration still to be enqueued
+
+    int plan(acav_mi *mi, const uint32_t *mtbuf, int idx, int64_t total_draws, int64_t L)
+    {
+        T = total_draws;
+        p0 = idx;
+        head = 624 - p0;
+        lmax = L;
+        const int64_t gen = T > head ? T - head : 0;  // words that must be generated past the host block
+        if (gen <= BLK_DEFAULT) {  // a single lane block, cut to size
+            W = 1;
+            blk = 624 * ((gen + 623) / 624);
+            nblocks = gen > 0 ? 1 : 0;
+        } else {
+            blk = BLK_DEFAULT;
+            nblocks = (gen + blk - 1) / blk;
+            W = 1;
+            while (W < 32 && W < nblocks) W *= 2;
+            if ((nblocks + W - 1) / W > NSLOT && (int64_t)W * blk < 2 * L) {  // a slot must hold a whole iteration twice over
+                blk = 624 * ((2 * L + 624 * (int64_t)W - 1) / (624 * (int64_t)W));
+                nblocks = (gen + blk - 1) / blk;
+            }
+        }
+        logW = 0;
+        while ((1 << logW) < W) ++logW;
+        S = (int64_t)W * blk;
+        nsuper = nblocks ? (nblocks + W - 1) / W : 0;
+        wraps = nsuper > NSLOT;
+        st = mi->ctx.stream;
+        smt = mi->st_mt;
+        for (int q = 0; q < NSLOT; ++q) ev_mt[q] = mi->ev_mt[q], ev_used[q] = mi->ev_used[q];
+        const int64_t slots = nsuper < NSLOT ? nsuper : NSLOT;
+        ACAV_TRY(mi->ring.ensure(sizeof(unsigned) * (size_t)(PAD + slots * S + (wraps ? lmax : 0) + 8)));
+        ACAV_TRY(mi->lane_states.ensure(sizeof(unsigned) * 625 * (size_t)W));
+        ring = mi->ring.as<unsigned>();
+        states = mi->lane_states.as<unsigned>();
+        // lane 0 = the host state; the leftover draws of its block are also what iteration 0 starts with when nothing
+        // is generated at all (T <= head)
+        uint32_t st0[625];
+        memcpy(st0, mtbuf, 624 * sizeof(uint32_t));
+        st0[624] = (uint32_t)p0;
+        ACAV_HIP_TRY(hipMemcpyAsync(states, st0, sizeof(st0), hipMemcpyHostToDevice, st));
+        if (head > 0) ACAV_HIP_TRY(hipMemcpyAsync(ring + PAD - head, mtbuf + p0, sizeof(unsigned) * (size_t)head, hipMemcpyHostToDevice, st));
+        ACAV_HIP_TRY(hipStreamSynchronize(st));  // st0 / mtbuf are the caller's locals
+        // jump polynomials: spreading the lanes (t^(2^r blk)) and hopping over the other lanes ((W-1) blk)
+        const int npoly = logW + 1;
+        std::vector<uint32_t> hp((size_t)npoly * 624, 0u);
+        for (int r = 0; r < logW; ++r) {
+            const uint32_t *g = mt_jump_poly(((int64_t)1 << r) * blk);
+            ACAV_REQUIRE(g, ACAV_ESTATE, "could not derive the MT19937 jump polynomial");
+            memcpy(&hp[(size_t)r * 624], g, 624 * sizeof(uint32_t));
+        }
+        if (W > 1 && nsuper > 1) {
+            const uint32_t *g = mt_jump_poly((int64_t)(W - 1) * blk);
+            ACAV_REQUIRE(g, ACAV_ESTATE, "could not derive the MT19937 jump polynomial");
+            memcpy(&hp[(size_t)logW * 624], g, 624 * sizeof(uint32_t));
+        }
+        ACAV_TRY(mi->polys.ensure(sizeof(uint32_t) * hp.size()));
+        polys = mi->polys.as<unsigned>();
+        ACAV_HIP_TRY(hipMemcpy(polys, hp.data(), sizeof(uint32_t) * hp.size(), hipMemcpyHostToDevice));
+        produced = 0, waited = -1, freed = 0;
+        // everything queued so far on the main stream happens before the first generator launch
+        ACAV_HIP_TRY(hipEventRecord(ev_used[0], st));
+        ACAV_HIP_TRY(hipStreamWaitEvent(smt, ev_used[0], 0));
+        // spread: lanes [2^r, 2^(r+1)) <- lanes [0, 2^r) jumped by 2^r blocks (before lane 0 starts consuming its state)
+        for (int r = 0; r < logW; ++r)
+            hipLaunchKernelGGL(k_mt_jump, dim3(1u << r), dim3(MT_THREADS), 0, smt, states, 0, 1 << r, polys + (size_t)r * 624);
+        ACAV_HIP_TRY(hipGetLastError());
+        for (int64_t q = 0; q < slots; ++q) ACAV_TRY(produce());
+        return ACAV_OK;
+    }
+    int produce()  // enqueue superblock `produced` (its slot is free)
+    {
+        const int64_t s = produced++;
+        const int slot = (int)(s % NSLOT);
+        if (s >= NSLOT) ACAV_HIP_TRY(hipStreamWaitEvent(smt, ev_used[slot], 0));  // the readers of superblock s - NSLOT are done
+        const int64_t left = nblocks - s * W;
+        const unsigned lanes = (unsigned)(left < W ? left : W);
+        unsigned *out0 = ring + PAD + (int64_t)slot * S;
+        hipLaunchKernelGGL(k_mt_generate_lanes, dim3(lanes), dim3(MT_THREADS), 0, smt, states, out0, (long long)blk,
+                           (long long)(s == 0 ? head : 0));
+        if (s + 1 < nsuper && W > 1)  // every lane hops over the W - 1 blocks of the other lanes
+            hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)W), dim3(MT_THREADS), 0, smt, states, 0, 0, polys + (size_t)logW * 624);
+        ACAV_HIP_TRY(hipGetLastError());
+        if (wraps && slot == 0 && s > 0)  // mirror of the slot's first lmax words behind the last slot
+            ACAV_HIP_TRY(hipMemcpyAsync(ring + PAD + NSLOT * S, out0, sizeof(unsigned) * (size_t)lmax, hipMemcpyDeviceToDevice, smt));
+        ACAV_HIP_TRY(hipEventRecord(ev_mt[slot], smt));
+        return ACAV_OK;
+    }
+    // called before the kernels of an iteration that reads draws [r0, r0 + n) are enqueued on st: make st wait for the
+    // superblocks it needs; returns the device pointer of draw r0
+    int acquire(int64_t r0, int64_t n, const unsigned **ptr)
+    {
+        const int64_t r1 = r0 + n;  // one past the last draw
+        const int64_t hi = r1 - 1 >= head ? (r1 - 1 - head) / S : -1;
+        ACAV_REQUIRE(hi < produced, ACAV_ESTATE, "MT stream schedule: superblock %lld needed, %lld produced", (long long)hi,
+                     (long long)produced);
+        for (int64_t s = waited + 1; s <= hi; ++s) ACAV_HIP_TRY(hipStreamWaitEvent(st, ev_mt[s % NSLOT], 0));
+        if (hi > waited) waited = hi;
+        *ptr = r0 < head ? ring + PAD - head + r0 : ring + PAD + (r0 - head) % (NSLOT * S);
+        return ACAV_OK;
+    }
+    // called after the last kernel reading the draws of the current iteration has been enqueued; next_r0 = first draw
+    // of the following iteration (T when there is none): superblocks entirely below it are free for the producer
+    int release(int64_t next_r0)
+    {
+        const int64_t lo = next_r0 >= head ? (next_r0 - head) / S : 0;
+        while (freed < lo && freed < nsuper) {
+            const int64_t s = freed++;
+            if (s + NSLOT < nsuper) {
+                ACAV_HIP_TRY(hipEventRecord(ev_used[s % NSLOT], st));
+                ACAV_TRY(produce());
+            }
+        }
+        return ACAV_OK;
+    }
+    // the generator state the host continues from: the 624-block holding the last draw, idx in 1..624
+    int final_state(uint32_t *mtbuf, int *idx) const
+    {
+        const int64_t q = (int64_t)p0 + T;  // one past the last draw, counted from word 0 of the host block
+        if (q <= 624) {
+            *idx = (int)q;  // the host block itself (mtbuf still holds it)
+            return ACAV_OK;
+        }
+        const int64_t base = 624 * ((q - 1) / 624);
+        const int64_t r = base - p0;  // draw index of the block's first word (>= head)
+        ACAV_HIP_TRY(hipMemcpy(mtbuf, ring + PAD + (r - head) % (NSLOT * S), 624 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        *idx = (int)(q - base);
+        return ACAV_OK;
+    }
+};
 
 static int ids_to_device32(acav_mi *mi, const int64_t *ids, int64_t n, DevBuf &stage, DevBuf &out32)
 {
@@ -1074,8 +1284,6 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
     ACAV_TRY(mi->A0.ensure(sizeof(int) * (size_t)(L + B)));  // before the conversion: ensure() does not copy
     ACAV_TRY(ids_to_device32(mi, candidates, L, mi->stage, mi->A0));
     ACAV_TRY(mi->A1.ensure(sizeof(int) * (size_t)(L + B)));
-    ACAV_TRY(mi->draws.ensure(sizeof(unsigned) * ((size_t)L * MT_GROUP + MT_PAD)));
-    ACAV_TRY(mi->draws2.ensure(sizeof(unsigned) * ((size_t)L * MT_GROUP + MT_PAD)));
     ACAV_TRY(mi->h.ensure(sizeof(int) * (size_t)L));
     ACAV_TRY(mi->head.ensure(sizeof(int) * (size_t)L));
     ACAV_TRY(mi->next.ensure(sizeof(int) * (size_t)L));
@@ -1097,63 +1305,37 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
         ACAV_TRY(mi->forced.ensure(sizeof(int) * (size_t)(iters * k + 1)));
         ACAV_HIP_TRY(hipMemcpyAsync(mi->forced.p, forced_pos, sizeof(int) * (size_t)(iters * k), hipMemcpyHostToDevice, st));
     }
-    // hand the host MT19937 stream to the device
+    // hand the host MT19937 stream to the device: W lanes generate it superblock by superblock on their own stream
+    // (MtStream); nothing they do depends on what gets selected (L shrinks by a fixed amount per iteration)
     unsigned mtbuf[625];
     int idx = 0;
     ACAV_TRY(acav_rng_get_state(rng, mtbuf, &idx));
-    mtbuf[624] = (unsigned)idx;
-    ACAV_HIP_TRY(hipMemcpyAsync(mi->mt.p, mtbuf, sizeof(mtbuf), hipMemcpyHostToDevice, st));
+    const int64_t dl = B - (keep_unselected ? B - k : 0);  // candidates consumed per iteration
+    int64_t total_draws = 0;
+    for (int64_t t = 0; t < iters; ++t) {
+        const int64_t lt = L - t * dl;
+        total_draws += lt > 1 ? lt - 1 : 0;
+    }
+    MtStream ms;
+    ACAV_TRY(ms.plan(mi, mtbuf, idx, total_draws, L));
 
     int *Acur = mi->A0.as<int>(), *Anew = mi->A1.as<int>();
     int64_t l = L;
-    hipStream_t smt = mi->st_mt;
-    unsigned *dbuf[2] = {mi->draws.as<unsigned>(), mi->draws2.as<unsigned>()};
-    // everything queued so far on the main stream (state upload) happens before the first MT launch
-    ACAV_HIP_TRY(hipEventRecord(mi->ev_used[0], st));
-    ACAV_HIP_TRY(hipStreamWaitEvent(smt, mi->ev_used[0], 0));
-    // The draws do not depend on what gets selected (L shrinks by a fixed amount per iteration), so the generator
-    // runs a whole GROUP of iterations ahead on its own stream: one launch and two event operations per MT_GROUP
-    // iterations instead of per iteration (the loop is host-launch bound otherwise).
-    const int64_t dl = B - (keep_unselected ? B - k : 0);  // candidates consumed per iteration
-    const int64_t ngroups = (iters + MT_GROUP - 1) / MT_GROUP;
-    auto group_draws = [&](int64_t g_) -> int64_t {  // draws of group g_ = sum over its iterations of (L_t - 1)
-        int64_t tot = 0;
-        for (int64_t t = g_ * MT_GROUP; t < iters && t < (g_ + 1) * MT_GROUP; ++t) {
-            const int64_t lt = L - t * dl;
-            tot += lt > 1 ? lt - 1 : 0;
-        }
-        return tot;
-    };
-    auto launch_mt = [&](int64_t g_) -> int {
-        const int cur_ = (int)(g_ & 1);
-        if (g_ >= 2) ACAV_HIP_TRY(hipStreamWaitEvent(smt, mi->ev_used[cur_], 0));  // its last reader (group g_-2) is done
-        const int64_t nd = group_draws(g_);
-        if (nd > 0)
-            hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(MT_THREADS), 0, smt, mi->mt.as<unsigned>(), dbuf[cur_],
-                               (long long)nd);
-        ACAV_HIP_TRY(hipEventRecord(mi->ev_mt[cur_], smt));
-        return ACAV_OK;
-    };
-    if (iters > 0) ACAV_TRY(launch_mt(0));
-    int64_t draw_off = 0;  // offset of this iteration's draws inside its group's buffer
+    int64_t r0 = 0;  // first draw of this iteration, counted from the first draw of the run
     for (int64_t it = 0; it < iters; ++it) {
         const int Li = (int)l;
-        const int64_t grp = it / MT_GROUP;
-        const int cur = (int)(grp & 1);
+        const int64_t nd = Li > 1 ? Li - 1 : 0;
         const unsigned grid = (unsigned)((Li + 255) / 256);
-        if (it % MT_GROUP == 0) {
-            if (grp + 1 < ngroups) ACAV_TRY(launch_mt(grp + 1));  // one group ahead, on its own stream
-            ACAV_HIP_TRY(hipStreamWaitEvent(st, mi->ev_mt[cur], 0));
-            draw_off = 0;
-        }
+        const unsigned *draws = nullptr;
+        ACAV_TRY(ms.acquire(r0, nd, &draws));
         int *hd = (it & 1) ? mi->head2.as<int>() : mi->head.as<int>();
         int *gg = (it & 1) ? mi->g2.as<int>() : mi->g.as<int>();
         int *hd_n = (it & 1) ? mi->head.as<int>() : mi->head2.as<int>();
         int *gg_n = (it & 1) ? mi->g.as<int>() : mi->g2.as<int>();
-        hipLaunchKernelGGL(k_fy_build, dim3(grid), dim3(256), 0, st, dbuf[cur] + draw_off, Li, mi->h.as<int>(), hd,
+        hipLaunchKernelGGL(k_fy_build, dim3(grid), dim3(256), 0, st, draws, Li, mi->h.as<int>(), hd,
                            mi->next.as<int>(), gg);
-        draw_off += Li > 1 ? Li - 1 : 0;
-        if (it % MT_GROUP == MT_GROUP - 1 || it + 1 == iters) ACAV_HIP_TRY(hipEventRecord(mi->ev_used[cur], st));
+        r0 += nd;
+        ACAV_TRY(ms.release(r0));  // k_fy_build is the only reader of the draws
         hipLaunchKernelGGL(k_fy_apply, dim3(grid), dim3(256), 0, st, Acur, Li, B, mi->h.as<int>(), hd,
                            mi->next.as<int>(), gg, mi->batch.as<int>(), Anew, hd_n, gg_n);
         ACAV_HIP_TRY(hipGetLastError());
@@ -1176,10 +1358,10 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
         if (trace_ids) ACAV_HIP_TRY(hipMemcpyAsync(trace_ids, mi->tr_ids.p, sizeof(long long) * (size_t)(iters * B), hipMemcpyDeviceToHost, st));
         if (trace_scores) ACAV_HIP_TRY(hipMemcpyAsync(trace_scores, mi->tr_sc.p, sizeof(double) * (size_t)(iters * B), hipMemcpyDeviceToHost, st));
     }
-    ACAV_HIP_TRY(hipStreamSynchronize(smt));
-    ACAV_HIP_TRY(hipMemcpyAsync(mtbuf, mi->mt.p, sizeof(mtbuf), hipMemcpyDeviceToHost, st));
+    ACAV_HIP_TRY(hipStreamSynchronize(mi->st_mt));
     ACAV_HIP_TRY(hipStreamSynchronize(st));
-    ACAV_TRY(acav_rng_set_state(rng, mtbuf, (int)mtbuf[624]));  // the stream continues on the host
+    ACAV_TRY(ms.final_state(mtbuf, &idx));
+    ACAV_TRY(acav_rng_set_state(rng, mtbuf, idx));  // the stream continues on the host
     if (n_selected) *n_selected = nsel;
     if (n_iters) *n_iters = iters;
     return ACAV_OK;

@@ -41,6 +41,11 @@ class Generator:
         _lib.check(_lib._lib.acav_rng_u32(self._h, C.byref(v)))
         return v.value
 
+    def jump(self, n):
+        """skip n draws (GF(2) jump-ahead): same state as n calls of u32()"""
+        _lib.check(_lib._lib.acav_rng_jump(self._h, int(n)))
+        return self
+
     def rand(self, *shape):
         """torch.rand(*shape) (float32, CPU) as a numpy array."""
         out = np.empty(shape, np.float32)

@@ -162,3 +162,25 @@ def test_product_never_imports_the_oracle():
         src = open(os.path.join(ROOT, "acav100m_amd", "csrc", f)).read()
         assert "libacav_oracle" not in src and "orc_" not in src, f
         assert not re.search(r'#include\s*[<"][^>"]*oracle', src), f
+
+
+def test_rng_jump_equals_sequential_draws(acav):
+    """GF(2) jump-ahead of the MT19937 stream (acav_mtjump.hip: characteristic polynomial by Berlekamp-Massey,
+    t^J mod phi, XOR-combination of windows) == drawing the words one by one.  The GPU generator lanes hop over each
+    other's blocks with the same polynomials."""
+    for seed, pre, n in [(0, 0, 1), (0, 0, 624), (0, 0, 625), (1, 100, 5000), (2, 7, 300_007), (3, 624, 19937 * 3 + 11)]:
+        a, b = acav.Generator(seed), acav.Generator(seed)
+        for _ in range(pre):
+            a.u32(), b.u32()
+        a.jump(n)
+        for _ in range(n):
+            b.u32()
+        (ma, ia), (mb, ib) = a.get_state(), b.get_state()
+        assert ia == ib and np.array_equal(ma, mb), (seed, pre, n)
+        assert [a.u32() for _ in range(700)] == [b.u32() for _ in range(700)]
+    # composition: two half jumps == one jump, far beyond anything one would draw sequentially
+    a, b = acav.Generator(9), acav.Generator(9)
+    n = 624 * 4096 * 31 + 12345
+    a.jump(n)
+    b.jump(n // 3).jump(n - n // 3)
+    assert a.get_state()[1] == b.get_state()[1] and np.array_equal(a.get_state()[0], b.get_state()[0])

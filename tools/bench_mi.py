@@ -16,6 +16,7 @@ v = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 c = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 dd = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 cpu_iters = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+max_iters = int(sys.argv[5]) if len(sys.argv) > 5 else -1  # bound the run (profiling at large V)
 rs = np.random.RandomState(0)
 comp = rs.randint(0, c, v)
 a = np.stack([np.where(rs.rand(v) < 0.5, comp, rs.randint(0, c, v)) for _ in range(dd)], 1).astype(np.int64)
@@ -27,9 +28,9 @@ acav100m_amd.manual_seed(0)
 m = get_measure("batch_mi")(a, ncentroids=c, batch_size=20, selection_size=4, device="cuda:0", keep_unselected=True)
 m.init(pairs, cand[1:])
 t0 = time.perf_counter()
-S, G, _, _ = m.run_greedy(subset, cand[:1], None)
+S, G, _, _ = m.run_greedy(subset, cand[:1], None, max_iters=max_iters)
 dt = time.perf_counter() - t0
-iters = (subset + 3) // 4
+iters = (subset + 3) // 4 if max_iters < 0 else min(max_iters, (subset + 3) // 4)
 out = {"V": v, "C": c, "D": dd, "P": len(pairs), "selected": len(S), "iters": iters, "seconds": dt,
        "us_per_iter": dt / iters * 1e6, "selected_clips_per_s": len(S) / dt, "curated_clips_per_s": v / dt,
        "perm_stream_GBs": sum(16 * (v - 1 - 4 * t) for t in range(iters)) / dt / 1e9}
