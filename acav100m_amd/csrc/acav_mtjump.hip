@@ -161,6 +161,16 @@ int mt_jump_window_host(uint32_t *window, int64_t J)
         const uint32_t *src = &X[(size_t)i];
         for (int k = 0; k < 624; ++k) Y[k] ^= src[k];
     }
+    // The low 31 bits of a window's word 0 are not part of the generator state (only its top bit feeds the
+    // recurrence), so the combination above carries whatever the source window held there -- not the stream word when
+    // the source is a freshly seeded array.  Recover them from the step that produced word 623:
+    //   X[J+623] = X[J+396] ^ twist((X[J-1] & UPPER) | (X[J] & LOWER))      (twist is invertible)
+    {
+        const uint32_t v = Y[623] ^ Y[396];
+        const uint32_t b0 = v >> 31;  // the matrix constant has its top bit set, y >> 1 has not
+        const uint32_t y = ((v ^ (b0 ? 0x9908b0dfu : 0u)) << 1) | b0;
+        Y[0] = (Y[0] & 0x80000000u) | (y & 0x7fffffffu);
+    }
     memcpy(window, Y, sizeof(Y));
     return ACAV_OK;
 }
