@@ -12,6 +12,7 @@
 //        (k_mi_select), float64, formula in oracle/acav_oracle.c "canon".
 //   calc_ids top-k, update_cache, update_candidates (batch.py:143-171)  k_mi_select.
 // The whole loop is enqueued without host synchronisation: L shrinks deterministically.
+#include <chrono>
 #include <cmath>
 
 #include "acav_common.h"
@@ -103,7 +104,7 @@ __device__ __forceinline__ void mi_select_body(
     const double *__restrict__ phi, MiScalars *__restrict__ sc, double *__restrict__ scores_out,
     long long *__restrict__ S_out, double *__restrict__ G_out, const int *__restrict__ forced_pos,
     int *__restrict__ trace_pos, long long *__restrict__ trace_ids, double *__restrict__ trace_scores,
-    int keep_unselected, int *__restrict__ requeue_out)
+    int keep_unselected, int *__restrict__ requeue_out, int requeue_stride = 1)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double *sS = reinterpret_cast<double *>(smem_raw);  // [B*P]
@@ -177,7 +178,7 @@ __device__ __forceinline__ void mi_select_body(
                 const int o = sId[w];
                 rank += (!(used >> w & 1ull) && (o < v || (o == v && w < tid))) ? 1 : 0;
             }
-            requeue_out[rank] = v;
+            requeue_out[rank * requeue_stride] = v;
         }
     }
     __syncthreads();
@@ -405,6 +406,7 @@ constexpr int MT_EPOCH = 24;                              // wide steps between 
 constexpr int MT_WIN = MT_BACK + MT_WIDE * MT_EPOCH;      // 16030 words = 62.6 KB of LDS
 constexpr int MT_GROUP = 8;   // greedy iterations whose draws one launch generates
 constexpr int MT_PAD = 1280;  // the generator completes the 624-word block of the last draw (+ up to 622 words of the last step)
+template <bool WRITE_BACK = true>
 __device__ __forceinline__ void mt_generate_body(unsigned *__restrict__ mt_state, unsigned *__restrict__ out, long long n)
 {
     __shared__ unsigned X[MT_WIN];
@@ -467,6 +469,7 @@ __device__ __forceinline__ void mt_generate_body(unsigned *__restrict__ mt_state
         __builtin_amdgcn_s_barrier();
     }
     __syncthreads();
+    if (!WRITE_BACK) return;
     // words [base, base+624) are inside the window: at most 622 words were generated past `need`
     const unsigned wb = (unsigned)(base - shift);
     for (unsigned k = tid; k < 624; k += MT_THREADS) mt_state[k] = X[wb + k];
@@ -480,15 +483,17 @@ __global__ __launch_bounds__(MT_THREADS) void k_mt_generate(unsigned *__restrict
 }
 
 // ONE stream from several workgroups ("lanes").  The stream past the host state is cut into blocks of `blk` words
-// (a multiple of 624); lane w of W generates blocks w, w + W, w + 2W, ... and hops over the other lanes' blocks with
-// the GF(2) jump polynomial t^((W-1) blk) mod phi (acav_mtjump.hip).  states[lane] = the 624 words preceding the lane's
-// next block + idx (624 = all consumed; lane 0 starts from the host state and first hands out what is left of it).
+// (a multiple of 624); lane w of W generates blocks w, w + W, w + 2W, ... and moves from one to the next with the GF(2)
+// jump polynomial t^(W blk) mod phi (acav_mtjump.hip).  states[lane] = the 624 words preceding the lane's current block
+// + idx (624 = all consumed; lane 0 starts from the host state and first hands out what is left of it); the generator
+// leaves it alone, k_mt_jump advances it.  W is a power of two: every polynomial needed -- t^(2^r blk) to spread the
+// lanes, t^(W blk) to advance them -- is a repeated square of t^blk.
 __global__ __launch_bounds__(MT_THREADS) void k_mt_generate_lanes(unsigned *__restrict__ states, unsigned *__restrict__ out0,
                                                                  long long blk, long long head)
 {
     const long long lane = blockIdx.x;
     const long long extra = lane == 0 ? head : 0;  // leftover draws of the host block, placed right before block 0
-    mt_generate_body(states + lane * 625, out0 + lane * blk - extra, blk + extra);
+    mt_generate_body<false>(states + lane * 625, out0 + lane * blk - extra, blk + extra);  // the state stays at the block start
 }
 
 // states[dst0 + e] <- the window J words ahead of states[src0 + e] (e = blockIdx.x), J given by its polynomial
@@ -613,6 +618,192 @@ __global__ __launch_bounds__(256) void k_fy_apply(const int *__restrict__ A, int
     fy_apply_body(A, L, B, h, head, next, g, batch_out, A_new, head_next, g_next, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
+// ------------------------------------------------------------------- tiled Fisher-Yates (single chunk)
+// The kernels above pay two device-scope atomics per candidate (list head exchange + max) -- at L = 10^6 that is the
+// whole iteration (k_fy_build 88 us of 165).  This evaluation of the SAME swap sequence keeps every atomic in LDS:
+//   k_fy_part    step j -> its target h_j; steps with h_j = j (and position L-1, which has no step) keep their own
+//                content reference; every other step is appended to the bucket of the TILE its target lies in
+//                (LDS histogram per workgroup, one global reservation per non-empty bin, unordered append)
+//   k_fy_tile    one workgroup per tile: the pull lists of the tile's positions are built in LDS (ds exchange / max),
+//                every entry finds its predecessor in its list, and the tile emits  src[j] = "content of position h_j
+//                as it was before any step" (A-ref) or "what step pred left behind" (E-ref pred),  g[q] = last step
+//                that pulled from q
+//   k_fy_gather_select   out[i] = A[src] with E-refs resolved through the g chains (expected length ~1), and -- in
+//                workgroup 0, which is the one that produces the B batch entries -- the scoring / top-k / commit of the
+//                greedy iteration (mi_select_body): the selection runs while the other workgroups still gather
+// Tiles are defined on e = L - 1 - h, the distance from the END of the list: the expected number of pulls on a
+// position is ~ln(L / (e + 1)), it depends on e (not on L, which shrinks every iteration), so one tiling computed for
+// the first iteration bounds every later one.  A tile is closed when it is `wcap` positions wide or its expected load
+// reaches 70 % of the LDS entry capacity; a (never expected) overload is handled by sub-ranging the tile, a bucket or
+// sub-range overflow raises the error flag and the run is refused -- never a wrong permutation.
+constexpr int FYA_CH = 4096;       // steps per k_fy_part workgroup
+constexpr int FYA_THREADS = 1024;
+constexpr int64_t FY_TILED_MAX = 16 << 20;
+constexpr unsigned FY_EREF = 0x80000000u;
+constexpr int FY_NBUF = 4;         // src / g buffers: k_fy_part + k_fy_tile may run this many iterations ahead of the gather
+constexpr int FY_SHARDS = 8;       // sub-buckets per tile (capg entries each), filled by workgroups b with b % 8 == shard
+constexpr int FYT_THREADS = 1024;  // k_fy_tile: the list walks are chains of dependent LDS reads -- many waves hide them
+
+__global__ __launch_bounds__(FYA_THREADS) void k_fy_part(const unsigned *__restrict__ draws, int L,
+                                                         const unsigned short *__restrict__ table, int ntab, int gsh, int NT,
+                                                         int capg, int2 *__restrict__ bucket, int *__restrict__ gcount,
+                                                         unsigned *__restrict__ src, unsigned *__restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fy_smem[];
+    int *lhist = reinterpret_cast<int *>(fy_smem), *lbase = lhist + NT;
+    unsigned short *ltab = reinterpret_cast<unsigned short *>(lbase + NT);  // the tile table, a few KB: LDS lookups
+    const int tid = threadIdx.x;
+    constexpr int PER = FYA_CH / FYA_THREADS;
+    const int base = blockIdx.x * FYA_CH;
+    unsigned dr[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {  // all draw loads in flight before anything else
+        const int j = base + u * FYA_THREADS + tid;
+        dr[u] = draws[j < L - 1 ? j : 0];
+    }
+    for (int t = tid; t < NT; t += FYA_THREADS) lhist[t] = 0;
+    for (int t = tid; t < ntab; t += FYA_THREADS) ltab[t] = table[t];
+    __syncthreads();
+    int hh[PER], tr[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int j = base + u * FYA_THREADS + tid;
+        tr[u] = -1;
+        hh[u] = 0;
+        if (j < L) {
+            int h = j;
+            if (j < L - 1) h = j + (int)(mt_temper(dr[u]) % (unsigned)(L - j));
+            if (h == j) {
+                src[j] = FY_EREF | (unsigned)j;  // the content of position j just before step j
+            } else {
+                const int tile = ltab[(L - 1 - h) >> gsh];
+                tr[u] = (tile << 16) | atomicAdd(&lhist[tile], 1);
+                hh[u] = h;
+            }
+        }
+    }
+    __syncthreads();
+    // one reservation per non-empty bin -- in the workgroup's SHARD of the tile's bucket (workgroup b lands on XCD
+    // b % 8: a shard is written through one L2 only)
+    const int shard = blockIdx.x & (FY_SHARDS - 1);
+    for (int t = tid; t < NT; t += FYA_THREADS) {
+        const int c = lhist[t];
+        lbase[t] = c ? atomicAdd(&gcount[t * FY_SHARDS + shard], c) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+        if (tr[u] >= 0) {
+            const int tile = tr[u] >> 16, pos = lbase[tile] + (tr[u] & 0xffff);
+            if (pos < capg)
+                bucket[((size_t)tile * FY_SHARDS + shard) * capg + pos] = make_int2(base + u * FYA_THREADS + tid, hh[u]);
+            else
+                atomicOr(err, 1u);
+        }
+}
+
+__global__ __launch_bounds__(FYT_THREADS) void k_fy_tile(int L, const int *__restrict__ ebound, int capg, int ecap, int wcap,
+                                                         const int2 *__restrict__ bucket, int *__restrict__ gcount,
+                                                         unsigned *__restrict__ src, int *__restrict__ g, unsigned *__restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fy_smem[];
+    int *lhead = reinterpret_cast<int *>(fy_smem);   // [wcap] newest entry of the position's pull list
+    int *lg = lhead + wcap;                            // [wcap] largest step that pulled from the position
+    int *ej = lg + wcap;                               // [ecap] step of the entry
+    unsigned short *ep = reinterpret_cast<unsigned short *>(ej + ecap);  // [ecap] local position
+    unsigned short *enx = ep + ecap;                   // [ecap] next entry of the list, 0xFFFF = end
+    __shared__ int lcnt;
+    __shared__ int soff[FY_SHARDS + 1];
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    const int e_lo = ebound[tile], e_hi = ebound[tile + 1];
+    if (e_lo > L - 1) return;  // the list no longer reaches this tile (no step targets it: its counts are 0)
+    const int q_lo = L - e_hi, w = e_hi - e_lo;  // positions q_lo .. q_lo + w - 1 (q_lo may be negative)
+    if (tid == 0) {
+        int tot = 0;
+        for (int sh = 0; sh < FY_SHARDS; ++sh) {
+            int c = gcount[tile * FY_SHARDS + sh];
+            gcount[tile * FY_SHARDS + sh] = 0;  // for the next iteration's k_fy_part
+            c = c > capg ? capg : c;           // k_fy_part has raised the error flag
+            soff[sh] = tot;
+            tot += c;
+        }
+        soff[FY_SHARDS] = tot;
+    }
+    __syncthreads();
+    const int count = soff[FY_SHARDS];
+    const int2 *bk = bucket + (size_t)tile * FY_SHARDS * capg;
+    const int nsub = count <= ecap ? 1 : (count + (ecap >> 2) - 1) / (ecap >> 2);
+    for (int r = 0; r < nsub; ++r) {
+        const int p0 = (int)((long long)w * r / nsub), p1 = (int)((long long)w * (r + 1) / nsub);
+        for (int p = p0 + tid; p < p1; p += FYT_THREADS) {
+            lhead[p] = -1;
+            lg[p] = -1;
+        }
+        if (tid == 0) lcnt = 0;
+        __syncthreads();
+        for (int x = tid; x < count; x += FYT_THREADS) {
+            int sh = 0;  // entry x of the concatenated shards
+#pragma unroll
+            for (int q = 1; q < FY_SHARDS; ++q) sh += x >= soff[q] ? 1 : 0;
+            const int2 jh = bk[(size_t)sh * capg + (x - soff[sh])];
+            const int p = jh.y - q_lo;
+            if (nsub > 1 && (p < p0 || p >= p1)) continue;
+            const int e = nsub == 1 ? x : atomicAdd(&lcnt, 1);
+            if (e < ecap) {
+                ej[e] = jh.x;
+                ep[e] = (unsigned short)p;
+                enx[e] = (unsigned short)atomicExch(&lhead[p], e);  // -1 -> 0xFFFF
+                atomicMax(&lg[p], jh.x);
+            } else {
+                atomicOr(err, 2u);
+            }
+        }
+        __syncthreads();
+        const int n = nsub == 1 ? count : (lcnt < ecap ? lcnt : ecap);
+        for (int e = tid; e < n; e += FYT_THREADS) {
+            const int p = ep[e], j = ej[e];
+            int pred = -1;
+            for (int x = lhead[p]; x >= 0; x = enx[x] == 0xFFFFu ? -1 : (int)enx[x]) {
+                const int jj = ej[x];
+                if (jj < j && jj > pred) pred = jj;
+            }
+            src[j] = pred >= 0 ? (FY_EREF | (unsigned)pred) : (unsigned)(q_lo + p);
+        }
+        for (int p = p0 + tid; p < p1; p += FYT_THREADS)
+            if (q_lo + p >= 0) g[q_lo + p] = lg[p];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fy_gather_select(
+    const int *__restrict__ A, int L, const unsigned *__restrict__ src, const int *__restrict__ g, int *__restrict__ A_new,
+    const int *__restrict__ asg, int D, int C, int P, const int *__restrict__ pairs, int *__restrict__ batch, int B, int k,
+    int *__restrict__ Nc, int *__restrict__ ac, int *__restrict__ bc, double *__restrict__ SN, double *__restrict__ Sa,
+    double *__restrict__ Sb, const double *__restrict__ phi, MiScalars *__restrict__ sc, long long *__restrict__ S_out,
+    double *__restrict__ G_out, const int *__restrict__ forced_pos, int *__restrict__ trace_pos,
+    long long *__restrict__ trace_ids, double *__restrict__ trace_scores, int keep_unselected)
+{
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i < L) {
+        const unsigned s = src[i];
+        int a = (int)(s & 0x7fffffffu);
+        if (s & FY_EREF) {  // what step a left behind: walk back to the position whose original content that was
+            int ga;
+            while ((ga = g[a]) >= 0) a = ga;
+        }
+        const int v = A[a];
+        if (i < B)
+            batch[i] = v;
+        else
+            A_new[i - B] = v;
+    }
+    if (blockIdx.x != 0) return;  // uniform
+    __threadfence_block();
+    __syncthreads();
+    mi_select_body(asg, D, C, P, pairs, batch, B, k, Nc, ac, bc, SN, Sa, Sb, phi, sc, nullptr, S_out, G_out, forced_pos,
+                   trace_pos, trace_ids, trace_scores, keep_unselected, A_new + (L - B));
+}
+
 // ------------------------------------------------------------------ several chunks in lockstep
 // The greedy loop of ONE chunk is a chain of small dependent kernels: most of the GPU idles, and several chunks
 // driven from several host threads do not overlap (the HIP runtime serialises the launches).  Chunks are
@@ -701,6 +892,9 @@ struct acav_mi {
     DevBuf removed, blockbest, ticket, tr_am;  // exact greedy
     DevBuf chunk_desc;                         // descriptor array of a multi-chunk run (lead handle)
     DevBuf lane_states, ring, polys;           // MT19937 lanes of the single-chunk greedy (MtStream)
+    DevBuf fy_table, fy_bounds, fy_bucket, fy_count, fy_src[FY_NBUF], fy_g[FY_NBUF], fy_err;  // tiled Fisher-Yates
+    hipStream_t st_fy = nullptr;               // k_fy_part / k_fy_tile of iteration t+1 run beside the gather of t
+    hipEvent_t ev_tile[FY_NBUF] = {}, ev_gather[FY_NBUF] = {};
     // the mt19937 stream does not depend on the selection state: it is generated one iteration ahead on
     // its own stream (double-buffered draws), overlapping the Fisher-Yates / select kernels
     hipStream_t st_mt = nullptr;
@@ -726,13 +920,13 @@ struct MtStream {
     int p0 = 0, W = 1, logW = 0;
     bool wraps = false;
     unsigned *ring = nullptr, *states = nullptr, *polys = nullptr;
-    hipStream_t st = nullptr, smt = nullptr;
+    hipStream_t st = nullptr, smt = nullptr;  // st: the stream of the kernel that reads the draws
     hipEvent_t ev_mt[NSLOT] = {nullptr, nullptr}, ev_used[NSLOT] = {nullptr, nullptr};
     int64_t produced = 0;  // superblocks enqueued on smt
     int64_t waited = -1;   // highest superblock `st` has been told to wait for
     int64_t freed = 0;     // superblocks [0, freed) are no longer read by any iteration still to be enqueued
 
-    int plan(acav_mi *mi, const uint32_t *mtbuf, int idx, int64_t total_draws, int64_t L)
+    int plan(acav_mi *mi, hipStream_t consumer, const uint32_t *mtbuf, int idx, int64_t total_draws, int64_t L)
     {
         T = total_draws;
         p0 = idx;
@@ -758,7 +952,7 @@ struct MtStream {
         S = (int64_t)W * blk;
         nsuper = nblocks ? (nblocks + W - 1) / W : 0;
         wraps = nsuper > NSLOT;
-        st = mi->ctx.stream;
+        st = consumer;
         smt = mi->st_mt;
         for (int q = 0; q < NSLOT; ++q) ev_mt[q] = mi->ev_mt[q], ev_used[q] = mi->ev_used[q];
         const int64_t slots = nsuper < NSLOT ? nsuper : NSLOT;
@@ -774,18 +968,14 @@ struct MtStream {
         ACAV_HIP_TRY(hipMemcpyAsync(states, st0, sizeof(st0), hipMemcpyHostToDevice, st));
         if (head > 0) ACAV_HIP_TRY(hipMemcpyAsync(ring + PAD - head, mtbuf + p0, sizeof(unsigned) * (size_t)head, hipMemcpyHostToDevice, st));
         ACAV_HIP_TRY(hipStreamSynchronize(st));  // st0 / mtbuf are the caller's locals
-        // jump polynomials: spreading the lanes (t^(2^r blk)) and hopping over the other lanes ((W-1) blk)
+        // jump polynomials t^(2^r blk): r < logW spreads the lanes, r = logW advances a lane to its next block
         const int npoly = logW + 1;
         std::vector<uint32_t> hp((size_t)npoly * 624, 0u);
-        for (int r = 0; r < logW; ++r) {
-            const uint32_t *g = mt_jump_poly(((int64_t)1 << r) * blk);
+        for (int r = 0; r < npoly; ++r) {
+            if (r == logW && nsuper <= 1) break;
+            const uint32_t *g = mt_jump_poly(((int64_t)1 << r) * blk);  // cached; each is the square of the one before
             ACAV_REQUIRE(g, ACAV_ESTATE, "could not derive the MT19937 jump polynomial");
             memcpy(&hp[(size_t)r * 624], g, 624 * sizeof(uint32_t));
-        }
-        if (W > 1 && nsuper > 1) {
-            const uint32_t *g = mt_jump_poly((int64_t)(W - 1) * blk);
-            ACAV_REQUIRE(g, ACAV_ESTATE, "could not derive the MT19937 jump polynomial");
-            memcpy(&hp[(size_t)logW * 624], g, 624 * sizeof(uint32_t));
         }
         ACAV_TRY(mi->polys.ensure(sizeof(uint32_t) * hp.size()));
         polys = mi->polys.as<unsigned>();
@@ -811,7 +1001,7 @@ struct MtStream {
         unsigned *out0 = ring + PAD + (int64_t)slot * S;
         hipLaunchKernelGGL(k_mt_generate_lanes, dim3(lanes), dim3(MT_THREADS), 0, smt, states, out0, (long long)blk,
                            (long long)(s == 0 ? head : 0));
-        if (s + 1 < nsuper && W > 1)  // every lane hops over the W - 1 blocks of the other lanes
+        if (s + 1 < nsuper)  // every lane moves on to its next block, W blocks further
             hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)W), dim3(MT_THREADS), 0, smt, states, 0, 0, polys + (size_t)logW * 624);
         ACAV_HIP_TRY(hipGetLastError());
         if (wraps && slot == 0 && s > 0)  // mirror of the slot's first lmax words behind the last slot
@@ -862,6 +1052,52 @@ struct MtStream {
     }
 };
 
+// Tiling of the tiled Fisher-Yates for a list of (at most) L0 candidates; see the kernels' header comment.
+struct FyPlan {
+    int gsh = 4, wcap = 256, ecap = 256, ecap_lds = 256, capg = 512, NT = 0;
+    std::vector<unsigned short> table;  // (e >> gsh) -> tile
+    std::vector<int> ebound;            // tile t covers e in [ebound[t], ebound[t+1])
+    void build(int64_t L0)
+    {
+        int cap = 256;
+        while (cap < 8192 && (int64_t)cap * 128 < L0) cap *= 2;
+        wcap = ecap = cap;
+        // capacity of ONE shard of a tile's bucket: with many k_fy_part workgroups the shards fill evenly (an eighth of
+        // the tile's load each, 4x headroom); with few, one shard may receive everything
+        capg = (L0 + FYA_CH - 1) / FYA_CH >= 64 ? cap / 2 : 2 * cap;
+        gsh = 0;
+        while ((1 << gsh) < cap / 16) ++gsh;
+        const int gran = 1 << gsh;
+        const double limit = 0.7 * ecap, lnL = log((double)L0);
+        table.assign((size_t)((L0 + gran - 1) >> gsh) + 1, 0);
+        ebound.clear();
+        int64_t e = 0;
+        while (e < L0) {
+            int width = 0;
+            double mass = 0.0;
+            do {  // expected pulls on the granule [x, x + gran): at most gran * ln(L0 / (x + 1))
+                const double x = (double)(e + width);
+                const double m = gran * (lnL - log(x + 1.0)) + 1.0;
+                if (width > 0 && mass + (m > 0 ? m : 0) > limit) break;
+                mass += m > 0 ? m : 0;
+                width += gran;
+            } while (width < wcap && e + width < L0);
+            const int t = (int)ebound.size();
+            ebound.push_back((int)e);
+            for (int64_t x = e; x < e + width; x += gran) table[(size_t)(x >> gsh)] = (unsigned short)t;
+            e += width;
+        }
+        ebound.push_back((int)e);
+        NT = (int)ebound.size() - 1;
+        ecap_lds = ecap;
+        if (const char *v = getenv("ACAV_FY_ECAP")) {  // tests: force the sub-ranged overload path
+            const int x = atoi(v);
+            if (x >= 16 && x < ecap) ecap_lds = x;
+        }
+    }
+    size_t tile_smem() const { return (size_t)wcap * 8 + (size_t)ecap_lds * 8; }
+};
+
 static int ids_to_device32(acav_mi *mi, const int64_t *ids, int64_t n, DevBuf &stage, DevBuf &out32)
 {
     hipStream_t st = mi->ctx.stream;
@@ -880,6 +1116,8 @@ static int ids_to_device32(acav_mi *mi, const int64_t *ids, int64_t n, DevBuf &s
     }
     return ACAV_OK;
 }
+
+ACAV_EXPORT int acav_mi_destroy(acav_mi *mi);
 
 ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignments, int64_t V, int D, int C,
                                const int32_t *pairs, int P, void *stream)
@@ -948,9 +1186,18 @@ ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignm
             rc = ACAV_EHIP;
         }
     }
+    if (rc == ACAV_OK) {
+        bool ok = hipStreamCreateWithFlags(&mi->st_fy, hipStreamNonBlocking) == hipSuccess;
+        for (int q = 0; q < FY_NBUF && ok; ++q)
+            ok = hipEventCreateWithFlags(&mi->ev_tile[q], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&mi->ev_gather[q], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            set_error("could not create the Fisher-Yates stream / events");
+            rc = ACAV_EHIP;
+        }
+    }
     if (rc != ACAV_OK) {
-        mi->ctx.fini();
-        delete mi;
+        acav_mi_destroy(mi);
         return rc;
     }
     *out = mi;
@@ -966,9 +1213,17 @@ ACAV_EXPORT int acav_mi_destroy(acav_mi *mi)
         (void)hipStreamSynchronize(mi->st_mt);
         (void)hipStreamDestroy(mi->st_mt);
     }
+    if (mi->st_fy) {
+        (void)hipStreamSynchronize(mi->st_fy);
+        (void)hipStreamDestroy(mi->st_fy);
+    }
     for (int q = 0; q < 2; ++q) {
         if (mi->ev_mt[q]) (void)hipEventDestroy(mi->ev_mt[q]);
         if (mi->ev_used[q]) (void)hipEventDestroy(mi->ev_used[q]);
+    }
+    for (int q = 0; q < FY_NBUF; ++q) {
+        if (mi->ev_tile[q]) (void)hipEventDestroy(mi->ev_tile[q]);
+        if (mi->ev_gather[q]) (void)hipEventDestroy(mi->ev_gather[q]);
     }
     mi->ctx.fini();
     delete mi;
@@ -1284,14 +1539,38 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
     ACAV_TRY(mi->A0.ensure(sizeof(int) * (size_t)(L + B)));  // before the conversion: ensure() does not copy
     ACAV_TRY(ids_to_device32(mi, candidates, L, mi->stage, mi->A0));
     ACAV_TRY(mi->A1.ensure(sizeof(int) * (size_t)(L + B)));
-    ACAV_TRY(mi->h.ensure(sizeof(int) * (size_t)L));
-    ACAV_TRY(mi->head.ensure(sizeof(int) * (size_t)L));
-    ACAV_TRY(mi->next.ensure(sizeof(int) * (size_t)L));
-    ACAV_TRY(mi->g.ensure(sizeof(int) * (size_t)L));
-    ACAV_TRY(mi->head2.ensure(sizeof(int) * (size_t)L));
-    ACAV_TRY(mi->g2.ensure(sizeof(int) * (size_t)L));
-    ACAV_HIP_TRY(hipMemsetAsync(mi->head.p, 0xFF, sizeof(int) * (size_t)L, st));
-    ACAV_HIP_TRY(hipMemsetAsync(mi->g.p, 0xFF, sizeof(int) * (size_t)L, st));
+    // the permutation of every iteration: tiled evaluation (all atomics in LDS) unless the list is too long for its
+    // tile table, or ACAV_FY_LEGACY=1 asks for the global-atomic kernels (k_fy_build / k_fy_apply)
+    const char *legacy = getenv("ACAV_FY_LEGACY");
+    const bool tiled = L <= FY_TILED_MAX && !(legacy && legacy[0] == '1');
+    FyPlan fp;
+    if (tiled) {
+        fp.build(L);
+        ACAV_TRY(mi->fy_table.ensure(sizeof(unsigned short) * fp.table.size()));
+        ACAV_TRY(mi->fy_bounds.ensure(sizeof(int) * fp.ebound.size()));
+        ACAV_TRY(mi->fy_bucket.ensure(sizeof(int2) * (size_t)fp.NT * FY_SHARDS * fp.capg));
+        ACAV_TRY(mi->fy_count.ensure(sizeof(int) * (size_t)fp.NT * FY_SHARDS));
+        ACAV_TRY(mi->fy_err.ensure(sizeof(unsigned)));
+        for (int q = 0; q < FY_NBUF; ++q) {
+            ACAV_TRY(mi->fy_src[q].ensure(sizeof(unsigned) * (size_t)L));
+            ACAV_TRY(mi->fy_g[q].ensure(sizeof(int) * (size_t)L));
+        }
+        ACAV_HIP_TRY(hipMemcpyAsync(mi->fy_table.p, fp.table.data(), sizeof(unsigned short) * fp.table.size(), hipMemcpyHostToDevice, st));
+        ACAV_HIP_TRY(hipMemcpyAsync(mi->fy_bounds.p, fp.ebound.data(), sizeof(int) * fp.ebound.size(), hipMemcpyHostToDevice, st));
+        ACAV_HIP_TRY(hipMemsetAsync(mi->fy_count.p, 0, sizeof(int) * (size_t)fp.NT * FY_SHARDS, st));
+        ACAV_HIP_TRY(hipMemsetAsync(mi->fy_err.p, 0, sizeof(unsigned), st));
+        ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fy_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)fp.tile_smem()));
+    } else {
+        ACAV_TRY(mi->h.ensure(sizeof(int) * (size_t)L));
+        ACAV_TRY(mi->head.ensure(sizeof(int) * (size_t)L));
+        ACAV_TRY(mi->next.ensure(sizeof(int) * (size_t)L));
+        ACAV_TRY(mi->g.ensure(sizeof(int) * (size_t)L));
+        ACAV_TRY(mi->head2.ensure(sizeof(int) * (size_t)L));
+        ACAV_TRY(mi->g2.ensure(sizeof(int) * (size_t)L));
+        ACAV_HIP_TRY(hipMemsetAsync(mi->head.p, 0xFF, sizeof(int) * (size_t)L, st));
+        ACAV_HIP_TRY(hipMemsetAsync(mi->g.p, 0xFF, sizeof(int) * (size_t)L, st));
+    }
     ACAV_TRY(mi->mt.ensure(sizeof(unsigned) * 625));
     ACAV_TRY(mi->batch.ensure(sizeof(int) * SEL_MAXB));
     ACAV_TRY(mi->S.ensure(sizeof(long long) * (size_t)cap));
@@ -1317,11 +1596,67 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
         total_draws += lt > 1 ? lt - 1 : 0;
     }
     MtStream ms;
-    ACAV_TRY(ms.plan(mi, mtbuf, idx, total_draws, L));
+    ACAV_TRY(ms.plan(mi, tiled ? mi->st_fy : st, mtbuf, idx, total_draws, L));
 
     int *Acur = mi->A0.as<int>(), *Anew = mi->A1.as<int>();
     int64_t l = L;
     int64_t r0 = 0;  // first draw of this iteration, counted from the first draw of the run
+    if (tiled) {
+        // two streams: k_fy_part + k_fy_tile (positions only, no content) run on st_fy up to FY_NBUF iterations ahead of
+        // the gather + selection on st; src / g are multi-buffered, the streams meet through two events per iteration
+        // (a cross-stream hand-off costs ~20 us of latency: with only two buffers it sat on the critical cycle)
+        hipStream_t sf = mi->st_fy;
+        ACAV_HIP_TRY(hipStreamSynchronize(st));  // tables, counters and the candidate list are in place
+        const bool timing = getenv("ACAV_MI_TIMING") != nullptr;
+        const auto t_loop0 = std::chrono::steady_clock::now();
+        const size_t smem_sel = sizeof(double) * (size_t)B * mi->P;
+        for (int64_t it = 0; it < iters; ++it) {
+            const int Li = (int)l, par = (int)(it % FY_NBUF);
+            const int64_t nd = Li > 1 ? Li - 1 : 0;
+            const unsigned *draws = nullptr;
+            ACAV_TRY(ms.acquire(r0, nd, &draws));
+            if (it >= FY_NBUF) ACAV_HIP_TRY(hipStreamWaitEvent(sf, mi->ev_gather[par], 0));  // src / g of iteration t - FY_NBUF are consumed
+            unsigned *src = mi->fy_src[par].as<unsigned>();
+            int *gq = mi->fy_g[par].as<int>();
+            hipLaunchKernelGGL(k_fy_part, dim3((unsigned)((Li + FYA_CH - 1) / FYA_CH)), dim3(FYA_THREADS),
+                               sizeof(int) * 2 * (size_t)fp.NT + sizeof(unsigned short) * fp.table.size(), sf, draws, Li,
+                               mi->fy_table.as<unsigned short>(), (int)fp.table.size(), fp.gsh, fp.NT, fp.capg,
+                               mi->fy_bucket.as<int2>(), mi->fy_count.as<int>(), src, mi->fy_err.as<unsigned>());
+            r0 += nd;
+            ACAV_TRY(ms.release(r0));  // k_fy_part is the only reader of the draws
+            hipLaunchKernelGGL(k_fy_tile, dim3((unsigned)fp.NT), dim3(FYT_THREADS), fp.tile_smem(), sf, Li, mi->fy_bounds.as<int>(), fp.capg,
+                               fp.ecap_lds, fp.wcap, mi->fy_bucket.as<int2>(), mi->fy_count.as<int>(), src, gq,
+                               mi->fy_err.as<unsigned>());
+            ACAV_HIP_TRY(hipEventRecord(mi->ev_tile[par], sf));
+            ACAV_HIP_TRY(hipStreamWaitEvent(st, mi->ev_tile[par], 0));
+            hipLaunchKernelGGL(k_fy_gather_select, dim3((unsigned)((Li + 255) / 256)), dim3(256), smem_sel, st, Acur, Li, src, gq, Anew,
+                               mi->asg.as<int>(), mi->D, mi->C, mi->P, mi->pairs.as<int>(), mi->batch.as<int>(), B, k,
+                               mi->Nc.as<int>(), mi->ac.as<int>(), mi->bc.as<int>(), mi->SN.as<double>(), mi->Sa.as<double>(),
+                               mi->Sb.as<double>(), mi->phi.as<double>(), mi->scalars.as<MiScalars>(),
+                               mi->S.as<long long>() + it * k, mi->G.as<double>() + it * k,
+                               forced_pos ? mi->forced.as<int>() + it * k : nullptr,
+                               trace_pos ? mi->tr_pos.as<int>() + it * k : nullptr,
+                               trace_ids ? mi->tr_ids.as<long long>() + it * B : nullptr,
+                               trace_scores ? mi->tr_sc.as<double>() + it * B : nullptr, keep_unselected);
+            ACAV_HIP_TRY(hipGetLastError());
+            ACAV_HIP_TRY(hipEventRecord(mi->ev_gather[par], st));
+            l = l - B + (keep_unselected ? B - k : 0);
+            int *t = Acur;
+            Acur = Anew;
+            Anew = t;
+        }
+        const auto t_loop1 = std::chrono::steady_clock::now();
+        ACAV_HIP_TRY(hipStreamSynchronize(sf));
+        if (timing) {
+            ACAV_HIP_TRY(hipStreamSynchronize(st));
+            const auto t_loop2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[acav] greedy loop: %lld iterations, host enqueue %.2f us/iteration, enqueue + drain %.2f us/iteration "
+                            "(tiles %d, cap %d, lanes %d)\n", (long long)iters,
+                    std::chrono::duration<double, std::micro>(t_loop1 - t_loop0).count() / (double)(iters ? iters : 1),
+                    std::chrono::duration<double, std::micro>(t_loop2 - t_loop0).count() / (double)(iters ? iters : 1), fp.NT,
+                    fp.ecap, ms.W);
+        }
+    } else
     for (int64_t it = 0; it < iters; ++it) {
         const int Li = (int)l;
         const int64_t nd = Li > 1 ? Li - 1 : 0;
@@ -1362,6 +1697,12 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
     ACAV_HIP_TRY(hipStreamSynchronize(st));
     ACAV_TRY(ms.final_state(mtbuf, &idx));
     ACAV_TRY(acav_rng_set_state(rng, mtbuf, idx));  // the stream continues on the host
+    if (tiled) {
+        unsigned ferr = 0;
+        ACAV_HIP_TRY(hipMemcpy(&ferr, mi->fy_err.p, sizeof(ferr), hipMemcpyDeviceToHost));
+        ACAV_REQUIRE(ferr == 0, ACAV_ESTATE,
+                     "tiled Fisher-Yates: a tile bucket overflowed (flags %u); re-run with ACAV_FY_LEGACY=1", ferr);
+    }
     if (n_selected) *n_selected = nsel;
     if (n_iters) *n_iters = iters;
     return ACAV_OK;

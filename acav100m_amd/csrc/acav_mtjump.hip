@@ -127,6 +127,18 @@ const uint32_t *mt_jump_poly(int64_t J)
     if (it != g_poly_cache.end()) return it->second.data();
     Poly p;
     p.clear();
+    if (J > 0 && (J & 1) == 0) {  // t^J = (t^(J/2))^2: the lane polynomials t^(2^r blk) come out as one squaring each
+        auto half = g_poly_cache.find(J / 2);
+        if (half != g_poly_cache.end()) {
+            for (int i = 0; i < MT_DEG; ++i)
+                if ((half->second[(size_t)(i >> 5)] >> (i & 31)) & 1u) p.flip(i);
+            square(p);
+            std::vector<uint32_t> out(624, 0u);
+            for (int i = 0; i < MT_DEG; ++i)
+                if (p.bit(i)) out[(size_t)(i >> 5)] |= 1u << (i & 31);
+            return g_poly_cache.emplace(J, std::move(out)).first->second.data();
+        }
+    }
     p.flip(0);  // 1
     int top = 63;
     while (top > 0 && !((J >> top) & 1)) --top;
