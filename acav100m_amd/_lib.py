@@ -22,6 +22,7 @@ SIGNATURES = {
     "acav_rng_seed": [vp, u32],
     "acav_rng_u32": [vp, C.POINTER(u32)],
     "acav_rng_jump": [vp, i64],
+    "acav_rng_py_shuffle": [vp, i64, vp],
     "acav_rng_rand_f32": [vp, vp, i64],
     "acav_rng_randperm": [vp, i64, vp],
     "acav_rng_get_state": [vp, vp, C.POINTER(i32)],

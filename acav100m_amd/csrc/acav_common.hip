@@ -202,6 +202,25 @@ ACAV_EXPORT int acav_rng_randperm(acav_rng *rng, int64_t n, int64_t *out_host)
     }
     return ACAV_OK;
 }
+// Python's random.shuffle(list(range(n))) on this generator's stream (CPython Lib/random.py: for i = n-1 .. 1:
+// j = _randbelow(i + 1), swap; _randbelow_with_getrandbits draws getrandbits(bit_length(i + 1)) =
+// genrand_uint32() >> (32 - k) until it is below i + 1).  The selection stage shuffles its candidate list with
+// Python's generator (run_greedy.py:40): a million-element list costs the interpreter 0.6 s, this loop 5 ms.
+ACAV_EXPORT int acav_rng_py_shuffle(acav_rng *rng, int64_t n, int64_t *out_host)
+{
+    ACAV_REQUIRE(rng && (out_host || n == 0) && n >= 0 && n <= 0xffffffffll, ACAV_EINVAL, "bad argument");
+    for (int64_t i = 0; i < n; ++i) out_host[i] = i;
+    for (int64_t i = n - 1; i >= 1; --i) {
+        const uint32_t m = (uint32_t)(i + 1);
+        const int k = 32 - __builtin_clz(m);  // bit_length
+        uint32_t r;
+        do r = rng->next() >> (32 - k); while (r >= m);
+        const int64_t t = out_host[i];
+        out_host[i] = out_host[r];
+        out_host[r] = t;
+    }
+    return ACAV_OK;
+}
 ACAV_EXPORT int acav_rng_get_state(const acav_rng *rng, uint32_t *mt624, int *idx)
 {
     ACAV_REQUIRE(rng && mt624 && idx, ACAV_EINVAL, "NULL argument");

@@ -10,7 +10,7 @@ Plan of a run (reference run_greedy.py:9-74):
 `_prepare` builds everything up to the measure call so that several chunks can be prepared first and then selected
 in lockstep (run.py).
 """
-import random
+import numpy as np
 
 from .measures import get_measure
 from .pairing import get_cluster_pairing
@@ -27,11 +27,11 @@ class _Plan:
         self.select = min(args.batch.selection_size, self.batch)
 
     def candidate_order(self, shuffle):
-        order = list(range(self.rows))
         if shuffle:
             print("shuffling candidates")
-            random.shuffle(order)  # Python's generator, not torch's (run_greedy.py:40)
-        return order
+            from ..rng import python_shuffled_range
+            return python_shuffled_range(self.rows)  # random.shuffle: Python's generator, not torch's (run_greedy.py:40)
+        return np.arange(self.rows, dtype=np.int64)
 
 
 def _prepare(args, assignments, clustering_types, subset_size, subset_ratio, measure_name='mi',

@@ -184,3 +184,19 @@ def test_rng_jump_equals_sequential_draws(acav):
     a.jump(n)
     b.jump(n // 3).jump(n - n // 3)
     assert a.get_state()[1] == b.get_state()[1] and np.array_equal(a.get_state()[0], b.get_state()[0])
+
+
+def test_python_shuffle_in_library_equals_random_shuffle(acav):
+    """run_greedy.py:38-41 shuffles the candidates with Python's generator; acav_rng_py_shuffle reproduces
+    random.shuffle(list(range(n))) and leaves `random` in the state the interpreter's own loop would."""
+    import random
+    from acav100m_amd.rng import python_shuffled_range
+    for seed, n in [(0, 1), (0, 2), (0, 10), (1, 1000), (5, 100003), (7, 65536)]:
+        random.seed(seed)
+        want = list(range(n))
+        random.shuffle(want)
+        after = [random.random(), random.getrandbits(40)]
+        random.seed(seed)
+        got = python_shuffled_range(n)
+        assert got.tolist() == want, (seed, n)
+        assert [random.random(), random.getrandbits(40)] == after, "generator state after the shuffle"
