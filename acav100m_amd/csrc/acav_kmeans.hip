@@ -659,7 +659,10 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict_
         fdp5 += fd_tloop0 - fd_tgrp;
         fdp6 += fd_tloop1 - fd_tloop0;
 #endif
-        float my_cn = INFINITY, my_sc = 1.0f;  // +inf beyond K: such a centre never wins and never becomes the runner-up
+        // beyond K: a huge FINITE norm -- such a centre never wins and never becomes the runner-up.  (+inf would turn
+        // into a NaN under the position tag, and fmaxf(s1, NaN) = s1 makes the runner-up collapse onto the minimum: every
+        // lane that mixes real and padding centres would send its row to the re-check.)
+        float my_cn = 3.0e38f, my_sc = 1.0f;
         if (kbase + tid < K) {
             my_cn = cn[kbase + tid];
             my_sc = counts[kbase + tid] < thr ? inv_r : 1.0f;
@@ -762,6 +765,216 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict_
         if (!((run.d2 - run.d1) > 2.0f * E)) {  // also catches NaN / inf
             const unsigned slot = atomicAdd(recheck_count, 1u);
             recheck_list[slot] = (int)(row0 + tid);
+        }
+    }
+}
+
+// k_assign_bf16_rw -- the same filter with the waves cut the other way ("row waves"): wave w owns ROWS 32 w .. 32 w + 31
+// of the workgroup's 128 against ALL 256 centres of the group (8 accumulator tiles of 32x32).
+//   * a wave reads and converts only its own rows' fp32 fragments: 8 v_cvt_pk_bf16_f32 per 32-column stage instead of
+//     32 (in the centre-quarter layout every wave re-read and re-converted all 128 rows); the bf16 centre fragments,
+//     which need no conversion, are the ones every wave reads
+//   * a lane ends up with all 128 centres of its half for ITS row: the top-2 scan completes in the lane, the two
+//     halves meet with one shfl_xor 32, and the running top-2 over centre groups stays in registers -- no cross-wave
+//     merge through LDS, no per-group scratch for it
+//   * the position tag needs 7 bits (128 distances per lane): 128 ulp = 2^-16 of the tagged distance.  That is charged
+//     to the two distances the acceptance test compares (|d1| + |d2|) instead of to (||x|| + cmax)^2; what is left in the
+//     e2 term are the 3 + 3 fp32 roundings of the two epilogues (< 6 x 2^-24 (||x|| + cmax)^2): e2 = 2^-20 here
+// Rings, swizzles, DMA shares, counted waits and the one raw barrier per stage are those of k_assign_bf16.
+template <bool NT>
+__global__ __launch_bounds__(256, 2) void k_assign_bf16_rw(const float *__restrict__ x, int64_t n, int d,
+                                                            const __bf16 *__restrict__ cb, const float *__restrict__ cn,
+                                                            const float *__restrict__ counts, int K, float thr, float r,
+                                                            const CentersAux *__restrict__ aux, float e1c, float e1r, float e2coef,
+                                                            int64_t *__restrict__ labels, int *__restrict__ recheck_list,
+                                                            unsigned *__restrict__ recheck_count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
+    float *sXr = reinterpret_cast<float *>(fd_smem);                        // [FD_DX][128][32] fp32
+    __bf16 *sCb = reinterpret_cast<__bf16 *>(fd_smem + FD_DX * FD_SLOT);    // [FD_DC][256][32] bf16
+    float *sCn = reinterpret_cast<float *>(fd_smem);  // [256] epilogue scratch, aliases the (idle) row ring
+    float *sSc = sCn + 256;                           // [256] 1, or 1/r for a discounted centre
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = row tile (32 rows)
+    const int l31 = lane & 31, h = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    const int nchunks = d / FD_BK;
+    const int ngroups = (K + 255) / 256;
+    const float inv_r = 1.0f / r;
+    // Centred mode (no centre is under-used: the filter multiplies by c - mu): every distance of a row carries the same
+    // constant ||x||^2 + M - 2 x.mu, M = any number.  It is left out of the compared values -- ||x||^2 is not added and
+    // M = ||c_0||^2 is subtracted from every ||c_k||^2 (exact by Sterbenz when the norms are within a factor 2, else one
+    // more rounding inside e2) -- so the position tag perturbs numbers of the size of the distance SPREAD, not of the
+    // squared norms.  With an under-used centre the division by r does not commute with a row constant: full values.
+    const bool centred = aux->any_disc == 0u;
+    const float cn_shift = centred ? cn[0] : 0.0f;
+
+    unsigned voffx[4], voffc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rr = (wq * 4 + q) * 8 + (lane >> 3);
+        const int rc = row0 + rr < n ? rr : (int)(n - 1 - row0);  // ragged tail: re-read the last row
+        voffx[q] = (unsigned)rc * (unsigned)d * 4u + (((lane & 7) ^ ((rr >> 1) & 7)) << 4);
+    }
+    const unsigned xring = lds_addr(sXr) + wq * 4096, cring = lds_addr(sCb) + wq * 4096;
+
+    float ssq[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ssq[e] = 0.f;
+    Top2 run = {INFINITY, 0x7fffffff, INFINITY};
+    float xn = 0.f;  // ||x||^2 of this lane's row
+
+    for (int cg = 0; cg < ngroups; ++cg) {
+        const int kbase = cg * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = (wq * 4 + q) * 16 + (lane >> 2);
+            const int rc = kbase + rr < K ? rr : K - 1 - kbase;
+            voffc[q] = (unsigned)rc * (unsigned)d * 2u + (((lane & 3) ^ ((rr >> 2) & 3)) << 4);
+        }
+        const char *gx = reinterpret_cast<const char *>(x + (size_t)row0 * d);
+        const char *gc = reinterpret_cast<const char *>(cb + (size_t)kbase * d);
+        int wx = 0, wc = 0;
+        auto issue_x = [&]() {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (NT) dma16_asm_nt(gx, voffx[q], xring + wx * FD_SLOT + q * 1024);
+                else dma16_asm(gx, voffx[q], xring + wx * FD_SLOT + q * 1024);
+            }
+            gx += FD_BK * 4;
+            wx = wx + 1 == FD_DX ? 0 : wx + 1;
+        };
+        auto issue_c = [&]() {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dma16_asm(gc, voffc[q], cring + wc * FD_SLOT + q * 1024);
+            gc += FD_BK * 2;
+            wc = wc + 1 == FD_DC ? 0 : wc + 1;
+        };
+
+        f32x16 acc[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave is done with the previous centre group's epilogue scratch
+        issue_x();
+        issue_c();
+        if (nchunks > 1) issue_x();
+        int rx = 0, rcs = 0;
+        const int swz = (l31 >> 1) & 7, swa = (l31 >> 2) & 3;
+        for (int c = 0; c < nchunks; ++c) {
+            if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const float *pxl = sXr + rx * (128 * 32) + wq * 1024 + l31 * 32;  // this lane's row of the wave's own tile
+            const __bf16 *pcl = sCb + rcs * (256 * 32) + l31 * 32;            // row l31 of centre tile 0 (+ 1024 per tile)
+            rx = rx + 1 == FD_DX ? 0 : rx + 1;
+            rcs = rcs + 1 == FD_DC ? 0 : rcs + 1;
+#define RW_LDB(ks, F0, F1)                                                                         \
+    const float4 F0 = *reinterpret_cast<const float4 *>(pxl + (((4 * (ks) + 2 * h) ^ swz) << 2));  \
+    const float4 F1 = *reinterpret_cast<const float4 *>(pxl + (((4 * (ks) + 2 * h + 1) ^ swz) << 2));
+#define RW_LDA(ks, ct) (*reinterpret_cast<const bf16x8 *>(pcl + (ct) * 1024 + (((2 * (ks) + h) ^ swa) << 3)))
+            RW_LDB(0, p0, p1)
+            bf16x8 a0[8], a1[8];
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) a0[ct] = RW_LDA(0, ct);
+            if (c + 1 < nchunks) issue_c();  // into the slots stage c-1 just vacated
+            if (c + 2 < nchunks) issue_x();
+            RW_LDB(1, q0, q1)
+            const bf16x8 b0 = cvt_bf16x8(p0, p1);
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) {
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ct], b0, acc[ct], 0, 0, 0);
+                a1[ct] = RW_LDA(1, ct);
+            }
+            const bf16x8 b1 = cvt_bf16x8(q0, q1);
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ct], b1, acc[ct], 0, 0, 0);
+            if (cg == 0) {  // uniform: canonical ||x||^2 of the lane's row, classes 16 ks + 8 h + e
+                ssq[0] = __builtin_fmaf(p0.x, p0.x, ssq[0]), ssq[1] = __builtin_fmaf(p0.y, p0.y, ssq[1]);
+                ssq[2] = __builtin_fmaf(p0.z, p0.z, ssq[2]), ssq[3] = __builtin_fmaf(p0.w, p0.w, ssq[3]);
+                ssq[4] = __builtin_fmaf(p1.x, p1.x, ssq[4]), ssq[5] = __builtin_fmaf(p1.y, p1.y, ssq[5]);
+                ssq[6] = __builtin_fmaf(p1.z, p1.z, ssq[6]), ssq[7] = __builtin_fmaf(p1.w, p1.w, ssq[7]);
+                ssq[8] = __builtin_fmaf(q0.x, q0.x, ssq[8]), ssq[9] = __builtin_fmaf(q0.y, q0.y, ssq[9]);
+                ssq[10] = __builtin_fmaf(q0.z, q0.z, ssq[10]), ssq[11] = __builtin_fmaf(q0.w, q0.w, ssq[11]);
+                ssq[12] = __builtin_fmaf(q1.x, q1.x, ssq[12]), ssq[13] = __builtin_fmaf(q1.y, q1.y, ssq[13]);
+                ssq[14] = __builtin_fmaf(q1.z, q1.z, ssq[14]), ssq[15] = __builtin_fmaf(q1.w, q1.w, ssq[15]);
+            }
+#undef RW_LDB
+#undef RW_LDA
+        }
+        // beyond K: a huge FINITE norm -- such a centre never wins and never becomes the runner-up.  (+inf would turn
+        // into a NaN under the position tag, and fmaxf(s1, NaN) = s1 makes the runner-up collapse onto the minimum: every
+        // lane that mixes real and padding centres would send its row to the re-check.)
+        float my_cn = 3.0e38f, my_sc = 1.0f;
+        if (kbase + tid < K) {
+            my_cn = cn[kbase + tid] - cn_shift;
+            my_sc = counts[kbase + tid] < thr ? inv_r : 1.0f;
+        }
+        __syncthreads();  // every wave has read its last fragments: the row ring becomes epilogue scratch
+        sCn[tid] = my_cn;
+        sSc[tid] = my_sc;
+        if (cg == 0) {
+            // canonical tree: (p0+p1)+(p2+p3) per group of 4 classes, then ((g0+g1)+(g2+g3)) + ((g4+g5)+(g6+g7)):
+            // g0,g1 = (ks 0, h 0), g2,g3 = (ks 0, h 1), g4,g5 = (ks 1, h 0), g6,g7 = (ks 1, h 1); fp32 + commutes bitwise
+            float ta = ((ssq[0] + ssq[1]) + (ssq[2] + ssq[3])) + ((ssq[4] + ssq[5]) + (ssq[6] + ssq[7]));
+            float tb = ((ssq[8] + ssq[9]) + (ssq[10] + ssq[11])) + ((ssq[12] + ssq[13]) + (ssq[14] + ssq[15]));
+            const float oa = __shfl_xor(ta, 32), ob = __shfl_xor(tb, 32);
+            ta = h ? oa + ta : ta + oa;  // (h 0) + (h 1) in both halves
+            tb = h ? ob + tb : tb + ob;
+            xn = norm2_from_sumsq(ta + tb);
+        }
+        __syncthreads();
+        // compare-free top-2 scan of this lane's 8 x 16 distances: the 7 low mantissa bits carry the position
+        float s1 = INFINITY, s2 = INFINITY;
+        const float xoff = centred ? 0.0f : xn;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int kl = ct * 32 + 4 * h + 8 * g;
+                const float4 cnv = *reinterpret_cast<const float4 *>(sCn + kl);
+                const float4 scv = *reinterpret_cast<const float4 *>(sSc + kl);
+                const float cn4[4] = {cnv.x, cnv.y, cnv.z, cnv.w};
+                const float sc4[4] = {scv.x, scv.y, scv.z, scv.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = __builtin_fmaf(-2.0f, acc[ct][4 * g + j], xoff);  // == (-2 dot) + xn
+                    v = v + cn4[j];
+                    v = v * sc4[j];  // * (1/r) where the exact path divides by r
+                    v = __uint_as_float((__float_as_uint(v) & 0xFFFFFF80u) | (unsigned)(ct * 16 + g * 4 + j));
+                    s2 = fminf(s2, fmaxf(s1, v));
+                    s1 = fminf(s1, v);
+                }
+            }
+        }
+        const unsigned c7 = __float_as_uint(s1) & 127u;  // (ct, g, j) of the lane's minimum
+        Top2 t = {s1, kbase + 4 * h + (int)((c7 >> 4) * 32 + ((c7 >> 2) & 3) * 8 + (c7 & 3)), s2}, o;
+        o.d1 = __shfl_xor(t.d1, 32);
+        o.k1 = __shfl_xor(t.k1, 32);
+        o.d2 = __shfl_xor(t.d2, 32);
+        run = top2_merge(run, top2_merge(t, o));
+    }
+    const int64_t row = row0 + wq * 32 + l31;
+    if (h == 0 && row < n) {
+        const float xnorm = __builtin_sqrtf(xn);
+        const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
+        const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
+        const float s = xnorm + cmax;
+        const float E = (e1c * cmaxc + e1r * cmax) * xnorm + e2coef * s * s;
+        labels[row] = (int64_t)run.k1;
+        // the position tag perturbs a distance by < 2^-16 of ITS OWN magnitude (and fl(1/r) by 2 ulp more): charged to the
+        // two distances that are compared instead of to (||x|| + cmax)^2 -- with a large common component the distances
+        // are orders of magnitude smaller than the norms
+        const float tagged = 1.6e-5f * (fabsf(run.d1) + fabsf(run.d2));  // > (2^-16 + 2^-22) x 1.01
+        if (!((run.d2 - run.d1) > 2.0f * E + tagged)) {  // also catches NaN / inf
+            const unsigned slot = atomicAdd(recheck_count, 1u);
+            recheck_list[slot] = (int)row;
         }
     }
 }
@@ -1681,6 +1894,9 @@ ACAV_EXPORT int acav_kmeans_set_state(acav_kmeans *km, const float *centers, con
     ACAV_HIP_TRY(hipMemcpyAsync(km->scalars.p, &s, sizeof(s), hipMemcpyHostToDevice, st));
     ACAV_HIP_TRY(hipStreamSynchronize(st));  // host staging buffers may go away
     km->count = count;
+    // the filter's centre copy depends on all three: centred or not is decided by whether any usage count is below the
+    // threshold (count / K)^p -- a stale "centred" copy under a discount would drop a row constant that no longer cancels
+    km->cb16_valid = false;
     return ACAV_OK;
 }
 
@@ -1735,10 +1951,12 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         const double acc = 1.01 * (double)km->d * ldexp(1.0, -24);  // accumulation error of one fp32 dot, relative
         const float e1c = (float)(2.02 * (ldexp(1.0, -8) * 1.002 + acc) * 1.001);   // x ||c'|| ||x||: bf16 roundings + filter dot
         const float e1r = (float)(2.02 * (acc + ldexp(1.0, -24)) * 1.001);           // x ||c|| ||x||: canonical dot, c - mu
-        const float e2 = (float)ldexp(1.0, -17);
-        // rows are read exactly once: non-temporal DMA policy (ACAV_FILTER_NT=0 restores the default policy)
-        const char *vnt = getenv("ACAV_FILTER_NT");
-        auto kern = (vnt && vnt[0] == '0') ? k_assign_bf16<false> : k_assign_bf16<true>;
+        // rows are read exactly once: non-temporal DMA policy (ACAV_FILTER_NT=0 restores the default policy);
+        // ACAV_FILTER_V1=1 selects the round-1 wave layout (wave = centre quarter) for A/B measurements
+        const char *vnt = getenv("ACAV_FILTER_NT"), *v1 = getenv("ACAV_FILTER_V1");
+        const bool nt = !(vnt && vnt[0] == '0'), rw = !(v1 && v1[0] == '1');
+        const float e2 = (float)ldexp(1.0, rw ? -20 : -17);  // row waves: epilogue roundings only, the tag is charged separately
+        auto kern = rw ? (nt ? k_assign_bf16_rw<true> : k_assign_bf16_rw<false>) : (nt ? k_assign_bf16<true> : k_assign_bf16<false>);
         ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, FD_SMEM));
         if (!km->ev_f0) {

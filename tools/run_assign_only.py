@@ -28,5 +28,11 @@ for _ in range(reps):
     lab, _ = km.calc_best(x, need_mean=(mode == "exact"))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+if mode != "exact":
+    import ctypes as C
+    from acav100m_amd import _lib
+    fm = C.c_float(0)
+    _lib.check(_lib._lib.acav_kmeans_filter_time(km._h, C.byref(fm)))
+    print("filter kernel alone: %.4f ms -> %.1f GB/s = %.3f of 8 TB/s" % (fm.value, (n * d * 4 + n * 8) / fm.value / 1e6, (n * d * 4 + n * 8) / fm.value / 1e6 / 8000))
 print(mode, "assign", n, "rows:", dt * 1e3, "ms ->", 2.0 * n * k * d / dt / 1e12, "TFLOP/s,", (n * d * 4 + n * 8) / dt / 1e9, "GB/s",
       km.filter_stats() if mode != "exact" else "")
