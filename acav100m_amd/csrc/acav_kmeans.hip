@@ -781,6 +781,12 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict_
 //     to the two distances the acceptance test compares (|d1| + |d2|) instead of to (||x|| + cmax)^2; what is left in the
 //     e2 term are the 3 + 3 fp32 roundings of the two epilogues (< 6 x 2^-24 (||x|| + cmax)^2): e2 = 2^-20 here
 // Rings, swizzles, DMA shares, counted waits and the one raw barrier per stage are those of k_assign_bf16.
+// Ablations of this kernel on one MI355X (1M x 1024, K = 256; wrong labels, timing only): full 0.93 ms; without the
+// centre DMA 0.71 ms; DMA only (no fragment reads, no MFMA) 0.78 ms -- the bf16 centre stage (16 KB from L2 per 16 KB of
+// rows from HBM) is the largest single cost.  A persistent 256-row workgroup (eight row waves sharing one centre stage,
+// DMA cursors running across tile boundaries, one workgroup per CU) halves that traffic and was SLOWER (0.94 vs 0.90 ms):
+// eight waves in lockstep on one barrier lose more than the centre traffic costs; two independent 128-row workgroups
+// per CU interleave their phases.  (round 2, measured and rejected)
 template <bool NT>
 __global__ __launch_bounds__(256, 2) void k_assign_bf16_rw(const float *__restrict__ x, int64_t n, int d,
                                                             const __bf16 *__restrict__ cb, const float *__restrict__ cn,
