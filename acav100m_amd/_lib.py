@@ -36,6 +36,7 @@ SIGNATURES = {
     "acav_kmeans_assign": [vp, vp, i64, vp, C.POINTER(f32)],
     "acav_kmeans_step": [vp, vp, i64, f64, vp, C.POINTER(f32)],
     "acav_kmeans_train": [vp, vp, i64, i64, f64, vp, i64],
+    "acav_kmeans_train_multi": [vp, i32, vp, vp, i64, f64, vp, vp],
     "acav_kmeans_apply_update": [vp, vp, i64, vp, f64],
     "acav_kmeans_sync": [vp],
     "acav_kmeans_timer_begin": [vp],

@@ -184,9 +184,8 @@ def train_clusters(args, table, resident):
         if w > 1:  # the clusterings are dealt out over the GPUs; state identical to the one-GPU run on every rank
             from ..parallel import train_epoch_view_parallel
             train_epoch_view_parallel(cl, resident, b, lr, warm)
-        else:
-            for v, km in cl.items():
-                km.train_epoch(resident[v], b, lr=lr, warm_best=warm[v])
+        else:  # all clusterings of the batch stream side by side on the GPU (independent SGD chains)
+            KMeans.train_epoch_multi(list(cl.values()), [resident[v] for v in cl], b, lr=lr, warm_bests=[warm[v] for v in cl])
         if rank == 0:
             save_clusterings(args, epoch, cl)
     return cl

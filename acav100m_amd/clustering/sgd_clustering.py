@@ -333,6 +333,43 @@ class KMeans:
         _lib.check(_lib._lib.acav_kmeans_train(h, xp, n, int(batch_size), float(lr),
                                                _lib.ptr(warm) if need else None, need))
 
+    @staticmethod
+    def train_epoch_multi(clusterings, xs, batch_size, lr=None, warm_bests=None):
+        """train_epoch for several clusterings of one device at once (acav_kmeans_train_multi): the reference steps
+        every clustering per batch (run_clustering.py:229-241); their SGD chains are independent, so the persistent
+        kernels run side by side -- same results as one train_epoch per clustering.  warm_bests[i] as in train_epoch
+        (None: drawn here, clustering by clustering -- pass them when the clusterings share a generator and the
+        reference's batch-by-batch interleaving of the draws matters)."""
+        kms = list(clusterings)
+        if not kms:
+            return
+        keep, ptrs, ns, warms, needs = [], [], [], [], []
+        for i, (km, x) in enumerate(zip(kms, xs)):
+            km._require_handle()
+            k, xp, n, _ = _as_f32_2d(x, km._shape[1])
+            need = km.warmup_steps(batch_size, n // batch_size)
+            if warm_bests is None or warm_bests[i] is None:
+                w = np.empty((need, batch_size), np.int64)
+                for t in range(need):
+                    w[t] = km.draw_warmup(batch_size)
+            else:
+                w = np.ascontiguousarray(warm_bests[i], np.int64)
+                assert w.shape == (need, batch_size), (w.shape, need, batch_size)
+            keep.append((k, w))
+            ptrs.append(xp.value)
+            ns.append(n)
+            warms.append(w.ctypes.data if need else None)
+            needs.append(need)
+        cnt = len(kms)
+        h_arr = (C.c_void_p * cnt)(*[km._h.value for km in kms])
+        x_arr = (C.c_void_p * cnt)(*ptrs)
+        w_arr = (C.c_void_p * cnt)(*warms)
+        n_arr = np.asarray(ns, np.int64)
+        nw_arr = np.asarray(needs, np.int64)
+        lr = kms[0].lr if lr is None else lr
+        _lib.check(_lib._lib.acav_kmeans_train_multi(h_arr, cnt, x_arr, _lib.ptr(n_arr), int(batch_size), float(lr), w_arr,
+                                                     _lib.ptr(nw_arr)))
+
     def train_epoch_distributed(self, x_local, batch_size, lr=None, chunk_steps=1024):
         """One epoch of the reference's multi-GPU add() loop (global batch = world * batch_size rows, rank-major)
         without a collective per step: see acav100m_amd/parallel/kmeans_dp.py:train_epoch_dp."""

@@ -2113,9 +2113,25 @@ ACAV_EXPORT int acav_kmeans_apply_update(acav_kmeans *km, const float *x, int64_
     return acav_kmeans_step(km, x, b, lr, best, nullptr);
 }
 
-ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, int64_t b, double lr,
-                                  const int64_t *warm_best, int64_t n_warm)
+// One training call in two halves, so that several clusterings can have their persistent kernels in flight together
+// (acav_kmeans_train_multi): train_launch() stages the inputs and, when the call is eligible, enqueues the persistent
+// kernel WITHOUT waiting; train_finish() waits, checks the kernel's error flag and -- if the launch gave up or was not
+// eligible -- runs the per-step launch path.  `budget` = workgroups that may still become co-resident on the device.
+struct TrainCall {
+    int64_t n = 0, b = 0, steps = 0, need = 0;
+    double lr = 0.0;
+    const float *fx = nullptr;
+    const int64_t *dw = nullptr;
+    const void *x_user = nullptr, *w_user = nullptr;
+    int nwg = 0;
+    bool launched = false, prof = false, active = false;
+    std::vector<float> thr;  // staging of the per-step thresholds: alive until the launch has been waited for
+};
+
+static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t n, int64_t b, double lr,
+                        const int64_t *warm_best, int64_t n_warm, int *budget)
 {
+    tc = TrainCall();
     ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");
     ACAV_REQUIRE(n >= 0 && b > 0 && n_warm >= 0, ACAV_EINVAL, "bad sizes");
     ACAV_REQUIRE(b <= SU_MAXB, ACAV_EINVAL, "batch size %lld above the supported %d", (long long)b, SU_MAXB);
@@ -2138,6 +2154,9 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
     ACAV_TRY(to_device(x, sizeof(float) * (size_t)n * km->d, km->stage_x, st, &dx));
     if (need) ACAV_TRY(to_device(warm_best, sizeof(int64_t) * (size_t)need * b, km->stage_forced, st, &dw));
     const float *fx = static_cast<const float *>(dx);
+    tc.active = true;
+    tc.n = n, tc.b = b, tc.steps = steps, tc.need = need, tc.lr = lr, tc.fx = fx, tc.dw = static_cast<const int64_t *>(dw);
+    tc.x_user = x, tc.w_user = warm_best;
     // ||x||^2 of every row once per call (it does not depend on the centres)
     if (steps > need) {
         const int64_t rows = steps * b;
@@ -2148,14 +2167,17 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
     }
     // persistent path: the whole call in one launch, centres resident in LDS (k_train_persistent)
     const int nwg = ((km->K + TP_NC - 1) / TP_NC) * (int)((b + TP_NR - 1) / TP_NR);
+    tc.nwg = nwg;
     const char *nop = getenv("ACAV_NO_PERSISTENT");
     const bool prof = getenv("ACAV_PROFILE_STEPS") != nullptr;
+    tc.prof = prof;
     const bool ragged = (km->d & 255) != 0;
     auto tkern = ragged ? (prof ? k_train_persistent<true, true> : k_train_persistent<true, false>)
                         : (prof ? k_train_persistent<false, true> : k_train_persistent<false, false>);
     // every workgroup of the launch must be resident at once: the occupancy query gives the workgroups one CU can
-    // hold (1: 97 KB of LDS each), times the CUs of the device.  Other streams may still hold CUs: the kernel's spins
-    // are bounded and a launch that gave up is re-run below on the per-step path from the saved state.
+    // hold (1: 97 KB of LDS each), times the CUs of the device, minus what other launches of this call already hold.
+    // Other streams may still hold CUs: the kernel's spins are bounded and a launch that gave up is re-run by
+    // train_finish() on the per-step path from the saved state.
     if (km->num_cus == 0) {
         hipDeviceProp_t prop;
         ACAV_HIP_TRY(hipGetDeviceProperties(&prop, km->ctx.device));
@@ -2163,45 +2185,53 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
     }
     int occ = 0;
     ACAV_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(tkern), 256, 0));
+    const int room = budget ? *budget : occ * km->num_cus;
     const bool persistent = steps > 0 && !(nop && nop[0] == '1') && (km->d % 4) == 0 && km->d <= TP_DS &&
-                            b <= TP_MAXB && nwg <= occ * km->num_cus && ((uintptr_t)fx & 15) == 0;
-    if (persistent) {
-        std::vector<float> thr((size_t)steps);
-        for (int64_t t = 0; t < steps; ++t)
-            thr[(size_t)t] = (float)pow((double)(km->count + t * b) / (double)km->K, km->reinit_p);
-        ACAV_TRY(km->thr.ensure(sizeof(float) * (size_t)steps));
-        ACAV_HIP_TRY(hipMemcpyAsync(km->thr.p, thr.data(), sizeof(float) * (size_t)steps, hipMemcpyHostToDevice, st));
-        ACAV_TRY(km->ctl.ensure(sizeof(TrainCtl)));
-        ACAV_HIP_TRY(hipMemsetAsync(km->ctl.p, 0, sizeof(TrainCtl), st));  // err = 0, every granule tag = 0 (never a live tag)
-        // the state as it is now, in case the launch gives up (1 MB at K=256, d=1024: a few microseconds)
-        const size_t cbytes = sizeof(float) * (size_t)km->K * km->d, kbytes = sizeof(float) * (size_t)km->K;
-        ACAV_TRY(km->backup.ensure(cbytes + 2 * kbytes + sizeof(StepScalars)));
-        char *bk = km->backup.as<char>();
-        ACAV_HIP_TRY(hipMemcpyAsync(bk, km->centers.p, cbytes, hipMemcpyDeviceToDevice, st));
-        ACAV_HIP_TRY(hipMemcpyAsync(bk + cbytes, km->cn.p, kbytes, hipMemcpyDeviceToDevice, st));
-        ACAV_HIP_TRY(hipMemcpyAsync(bk + cbytes + kbytes, km->counts.p, kbytes, hipMemcpyDeviceToDevice, st));
-        ACAV_HIP_TRY(hipMemcpyAsync(bk + cbytes + 2 * kbytes, km->scalars.p, sizeof(StepScalars), hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(tkern, dim3((km->K + TP_NC - 1) / TP_NC, (unsigned)((b + TP_NR - 1) / TP_NR)),
-                           dim3(256), 0, st, fx, km->xn.as<float>(), (int)b, km->d, km->K, km->centers.as<float>(),
-                           km->cn.as<float>(), km->counts.as<float>(), km->thr.as<float>(), lr, (float)km->reinit_r,
-                           static_cast<const int64_t *>(dw), (int)need, (int)steps, km->ctl.as<TrainCtl>(),
-                           km->scalars.as<StepScalars>(), nwg);
-        ACAV_HIP_TRY(hipGetLastError());
+                            b <= TP_MAXB && nwg <= room && nwg <= occ * km->num_cus && ((uintptr_t)fx & 15) == 0;
+    if (!persistent) return ACAV_OK;
+    if (budget) *budget -= nwg;
+    tc.thr.resize((size_t)steps);
+    for (int64_t t = 0; t < steps; ++t)
+        tc.thr[(size_t)t] = (float)pow((double)(km->count + t * b) / (double)km->K, km->reinit_p);
+    ACAV_TRY(km->thr.ensure(sizeof(float) * (size_t)steps));
+    ACAV_HIP_TRY(hipMemcpyAsync(km->thr.p, tc.thr.data(), sizeof(float) * (size_t)steps, hipMemcpyHostToDevice, st));
+    ACAV_TRY(km->ctl.ensure(sizeof(TrainCtl)));
+    ACAV_HIP_TRY(hipMemsetAsync(km->ctl.p, 0, sizeof(TrainCtl), st));  // err = 0, every granule tag = 0 (never a live tag)
+    // the state as it is now, in case the launch gives up (1 MB at K=256, d=1024: a few microseconds)
+    const size_t cbytes = sizeof(float) * (size_t)km->K * km->d, kbytes = sizeof(float) * (size_t)km->K;
+    ACAV_TRY(km->backup.ensure(cbytes + 2 * kbytes + sizeof(StepScalars)));
+    char *bk = km->backup.as<char>();
+    ACAV_HIP_TRY(hipMemcpyAsync(bk, km->centers.p, cbytes, hipMemcpyDeviceToDevice, st));
+    ACAV_HIP_TRY(hipMemcpyAsync(bk + cbytes, km->cn.p, kbytes, hipMemcpyDeviceToDevice, st));
+    ACAV_HIP_TRY(hipMemcpyAsync(bk + cbytes + kbytes, km->counts.p, kbytes, hipMemcpyDeviceToDevice, st));
+    ACAV_HIP_TRY(hipMemcpyAsync(bk + cbytes + 2 * kbytes, km->scalars.p, sizeof(StepScalars), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(tkern, dim3((km->K + TP_NC - 1) / TP_NC, (unsigned)((b + TP_NR - 1) / TP_NR)),
+                       dim3(256), 0, st, fx, km->xn.as<float>(), (int)b, km->d, km->K, km->centers.as<float>(),
+                       km->cn.as<float>(), km->counts.as<float>(), km->thr.as<float>(), lr, (float)km->reinit_r,
+                       tc.dw, (int)need, (int)steps, km->ctl.as<TrainCtl>(), km->scalars.as<StepScalars>(), nwg);
+    ACAV_HIP_TRY(hipGetLastError());
+    tc.launched = true;
+    return ACAV_OK;
+}
+
+static int train_finish(acav_kmeans *km, TrainCall &tc)
+{
+    if (!tc.active) return ACAV_OK;
+    ACAV_HIP_TRY(hipSetDevice(km->ctx.device));
+    hipStream_t st = km->ctx.stream;
+    const int64_t steps = tc.steps, need = tc.need, b = tc.b;
+    if (tc.launched) {
+        const bool prof = tc.prof;
+        const int nwg = tc.nwg;
         struct { unsigned err, pad[3]; unsigned long long prof[8]; unsigned long long prof_wg[256][8]; } head{};
         ACAV_HIP_TRY(hipMemcpyAsync(&head, km->ctl.p, prof ? sizeof(head) : 16, hipMemcpyDeviceToHost, st));
-        ACAV_HIP_TRY(hipStreamSynchronize(st));  // also covers the thr staging vector going out of scope
+        ACAV_HIP_TRY(hipStreamSynchronize(st));  // also covers the thr staging vector
         if (prof) {
             const double den = (double)(steps > need ? steps - need : 1);
             fprintf(stderr, "[acav] persistent epoch: %lld steps; cycles/step: wait+dma-issue %.0f, fma %.0f, exchange %.0f, "
                             "update %.0f (hist %.0f, rows+apply %.0f), total %.0f\n", (long long)steps, head.prof[0] / den,
                     head.prof[1] / den, head.prof[2] / den, head.prof[3] / den, head.prof[5] / den, head.prof[6] / den,
                     head.prof[4] / den);
-            for (int w = 0; w < nwg && w < 256; w += 1) {
-                if (w % 16 == 0 || w == nwg - 1)
-                    fprintf(stderr, "[acav]   wg %3d: wait %.0f fma %.0f exch %.0f upd %.0f (rows %.0f)\n", w,
-                            head.prof_wg[w][0] / den, head.prof_wg[w][1] / den, head.prof_wg[w][2] / den,
-                            head.prof_wg[w][3] / den, head.prof_wg[w][6] / den);
-            }
             double mx[4] = {0, 0, 0, 0}, mn[4] = {1e30, 1e30, 1e30, 1e30};
             for (int w = 0; w < nwg && w < 256; ++w)
                 for (int q = 0; q < 4; ++q) {
@@ -2217,20 +2247,76 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
             km->cb16_valid = false;
             km->n_step_launches += steps;
             km->n_persistent_launches += 1;
+            tc.active = false;
             return ACAV_OK;
         }
         // the launch gave up at an exchange (not all workgroups resident: the GPU is shared): restore the state it
         // started from and take the per-step launch path for this call
         km->n_persistent_fallbacks += 1;
+        const size_t cbytes = sizeof(float) * (size_t)km->K * km->d, kbytes = sizeof(float) * (size_t)km->K;
+        char *bk = km->backup.as<char>();
         ACAV_HIP_TRY(hipMemcpyAsync(km->centers.p, bk, cbytes, hipMemcpyDeviceToDevice, st));
         ACAV_HIP_TRY(hipMemcpyAsync(km->cn.p, bk + cbytes, kbytes, hipMemcpyDeviceToDevice, st));
         ACAV_HIP_TRY(hipMemcpyAsync(km->counts.p, bk + cbytes + kbytes, kbytes, hipMemcpyDeviceToDevice, st));
         ACAV_HIP_TRY(hipMemcpyAsync(km->scalars.p, bk + cbytes + 2 * kbytes, sizeof(StepScalars), hipMemcpyDeviceToDevice, st));
     }
     for (int64_t t = 0; t < steps; ++t) {
-        const int64_t *f = t < need ? static_cast<const int64_t *>(dw) + t * b : nullptr;
-        ACAV_TRY(step_device(km, fx + (size_t)t * b * km->d, b, lr, f, km->xn.as<float>() + t * b));
+        const int64_t *f = t < need ? tc.dw + t * b : nullptr;
+        ACAV_TRY(step_device(km, tc.fx + (size_t)t * b * km->d, b, tc.lr, f, km->xn.as<float>() + t * b));
     }
-    if (dx != x || (need && dw != warm_best)) ACAV_HIP_TRY(hipStreamSynchronize(st));
+    if ((const void *)tc.fx != tc.x_user || (need && (const void *)tc.dw != tc.w_user)) ACAV_HIP_TRY(hipStreamSynchronize(st));
+    tc.active = false;
+    return ACAV_OK;
+}
+
+ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, int64_t b, double lr,
+                                  const int64_t *warm_best, int64_t n_warm)
+{
+    TrainCall tc;
+    ACAV_TRY(train_launch(km, tc, x, n, b, lr, warm_best, n_warm, nullptr));
+    return train_finish(km, tc);
+}
+
+// The same call for SEVERAL clusterings at once (independent handles on one device, e.g. the audio and visual views of
+// one batch stream, or the 5 + 5 layers of the real pipeline -- run_clustering.py:229-241 steps every clustering per
+// batch): their persistent kernels are enqueued on their own streams before any is waited for, as many at a time as
+// fit on the device together (a step is latency-bound -- 128 of 256 CUs at K = 256 -- so two chains side by side run at
+// the speed of one).  Results are exactly those of acav_kmeans_train called per handle.
+ACAV_EXPORT int acav_kmeans_train_multi(acav_kmeans *const *kms, int count, const float *const *xs, const int64_t *ns, int64_t b,
+                                        double lr, const int64_t *const *warm_best, const int64_t *n_warm)
+{
+    ACAV_REQUIRE(kms && xs && ns && n_warm && count >= 0, ACAV_EINVAL, "NULL argument");
+    if (count == 0) return ACAV_OK;
+    for (int i = 0; i < count; ++i) {
+        ACAV_REQUIRE(kms[i], ACAV_EINVAL, "handle %d is NULL", i);
+        ACAV_REQUIRE(kms[i]->ctx.device == kms[0]->ctx.device, ACAV_EINVAL, "handle %d lives on another device", i);
+        for (int e = 0; e < i; ++e) ACAV_REQUIRE(kms[e] != kms[i], ACAV_EINVAL, "handle %d given twice", i);
+    }
+    std::vector<TrainCall> calls((size_t)count);
+    hipDeviceProp_t prop;
+    ACAV_HIP_TRY(hipGetDeviceProperties(&prop, kms[0]->ctx.device));
+    int first = 0;
+    while (first < count) {  // groups of launches that fit on the device together
+        int budget = prop.multiProcessorCount, last = first;
+        for (; last < count; ++last) {
+            const int before = budget;
+            ACAV_TRY(train_launch(kms[last], calls[(size_t)last], xs[last], ns[last], b, lr,
+                                  warm_best ? warm_best[last] : nullptr, n_warm[last], &budget));
+            if (calls[(size_t)last].active && !calls[(size_t)last].launched && last > first && before < prop.multiProcessorCount) {
+                // did not fit beside the ones already in flight: finish those first, then it gets the whole device
+                break;
+            }
+        }
+        const bool retry = last < count && calls[(size_t)last].active && !calls[(size_t)last].launched;
+        for (int i = first; i < last; ++i) ACAV_TRY(train_finish(kms[i], calls[(size_t)i]));
+        if (retry) {
+            int whole = prop.multiProcessorCount;
+            ACAV_TRY(train_launch(kms[last], calls[(size_t)last], xs[last], ns[last], b, lr,
+                                  warm_best ? warm_best[last] : nullptr, n_warm[last], &whole));
+            ACAV_TRY(train_finish(kms[last], calls[(size_t)last]));
+            ++last;
+        }
+        first = last;
+    }
     return ACAV_OK;
 }

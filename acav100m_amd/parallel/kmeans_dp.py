@@ -145,8 +145,12 @@ def train_epoch_view_parallel(engines, rows, b, lr, warm):
     every rank from the same stream, so the generators stay in step)."""
     rank, w = world()
     views = list(engines)
-    for i, v in enumerate(views):
-        if i % w == rank:
+    mine = [v for i, v in enumerate(views) if i % w == rank]
+    multi = getattr(type(engines[mine[0]]), "train_epoch_multi", None) if mine else None
+    if multi is not None:  # this rank's share side by side on its GPU
+        multi([engines[v] for v in mine], [rows[v] for v in mine], b, lr=lr, warm_bests=[warm[v] for v in mine])
+    else:
+        for v in mine:
             engines[v].train_epoch(rows[v], b, lr=lr, warm_best=warm[v])
     for i, v in enumerate(views):
         if i % w == rank:

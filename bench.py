@@ -200,10 +200,10 @@ def main():
         t0 = time.perf_counter()
         for epoch in range(EPOCHS):
             lr = 0.1 ** (2 + epoch // 5)
-            for km, x in zip(kms, xs):
-                if world == 1:
-                    km.train_epoch(x, b, lr=lr)
-                else:  # reference DDP semantics: global batch = world * b rows per step; rows all-gathered in bulk
+            if world == 1:  # the two views' SGD chains are independent: side by side on the GPU (run_clustering does the same)
+                KMeans.train_epoch_multi(kms, xs, b, lr=lr)
+            else:  # reference DDP semantics: global batch = world * b rows per step; rows all-gathered in bulk
+                for km, x in zip(kms, xs):
                     km.train_epoch_distributed(x, b, lr=lr)
         for km in kms:
             km.synchronize()

@@ -340,3 +340,35 @@ def test_edge_cases_empty_single_and_limits(env):
         km.calc_best(torch.zeros((4, d + 1), device="cuda"))  # wrong feature width
     with pytest.raises((ValueError, acav.AcavError)):
         KMeans(None, d, 0).to("cuda:0")            # the handle is created on the move to the device
+
+
+def test_train_epoch_multi_equals_one_by_one(env):
+    """acav_kmeans_train_multi: several clusterings' persistent kernels in flight together (two 1024-d views at K=256 =
+    2 x 128 workgroups = every CU; plus a third that no longer fits and waits its turn, and one that is not eligible for
+    the persistent kernel at all).  State of every clustering == its own train_epoch == the oracle."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    shapes = [(1024, 256), (1024, 256), (512, 64), (2048, 40)]  # d=2048: per-step path
+    n, b = 4096 + 2560, 32
+    xs = [_mixture(40 + i, n, d, K) for i, (d, K) in enumerate(shapes)]
+    xts = [torch.from_numpy(x).cuda() for x in xs]
+    acav.manual_seed(23)
+    kms = [KMeans(None, d, K).to("cuda:0") for d, K in shapes]
+    refs = [O.KMeans(d, K, O.Rng(0), centers=km._centers0.copy()) for (d, K), km in zip(shapes, kms)]
+    lab_rs = np.random.RandomState(9)
+    for epoch in range(2):
+        warm = []
+        for km, (d, K) in zip(kms, shapes):
+            need = km.warmup_steps(b, n // b)
+            warm.append(lab_rs.randint(0, K, (need, b)).astype(np.int64))
+        KMeans.train_epoch_multi(kms, xts, b, lr=0.01, warm_bests=warm)
+        for km, ref, x, w in zip(kms, refs, xs, warm):
+            for t in range(n // b):
+                xb = x[t * b:(t + 1) * b]
+                if t < len(w):
+                    ref.apply_update(xb, w[t], 0.01)  # counts the batch as add() does
+                else:
+                    ref.lr = 0.01
+                    ref.add(xb)
+            assert np.array_equal(km.centers.numpy(), ref.centers), f"epoch {epoch}"
+            assert np.array_equal(km.counts.numpy(), ref.counts) and km.count == ref.count
