@@ -57,7 +57,20 @@ def main(argv=None):
             return None
     else:
         launch.init_process_group(kwargs.get('computation.dist_backend', 'nccl'))
+    _seed_from_env()
     return getattr(Cli(), command)(**kwargs)
+
+
+def _seed_from_env():
+    """ACAV_SEED=<int>: seed the torch-stream generator and Python's `random` in this process (the reference's CLIs
+    never seed -- `computation.random_seed` is unused there; every process of a spawned run gets the same seed)."""
+    import os
+    seed = os.environ.get('ACAV_SEED')
+    if seed is not None:
+        import random
+        from ..rng import manual_seed
+        manual_seed(int(seed))
+        random.seed(int(seed))
 
 
 if __name__ == '__main__':

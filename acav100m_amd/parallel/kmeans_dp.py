@@ -102,6 +102,15 @@ def average_state(centers, counts):
     if w == 1:
         return centers, counts
     buf = torch.cat([centers.reshape(-1), counts.reshape(-1)])
+    # Ranks that drew the same initial state (same seed: the normal case here) must keep it bit for bit -- (c + c + c) / 3
+    # is not c in fp32, and an N-GPU run is meant to produce the files of the one-GPU run.  Only ranks that really
+    # differ are averaged, as the reference does.
+    digest = buf.view(torch.int32).to(torch.int64).sum().reshape(1)
+    lo, hi = digest.clone(), digest.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if int(lo.item()) == int(hi.item()):
+        return centers, counts
     dist.all_reduce(buf)
     buf = buf * (1.0 / w)
     n = centers.numel()

@@ -1,6 +1,7 @@
 """`python cli.py run|reduce_csvs --shards_path=<brace glob .pkl> --meta_path=<dir> --out_path=<file|dir>`
 -- the entry points of subset_selection/code/cli.py:17-100 + args.py:11-34 on the MI355X hot path."""
 import datetime
+import os
 import sys
 import time
 from pathlib import Path
@@ -77,15 +78,30 @@ def main(argv=None):
         if command == 'run' and kwargs.get('chunk_size') is not None:
             import torch
             want = kwargs.get('computation.num_gpus')
-            want = torch.cuda.device_count() if want is None else min(int(want), torch.cuda.device_count())
+            have = torch.cuda.device_count()
+            if os.environ.get('ACAV_OVERSUBSCRIBE') == '1':  # tests: several processes share a GPU
+                have = max(have, int(want or have))
+            want = have if want is None else min(int(want), have)
             if want > 1:
                 launch.spawn_per_gpu('acav100m_amd.subset_selection.cli', argv, want, {'ACAV_NO_GROUP': '1'})
                 return None
     else:
-        import os
         os.environ.setdefault('ACAV_NO_GROUP', '1')
         launch.bind_device()
+    _seed_from_env()
     return getattr(Cli(), command)(**kwargs)
+
+
+def _seed_from_env():
+    """ACAV_SEED=<int>: seed the torch-stream generator and Python's `random` in this process (the reference's CLIs
+    never seed -- `computation.random_seed` is unused there; every process of a spawned run gets the same seed)."""
+    import os
+    seed = os.environ.get('ACAV_SEED')
+    if seed is not None:
+        import random
+        from ..rng import manual_seed
+        manual_seed(int(seed))
+        random.seed(int(seed))
 
 
 if __name__ == '__main__':

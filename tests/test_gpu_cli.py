@@ -161,3 +161,74 @@ def test_chunked_run_lockstep_chunks(workdir):
         want += [filenames[s] for s in sorted(res["S"])]
     got = [r[1] for r in csv.reader(_io.StringIO("\n".join(lines)))]
     assert got == want
+
+
+def _run_cli(module, argv, extra_env):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-m", module] + argv, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_cluster_cli_spawns_one_process_per_gpu(workdir):
+    """`cli.py cluster --computation.num_gpus=2` started plainly re-executes itself once per GPU like the reference
+    (script.py:52-65); the processes join a group, deal the 10 clusterings out between them (view-parallel training),
+    broadcast the states and label their own shards.  Two processes on the one GPU of this box (gloo): the files must
+    be those of the one-process run, byte for byte in the labels."""
+    root, glob = workdir
+    common = ["cluster", "--feature_path=" + glob, "--meta_path=" + os.path.join(root, "videos")]
+    out1, out2 = os.path.join(root, "cl_one"), os.path.join(root, "cl_two")
+    _run_cli("acav100m_amd.clustering.cli", common + ["--out_path=" + out1, "--computation.num_gpus=1"], {"ACAV_SEED": "0"})
+    log = _run_cli("acav100m_amd.clustering.cli", common + ["--out_path=" + out2, "--computation.num_gpus=2"],
+                   {"ACAV_SEED": "0", "ACAV_DIST_BACKEND": "gloo"})
+    assert log.count("done") == 2
+    for s in range(4):
+        name = "shard-%06d.pkl" % s
+        a = pickle.load(open(os.path.join(out1, name), "rb"))
+        b = pickle.load(open(os.path.join(out2, name), "rb"))
+        assert len(a) == len(b) == 256
+        for ra, rb in zip(a, b):
+            assert ra["filename"] == rb["filename"]
+            for key in ("audio_assignments", "video_assignments"):
+                assert {k: int(v) for k, v in ra[key][0]["array"].items()} == {k: int(v) for k, v in rb[key][0]["array"].items()}
+    # the checkpoints are the reference's file: torch.save of {model_key: {layer: attrs}}, written by rank 0 only
+    import torch
+    caches = sorted(f for f in os.listdir(out2) if f.startswith("cache_epoch_"))
+    assert len(caches) == 2
+    c1 = torch.load(os.path.join(out1, caches[-1]), weights_only=False)
+    c2 = torch.load(os.path.join(out2, caches[-1]), weights_only=False)
+    assert sorted(c1.keys()) == sorted(c2.keys()) and len(c1) == 2
+    for mk in c1:
+        assert sorted(c1[mk].keys()) == ["layer_%d" % i for i in range(5)]
+        for layer in c1[mk]:
+            assert np.array_equal(c1[mk][layer]["centers"], c2[mk][layer]["centers"])
+            assert c1[mk][layer]["count"] == c2[mk][layer]["count"]
+    logs = [f for f in os.listdir(out2) if f.startswith("log_")]
+    assert len(logs) == 2  # one manifest per process, each listing its own shards (save.py:9-17)
+
+
+def test_subset_cli_chunks_spawn_per_gpu(workdir):
+    """`cli.py run --chunk_size=2 --computation.num_gpus=2`: one process per GPU (chunk.py:28,53), no process group,
+    every process selects from its own block of chunks into caches/cache_{parent pid}_{rank}_{i}_output.csv;
+    reduce_csvs merges them."""
+    root, glob = workdir
+    src = os.path.join(root, "cl_one")
+    if not os.path.isfile(os.path.join(src, "shard-000000.pkl")):
+        pytest.skip("clustering spawn test did not run")
+    out = os.path.join(root, "sel_two", "output.csv")
+    args = ["--shards_path=" + os.path.join(src, "shard-{000000..000003}.pkl"), "--meta_path=" + os.path.join(root, "videos"),
+            "--out_path=" + out, "--chunk_size=2", "--computation.num_gpus=2"]
+    _run_cli("acav100m_amd.subset_selection.cli", ["run"] + args, {"ACAV_SEED": "0", "ACAV_OVERSUBSCRIBE": "1"})
+    caches = sorted(os.listdir(os.path.join(root, "sel_two", "caches")))
+    assert len(caches) == 2 and {c.split("_")[2] for c in caches} == {"0", "1"}, caches  # ranks 0 and 1, same parent pid
+    assert len({c.split("_")[1] for c in caches}) == 1
+    _run_cli("acav100m_amd.subset_selection.cli", ["reduce_csvs"] + args, {})
+    rows = list(csv.reader(open(out)))
+    assert len(rows) == 2 * round(0.2 * 512) and len({tuple(r[:2]) for r in rows}) == len(rows)
+    assert {r[0] for r in rows} == {"shard-%06d" % s for s in range(4)}
