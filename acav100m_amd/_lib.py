@@ -39,6 +39,18 @@ SIGNATURES = {
     "acav_kmeans_train_multi": [vp, i32, vp, vp, i64, f64, vp, vp],
     "acav_kmeans_apply_update": [vp, vp, i64, vp, f64],
     "acav_kmeans_sync": [vp],
+    "acav_kmeans_shape": [vp, C.POINTER(i32), C.POINTER(i32)],
+    "acav_kmeans_stream": [vp, pp],
+    "acav_comm_unique_id": [vp],
+    "acav_comm_init": [pp, i32, i32, i32, vp, vp],
+    "acav_comm_destroy": [vp],
+    "acav_comm_info": [vp, C.POINTER(i32), C.POINTER(i32)],
+    "acav_comm_sync": [vp],
+    "acav_comm_allreduce_f32": [vp, vp, i64],
+    "acav_comm_allgather": [vp, vp, vp, i64],
+    "acav_comm_broadcast": [vp, vp, i64, i32],
+    "acav_kmeans_allreduce_init": [vp, vp],
+    "acav_kmeans_train_dp": [vp, vp, vp, i64, i64, f64, vp, i64, i64],
     "acav_kmeans_timer_begin": [vp],
     "acav_kmeans_timer_end": [vp, C.POINTER(f32)],
     "acav_kmeans_stats": [vp, C.POINTER(i64), C.POINTER(i64)],

@@ -373,8 +373,36 @@ class KMeans:
     def train_epoch_distributed(self, x_local, batch_size, lr=None, chunk_steps=1024):
         """One epoch of the reference's multi-GPU add() loop (global batch = world * batch_size rows, rank-major)
         without a collective per step: see acav100m_amd/parallel/kmeans_dp.py:train_epoch_dp."""
-        from ..parallel import train_epoch_dp
-        train_epoch_dp(self, x_local, int(batch_size), self.lr if lr is None else lr, chunk_steps=chunk_steps)
+        lr = self.lr if lr is None else lr
+        from ..parallel.rccl_comm import default_comm
+        comm = default_comm() if hasattr(x_local, "is_cuda") and x_local.is_cuda else None
+        if comm is None:  # gloo / host tensors (CPU tests): the same schedule through torch.distributed
+            from ..parallel import train_epoch_dp
+            return train_epoch_dp(self, x_local, int(batch_size), lr, chunk_steps=chunk_steps)
+        self.train_epoch_comm(comm, x_local, int(batch_size), lr, chunk_steps)
+
+    def train_epoch_comm(self, comm, x_local, b_local, lr, chunk_steps=1024):
+        """acav_kmeans_train_dp: the DDP epoch with the bulk row exchange through RCCL inside the library -- no torch
+        op between the collective and the SGD chain.  Only the warm-up labels (drawn per rank) are exchanged here, once."""
+        import torch
+        keep, xp, n_local, on_gpu = _as_f32_2d(x_local, self._shape[1])
+        w = comm.world
+        steps = n_local // b_local
+        need = self.warmup_steps(w * b_local, steps)
+        warm = None
+        if need:
+            mine = np.stack([self.draw_warmup(b_local) for _ in range(need)]).astype(np.int64)  # [need, b_local]
+            if w > 1:
+                dev = x_local.device
+                send = torch.from_numpy(mine).to(dev)
+                recv = torch.empty((w, need, b_local), dtype=torch.long, device=dev)
+                comm.allgather(send, recv)
+                comm.synchronize()
+                warm = np.ascontiguousarray(recv.cpu().numpy().transpose(1, 0, 2).reshape(need, w * b_local))
+            else:
+                warm = np.ascontiguousarray(mine)
+        _lib.check(_lib._lib.acav_kmeans_train_dp(self._require_handle(), comm._h, xp, n_local, int(b_local), float(lr),
+                                                  _lib.ptr(warm) if need else None, need, int(chunk_steps)))
 
     # ------------------------------------------------- state exchange (parallel/kmeans_dp.py:broadcast_state)
     def state_arrays(self):

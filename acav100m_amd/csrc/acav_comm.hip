@@ -1,0 +1,283 @@
+// acav_comm.hip -- the collectives of the path through RCCL, behind the C ABI (SURVEY 8(b) minimum export set:
+// comm_init(rank, world, unique_id), allreduce_init(comm)).  Replaces what the reference does through torch.distributed
+// in KMeans.initialize / KMeans.add (clustering/code/sgd_clustering.py:88-92, 97, 115, 126; mps/distributed.py:139-155).
+//
+// What the path really exchanges between GPUs (one process per GPU, xGMI):
+//   initialize()      one all-reduce of [centres | counts]                       (K d + K floats, once)
+//   DDP training      the ROWS of the steps ahead, all-gathered in bulk (acav_kmeans_train_dp): step t's global batch
+//                     is the rank-major concatenation of every rank's rows [t b, (t+1) b); the SGD chain itself runs
+//                     replicated and device-resident on every rank -- no collective on the 4-7 us step path
+//   view-parallel     broadcast of a clustering's state from the rank that trained it (K d + K floats per epoch)
+// RCCL is resolved at run time (dlopen of the librccl the process already has -- torch's -- else the ROCm one): the
+// library loads and every other entry point works on a box without RCCL; only acav_comm_* report ACAV_ESTATE there.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "acav_common.h"
+
+using namespace acav;
+
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char *nm : names) {  // the copy already in the process first (torch bundles its own)
+        r.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+        if (r.lib) break;
+    }
+    for (const char *nm : names) {
+        if (r.lib) break;
+        r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!r.lib) return r;
+#define ACAV_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name))
+    ACAV_SYM(GetUniqueId, "ncclGetUniqueId");
+    ACAV_SYM(CommInitRank, "ncclCommInitRank");
+    ACAV_SYM(CommDestroy, "ncclCommDestroy");
+    ACAV_SYM(AllReduce, "ncclAllReduce");
+    ACAV_SYM(AllGather, "ncclAllGather");
+    ACAV_SYM(Broadcast, "ncclBroadcast");
+    ACAV_SYM(GetErrorString, "ncclGetErrorString");
+#undef ACAV_SYM
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.AllGather && r.Broadcast;
+    return r;
+}
+
+#define ACAV_NCCL_TRY(expr)                                                                                  \
+    do {                                                                                                     \
+        ncclResult_t _r = (expr);                                                                            \
+        if (_r != ncclSuccess) {                                                                             \
+            acav::set_error("%s failed: %s", #expr, rccl().GetErrorString ? rccl().GetErrorString(_r) : "?"); \
+            return ACAV_EHIP;                                                                                \
+        }                                                                                                    \
+    } while (0)
+
+// [rank][step][row][:] -> [step][rank][row][:]: the all-gathered rows of `steps` steps become the global batches
+__global__ __launch_bounds__(256) void k_interleave_rows(const float4 *__restrict__ in, float4 *__restrict__ out, int world,
+                                                         int steps, int bl, int d4)
+{
+    const int64_t total = (int64_t)world * steps * bl * d4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % d4);
+        int64_t r = i / d4;  // output row: (t * world + rank) * bl + row
+        const int row = (int)(r % bl);
+        r /= bl;
+        const int rank = (int)(r % world), t = (int)(r / world);
+        out[i] = in[(((int64_t)rank * steps + t) * bl + row) * d4 + c];
+    }
+}
+
+__global__ void k_scale_f32(float *__restrict__ v, int64_t n, float s)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = v[i] * s;
+}
+
+}  // namespace
+
+struct acav_comm {
+    StreamCtx ctx;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    DevBuf gather[2], batches[2], flat;
+    hipEvent_t ev_gathered[2] = {nullptr, nullptr}, ev_trained[2] = {nullptr, nullptr};
+};
+
+ACAV_EXPORT int acav_comm_unique_id(uint8_t *id128)
+{
+    ACAV_REQUIRE(id128, ACAV_EINVAL, "NULL argument");
+    ACAV_REQUIRE(rccl().ok, ACAV_ESTATE, "RCCL is not available in this process (librccl.so not found)");
+    ncclUniqueId id;
+    ACAV_NCCL_TRY(rccl().GetUniqueId(&id));
+    memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return ACAV_OK;
+}
+
+ACAV_EXPORT int acav_comm_destroy(acav_comm *c)
+{
+    if (!c) return ACAV_OK;
+    (void)hipSetDevice(c->ctx.device);
+    if (c->ctx.stream) (void)hipStreamSynchronize(c->ctx.stream);
+    if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+    for (int q = 0; q < 2; ++q) {
+        if (c->ev_gathered[q]) (void)hipEventDestroy(c->ev_gathered[q]);
+        if (c->ev_trained[q]) (void)hipEventDestroy(c->ev_trained[q]);
+    }
+    c->ctx.fini();
+    delete c;
+    return ACAV_OK;
+}
+
+ACAV_EXPORT int acav_comm_init(acav_comm **out, int device, int rank, int world, const uint8_t *id128, void *stream)
+{
+    ACAV_REQUIRE(out && id128, ACAV_EINVAL, "NULL argument");
+    ACAV_REQUIRE(world >= 1 && rank >= 0 && rank < world, ACAV_EINVAL, "bad rank %d / world %d", rank, world);
+    ACAV_REQUIRE(rccl().ok, ACAV_ESTATE, "RCCL is not available in this process (librccl.so not found)");
+    acav_comm *c = new (std::nothrow) acav_comm;
+    ACAV_REQUIRE(c, ACAV_ENOMEM, "out of host memory");
+    int rc = c->ctx.init(device, stream);
+    if (rc != ACAV_OK) {
+        delete c;
+        return rc;
+    }
+    c->rank = rank, c->world = world;
+    ncclUniqueId id;
+    memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    ncclResult_t r = rccl().CommInitRank(&c->comm, world, id, rank);
+    bool ok = r == ncclSuccess;
+    if (!ok) set_error("ncclCommInitRank failed: %s", rccl().GetErrorString ? rccl().GetErrorString(r) : "?");
+    for (int q = 0; q < 2 && ok; ++q) {
+        ok = hipEventCreateWithFlags(&c->ev_gathered[q], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_trained[q], hipEventDisableTiming) == hipSuccess;
+        if (!ok) set_error("could not create events");
+    }
+    if (!ok) {
+        c->comm = r == ncclSuccess ? c->comm : nullptr;
+        acav_comm_destroy(c);
+        return ACAV_EHIP;
+    }
+    *out = c;
+    return ACAV_OK;
+}
+
+ACAV_EXPORT int acav_comm_info(const acav_comm *c, int *rank, int *world)
+{
+    ACAV_REQUIRE(c, ACAV_EINVAL, "handle is NULL");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return ACAV_OK;
+}
+
+ACAV_EXPORT int acav_comm_sync(acav_comm *c)
+{
+    ACAV_REQUIRE(c, ACAV_EINVAL, "handle is NULL");
+    ACAV_HIP_TRY(hipStreamSynchronize(c->ctx.stream));
+    return ACAV_OK;
+}
+
+// in-place sum over the ranks of n floats (device memory); rank order of the summation is RCCL's
+ACAV_EXPORT int acav_comm_allreduce_f32(acav_comm *c, float *buf_dev, int64_t n)
+{
+    ACAV_REQUIRE(c && buf_dev && n >= 0, ACAV_EINVAL, "bad argument");
+    ACAV_REQUIRE(is_device_ptr(buf_dev), ACAV_EINVAL, "buffer must be device memory");
+    ACAV_HIP_TRY(hipSetDevice(c->ctx.device));
+    ACAV_NCCL_TRY(rccl().AllReduce(buf_dev, buf_dev, (size_t)n, ncclFloat32, ncclSum, c->comm, c->ctx.stream));
+    return ACAV_OK;
+}
+
+// recv[rank r] = send of rank r (bytes each), device memory on both sides
+ACAV_EXPORT int acav_comm_allgather(acav_comm *c, const void *send_dev, void *recv_dev, int64_t bytes)
+{
+    ACAV_REQUIRE(c && send_dev && recv_dev && bytes >= 0, ACAV_EINVAL, "bad argument");
+    ACAV_REQUIRE(is_device_ptr(send_dev) && is_device_ptr(recv_dev), ACAV_EINVAL, "buffers must be device memory");
+    ACAV_HIP_TRY(hipSetDevice(c->ctx.device));
+    ACAV_NCCL_TRY(rccl().AllGather(send_dev, recv_dev, (size_t)bytes, ncclInt8, c->comm, c->ctx.stream));
+    return ACAV_OK;
+}
+
+ACAV_EXPORT int acav_comm_broadcast(acav_comm *c, void *buf_dev, int64_t bytes, int root)
+{
+    ACAV_REQUIRE(c && buf_dev && bytes >= 0 && root >= 0 && root < c->world, ACAV_EINVAL, "bad argument");
+    ACAV_REQUIRE(is_device_ptr(buf_dev), ACAV_EINVAL, "buffer must be device memory");
+    ACAV_HIP_TRY(hipSetDevice(c->ctx.device));
+    ACAV_NCCL_TRY(rccl().Broadcast(buf_dev, buf_dev, (size_t)bytes, ncclInt8, root, c->comm, c->ctx.stream));
+    return ACAV_OK;
+}
+
+// KMeans.initialize() (sgd_clustering.py:88-92): all-reduce(SUM) of centres and counts, times 1/world
+ACAV_EXPORT int acav_kmeans_allreduce_init(acav_kmeans *km, acav_comm *c)
+{
+    ACAV_REQUIRE(km && c, ACAV_EINVAL, "NULL argument");
+    int K = 0, d = 0;
+    ACAV_TRY(acav_kmeans_shape(km, &K, &d));
+    const int64_t nc = (int64_t)K * d, n = nc + K;
+    ACAV_HIP_TRY(hipSetDevice(c->ctx.device));
+    ACAV_TRY(c->flat.ensure(sizeof(float) * (size_t)n));
+    float *flat = c->flat.as<float>();
+    int64_t count = 0, fb = 0;
+    ACAV_TRY(acav_kmeans_get_state(km, flat, flat + nc, &count, &fb));  // device destination: device-to-device copies
+    ACAV_TRY(acav_comm_allreduce_f32(c, flat, n));
+    if (c->world > 1) {
+        hipLaunchKernelGGL(k_scale_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->ctx.stream, flat, n,
+                           1.0f / (float)c->world);
+        ACAV_HIP_TRY(hipGetLastError());
+    }
+    ACAV_HIP_TRY(hipStreamSynchronize(c->ctx.stream));
+    return acav_kmeans_set_state(km, flat, flat + nc, count, fb);
+}
+
+// One epoch of the reference's multi-GPU add() loop (sgd_clustering.py:94-129 under is_distributed): every rank feeds
+// b_local rows per step, the global batch is the rank-major concatenation.  The rows of `chunk_steps` steps are
+// all-gathered at a time on the communicator's stream (double-buffered: the gather of chunk c+1 overlaps the training
+// of chunk c), re-ordered into global batches by k_interleave_rows, and trained by acav_kmeans_train on every rank --
+// identical state everywhere, no collective on the step path.  warm_global [n_warm, world * b_local]: the labels of the
+// warm-up steps, already in global-batch order (drawn per rank, exchanged once by the caller).
+ACAV_EXPORT int acav_kmeans_train_dp(acav_kmeans *km, acav_comm *c, const float *x_local_dev, int64_t n_local, int64_t b_local,
+                                     double lr, const int64_t *warm_global, int64_t n_warm, int64_t chunk_steps)
+{
+    ACAV_REQUIRE(km && c && (x_local_dev || n_local == 0), ACAV_EINVAL, "NULL argument");
+    ACAV_REQUIRE(n_local >= 0 && b_local > 0 && chunk_steps > 0 && n_warm >= 0, ACAV_EINVAL, "bad sizes");
+    int K = 0, d = 0;
+    ACAV_TRY(acav_kmeans_shape(km, &K, &d));
+    ACAV_REQUIRE((d & 3) == 0, ACAV_EINVAL, "d = %d must be a multiple of 4 for the bulk exchange", d);
+    const int64_t steps = n_local / b_local;
+    if (steps == 0) return ACAV_OK;
+    ACAV_REQUIRE(is_device_ptr(x_local_dev), ACAV_EINVAL, "x_local must be device memory");
+    const int w = c->world;
+    const int64_t bg = (int64_t)w * b_local;
+    ACAV_HIP_TRY(hipSetDevice(c->ctx.device));
+    hipStream_t sc = c->ctx.stream;
+    void *st_train = nullptr;
+    ACAV_TRY(acav_kmeans_stream(km, &st_train));
+    const size_t chunk_bytes = sizeof(float) * (size_t)chunk_steps * (size_t)bg * (size_t)d;
+    for (int q = 0; q < 2; ++q) {
+        ACAV_TRY(c->gather[q].ensure(chunk_bytes));
+        ACAV_TRY(c->batches[q].ensure(chunk_bytes));
+    }
+    int64_t warm_done = 0;
+    auto gather = [&](int64_t c0, int par) -> int {  // rows of steps [c0, c0 + s) of every rank -> batches[par]
+        const int64_t s = steps - c0 < chunk_steps ? steps - c0 : chunk_steps;
+        const size_t bytes = sizeof(float) * (size_t)s * (size_t)b_local * (size_t)d;
+        ACAV_HIP_TRY(hipStreamWaitEvent(sc, c->ev_trained[par], 0));  // the chunk trained from this buffer is done
+        ACAV_NCCL_TRY(rccl().AllGather(x_local_dev + (size_t)c0 * b_local * d, c->gather[par].p, bytes, ncclInt8, c->comm, sc));
+        const int64_t total4 = (int64_t)w * s * b_local * (d / 4);
+        const unsigned grid = (unsigned)(total4 / 256 + 1 < 4096 ? total4 / 256 + 1 : 4096);
+        hipLaunchKernelGGL(k_interleave_rows, dim3(grid), dim3(256), 0, sc, c->gather[par].as<float4>(),
+                           c->batches[par].as<float4>(), w, (int)s, (int)b_local, d / 4);
+        ACAV_HIP_TRY(hipGetLastError());
+        ACAV_HIP_TRY(hipEventRecord(c->ev_gathered[par], sc));
+        return ACAV_OK;
+    };
+    for (int q = 0; q < 2; ++q) ACAV_HIP_TRY(hipEventRecord(c->ev_trained[q], (hipStream_t)st_train));  // both buffers free
+    ACAV_TRY(gather(0, 0));
+    int par = 0;
+    for (int64_t c0 = 0; c0 < steps; c0 += chunk_steps, par ^= 1) {
+        const int64_t s = steps - c0 < chunk_steps ? steps - c0 : chunk_steps;
+        if (c0 + s < steps) ACAV_TRY(gather(c0 + s, par ^ 1));  // next chunk travels while this one trains
+        ACAV_HIP_TRY(hipStreamWaitEvent((hipStream_t)st_train, c->ev_gathered[par], 0));
+        int64_t nw = n_warm - warm_done;
+        nw = nw < 0 ? 0 : (nw > s ? s : nw);
+        ACAV_TRY(acav_kmeans_train(km, c->batches[par].as<float>(), s * bg, bg, lr, nw ? warm_global + warm_done * bg : nullptr, nw));
+        warm_done += nw;
+        ACAV_HIP_TRY(hipEventRecord(c->ev_trained[par], (hipStream_t)st_train));
+    }
+    ACAV_HIP_TRY(hipStreamSynchronize(sc));
+    return acav_kmeans_sync(km);
+}

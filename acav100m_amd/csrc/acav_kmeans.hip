@@ -1799,6 +1799,19 @@ ACAV_EXPORT int acav_kmeans_destroy(acav_kmeans *km)
     return ACAV_OK;
 }
 
+ACAV_EXPORT int acav_kmeans_shape(const acav_kmeans *km, int *k, int *d)
+{
+    ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");
+    if (k) *k = km->K;
+    if (d) *d = km->d;
+    return ACAV_OK;
+}
+ACAV_EXPORT int acav_kmeans_stream(const acav_kmeans *km, void **stream)
+{
+    ACAV_REQUIRE(km && stream, ACAV_EINVAL, "NULL argument");
+    *stream = km->ctx.stream;
+    return ACAV_OK;
+}
 ACAV_EXPORT int acav_kmeans_sync(acav_kmeans *km)
 {
     ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");

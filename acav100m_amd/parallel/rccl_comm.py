@@ -1,0 +1,78 @@
+"""acav_comm -- the path's collectives through RCCL behind the C ABI (acav100m_amd/csrc/acav_comm.hip), for the
+one-process-per-GPU runs.  The 128-byte RCCL id is the only thing that needs a side channel: it travels through the
+torch.distributed group the launcher set up (a store-backed broadcast), after which the rows of the DDP epochs move
+GPU to GPU with no torch op in between.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from .collectives import world
+
+_default = None
+
+
+class Comm:
+    def __init__(self, rank, world_size, id128, device):
+        lib = _lib.load_library()
+        self._h = None
+        h = C.c_void_p()
+        ident = np.ascontiguousarray(id128, np.uint8)
+        assert ident.size == 128
+        _lib.check(lib.acav_comm_init(C.byref(h), int(device), int(rank), int(world_size), _lib.ptr(ident), None))
+        self._h, self.rank, self.world = h, int(rank), int(world_size)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None and _lib._lib is not None:
+            _lib._lib.acav_comm_destroy(h)
+
+    @staticmethod
+    def unique_id():
+        ident = np.zeros(128, np.uint8)
+        _lib.check(_lib.load_library().acav_comm_unique_id(_lib.ptr(ident)))
+        return ident
+
+    @classmethod
+    def from_process_group(cls, device=None):
+        """one communicator over the ranks of the default torch.distributed group (or a world of one without it)"""
+        import torch
+        import torch.distributed as dist
+        rank, w = world()
+        device = torch.cuda.current_device() if device is None else device
+        ident = cls.unique_id() if rank == 0 else np.zeros(128, np.uint8)
+        if w > 1:
+            on = torch.device("cuda", device) if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = torch.from_numpy(ident).to(on)
+            dist.broadcast(t, 0)
+            ident = t.cpu().numpy()
+        return cls(rank, w, ident, device)
+
+    # thin wrappers over device tensors (anything with data_ptr())
+    def allreduce_(self, t):
+        _lib.check(_lib._lib.acav_comm_allreduce_f32(self._h, _lib.ptr(t), t.numel()))
+        return t
+
+    def allgather(self, send, recv):
+        _lib.check(_lib._lib.acav_comm_allgather(self._h, _lib.ptr(send), _lib.ptr(recv), send.numel() * send.element_size()))
+        return recv
+
+    def broadcast_(self, t, root):
+        _lib.check(_lib._lib.acav_comm_broadcast(self._h, _lib.ptr(t), t.numel() * t.element_size(), int(root)))
+        return t
+
+    def synchronize(self):
+        _lib.check(_lib._lib.acav_comm_sync(self._h))
+
+
+def default_comm():
+    """the process-wide communicator over the launcher's group, created on first use; None when RCCL is not the
+    backend in use (CPU tests under gloo keep the torch.distributed plumbing)"""
+    global _default
+    if _default is None:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl":
+            return None
+        _default = Comm.from_process_group()
+    return _default

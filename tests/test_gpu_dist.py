@@ -120,3 +120,43 @@ def test_two_ranks_on_one_gpu_bulk_gathered_epoch(tmp_path):
             ref.add(xb, 0.01)
     rc, rcnt, rcount, _ = ref.get_state()
     assert np.array_equal(r0["c"], rc) and np.array_equal(r0["n"], rcnt) and int(r0["count"]) == rcount
+
+
+def test_comm_c_abi_world1():
+    """The C-ABI communicator (acav_comm_*, RCCL resolved at run time) with a world of one on the real GPU: init from a
+    unique id, all-reduce / all-gather / broadcast are identities, acav_kmeans_allreduce_init leaves the state bit for
+    bit, and acav_kmeans_train_dp (bulk row exchange + interleave kernel + device-resident epoch, 3 chunks, warm-up
+    inside) == the plain epoch == the oracle."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ctypes as C
+    import acav100m_amd
+    from acav100m_amd import _lib
+    from acav100m_amd.clustering import KMeans
+    from acav100m_amd.parallel.rccl_comm import Comm
+    from oracle import oracle as O
+    comm = Comm(0, 1, Comm.unique_id(), 0)
+    t = torch.arange(1000, dtype=torch.float32, device="cuda")
+    want = t.clone()
+    comm.allreduce_(t)
+    out = torch.empty_like(t)
+    comm.allgather(t, out)
+    comm.broadcast_(t, 0)
+    comm.synchronize()
+    assert torch.equal(t, want) and torch.equal(out, want)
+    d, k, b, steps = 256, 40, 32, 40
+    rs = np.random.RandomState(1)
+    x = (rs.randn(k, d)[rs.randint(0, k, steps * b)] * 3 + rs.randn(steps * b, d)).astype(np.float32)
+    acav100m_amd.manual_seed(9)
+    km = KMeans(None, d, k).to("cuda:0")
+    before = km.centers.numpy().copy()
+    _lib.check(_lib._lib.acav_kmeans_allreduce_init(km._h, comm._h))
+    assert np.array_equal(km.centers.numpy(), before)
+    ref = O.KMeans(d, k, O.Rng(9))
+    xt = torch.from_numpy(x).cuda()
+    for epoch in range(2):
+        km.train_epoch_comm(comm, xt, b, 0.01, chunk_steps=16)
+        ref.train_epoch(x, b, 0.01)
+        assert np.array_equal(km.centers.numpy(), ref.centers), f"epoch {epoch}"
+        assert np.array_equal(km.counts.numpy(), ref.counts) and km.count == ref.count
