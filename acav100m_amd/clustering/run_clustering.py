@@ -147,8 +147,79 @@ def save_clusterings(args, epoch, cl):
     torch.save(nested, str(path))
 
 
-def train_clusters(args, table, resident):
-    cl, loaded = load_clusterings(args, table)
+class _RowGroups:
+    """The feature shards as a sequence of ROW GROUPS that fit the device budget.
+
+    The reference never holds more than a batch (clustering/code/data/clustering.py:17-66, run_clustering.py:132-177:
+    a DataLoader over the shards, re-read every epoch).  Here a group is as many consecutive shards as fit in half the
+    budget (the next group is unpickled / memory-mapped by a host thread while the GPU works on the current one);
+    when everything fits there is ONE group and its device tensors stay resident across epochs and the assign sweep.
+    Nothing holds [N, d] for all N unless N fits."""
+
+    def __init__(self, args, paths, sizes, row_bytes, budget):
+        self.args = args
+        self.model_order = list(args.models or [])
+        self.audio_models = tuple(args.model_types.audio or ())
+        total = sum(sizes[p.stem] for p in paths) * row_bytes
+        if total <= budget:
+            self.groups = [list(paths)]
+        else:
+            self.groups, cur, cur_bytes = [], [], 0
+            for p in paths:
+                nbytes = sizes[p.stem] * row_bytes
+                if cur and cur_bytes + nbytes > budget // 2:
+                    self.groups.append(cur)
+                    cur, cur_bytes = [], 0
+                cur.append(p)
+                cur_bytes += nbytes
+            if cur:
+                self.groups.append(cur)
+            print("streaming {} shards in {} groups (device budget {:.1f} MB, data {:.1f} MB)".format(
+                len(paths), len(self.groups), budget / 1e6, total / 1e6))
+        self._resident = None
+
+    @property
+    def streamed(self):
+        return len(self.groups) > 1
+
+    def _load(self, group):
+        return io.load_feature_shards(group, model_order=self.model_order, audio_models=self.audio_models)
+
+    def __iter__(self):
+        """-> (index, table, {view: device tensor [rows, d]})"""
+        import torch
+        dev = _device(self.args)
+        if not self.streamed:
+            if self._resident is None:
+                table = self._load(self.groups[0])
+                self._resident = (table, OrderedDict((v, torch.from_numpy(m).to(dev)) for v, m in table.views.items()))
+            yield (0,) + self._resident
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            pending = pool.submit(self._load, self.groups[0])
+            for gi in range(len(self.groups)):
+                table = pending.result()
+                if gi + 1 < len(self.groups):
+                    pending = pool.submit(self._load, self.groups[gi + 1])  # host work beside the GPU's
+                yield gi, table, OrderedDict((v, torch.from_numpy(np.ascontiguousarray(m)).to(dev)) for v, m in table.views.items())
+
+
+def _device_budget(args):
+    """bytes of feature rows the device may hold at once: data.resident_bytes / ACAV_RESIDENT_BYTES, else 60 % of the
+    free HBM (288 GB on MI355X: cfg2/cfg3's 2 x 4.1 GB are resident, cfg5's 2 x 410 GB stream)"""
+    import os
+    import torch
+    v = os.environ.get('ACAV_RESIDENT_BYTES') or args.data.resident_bytes
+    if v:
+        return int(float(v))
+    free, _total = torch.cuda.mem_get_info()
+    return int(free * 0.6)
+
+
+def train_clusters(args, probe, groups):
+    import torch
+    cl, loaded = load_clusterings(args, probe)
     if loaded and not args.clustering.resume_training:
         return cl
     pre = args.clustering.cached_epoch if loaded else 0
@@ -158,8 +229,6 @@ def train_clusters(args, table, resident):
     # of every epoch -- the N-GPU run produces the files of the one-GPU run.
     epochs = int(args.clustering.epochs)
     b = int(args.data.batch_size)
-    n = len(table)
-    steps = n // b  # drop_last (run_clustering.py:139)
     print("training sgd kmeans for views: {}".format([v[1:] for v in cl]))
     for epoch in range(pre, pre + epochs):
         lr = 0.1 ** (2 + epoch // 5)
@@ -173,55 +242,72 @@ def train_clusters(args, table, resident):
         gen = next(iter(cl.values()))._generator
         gen.u32()
         gen.u32()
-        # warm-up labels, drawn batch by batch across the clusterings like the reference loop (every rank draws
-        # all of them from the same stream, so the generators stay in step whoever trains which clustering)
-        need = {v: km.warmup_steps(b, steps) for v, km in cl.items()}
-        warm = {v: np.empty((need[v], b), np.int64) for v in cl}
-        for t in range(max(need.values(), default=0)):
-            for v, km in cl.items():
-                if t < need[v]:
-                    warm[v][t] = km.draw_warmup(b)
-        if w > 1:  # the clusterings are dealt out over the GPUs; state identical to the one-GPU run on every rank
-            from ..parallel import train_epoch_view_parallel
-            train_epoch_view_parallel(cl, resident, b, lr, warm)
-        else:  # all clusterings of the batch stream side by side on the GPU (independent SGD chains)
-            KMeans.train_epoch_multi(list(cl.values()), [resident[v] for v in cl], b, lr=lr, warm_bests=[warm[v] for v in cl])
+        carry = None  # rows of the previous group that did not fill a batch: the batch stream runs across groups
+        last = len(groups.groups) - 1
+        for gi, table, rows in groups:
+            if carry is not None:
+                rows = OrderedDict((v, torch.cat([carry[v], rows[v]])) for v in rows)
+            n = next(iter(rows.values())).shape[0] if rows else 0
+            usable = (n // b) * b  # whole batches; the tail waits for the next group, or is dropped at the very end
+            carry = OrderedDict((v, x[usable:].clone()) for v, x in rows.items()) if gi < last and usable < n else None
+            steps = usable // b
+            if steps == 0:
+                continue
+            # warm-up labels, drawn batch by batch across the clusterings like the reference loop (every rank draws
+            # all of them from the same stream, so the generators stay in step whoever trains which clustering)
+            need = {v: km.warmup_steps(b, steps) for v, km in cl.items()}
+            warm = {v: np.empty((need[v], b), np.int64) for v in cl}
+            for t in range(max(need.values(), default=0)):
+                for v, km in cl.items():
+                    if t < need[v]:
+                        warm[v][t] = km.draw_warmup(b)
+            part = OrderedDict((v, x[:usable]) for v, x in rows.items())
+            if w > 1:  # the clusterings are dealt out over the GPUs; states are exchanged once per epoch
+                from ..parallel import train_epoch_view_parallel
+                train_epoch_view_parallel(cl, part, b, lr, warm, broadcast=False)
+            else:  # all clusterings of the batch stream side by side on the GPU (independent SGD chains)
+                KMeans.train_epoch_multi(list(cl.values()), [part[v] for v in cl], b, lr=lr, warm_bests=[warm[v] for v in cl])
+        if w > 1:  # state identical to the one-GPU run on every rank
+            from ..parallel import broadcast_states
+            broadcast_states(cl)
         if rank == 0:
             save_clusterings(args, epoch, cl)
     return cl
 
 
-def assign_clusters(args, table, resident, cl, shard_names):
+def assign_clusters(args, groups, cl, shard_names):
     """run_clustering.py:180-272: label every row of this rank's shards, write {out}/{shard}.pkl."""
     out_dir = Path(args.data.output.path)
     prefix = '' if args.clustering.cached_epoch is None else 'epoch_{}_'.format(args.clustering.cached_epoch)
     print("extracting clustering for views: {}".format([v[1:] for v in cl]))
-    labels = OrderedDict()
-    for v, km in cl.items():
-        best, _ = km.calc_best(resident[v], need_mean=False)
-        labels[v] = best.cpu().numpy()
+    mine = set(shard_names)
     saved = []
-    for shard in shard_names:
-        out_path = out_dir / (prefix + shard + '.pkl')
-        plain = out_dir / (shard + '.pkl')
-        if plain.is_file():  # already processed (run_clustering.py:248-250)
+    for gi, table, rows in groups:
+        todo = [s for s in table.shard_rows if s in mine and not (out_dir / (s + '.pkl')).is_file()]  # :248-250
+        if not todo:
             continue
-        ids = table.shard_rows.get(shard)
-        if not ids:  # unreadable (reported and skipped by the loader) or empty shard: nothing to write
-            continue
-        size = table.shard_size[ids[0]]
-        if len(ids) < round(size * args.data.output.shard_ok_ratio):
-            continue  # too incomplete to save (:261-268)
-        rows = io.assignment_rows(table, labels, ids)
-        io.dump_pickle(rows, out_path)
-        if io.sidecar_mode() == 'write':  # columnar twin for our own subset-selection loader (opt-in: extra files)
-            io.write_assignment_sidecar(out_path, rows)
-        saved.append(out_path)
-    return saved
+        labels = OrderedDict()
+        for v, km in cl.items():
+            best, _ = km.calc_best(rows[v], need_mean=False)
+            labels[v] = best.cpu().numpy()
+        for shard in todo:
+            ids = table.shard_rows.get(shard)
+            if not ids:  # unreadable (reported and skipped by the loader) or empty shard: nothing to write
+                continue
+            size = table.shard_size[ids[0]]
+            if len(ids) < round(size * args.data.output.shard_ok_ratio):
+                continue  # too incomplete to save (:261-268)
+            out_path = out_dir / (prefix + shard + '.pkl')
+            out_rows = io.assignment_rows(table, labels, ids)
+            io.dump_pickle(out_rows, out_path)
+            if io.sidecar_mode() == 'write':  # columnar twin for our own subset-selection loader (opt-in: extra files)
+                io.write_assignment_sidecar(out_path, out_rows)
+            saved.append(out_path)
+    order = {s: i for i, s in enumerate(shard_names)}
+    return sorted(saved, key=lambda p: order.get(p.name[len(prefix):-4], 0))
 
 
 def run_clustering(args):
-    import torch
     paths = [Path(p) for p in sorted(io.brace_expand(args.data.path))]
     sizes = io.shard_sizes_from_meta(paths, args.data.meta.path)
     if args.data.meta.path is not None:  # side effect of the reference: meta_cache.pkl in the meta dir
@@ -232,13 +318,14 @@ def run_clustering(args):
         return []
     print(f"processing {len(paths)} shards")
     rank, w = world()
-    table = io.load_feature_shards(paths, model_order=list(args.models or []),
+    # the first shard tells the views and their widths (the order KMeans objects are created in, and the row size)
+    probe = io.load_feature_shards(paths[:1], model_order=list(args.models or []),
                                    audio_models=tuple(args.model_types.audio or ()))
-    dev = _device(args)
-    resident = OrderedDict((v, torch.from_numpy(m).to(dev)) for v, m in table.views.items())
-    cl = train_clusters(args, table, resident)
+    row_bytes = 4 * sum(m.shape[1] for m in probe.views.values())
+    groups = _RowGroups(args, paths, sizes, row_bytes, _device_budget(args))
+    cl = train_clusters(args, probe, groups)
     mine = [p.stem for p in paths][rank::w]  # assign: shards strided over ranks (mps/distributed.py:439)
-    return assign_clusters(args, table, resident, cl, mine)
+    return assign_clusters(args, groups, cl, mine)
 
 
 def store_shards_set(args, saved_paths):

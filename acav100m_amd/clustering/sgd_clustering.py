@@ -417,7 +417,10 @@ class KMeans:
             _lib.check(_lib._lib.acav_kmeans_set_state(self._h, _lib.ptr(c), _lib.ptr(n), int(count), int(fallback)))
 
     def skip_epoch(self, rows):
-        """another rank trains this clustering over `rows` rows this epoch; its state arrives by broadcast"""
+        """another rank trains this clustering over `rows` rows; its state arrives by broadcast at the end of the epoch.
+        `count` advances here all the same: the warm-up plan of the next row group (and with it the number of draws from
+        the shared generator) must be the owner's"""
+        self.count = self.count + int(rows)
 
     def get_attrs_plain(self):
         """get_attrs() without the args object (what the checkpoint files hold)"""

@@ -85,6 +85,7 @@ CLUSTERING_DEFAULTS = {
     'data': {
         'path': 'data',
         'batch_size': 32,
+        'resident_bytes': None,  # ours: device budget for feature rows; beyond it the shards stream in groups
         'meta': {'path': None},
         'output': {'path': 'output', 'shard_ok_ratio': 0.99},
     },

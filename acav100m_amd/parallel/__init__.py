@@ -14,5 +14,5 @@ RCCL over xGMI on ROCm; "gloo" in the CPU tests).  Only the exchanges the path r
   MI selection       none: chunks are independent (chunk.py:21-53)
 """
 from .collectives import gather_rows_and_labels, shard_slice, world  # noqa: F401
-from .kmeans_dp import (average_state, broadcast_state, distributed_add, train_epoch_dp,  # noqa: F401
-                        train_epoch_view_parallel)
+from .kmeans_dp import (average_state, broadcast_state, broadcast_states, distributed_add,  # noqa: F401
+                        train_epoch_dp, train_epoch_view_parallel)

@@ -140,7 +140,14 @@ def _collective_device():
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
-def train_epoch_view_parallel(engines, rows, b, lr, warm):
+def broadcast_states(engines):
+    """every clustering's state from the rank that trains it (view i -> rank i % world)"""
+    rank, w = world()
+    for i, v in enumerate(engines):
+        broadcast_state(engines[v], i % w)
+
+
+def train_epoch_view_parallel(engines, rows, b, lr, warm, broadcast=True):
     """One epoch of every clustering with the clusterings dealt out over the ranks (view i -> rank i % world).
 
     What several GPUs are FOR in this stage: the SGD chain of ONE clustering is a sequence of n/b dependent steps
@@ -166,5 +173,5 @@ def train_epoch_view_parallel(engines, rows, b, lr, warm):
             engines[v].synchronize()
         else:
             engines[v].skip_epoch(rows[v].shape[0] // b * b)  # keeps `count` (and hence the next warm-up plan) in step
-    for i, v in enumerate(views):
-        broadcast_state(engines[v], i % w)
+    if broadcast:  # a streamed epoch calls this once per row group and exchanges the states at the end of the epoch
+        broadcast_states(engines)
