@@ -1531,6 +1531,7 @@ __global__ __launch_bounds__(256) void k_train_persistent(
         const float *xb = x + (size_t)t * b * d;
         const long long c0 = TP_CLK();
         if (t < need) {
+            __syncthreads();  // every wave has read the previous step's labels (an untouched workgroup has no other barrier)
             if (tid < b) sBest[tid] = (int)forced[(size_t)t * b + tid];
             __syncthreads();
         } else {
@@ -1711,6 +1712,284 @@ __global__ __launch_bounds__(256) void k_train_persistent(
         for (int c8 = 0; c8 < nck; ++c8) {
             const float4 v = *reinterpret_cast<const float4 *>(sC + c8 * TP_DS + wave * 256 + ((lane ^ (c8 & 7)) << 2));
             if (col_ok) *reinterpret_cast<float4 *>(centers + (size_t)(kbase + c8) * d + wave * 256 + (lane << 2)) = v;
+        }
+    }
+    if (blockIdx.y == 0 && !sDead && tid < nck) {
+        cn[kbase + tid] = sCn[tid];
+        counts[kbase + tid] = sCnt[tid];
+    }
+}
+
+// ---------------------------------------------------------------- k_train_persistent_wide
+// The same owner-computes epoch for shapes whose 8-centre groups outnumber the CUs (K = 1024: 128 groups x 4 row groups):
+// a workgroup owns NCP x 8 centres (NCP "centre passes").  LDS rows have the run-time stride ds = d rounded up to 256
+// columns (a 128-d view keeps 64 centres in 64 KB), the work items of the FMA phase are (centre pass, column block)
+// pairs dealt round-robin over the 4 waves, wave 0 folds each pass's segments left to right and keeps the best key over
+// the passes, and the sweep reads up to 64 centre groups (32 granules per lane).  The update walks the passes; a step
+// touches ~b / (K / (8 NCP)) centres of a workgroup, almost always none or one.  Same exchange, same arithmetic, same
+// bit-exact result as k_train_persistent -- which stays the kernel of every shape it can hold (K d <= 256 x 1024).
+constexpr int TPW_SW = 32;  // granules per lane in the sweep: up to 64 centre groups
+
+template <bool RAGGED>
+__device__ __forceinline__ void tpw_dma_block(float *lds, const float *__restrict__ src, int first_row, int nrows_valid, int d,
+                                              int ds, int blk, int lane)
+{
+#pragma unroll
+    for (int row = 0; row < 8; ++row) {
+        const int grow = first_row + (row < nrows_valid ? row : 0);
+        const int col = blk * 256 + ((lane ^ (row & 7)) << 2);
+        const float *g = src + (size_t)grow * d + col;
+        if (!RAGGED || col < d)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)(lds + row * ds + blk * 256), 16, 0, 0);
+    }
+}
+
+// ||c||^2 of the centres flagged in pend8 among rows [row0, row0 + 8) of sC (half-wave per centre, canonical chains)
+__device__ __forceinline__ void tpw_refresh_norms(unsigned pend8, const float *sC, float *sCn, int row0, int ds, int wave, int lane, int d)
+{
+    const int c8 = 2 * wave + (lane >> 5), q = lane & 31;
+    const bool mine = (pend8 >> c8) & 1u;
+    float p = 0.f;
+    if (mine) {
+        const float *base = sC + (row0 + c8) * ds + ((((q >> 2) ^ (c8 & 7))) << 2) + (q & 3);
+        const int nu = (d + 31) >> 5;  // columns past d read the zero padding
+#pragma unroll 8
+        for (int u = 0; u < nu; ++u) {
+            const float v = base[u * 32];
+            p = __builtin_fmaf(v, v, p);
+        }
+    }
+    p = p + __shfl_xor(p, 1);
+    p = p + __shfl_xor(p, 2);
+    p = p + __shfl_xor(p, 4);
+    p = p + __shfl_xor(p, 8);
+    p = p + __shfl_xor(p, 16);
+    if (q == 0 && mine) sCn[row0 + c8] = norm2_from_sumsq(p);
+}
+
+template <bool RAGGED, int NCP>
+__global__ __launch_bounds__(256) void k_train_persistent_wide(
+    const float *__restrict__ x, const float *__restrict__ xn, int b, int d, int ds, int K, float *__restrict__ centers,
+    float *__restrict__ cn, float *__restrict__ counts, const float *__restrict__ thr, double lr0, float r,
+    const int64_t *__restrict__ forced, int need, int T, TrainCtl *__restrict__ ctl, StepScalars *__restrict__ sc)
+{
+    constexpr int NCW = 8 * NCP;  // centres per workgroup
+    extern __shared__ __attribute__((aligned(16))) unsigned char tpw_smem[];
+    float *sC = reinterpret_cast<float *>(tpw_smem);  // [NCW][ds]
+    float *sX0 = sC + NCW * ds;                        // [2][8][ds]
+    float *sCn = sX0 + 2 * 8 * ds;                     // [NCW]
+    float *sCnt = sCn + NCW;                           // [NCW]
+    float *sPart = sCnt + NCW;                         // [NCP][4][64]
+    int *sBest = reinterpret_cast<int *>(sPart + NCP * 4 * 64);  // [32]
+    __shared__ int sDead;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kk = lane >> 3, ii = lane & 7;
+    const int kbase = blockIdx.x * NCW, rbase = blockIdx.y * TP_NR;
+    const int nck = min(NCW, K - kbase), nrv = min(TP_NR, b - rbase);
+    const int nblk = (d + 255) >> 8;
+    const int ncg = gridDim.x;
+    const bool active = wave < nblk;  // this wave has a column block (DMA and update)
+    const bool col_ok = !RAGGED || wave * 256 + (lane << 2) < d;
+    auto sX = [&](int par) { return sX0 + par * 8 * ds; };
+
+    if (RAGGED && active) {  // ragged last block: columns d .. 256 nblk - 1 must read as zero for good
+        for (int row = 0; row < NCW; ++row)
+            *reinterpret_cast<float4 *>(sC + row * ds + wave * 256 + (lane << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int row = 0; row < 16; ++row)
+            *reinterpret_cast<float4 *>(sX0 + row * ds + wave * 256 + (lane << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // before the DMA below writes the same rows
+    }
+    if (active)
+        for (int cp = 0; cp < NCP; ++cp)
+            if (cp * 8 < nck) tpw_dma_block<RAGGED>(sC + cp * 8 * ds, centers, kbase + cp * 8, min(8, nck - cp * 8), d, ds, wave, lane);
+    if (tid < NCW) {
+        const int k = kbase + (tid < nck ? tid : 0);
+        sCn[tid] = cn[k];
+        sCnt[tid] = counts[k];
+    }
+    if (tid == 0) sDead = 0;
+    if (need < T && active) tpw_dma_block<RAGGED>(sX(need & 1), x + (size_t)need * b * d, rbase, nrv, d, ds, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    unsigned nsync = 0;
+    unsigned long long pend = 0;  // centres whose ||c||^2 is stale: refreshed under the next step's FMA phase
+    for (int t = 0; t < T; ++t) {
+        const float *xb = x + (size_t)t * b * d;
+        if (t < need) {
+            __syncthreads();  // every wave has read the previous step's labels (an untouched workgroup has no other barrier)
+            if (tid < b) sBest[tid] = (int)forced[(size_t)t * b + tid];
+            __syncthreads();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my block of step t's rows landed (issued one step ago)
+            float xn_t = 0.f, thr_t = 0.f;
+            if (wave == 0) {  // in flight under the FMA chain
+                xn_t = xn[(size_t)t * b + rbase + (ii < nrv ? ii : 0)];
+                thr_t = thr[t];
+            }
+            if (t + 1 < T && active) tpw_dma_block<RAGGED>(sX((t + 1) & 1), x + (size_t)(t + 1) * b * d, rbase, nrv, d, ds, wave, lane);
+            const float *xs = sX(t & 1);
+            for (int item = wave; item < nblk * NCP; item += 4) {  // (centre pass, column block) pairs over the 4 waves
+                const int cp = item / nblk, blk = item - cp * nblk;
+                sPart[(cp * 4 + blk) * 64 + lane] =
+                    dot_blocks<1>(sC + (cp * 8 + kk) * ds + blk * 256, xs + ii * ds + blk * 256, kk << 2, ii << 2, 0.f, true);
+            }
+            if (pend) {  // uniform: the previous update's norm refresh, off the update's critical path
+                for (int cp = 0; cp < NCP; ++cp) {
+                    const unsigned p8 = (unsigned)(pend >> (cp * 8)) & 0xFFu;
+                    if (p8) tpw_refresh_norms(p8, sC, sCn, cp * 8, ds, wave, lane, d);
+                }
+                pend = 0;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                unsigned long long key = ~0ull;
+                for (int cp = 0; cp < NCP; ++cp) {
+                    float acc = sPart[(cp * 4) * 64 + lane];
+                    for (int w = 1; w < nblk; ++w) acc = acc + sPart[(cp * 4 + w) * 64 + lane];  // canonical left fold
+                    const int lc = cp * 8 + kk;
+                    if (lc < nck && ii < nrv) {
+                        const unsigned long long kc = pack_key(dist_epilogue(acc, xn_t, sCn[lc], sCnt[lc] < thr_t, r), kbase + lc);
+                        key = kc < key ? kc : key;
+                    }
+                }
+                unsigned long long o = __shfl_xor(key, 8);
+                key = o < key ? o : key;
+                o = __shfl_xor(key, 16);
+                key = o < key ? o : key;
+                o = __shfl_xor(key, 32);
+                key = o < key ? o : key;
+                const unsigned long long tag = (unsigned long long)((nsync % 65535u) + 1u) << 48;
+                unsigned long long(*ring)[TP_MAXB] = ctl->gran[nsync % TP_RING];
+                if (lane < nrv) {
+                    const unsigned long long local = (key == ~0ull) ? 0xFFFFull : ((key & 0xffffffffull) - (unsigned)kbase);
+                    __hip_atomic_store(&ring[blockIdx.x][rbase + lane], tag | (local << 32) | (key >> 32), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const int srow = lane & 31, half = lane >> 5;
+                unsigned long long bestkey = ~0ull;
+                unsigned ok = 1;
+                unsigned long long g[TPW_SW];
+                unsigned needm = 0;  // bit u: granule u of this lane not yet seen with this step's tag
+#pragma unroll
+                for (int u = 0; u < TPW_SW; ++u)
+                    if (srow < b && half + 2 * u < ncg) needm |= 1u << u;
+                for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+                    for (int u = 0; u < TPW_SW; ++u)
+                        if ((needm >> u) & 1u)
+                            g[u] = __hip_atomic_load(&ring[half + 2 * u][srow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int u = 0; u < TPW_SW; ++u)
+                        if (((needm >> u) & 1u) && (g[u] >> 48) == (tag >> 48)) needm &= ~(1u << u);
+                    if (__all(needm == 0)) break;
+                    if (spins > TP_SPIN_LIMIT || (spins & 1023) == 1023) {
+                        if (spins > TP_SPIN_LIMIT || __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            if (lane == 0) __hip_atomic_store(&ctl->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = 0;
+                            break;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < TPW_SW; ++u) {
+                    const int cg = half + 2 * u;
+                    if (srow < b && cg < ncg && ok) {
+                        const unsigned loc = (unsigned)(g[u] >> 32) & 0xFFFFu;
+                        const unsigned long long cand =
+                            loc == 0xFFFFu ? ~0ull : (((g[u] & 0xffffffffull) << 32) | (unsigned)(cg * NCW + loc));
+                        bestkey = cand < bestkey ? cand : bestkey;
+                    }
+                }
+                o = __shfl_xor(bestkey, 32);
+                bestkey = o < bestkey ? o : bestkey;
+                if (lane < b) sBest[lane] = (int)(bestkey & 0xffffffffull);
+                if (!ok && lane == 0) sDead = 1;
+            }
+            ++nsync;
+            __syncthreads();
+            if (sDead) break;  // uniform
+        }
+        // ---- update: every replica of a centre group does the same arithmetic; wave w owns column block w
+        const int best = (lane < b) ? sBest[lane] : -1;
+        double lr = lr0;
+        bool fell = false;
+        if ((double)b * lr0 >= 1.0) {  // lr fallback (:116-119) possible at all?  (never at the defaults 32 * 0.01)
+            int cmaxi = 0;
+#pragma unroll
+            for (int i = 0; i < TP_MAXB; ++i) {
+                const int li = __builtin_amdgcn_readlane(best, i);  // scalar; -1 for rows >= b
+                const int c = __popcll(__ballot(lane < b && best == li));
+                cmaxi = (i < b && c > cmaxi) ? c : cmaxi;
+            }
+            if ((double)(float)cmaxi * lr >= 1.0) {
+                lr = 0.5 / (double)(float)cmaxi;
+                fell = true;
+            }
+        }
+        const float lr32 = (float)lr;
+        if (fell && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) sc->fallback += 1;
+        if (__ballot(lane < b && best >= kbase && best < kbase + nck) == 0ull) continue;  // uniform: nothing of mine was hit
+        for (int cp = 0; cp < NCP; ++cp) {
+            unsigned long long msk[8];
+            unsigned touched = 0;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                msk[c8] = (cp * 8 + c8 < nck) ? __ballot(lane < b && best == kbase + cp * 8 + c8) : 0ull;
+                touched |= (msk[c8] ? 1u : 0u) << c8;
+            }
+            if (!touched) continue;  // uniform over the workgroup
+            if (active) {
+                float4 dl[8];
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    unsigned long long m = msk[c8];
+                    bool have = false;
+                    while (m) {  // rows of the batch with this label, ascending (torch_scatter's CPU order)
+                        const int i = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const float4 x4 = col_ok ? *reinterpret_cast<const float4 *>(xb + (size_t)i * d + wave * 256 + (lane << 2))
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 v = make_float4(x4.x * lr32, x4.y * lr32, x4.z * lr32, x4.w * lr32);
+                        dl[c8] = have ? make_float4(dl[c8].x + v.x, dl[c8].y + v.y, dl[c8].z + v.z, dl[c8].w + v.w) : v;
+                        have = true;
+                    }
+                }
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    if (msk[c8] && col_ok) {
+                        const float f = 1.0f - (float)__popcll(msk[c8]) * lr32;
+                        float4 *pc4 = reinterpret_cast<float4 *>(sC + (cp * 8 + c8) * ds + wave * 256 + ((lane ^ (c8 & 7)) << 2));
+                        const float4 c4 = *pc4;
+                        *pc4 = make_float4(c4.x * f + dl[c8].x, c4.y * f + dl[c8].y, c4.z * f + dl[c8].z, c4.w * f + dl[c8].w);
+                    }
+                }
+            }
+            if (tid < 8 && ((touched >> tid) & 1u)) {
+                int cnt = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cnt = (e == (int)tid) ? __popcll(msk[e]) : cnt;
+                sCnt[cp * 8 + tid] = sCnt[cp * 8 + tid] + (float)cnt;
+            }
+            pend |= (unsigned long long)touched << (cp * 8);
+        }
+        __syncthreads();  // the updated centres and counts are in place before the next step reads them
+    }
+    if (pend) {  // uniform
+        for (int cp = 0; cp < NCP; ++cp) {
+            const unsigned p8 = (unsigned)(pend >> (cp * 8)) & 0xFFu;
+            if (p8) tpw_refresh_norms(p8, sC, sCn, cp * 8, ds, wave, lane, d);
+        }
+        __syncthreads();
+    }
+    // ---- write the owned state back (one replica per centre group)
+    if (blockIdx.y == 0 && !sDead && active) {
+        for (int c = 0; c < nck; ++c) {
+            const float4 v = *reinterpret_cast<const float4 *>(sC + c * ds + wave * 256 + ((lane ^ (c & 7)) << 2));
+            if (col_ok) *reinterpret_cast<float4 *>(centers + (size_t)(kbase + c) * d + wave * 256 + (lane << 2)) = v;
         }
     }
     if (blockIdx.y == 0 && !sDead && tid < nck) {
@@ -2199,10 +2478,32 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
     int occ = 0;
     ACAV_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(tkern), 256, 0));
     const int room = budget ? *budget : occ * km->num_cus;
-    const bool persistent = steps > 0 && !(nop && nop[0] == '1') && (km->d % 4) == 0 && km->d <= TP_DS &&
-                            b <= TP_MAXB && nwg <= room && nwg <= occ * km->num_cus && ((uintptr_t)fx & 15) == 0;
+    const bool shape_ok = steps > 0 && !(nop && nop[0] == '1') && (km->d % 4) == 0 && km->d <= TP_DS && b <= TP_MAXB &&
+                          ((uintptr_t)fx & 15) == 0;
+    bool persistent = shape_ok && nwg <= room && nwg <= occ * km->num_cus;
+    // more 8-centre groups than CUs (K = 1024): NCP x 8 centres per workgroup (k_train_persistent_wide) -- the smallest
+    // NCP whose grid fits 3/4 of the device, else the whole device, within the LDS of a CU
+    int ncp = 1, ds = 0, wide_wg = 0;
+    size_t wide_smem = 0;
+    if (shape_ok && !persistent && nwg > occ * km->num_cus) {
+        ds = ((km->d + 255) / 256) * 256;
+        const int rgroups = (int)((b + TP_NR - 1) / TP_NR);
+        int best_ncp = 0;
+        for (int pass = 0; pass < 2 && !best_ncp; ++pass)
+            for (int c : {2, 4, 8}) {
+                const int groups = (km->K + 8 * c - 1) / (8 * c);
+                const size_t smem = sizeof(float) * ((size_t)(8 * c + 16) * ds + 2 * 8 * c + 256 * c + 32);
+                const int lim = pass == 0 ? (3 * km->num_cus) / 4 : km->num_cus;
+                if (groups <= 64 && smem <= 160 * 1024 - 1024 && groups * rgroups <= lim && groups * rgroups <= room) {
+                    best_ncp = c, wide_wg = groups * rgroups, wide_smem = smem;
+                    break;
+                }
+            }
+        if (best_ncp) ncp = best_ncp, persistent = true;
+    }
     if (!persistent) return ACAV_OK;
-    if (budget) *budget -= nwg;
+    tc.nwg = ncp == 1 ? nwg : wide_wg;
+    if (budget) *budget -= tc.nwg;
     tc.thr.resize((size_t)steps);
     for (int64_t t = 0; t < steps; ++t)
         tc.thr[(size_t)t] = (float)pow((double)(km->count + t * b) / (double)km->K, km->reinit_p);
@@ -2218,10 +2519,24 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
     ACAV_HIP_TRY(hipMemcpyAsync(bk + cbytes, km->cn.p, kbytes, hipMemcpyDeviceToDevice, st));
     ACAV_HIP_TRY(hipMemcpyAsync(bk + cbytes + kbytes, km->counts.p, kbytes, hipMemcpyDeviceToDevice, st));
     ACAV_HIP_TRY(hipMemcpyAsync(bk + cbytes + 2 * kbytes, km->scalars.p, sizeof(StepScalars), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(tkern, dim3((km->K + TP_NC - 1) / TP_NC, (unsigned)((b + TP_NR - 1) / TP_NR)),
-                       dim3(256), 0, st, fx, km->xn.as<float>(), (int)b, km->d, km->K, km->centers.as<float>(),
-                       km->cn.as<float>(), km->counts.as<float>(), km->thr.as<float>(), lr, (float)km->reinit_r,
-                       tc.dw, (int)need, (int)steps, km->ctl.as<TrainCtl>(), km->scalars.as<StepScalars>(), nwg);
+    if (ncp == 1) {
+        hipLaunchKernelGGL(tkern, dim3((km->K + TP_NC - 1) / TP_NC, (unsigned)((b + TP_NR - 1) / TP_NR)),
+                           dim3(256), 0, st, fx, km->xn.as<float>(), (int)b, km->d, km->K, km->centers.as<float>(),
+                           km->cn.as<float>(), km->counts.as<float>(), km->thr.as<float>(), lr, (float)km->reinit_r,
+                           tc.dw, (int)need, (int)steps, km->ctl.as<TrainCtl>(), km->scalars.as<StepScalars>(), nwg);
+    } else {
+        tc.prof = false;  // the wide kernel carries no phase timers
+        using WideKernel = void (*)(const float *, const float *, int, int, int, int, float *, float *, float *, const float *,
+                                    double, float, const int64_t *, int, int, TrainCtl *, StepScalars *);
+        WideKernel wk = nullptr;
+        if (ragged) wk = ncp == 2 ? k_train_persistent_wide<true, 2> : ncp == 4 ? k_train_persistent_wide<true, 4> : k_train_persistent_wide<true, 8>;
+        else wk = ncp == 2 ? k_train_persistent_wide<false, 2> : ncp == 4 ? k_train_persistent_wide<false, 4> : k_train_persistent_wide<false, 8>;
+        ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_smem));
+        hipLaunchKernelGGL(wk, dim3((km->K + 8 * ncp - 1) / (8 * ncp), (unsigned)((b + TP_NR - 1) / TP_NR)), dim3(256), wide_smem, st,
+                           fx, km->xn.as<float>(), (int)b, km->d, ds, km->K, km->centers.as<float>(), km->cn.as<float>(),
+                           km->counts.as<float>(), km->thr.as<float>(), lr, (float)km->reinit_r, tc.dw, (int)need, (int)steps,
+                           km->ctl.as<TrainCtl>(), km->scalars.as<StepScalars>());
+    }
     ACAV_HIP_TRY(hipGetLastError());
     tc.launched = true;
     return ACAV_OK;
