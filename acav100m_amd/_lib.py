@@ -56,6 +56,12 @@ SIGNATURES = {
     "acav_kmeans_stats": [vp, C.POINTER(i64), C.POINTER(i64)],
     "acav_kmeans_filter_stats": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
     "acav_kmeans_filter_time": [vp, C.POINTER(f32)],
+    "acav_contrastive_create": [pp, i32, i32, i32, i32, vp, vp],
+    "acav_contrastive_destroy": [vp],
+    "acav_contrastive_get_params": [vp, vp, C.POINTER(i64)],
+    "acav_contrastive_set_params": [vp, vp],
+    "acav_contrastive_train": [vp, vp, vp, vp, i64, f64, vp, vp],
+    "acav_contrastive_infer": [vp, vp, vp, i64, vp],
     "acav_mi_create": [pp, i32, vp, i64, i32, i32, vp, i32, vp],
     "acav_mi_destroy": [vp],
     "acav_mi_add_samples": [vp, vp, i64],

@@ -123,6 +123,8 @@ SUBSET_DEFAULTS = {
     'subset': {'ratio': 0.2, 'size': None},
     'clustering': {'pairing': 'combination'},
     'batch': {'batch_size': 20, 'selection_size': 4, 'keep_unselected': True},
+    'contrastive': {'num_epochs': 3, 'num_warmup_steps': 1, 'base_lr': 2e-4, 'train_batch_size': 128, 'test_batch_size': 128,
+                    'cached_epoch': None, 'train_from_cached': False},
     'measure_name': 'batch_mi',
     'shuffle_candidates': True,
     'chunk_size': None,

@@ -46,7 +46,11 @@ def prepare(**kwargs):
 
 
 def run(args):
-    assert args.measure_name != 'contrastive', "the contrastive baseline is outside the hot path (SURVEY 8(f))"
+    """cli.py:90-100"""
+    if args.measure_name == 'contrastive':
+        assert args.chunk_size is None, "the chunked contrastive mode (chunk_contrastive.py) is not built: run it on all shards"
+        from .run_contrastive import run_single_contrastive
+        return run_single_contrastive(args)
     return run_single(args) if args.chunk_size is None else run_chunks(args)
 
 
@@ -64,6 +68,10 @@ class Cli:
         return out
 
     reduce = reduce_csvs
+
+    def merge_contrastive(self, **kwargs):
+        from .run_contrastive import merge_contrastive
+        return merge_contrastive(prepare(**kwargs))
 
 
 def main(argv=None):

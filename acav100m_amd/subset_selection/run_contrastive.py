@@ -1,0 +1,134 @@
+"""The contrastive baseline's drivers (subset_selection/code/run_contrastive.py:16-110,236-273, merge_contrastive.py):
+train the audio-visual InfoNCE model on the feature shards, score every clip, write the per-process inference cache;
+`merge_contrastive` sorts the caches by score and writes output.csv.  Host orchestration around
+measures/contrastive.Contrastive; single process per run like the reference's non-distributed path."""
+import os
+import shutil
+from pathlib import Path
+
+import numpy as np
+
+from .. import shards as io
+from .measures.contrastive import Contrastive
+
+VIDEO_KEY, AUDIO_KEY, LAYER = ('SLOWFAST_8x8_R50', 'kinetics-400'), ('VGGish', 'YouTube-8M'), 'layer_4'
+
+
+def _penultimate_views(table):
+    """the two feature matrices the reference model reads (contrastive.py:111-112): batch['SLOWFAST_8x8_R50/kinetics-400']
+    ['layer_4'] and batch['VGGish/YouTube-8M']['layer_4']; other extractors: the last layer of the video / audio model"""
+    def pick(kind, want):
+        views = [(v, m) for v, m in table.views.items() if v[0] == kind]
+        assert views, "no {} features in the shards".format(kind)
+        for v, m in views:
+            if table.tags.get((v[0], v[1])) == want and v[2] == LAYER:
+                return m
+        return sorted(views, key=lambda vm: vm[0][2])[-1][1]
+    return pick('video', VIDEO_KEY), pick('audio', AUDIO_KEY)
+
+
+def feature_batches(table, batch_size):
+    """-> (visual [n, vis], audio [n, aud], offsets, rows): consecutive batches of `batch_size` clips in shard order with
+    duplicate clips (same file stem) dropped inside a batch, first occurrence kept (contrastive.py:103-115)."""
+    visual, audio = _penultimate_views(table)
+    keep, offsets = [], [0]
+    n = len(table)
+    for s in range(0, n, batch_size):
+        seen = set()
+        for r in range(s, min(n, s + batch_size)):
+            stem = Path(table.filename[r]).stem
+            if stem not in seen:
+                seen.add(stem)
+                keep.append(r)
+        offsets.append(len(keep))
+    idx = np.asarray(keep, np.int64)
+    rows = [{'id': Path(table.filename[r]).stem, 'filename': table.filename[r], 'shard_name': table.shard_name[r]} for r in keep]
+    return np.ascontiguousarray(visual[idx]), np.ascontiguousarray(audio[idx]), np.asarray(offsets, np.int64), rows
+
+
+def _run(args, paths):
+    """run_contrastive.py:16-51: load a cached model or train, then score every clip"""
+    cfg = args.contrastive
+    table = io.load_feature_shards([Path(p) for p in paths])
+    visual, audio, offsets, rows = feature_batches(table, int(cfg.train_batch_size))
+    measure = Contrastive(cfg.num_epochs, args.computation.device, cfg.base_lr, cfg.num_warmup_steps,
+                          sizes=(visual.shape[1], audio.shape[1]))
+    trained = False
+    if cfg.cached_epoch is not None:
+        cache_path = measure.get_cache_path_load(args, paths, cfg.cached_epoch)
+        if cache_path is not None and Path(cache_path).is_file():
+            if args.verbose:
+                print("cache file found: {}".format(Path(cache_path).stem))
+                print("loading from cached file")
+            measure.load_cache(args, paths, cfg.cached_epoch)
+            trained = not cfg.train_from_cached
+        elif args.verbose:
+            print("no cache file found")
+            print("training from scratch")
+    if not trained:
+        print("training contrastive loss")
+        measure.train(args, paths, (visual, audio, offsets), args.log_every, args.verbose)
+    print("(node 0) running inference")
+    tv, ta, toff, trows = feature_batches(table, int(cfg.test_batch_size))
+    metas = io.load_metas([Path(p) for p in paths], args.data.meta.path)
+    scores, ids, _ = measure.infer(args, (tv, ta, toff), trows, metas, args.subset.size, args.verbose)
+    print("(node 0) done inference")
+    return measure, scores, [trows[i] for i in ids]
+
+
+def run_single_contrastive(args):
+    """run_contrastive.py:236-247: the whole dataset is scored (subset.size = None, ratio = 1); the selection is made
+    afterwards by `merge_contrastive` from the inference caches"""
+    args.parent_pid = str(args.parent_pid or os.getpid())
+    args.node_rank = 0 if args.node_rank is None else args.node_rank
+    args.chunk_num = 0 if args.chunk_num is None else args.chunk_num
+    paths = [p for p in sorted(io.brace_expand(args.data.path)) if Path(p).is_file()]
+    args.subset.size = None
+    args.subset.ratio = 1.0
+    out = _run(args, paths)
+    print("done")
+    return out
+
+
+def merge_contrastive(args):
+    """merge_contrastive.py:107-131 without the shell: concatenate the inference caches of the run with the most files,
+    sort by score descending (then by the rest of the line, duplicates of the sort key dropped: `sort -t , -u -k 1,1gr
+    -k 2`), drop the score column, drop repeated lines, write output.csv."""
+    out_path = Path(args.data.output.path)
+    cache_dir = out_path.parent / 'caches'
+    groups = {}
+    for p in cache_dir.glob("{}_contrastive_inferred_cache_*_*.csv".format(out_path.stem)):
+        groups.setdefault('_'.join(p.stem.split('_')[:-1]), []).append(p)
+    assert groups, "no inference caches under {}".format(cache_dir)
+    most = max(len(v) for v in groups.values())
+    name, paths = [(k, v) for k, v in groups.items() if len(v) == most][0]
+    print("loading from cache {}".format(name))
+    print("{} total cache files".format(len(paths)))
+    lines = []
+    for p in sorted(paths):
+        with open(p) as f:
+            lines.extend(line.rstrip('\n') for line in f if line.strip())
+    merged = cache_dir / ('merged_' + out_path.name)
+    merged.write_text(''.join(line + '\n' for line in lines))
+
+    def key(line):
+        score, rest = line.split(',', 1)
+        return (-float(score), rest)
+    ordered, seen = [], set()
+    for line in sorted(lines, key=key):
+        k = key(line)
+        if k not in seen:
+            seen.add(k)
+            ordered.append(line)
+    (cache_dir / ('sorted_' + out_path.name)).write_text(''.join(line + '\n' for line in ordered))
+    unique, seen = [], set()
+    for line in ordered:
+        rest = line.split(',', 1)[1]
+        if rest not in seen:
+            seen.add(rest)
+            unique.append(rest)
+    final = cache_dir / ('unique_' + out_path.name)
+    final.write_text(''.join(line + '\n' for line in unique))
+    shutil.copy(final, out_path)
+    print("done")
+    return out_path, len(unique)

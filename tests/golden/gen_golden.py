@@ -7,13 +7,15 @@ this script and the tiny stand-in modules under _stubs/ for the reference's un-v
 imports (torch_scatter, diffdist, wget, braceexpand).
 
     python tests/golden/gen_golden.py            # all three groups
-    python tests/golden/gen_golden.py kmeans|mi|mi_exact|rng|cli
+    python tests/golden/gen_golden.py kmeans|mi|mi_exact|rng|cli|contrastive
 
 Groups:
   rng.npz     torch.manual_seed/rand/randperm and random.shuffle streams (G6)
   kmeans_*.npz   KMeans state after every epoch, warm-up labels, per-step means, labels (G1/G2)
   mi_*.npz    per-iteration trace of EfficientBatchMI greedy: batch ids, fp32 scores [B,P],
               picked positions / ids; final S and GAIN (G3)
+  contrastive_*.npz   the contrastive baseline: seeded init, per-batch loss/acc of its train loop, trained
+              parameters, infer() scores
   cli_clustering.npz / cli_output.csv   the reference's two CLIs end to end on synthetic shards
               regenerated from a seed by tests/golden/synth.py (G5)
 The two reference stages have clashing top-level module names, so each group runs in its own
@@ -322,6 +324,62 @@ def gen_cli_subset(root):
     print("cli_output.csv written:", len(text.splitlines()), "lines; first:", text.splitlines()[0])
 
 
+# ----------------------------------------------------------------------------- contrastive
+def gen_contrastive():
+    """reference contrastive baseline (measures/contrastive/module.py:9-98, contrastive.py:27-132): the module's
+    initial parameters from a seeded generator, per-batch loss / accuracy of its train loop (AdamW amsgrad, linear
+    warm-up schedule per epoch, gradients NEVER zeroed -- contrastive.py:92-101 has no zero_grad), parameters after
+    training, and infer() scores."""
+    sys.path.insert(0, STUBS)
+    sys.path.insert(1, os.path.join(REF, "subset_selection", "code"))
+    import torch
+    from measures.contrastive.module import ContrastiveModule
+    from measures.contrastive import contrastive as C
+    cases = {"a": dict(seed=0, vis=96, aud=32, out=None, B=16, nb=6, epochs=2, base_lr=1e-3, warm=1),
+             "b": dict(seed=3, vis=80, aud=48, out=24, B=24, nb=5, epochs=3, base_lr=2e-4, warm=1),
+             "c": dict(seed=5, vis=2304, aud=128, out=None, B=128, nb=3, epochs=1, base_lr=2e-4, warm=1)}
+    for name, c in cases.items():
+        torch.manual_seed(c["seed"])
+        model = ContrastiveModule(c["vis"], c["aud"], c["out"])
+        rs = np.random.RandomState(100 + c["seed"])
+        n = c["B"] * c["nb"]
+        comp = rs.randint(0, 12, n)
+        cv, ca = rs.randn(12, c["vis"]).astype(np.float32), rs.randn(12, c["aud"]).astype(np.float32)
+        visual = (cv[comp] + 0.5 * rs.randn(n, c["vis"])).astype(np.float32)
+        audio = (ca[comp] + 0.5 * rs.randn(n, c["aud"])).astype(np.float32)
+        out = {k: np.array(v) for k, v in c.items() if v is not None}
+        sd0 = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+        if name != "c":
+            out.update({"p0_" + k: v for k, v in sd0.items()})
+        else:  # 1.2 MB of weights: keep the first rows (the seeded init is pinned by cases a/b)
+            out.update({"p0_" + k: v[:4] for k, v in sd0.items()})
+            out["p0_full_sum"] = np.array([float(v.astype(np.float64).sum()) for v in sd0.values()])
+        out["visual"], out["audio"] = (visual, audio) if name != "c" else (visual[:, :8], audio[:, :8])
+        out["data_seed"] = np.array(100 + c["seed"])
+        model.train()
+        opt = C.get_optimizer(model.parameters(), c["base_lr"])
+        losses, accs, lrs = [], [], []
+        vt, at = torch.from_numpy(visual), torch.from_numpy(audio)
+        for epoch in range(c["epochs"]):
+            opt, lr = C.update_lr(opt, epoch, c["epochs"], c["base_lr"], c["warm"])
+            lrs.append(lr)
+            for bi in range(c["nb"]):
+                sl = slice(bi * c["B"], (bi + 1) * c["B"])
+                loss, acc = model(vt[sl], at[sl])
+                loss.backward()  # no zero_grad anywhere in the reference loop: the gradients accumulate
+                opt.step()
+                losses.append(loss.item())
+                accs.append(acc.item())
+        out["losses"], out["accs"], out["lrs"] = np.array(losses), np.array(accs), np.array(lrs)
+        sd1 = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+        out.update({"p1_" + k: (v if name != "c" else v[:4]) for k, v in sd1.items()})
+        model.eval()
+        with torch.no_grad():
+            out["infer"] = model.infer(vt, at).numpy()
+        np.savez_compressed(os.path.join(HERE, f"contrastive_{name}.npz"), **out)
+        print(f"contrastive_{name}.npz written: loss {losses[0]:.4f} -> {losses[-1]:.4f}")
+
+
 def gen_cli():
     import tempfile
     root = tempfile.mkdtemp(prefix="acav_golden_")
@@ -336,9 +394,10 @@ if __name__ == "__main__":
     if sys.argv[1:2] == ["cli_subset"]:
         gen_cli_subset(sys.argv[2])
         sys.exit(0)
-    which = sys.argv[1:] or ["rng", "kmeans", "mi", "mi_exact", "cli"]
+    which = sys.argv[1:] or ["rng", "kmeans", "mi", "mi_exact", "cli", "contrastive"]
     if len(which) > 1:
         for w in which:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
-        {"rng": gen_rng, "kmeans": gen_kmeans, "mi": gen_mi, "mi_exact": gen_mi_exact, "cli": gen_cli}[which[0]]()
+        {"rng": gen_rng, "kmeans": gen_kmeans, "mi": gen_mi, "mi_exact": gen_mi_exact, "cli": gen_cli,
+         "contrastive": gen_contrastive}[which[0]]()

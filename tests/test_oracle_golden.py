@@ -191,3 +191,53 @@ def test_mi_exact_greedy_golden(golden_dir, name, measure):
     if measure == "mem_mi" and name in ("a", "b"):
         free = O.BatchMI(a, c, pairs).run_exact(cand[1:], cand[:1], subset)
         assert np.array_equal(free["S"], g["mem_mi_S"][1:])
+
+
+def _contrastive_data(seed, n, vis, aud):
+    """the generator recipe of tests/golden/gen_golden.py:gen_contrastive (case c only stores the first columns)"""
+    rs = np.random.RandomState(seed)
+    comp = rs.randint(0, 12, n)
+    cv, ca = rs.randn(12, vis).astype(np.float32), rs.randn(12, aud).astype(np.float32)
+    return (cv[comp] + 0.5 * rs.randn(n, vis)).astype(np.float32), (ca[comp] + 0.5 * rs.randn(n, aud)).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_contrastive_oracle_vs_reference(golden_dir, name):
+    """oracle/contrastive_ref.py against the reference module's own run: nn.Linear init from the seeded torch stream
+    (bit-exact), per-batch loss / accuracy over the epochs (gradients accumulating, AdamW amsgrad, per-epoch lr),
+    trained parameters and infer() scores within 1e-4 relative (the reference sums its GEMMs in MKL's order)."""
+    from oracle import oracle as O
+    from oracle import contrastive_ref as CR
+    g = np.load(os.path.join(golden_dir, f"contrastive_{name}.npz"))
+    vis, aud, B, nb, epochs = int(g["vis"]), int(g["aud"]), int(g["B"]), int(g["nb"]), int(g["epochs"])
+    out = int(g["out"]) if "out" in g.files else min(vis, aud)
+    rng = O.Rng(int(g["seed"]))
+    wv, bv = CR.linear_init(lambda n: rng.rand(n), out, vis)
+    wa, ba = CR.linear_init(lambda n: rng.rand(n), out, aud)
+    init = {"visual_linear.weight": wv, "visual_linear.bias": bv, "audio_linear.weight": wa, "audio_linear.bias": ba}
+    for k, v in init.items():
+        ref = g["p0_" + k]
+        assert np.array_equal(v[:len(ref)], ref), f"{k}: seeded init differs from torch"
+    if name == "c":
+        visual, audio = _contrastive_data(int(g["data_seed"]), B * nb, vis, aud)
+        assert np.array_equal(visual[:, :8], g["visual"]) and np.array_equal(audio[:, :8], g["audio"])
+        sums = [float(v.astype(np.float64).sum()) for v in init.values()]
+        np.testing.assert_allclose(sums, g["p0_full_sum"], rtol=1e-12)
+    else:
+        visual, audio = g["visual"], g["audio"]
+    m = CR.Contrastive(wv, bv, wa, ba)
+    losses, accs = [], []
+    for epoch in range(epochs):
+        lr = CR.epoch_lr(epoch, epochs, float(g["base_lr"]), int(g["warm"]))
+        assert abs(lr - g["lrs"][epoch]) < 1e-15
+        for bi in range(nb):
+            sl = slice(bi * B, (bi + 1) * B)
+            lo, ac = m.train_batch(visual[sl], audio[sl], lr)
+            losses.append(lo)
+            accs.append(ac)
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-5)
+    np.testing.assert_allclose(accs, g["accs"], atol=1e-4)
+    for k, v in zip(init, m.p):
+        ref = g["p1_" + k]
+        np.testing.assert_allclose(v[:len(ref)], ref, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(m.infer(visual, audio), g["infer"], rtol=1e-4, atol=1e-6)
