@@ -26,7 +26,7 @@ collective on the step path); assign is local; the MI selection runs per rank on
 chunked mode with one chunk per GPU (chunk.py:21-53) -- no exchange.
 
 The JSON line also carries
-  roofline      k_assign_bf16, the HBM-bound kernel of the path: algorithmic bytes N*d*4 + N*8 per launch over the
+  roofline      k_assign_bf16_rw, the HBM-bound kernel of the path: algorithmic bytes N*d*4 + N*8 per launch over the
                 kernel's duration measured with HIP events on the library's stream around that launch alone
                 (`sweep_*` keys: the whole calc_best sweep incl. centre preparation and the exact re-check pass)
   roofline_mi   the candidate-permutation stream of the greedy loop (16 L bytes per iteration) vs HBM
@@ -281,7 +281,7 @@ def main():
                        "assign_sweep_ms": s_ms, "mi_us_per_iteration": st["mi"] * 1e6 / iters,
                        "train_clips_per_s": n / st["train"], "assign_clips_per_s": n / st["assign"],
                        "mi_clips_per_s": n / st["mi"]},
-            "roofline": {"kernel": "k_assign_bf16", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "k_assign_bf16_rw", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                          "traffic_from_committed_profile": traffic_profile,
                          "launch_ms": f_ms, "algorithmic_bytes": bytes_per_launch,
@@ -295,7 +295,7 @@ def main():
                             "frac": perm_bytes / st["mi"] / 1e9 / HBM_PEAK_GBS,
                             "note": "16 L bytes per iteration (int64 candidate permutation read + write, SURVEY 8(d)) over "
                                     "the whole selection incl. its host part (python shuffle, table set-up)"},
-            "train_kernel": {"kernel": "k_train_persistent" if world == 1 else
+            "train_kernel": {"kernel": "k_train_persistent (both views' launches side by side: acav_kmeans_train_multi)" if world == 1 else
                              "k_step_dist_dma + k_step_update (global batch %d)" % (b * world),
                              "bound": "latency (dependent chain of %d steps per epoch and view)" % (n // b),
                              "us_per_step": st["train"] * 1e6 / train_steps},

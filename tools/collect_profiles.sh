@@ -1,33 +1,57 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence behind bench.py's roofline object on the GPU box:
-#   tools/collect_profiles.sh <prefix>      (e.g. r01_final)  -> gpurun_out/profiles/<prefix>_*
-# Three separate runs of the same command, as the MI355X guide prescribes: kernel trace + stats, then one --pmc
-# pass per counter (never combined with a trace domain).  Copy the results into profiles/ afterwards.
+# Collect the rocprofv3 evidence behind bench.py's roofline objects and DESIGN.md's tables on the GPU box:
+#   tools/collect_profiles.sh <prefix>      (e.g. r02)  -> gpurun_out/profiles/<prefix>_*
+# Separate runs, as the MI355X guide prescribes: kernel trace + stats, then one --pmc pass per counter (never combined
+# with a trace domain).  Copy the results into profiles/ afterwards.
 set -u
-P=${1:-r01}
+P=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profiles
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
-timeout 600 $CMD > "$OUT/${P}_bench_1gpu.json" 2> /dev/null
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- $CMD > "$OUT/${P}_bench_under_rocprof.json" 2> /dev/null
-cp "$OUT"/kt/*kernel_stats.csv "$OUT/${P}_kernel_stats.csv" 2> /dev/null
-for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 900 rocprofv3 --pmc $C --kernel-include-regex "k_assign" --output-format csv -d "$OUT/pmc_$C" -o pmc -- $CMD > /dev/null 2>&1
-    L=$(echo $C | tr 'A-Z' 'a-z' | sed 's/_size//')
-    cp "$OUT"/pmc_$C/*counter_collection.csv "$OUT/${P}_pmc_${L}_counter_collection.csv" 2> /dev/null
-done
+stats() {  # stats <tag> <cmd...>: kernel-trace statistics of a command -> ${P}_<tag>_kernel_stats.csv, stdout -> ${P}_<tag>.txt
+    local tag=$1; shift
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$tag" -o kt -- "$@" > "$OUT/${P}_${tag}.txt" 2> /dev/null
+    cp "$OUT"/kt_$tag/*kernel_stats.csv "$OUT/${P}_${tag}_kernel_stats.csv" 2> /dev/null
+    rm -rf "$OUT/kt_$tag"
+}
+pmc() {  # pmc <tag> <kernel regex> <counters> <cmd...>
+    local tag=$1 re=$2 ctr=$3; shift 3
+    timeout 900 rocprofv3 --pmc $ctr --kernel-include-regex "$re" --output-format csv -d "$OUT/pmc_$tag" -o pmc -- "$@" > /dev/null 2>&1
+    cp "$OUT"/pmc_$tag/*counter_collection.csv "$OUT/${P}_pmc_${tag}_counter_collection.csv" 2> /dev/null
+    rm -rf "$OUT/pmc_$tag"
+}
+# 1. the driver's command (one step: 150k greedy launches make the trace large), alone and under the tracer
+timeout 900 python bench.py --steps 2 --warmup 1 > "$OUT/${P}_bench_1gpu.json" 2> /dev/null
+stats bench_under_rocprof python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-variants
+# 2. the assign sweep alone (the kernel of bench.py's `roofline`): stats, HBM traffic, pipe counters; round-1 layout for the A/B
+stats assign_filter python tools/run_assign_only.py 1000000 20 filter
+pmc fetch "k_assign" FETCH_SIZE python tools/run_assign_only.py 1000000 5 filter
+pmc write "k_assign" WRITE_SIZE python tools/run_assign_only.py 1000000 5 filter
 python tools/summarize_pmc.py "$OUT" "$P"
-# the other kernels DESIGN.md quotes: MI greedy (one chunk, 8 chunks in lockstep) and the exact fp32 assign sweep
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktmi" -o kt -- python tools/bench_mi.py 100000 256 2 > "$OUT/${P}_mi_one_chunk.json" 2> /dev/null
-cp "$OUT"/ktmi/*kernel_stats.csv "$OUT/${P}_mi_one_chunk_kernel_stats.csv" 2> /dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktml" -o kt -- python tools/bench_mi_lockstep.py 100000 256 2 8 > "$OUT/${P}_mi_lockstep8.json" 2> /dev/null
-cp "$OUT"/ktml/*kernel_stats.csv "$OUT/${P}_mi_lockstep8_kernel_stats.csv" 2> /dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktex" -o kt -- python tools/run_assign_only.py 1000000 3 exact > "$OUT/${P}_assign_exact.txt" 2> /dev/null
-cp "$OUT"/ktex/*kernel_stats.csv "$OUT/${P}_assign_exact_kernel_stats.csv" 2> /dev/null
-timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "k_assign_f32" --output-format csv -d "$OUT/pmcex" -o pmc -- python tools/run_assign_only.py 1000000 2 exact > /dev/null 2>&1
-cp "$OUT"/pmcex/*counter_collection.csv "$OUT/${P}_assign_exact_pmc_mfma_counter_collection.csv" 2> /dev/null
-for f in "$OUT/${P}_mi_one_chunk.json" "$OUT/${P}_mi_lockstep8.json"; do grep "^{" "$f" | tail -1 > "$f.tmp" && mv "$f.tmp" "$f"; done
-rm -rf "$OUT/kt" "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT/ktmi" "$OUT/ktml" "$OUT/ktex" "$OUT/pmcex"
+for C in SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS SQ_BUSY_CYCLES; do
+    pmc "rw_$C" "k_assign_bf16" $C python tools/run_assign_only.py 1000000 5 filter
+    ACAV_FILTER_V1=1 pmc "v1_$C" "k_assign_bf16" $C python tools/run_assign_only.py 1000000 5 filter
+done
+ACAV_FILTER_V1=1 timeout 300 python tools/run_assign_only.py 1000000 20 filter > "$OUT/${P}_assign_filter_v1.txt" 2> /dev/null
+python tools/summarize_counters.py "$OUT" "$P" > "$OUT/${P}_assign_pipe_counters.json"
+stats assign_exact python tools/run_assign_only.py 1000000 3 exact
+stats assign_k1024 python tools/run_assign_only.py 1000000 3 filter 1024 1024
+# 3. MI greedy: one chunk at V = 1M (3000 iterations) and V = 100k, legacy global-atomic kernels for the A/B, 8 chunks in lockstep
+stats mi_1m python tools/bench_mi.py 1000000 256 2 0 3000
+ACAV_FY_LEGACY=1 stats mi_1m_legacy python tools/bench_mi.py 1000000 256 2 0 3000
+stats mi_100k python tools/bench_mi.py 100000 256 2
+stats mi_lockstep8 python tools/bench_mi_lockstep.py 100000 256 2 8
+ACAV_MI_TIMING=1 timeout 300 python tools/bench_mi.py 1000000 256 2 0 20000 > "$OUT/${P}_mi_1m_steady.txt" 2>&1
+# 4. SGD step per shape (persistent / wide persistent / per-step launches)
+: > "$OUT/${P}_train_shapes.txt"
+for shape in "1024 256" "512 64" "1024 1024" "128 1024" "2048 1024" "2048 256"; do
+    set -- $shape
+    echo "d=$1 K=$2" >> "$OUT/${P}_train_shapes.txt"
+    BENCH_D=$1 BENCH_K=$2 timeout 300 python tools/bench_train_b.py 32 2> /dev/null | tail -1 >> "$OUT/${P}_train_shapes.txt"
+    ACAV_NO_PERSISTENT=1 BENCH_D=$1 BENCH_K=$2 timeout 300 python tools/bench_train_b.py 32 2> /dev/null | tail -1 | sed 's/^/   per-step launches: /' >> "$OUT/${P}_train_shapes.txt"
+done
+ACAV_PROFILE_STEPS=1 BENCH_D=1024 BENCH_K=256 timeout 300 python tools/bench_train_b.py 32 > "$OUT/${P}_train_phase_cycles.txt" 2>&1
+for f in "$OUT"/${P}_*.txt; do sed -i '/amdgpu.ids/d' "$f"; done
+for f in "$OUT/${P}_mi_1m.txt" "$OUT/${P}_mi_1m_legacy.txt" "$OUT/${P}_mi_100k.txt" "$OUT/${P}_mi_lockstep8.txt" "$OUT/${P}_bench_under_rocprof.txt"; do grep "^{" "$f" | tail -1 > "$f.tmp" && mv "$f.tmp" "${f%.txt}.json" && rm -f "$f"; done
 ls -la "$OUT"

@@ -25,14 +25,14 @@ def per_kernel(path):
 
 fetch = per_kernel(f"{out}/{prefix}_pmc_fetch_counter_collection.csv")
 write = per_kernel(f"{out}/{prefix}_pmc_write_counter_collection.csv")
-fk = fetch.get("k_assign_bf16", 0.0)
-wk = write.get("k_assign_bf16", 0.0)
+fk = fetch.get("k_assign_bf16_rw", fetch.get("k_assign_bf16", 0.0))
+wk = write.get("k_assign_bf16_rw", write.get("k_assign_bf16", 0.0))
 traffic = (2.0 * fk + wk + 2.0 * fetch.get("k_assign_f32", 0.0) + write.get("k_assign_f32", 0.0)) * 1024.0
 alg = N * D * 4 + N * 8
 json.dump({
-    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-include-regex k_assign -- python bench.py --steps 2 "
-               "--warmup 1 --no-cpu-baseline (separate passes; tools/collect_profiles.sh)",
-    "kernel": "k_assign_bf16 + k_assign_f32 (exact re-check pass, empty list on this data)",
+    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-include-regex k_assign -- python tools/run_assign_only.py "
+               "1000000 5 filter (separate passes; tools/collect_profiles.sh)",
+    "kernel": "k_assign_bf16_rw + k_assign_f32 (exact re-check pass, empty list on this data)",
     "rows": N, "d": D, "K": K,
     "FETCH_SIZE_raw_KB": fetch, "WRITE_SIZE_raw_KB": write,
     "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads "
