@@ -644,17 +644,17 @@ constexpr int FY_NBUF = 4;         // src / g buffers: k_fy_part + k_fy_tile may
 constexpr int FY_SHARDS = 8;       // sub-buckets per tile (capg entries each), filled by workgroups b with b % 8 == shard
 constexpr int FYT_THREADS = 1024;  // k_fy_tile: the list walks are chains of dependent LDS reads -- many waves hide them
 
-__global__ __launch_bounds__(FYA_THREADS) void k_fy_part(const unsigned *__restrict__ draws, int L,
-                                                         const unsigned short *__restrict__ table, int ntab, int gsh, int NT,
-                                                         int capg, int2 *__restrict__ bucket, int *__restrict__ gcount,
-                                                         unsigned *__restrict__ src, unsigned *__restrict__ err)
+__device__ __forceinline__ void fy_part_body(const unsigned *__restrict__ draws, int L, const unsigned short *__restrict__ table,
+                                             int ntab, int gsh, int NT, int capg, int2 *__restrict__ bucket,
+                                             int *__restrict__ gcount, unsigned *__restrict__ src, unsigned *__restrict__ err,
+                                             int bx)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fy_smem[];
     int *lhist = reinterpret_cast<int *>(fy_smem), *lbase = lhist + NT;
     unsigned short *ltab = reinterpret_cast<unsigned short *>(lbase + NT);  // the tile table, a few KB: LDS lookups
     const int tid = threadIdx.x;
     constexpr int PER = FYA_CH / FYA_THREADS;
-    const int base = blockIdx.x * FYA_CH;
+    const int base = bx * FYA_CH;
     unsigned dr[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {  // all draw loads in flight before anything else
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(FYA_THREADS) void k_fy_part(const unsigned *__restr
     __syncthreads();
     // one reservation per non-empty bin -- in the workgroup's SHARD of the tile's bucket (workgroup b lands on XCD
     // b % 8: a shard is written through one L2 only)
-    const int shard = blockIdx.x & (FY_SHARDS - 1);
+    const int shard = bx & (FY_SHARDS - 1);
     for (int t = tid; t < NT; t += FYA_THREADS) {
         const int c = lhist[t];
         lbase[t] = c ? atomicAdd(&gcount[t * FY_SHARDS + shard], c) : 0;
@@ -702,9 +702,17 @@ __global__ __launch_bounds__(FYA_THREADS) void k_fy_part(const unsigned *__restr
         }
 }
 
-__global__ __launch_bounds__(FYT_THREADS) void k_fy_tile(int L, const int *__restrict__ ebound, int capg, int ecap, int wcap,
-                                                         const int2 *__restrict__ bucket, int *__restrict__ gcount,
-                                                         unsigned *__restrict__ src, int *__restrict__ g, unsigned *__restrict__ err)
+__global__ __launch_bounds__(FYA_THREADS) void k_fy_part(const unsigned *__restrict__ draws, int L,
+                                                         const unsigned short *__restrict__ table, int ntab, int gsh, int NT,
+                                                         int capg, int2 *__restrict__ bucket, int *__restrict__ gcount,
+                                                         unsigned *__restrict__ src, unsigned *__restrict__ err)
+{
+    fy_part_body(draws, L, table, ntab, gsh, NT, capg, bucket, gcount, src, err, (int)blockIdx.x);
+}
+
+__device__ __forceinline__ void fy_tile_body(int L, const int *__restrict__ ebound, int capg, int ecap, int wcap,
+                                             const int2 *__restrict__ bucket, int *__restrict__ gcount, unsigned *__restrict__ src,
+                                             int *__restrict__ g, unsigned *__restrict__ err, int tile)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fy_smem[];
     int *lhead = reinterpret_cast<int *>(fy_smem);   // [wcap] newest entry of the position's pull list
@@ -714,7 +722,7 @@ __global__ __launch_bounds__(FYT_THREADS) void k_fy_tile(int L, const int *__res
     unsigned short *enx = ep + ecap;                   // [ecap] next entry of the list, 0xFFFF = end
     __shared__ int lcnt;
     __shared__ int soff[FY_SHARDS + 1];
-    const int tid = threadIdx.x, tile = blockIdx.x;
+    const int tid = threadIdx.x;
     const int e_lo = ebound[tile], e_hi = ebound[tile + 1];
     if (e_lo > L - 1) return;  // the list no longer reaches this tile (no step targets it: its counts are 0)
     const int q_lo = L - e_hi, w = e_hi - e_lo;  // positions q_lo .. q_lo + w - 1 (q_lo may be negative)
@@ -775,15 +783,22 @@ __global__ __launch_bounds__(FYT_THREADS) void k_fy_tile(int L, const int *__res
     }
 }
 
-__global__ __launch_bounds__(256) void k_fy_gather_select(
+__global__ __launch_bounds__(FYT_THREADS) void k_fy_tile(int L, const int *__restrict__ ebound, int capg, int ecap, int wcap,
+                                                         const int2 *__restrict__ bucket, int *__restrict__ gcount,
+                                                         unsigned *__restrict__ src, int *__restrict__ g, unsigned *__restrict__ err)
+{
+    fy_tile_body(L, ebound, capg, ecap, wcap, bucket, gcount, src, g, err, (int)blockIdx.x);
+}
+
+__device__ __forceinline__ void fy_gather_select_body(
     const int *__restrict__ A, int L, const unsigned *__restrict__ src, const int *__restrict__ g, int *__restrict__ A_new,
     const int *__restrict__ asg, int D, int C, int P, const int *__restrict__ pairs, int *__restrict__ batch, int B, int k,
     int *__restrict__ Nc, int *__restrict__ ac, int *__restrict__ bc, double *__restrict__ SN, double *__restrict__ Sa,
     double *__restrict__ Sb, const double *__restrict__ phi, MiScalars *__restrict__ sc, long long *__restrict__ S_out,
     double *__restrict__ G_out, const int *__restrict__ forced_pos, int *__restrict__ trace_pos,
-    long long *__restrict__ trace_ids, double *__restrict__ trace_scores, int keep_unselected)
+    long long *__restrict__ trace_ids, double *__restrict__ trace_scores, int keep_unselected, int bx)
 {
-    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    const int i = (int)(bx * 256 + threadIdx.x);
     if (i < L) {
         const unsigned s = src[i];
         int a = (int)(s & 0x7fffffffu);
@@ -797,11 +812,82 @@ __global__ __launch_bounds__(256) void k_fy_gather_select(
         else
             A_new[i - B] = v;
     }
-    if (blockIdx.x != 0) return;  // uniform
+    if (bx != 0) return;  // uniform
     __threadfence_block();
     __syncthreads();
     mi_select_body(asg, D, C, P, pairs, batch, B, k, Nc, ac, bc, SN, Sa, Sb, phi, sc, nullptr, S_out, G_out, forced_pos,
                    trace_pos, trace_ids, trace_scores, keep_unselected, A_new + (L - B));
+}
+
+__global__ __launch_bounds__(256) void k_fy_gather_select(
+    const int *__restrict__ A, int L, const unsigned *__restrict__ src, const int *__restrict__ g, int *__restrict__ A_new,
+    const int *__restrict__ asg, int D, int C, int P, const int *__restrict__ pairs, int *__restrict__ batch, int B, int k,
+    int *__restrict__ Nc, int *__restrict__ ac, int *__restrict__ bc, double *__restrict__ SN, double *__restrict__ Sa,
+    double *__restrict__ Sb, const double *__restrict__ phi, MiScalars *__restrict__ sc, long long *__restrict__ S_out,
+    double *__restrict__ G_out, const int *__restrict__ forced_pos, int *__restrict__ trace_pos,
+    long long *__restrict__ trace_ids, double *__restrict__ trace_scores, int keep_unselected)
+{
+    fy_gather_select_body(A, L, src, g, A_new, asg, D, C, P, pairs, batch, B, k, Nc, ac, bc, SN, Sa, Sb, phi, sc, S_out, G_out,
+                          forced_pos, trace_pos, trace_ids, trace_scores, keep_unselected, (int)blockIdx.x);
+}
+
+// Several independent chunks (chunk.py:21-53) through the same three kernels with ONE launch each per iteration:
+// blockIdx.y picks the chunk, everything per chunk comes from a descriptor, everything that changes per iteration is a
+// function of the iteration number (L_t = L0 - t dl, buffer parities, the position of the iteration's draws in the
+// chunk's generator ring: r0(t) = t (L0 - 1) - dl t (t - 1) / 2).  Same device functions: same results per chunk.
+struct TileChunk {
+    const unsigned *ring;  // draw r' (counted from the first GENERATED word) at ring[r' mod ring_words]; r < head: ring[r - head]
+    long long head, ring_words;
+    const unsigned short *table;
+    const int *ebound;
+    int2 *bucket;
+    int *gcount;
+    unsigned *src[FY_NBUF];
+    int *g[FY_NBUF];
+    int *A[2];
+    unsigned *err;
+    const int *asg, *pairs;
+    int *batch, *Nc, *ac, *bc;
+    double *SN, *Sa, *Sb;
+    const double *phi;
+    MiScalars *sc;
+    long long *S;
+    double *G;
+    int L0, iters, ntab, gsh, NT, capg, ecap, wcap, D, C, P, pad;
+};
+
+__device__ __forceinline__ const unsigned *chunk_draw_ptr(const TileChunk &c, int it, int dl)
+{
+    const long long r0 = (long long)it * (c.L0 - 1) - (long long)dl * it * (it - 1) / 2;
+    return r0 < c.head ? c.ring - (c.head - r0) : c.ring + (r0 - c.head) % c.ring_words;
+}
+
+__global__ __launch_bounds__(FYA_THREADS) void k_fy_part_multi(const TileChunk *__restrict__ cd, int it, int dl)
+{
+    const TileChunk &c = cd[blockIdx.y];
+    const int L = c.L0 - it * dl;
+    if (it >= c.iters || (int)blockIdx.x * FYA_CH >= L) return;
+    fy_part_body(chunk_draw_ptr(c, it, dl), L, c.table, c.ntab, c.gsh, c.NT, c.capg, c.bucket, c.gcount, c.src[it % FY_NBUF], c.err,
+                 (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(FYT_THREADS) void k_fy_tile_multi(const TileChunk *__restrict__ cd, int it, int dl)
+{
+    const TileChunk &c = cd[blockIdx.y];
+    if (it >= c.iters || (int)blockIdx.x >= c.NT) return;
+    fy_tile_body(c.L0 - it * dl, c.ebound, c.capg, c.ecap, c.wcap, c.bucket, c.gcount, c.src[it % FY_NBUF], c.g[it % FY_NBUF], c.err,
+                 (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void k_fy_gather_select_multi(const TileChunk *__restrict__ cd, int it, int dl, int B, int k,
+                                                                int keep_unselected)
+{
+    const TileChunk &c = cd[blockIdx.y];
+    const int L = c.L0 - it * dl;
+    if (it >= c.iters || (int)blockIdx.x * 256 >= L) return;
+    fy_gather_select_body(c.A[it & 1], L, c.src[it % FY_NBUF], c.g[it % FY_NBUF], c.A[(it + 1) & 1], c.asg, c.D, c.C, c.P, c.pairs,
+                          c.batch, B, k, c.Nc, c.ac, c.bc, c.SN, c.Sa, c.Sb, c.phi, c.sc, c.S + (size_t)it * k,
+                          c.G + (size_t)it * k, nullptr, nullptr, nullptr, nullptr, keep_unselected, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------ several chunks in lockstep
@@ -1098,6 +1184,28 @@ struct FyPlan {
     size_t tile_smem() const { return (size_t)wcap * 8 + (size_t)ecap_lds * 8; }
 };
 
+// tiling of a list of (at most) L candidates and the handle's buffers for it: table, tile bounds, sharded buckets and their
+// counters (zeroed), error flag (cleared), FY_NBUF src / g buffers; uploads are stream-ordered on st (fp must stay alive
+// until st has been synchronised)
+static int fy_setup(acav_mi *mi, int64_t L, FyPlan &fp, hipStream_t st)
+{
+    fp.build(L);
+    ACAV_TRY(mi->fy_table.ensure(sizeof(unsigned short) * fp.table.size()));
+    ACAV_TRY(mi->fy_bounds.ensure(sizeof(int) * fp.ebound.size()));
+    ACAV_TRY(mi->fy_bucket.ensure(sizeof(int2) * (size_t)fp.NT * FY_SHARDS * fp.capg));
+    ACAV_TRY(mi->fy_count.ensure(sizeof(int) * (size_t)fp.NT * FY_SHARDS));
+    ACAV_TRY(mi->fy_err.ensure(sizeof(unsigned)));
+    for (int q = 0; q < FY_NBUF; ++q) {
+        ACAV_TRY(mi->fy_src[q].ensure(sizeof(unsigned) * (size_t)L));
+        ACAV_TRY(mi->fy_g[q].ensure(sizeof(int) * (size_t)L));
+    }
+    ACAV_HIP_TRY(hipMemcpyAsync(mi->fy_table.p, fp.table.data(), sizeof(unsigned short) * fp.table.size(), hipMemcpyHostToDevice, st));
+    ACAV_HIP_TRY(hipMemcpyAsync(mi->fy_bounds.p, fp.ebound.data(), sizeof(int) * fp.ebound.size(), hipMemcpyHostToDevice, st));
+    ACAV_HIP_TRY(hipMemsetAsync(mi->fy_count.p, 0, sizeof(int) * (size_t)fp.NT * FY_SHARDS, st));
+    ACAV_HIP_TRY(hipMemsetAsync(mi->fy_err.p, 0, sizeof(unsigned), st));
+    return ACAV_OK;
+}
+
 static int ids_to_device32(acav_mi *mi, const int64_t *ids, int64_t n, DevBuf &stage, DevBuf &out32)
 {
     hipStream_t st = mi->ctx.stream;
@@ -1233,6 +1341,132 @@ ACAV_EXPORT int acav_mi_destroy(acav_mi *mi)
 // lockstep: the same kernels as acav_mi_run_greedy, one launch serving every chunk (see ChunkDesc).  All handles
 // must live on the same device; the first handle's streams carry the work.  Results per chunk are exactly those
 // of acav_mi_run_greedy called with that chunk's arguments and generator.
+// the lockstep run on the lane generator + tiled Fisher-Yates kernels (every chunk's list within FY_TILED_MAX)
+static int run_greedy_multi_tiled(acav_mi **mis, int nchunks, const int64_t *const *candidates, const int64_t *L,
+                                  const int64_t *const *start, const int *ns, const int64_t *subset, int B, int k,
+                                  int keep_unselected, acav_rng **rngs, int64_t *const *S_out, double *const *GAIN_out,
+                                  int64_t *n_selected, int64_t *n_iters)
+{
+    acav_mi *lead = mis[0];
+    hipStream_t st = lead->ctx.stream, sf = lead->st_fy;
+    const int64_t dl = B - (keep_unselected ? B - k : 0);
+    std::vector<TileChunk> desc((size_t)nchunks);
+    std::vector<int64_t> iters((size_t)nchunks, 0), r0((size_t)nchunks, 0);
+    std::vector<FyPlan> plans((size_t)nchunks);
+    std::vector<MtStream> streams((size_t)nchunks);
+    int64_t iters_max = 0, lmax = 0;
+    int pmax = 1, ntmax = 1;
+    size_t part_smem = 0, tile_smem = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        acav_mi *mi = mis[c];
+        ACAV_HIP_TRY(hipStreamSynchronize(mi->ctx.stream));  // whatever the handle was doing on its own stream is over
+        if (ns[c]) ACAV_TRY(acav_mi_add_samples(mi, start[c], ns[c]));
+        int64_t nS = 0, l = L[c], itc = 0, draws = 0;
+        while (nS < subset[c]) {
+            ACAV_REQUIRE(l >= B, ACAV_ERANGE, "chunk %d: %lld candidates left < batch_size %d (batch.py:143-150)", c,
+                         (long long)l, B);
+            draws += l > 1 ? l - 1 : 0;
+            nS += k;
+            l -= dl;
+            ++itc;
+        }
+        iters[(size_t)c] = itc;
+        iters_max = itc > iters_max ? itc : iters_max;
+        lmax = L[c] > lmax ? L[c] : lmax;
+        pmax = mi->P > pmax ? mi->P : pmax;
+        const size_t Lc = (size_t)L[c];
+        ACAV_TRY(mi->A0.ensure(sizeof(int) * (Lc + B)));
+        ACAV_TRY(ids_to_device32(mi, candidates[c], L[c], mi->stage, mi->A0));
+        ACAV_TRY(mi->A1.ensure(sizeof(int) * (Lc + B)));
+        ACAV_TRY(mi->batch.ensure(sizeof(int) * SEL_MAXB));
+        ACAV_TRY(mi->S.ensure(sizeof(long long) * (size_t)(itc * k + 1)));
+        ACAV_TRY(mi->G.ensure(sizeof(double) * (size_t)(itc * k + 1)));
+        FyPlan &fp = plans[(size_t)c];
+        ACAV_TRY(fy_setup(mi, L[c], fp, st));
+        ntmax = fp.NT > ntmax ? fp.NT : ntmax;
+        const size_t ps = sizeof(int) * 2 * (size_t)fp.NT + sizeof(unsigned short) * fp.table.size();
+        part_smem = ps > part_smem ? ps : part_smem;
+        tile_smem = fp.tile_smem() > tile_smem ? fp.tile_smem() : tile_smem;
+        unsigned mtbuf[625];
+        int idx = 0;
+        ACAV_TRY(acav_rng_get_state(rngs[c], mtbuf, &idx));
+        MtStream &ms = streams[(size_t)c];
+        ACAV_TRY(ms.plan(mi, sf, mtbuf, idx, draws, L[c]));
+        TileChunk &d = desc[(size_t)c];
+        d.ring = ms.ring + MtStream::PAD;
+        d.head = ms.head;
+        d.ring_words = ms.wraps ? MtStream::NSLOT * ms.S : ((long long)1 << 62);
+        d.table = mi->fy_table.as<unsigned short>(), d.ebound = mi->fy_bounds.as<int>();
+        d.bucket = mi->fy_bucket.as<int2>(), d.gcount = mi->fy_count.as<int>(), d.err = mi->fy_err.as<unsigned>();
+        for (int q = 0; q < FY_NBUF; ++q) d.src[q] = mi->fy_src[q].as<unsigned>(), d.g[q] = mi->fy_g[q].as<int>();
+        d.A[0] = mi->A0.as<int>(), d.A[1] = mi->A1.as<int>();
+        d.asg = mi->asg.as<int>(), d.pairs = mi->pairs.as<int>(), d.batch = mi->batch.as<int>();
+        d.Nc = mi->Nc.as<int>(), d.ac = mi->ac.as<int>(), d.bc = mi->bc.as<int>();
+        d.SN = mi->SN.as<double>(), d.Sa = mi->Sa.as<double>(), d.Sb = mi->Sb.as<double>();
+        d.phi = mi->phi.as<double>(), d.sc = mi->scalars.as<MiScalars>();
+        d.S = mi->S.as<long long>(), d.G = mi->G.as<double>();
+        d.L0 = (int)L[c], d.iters = (int)itc, d.ntab = (int)fp.table.size(), d.gsh = fp.gsh, d.NT = fp.NT, d.capg = fp.capg;
+        d.ecap = fp.ecap_lds, d.wcap = fp.wcap, d.D = mi->D, d.C = mi->C, d.P = mi->P, d.pad = 0;
+    }
+    ACAV_TRY(lead->chunk_desc.ensure(sizeof(TileChunk) * (size_t)nchunks));
+    ACAV_HIP_TRY(hipMemcpyAsync(lead->chunk_desc.p, desc.data(), sizeof(TileChunk) * (size_t)nchunks, hipMemcpyHostToDevice, st));
+    ACAV_HIP_TRY(hipStreamSynchronize(st));  // tables, counters, candidate lists and descriptors are in place
+    ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fy_tile_multi), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)tile_smem));
+    const TileChunk *dcd = lead->chunk_desc.as<TileChunk>();
+    const size_t sel_smem = sizeof(double) * (size_t)B * (size_t)pmax;
+    for (int64_t it = 0; it < iters_max; ++it) {
+        const int par = (int)(it % FY_NBUF);
+        const int64_t lt = lmax - it * dl;  // the longest list still in play bounds the grids
+        for (int c = 0; c < nchunks; ++c) {
+            if (it >= iters[(size_t)c]) continue;
+            const int64_t Lc = L[c] - it * dl, nd = Lc > 1 ? Lc - 1 : 0;
+            const unsigned *unused = nullptr;
+            ACAV_TRY(streams[(size_t)c].acquire(r0[(size_t)c], nd, &unused));
+            r0[(size_t)c] += nd;
+        }
+        if (it >= FY_NBUF) ACAV_HIP_TRY(hipStreamWaitEvent(sf, lead->ev_gather[par], 0));
+        hipLaunchKernelGGL(k_fy_part_multi, dim3((unsigned)((lt + FYA_CH - 1) / FYA_CH), (unsigned)nchunks), dim3(FYA_THREADS), part_smem,
+                           sf, dcd, (int)it, (int)dl);
+        for (int c = 0; c < nchunks; ++c)
+            if (it < iters[(size_t)c]) ACAV_TRY(streams[(size_t)c].release(r0[(size_t)c]));  // k_fy_part is the only reader of the draws
+        hipLaunchKernelGGL(k_fy_tile_multi, dim3((unsigned)ntmax, (unsigned)nchunks), dim3(FYT_THREADS), tile_smem, sf, dcd, (int)it,
+                           (int)dl);
+        ACAV_HIP_TRY(hipEventRecord(lead->ev_tile[par], sf));
+        ACAV_HIP_TRY(hipStreamWaitEvent(st, lead->ev_tile[par], 0));
+        hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((unsigned)((lt + 255) / 256), (unsigned)nchunks), dim3(256), sel_smem, st, dcd,
+                           (int)it, (int)dl, B, k, keep_unselected);
+        ACAV_HIP_TRY(hipGetLastError());
+        ACAV_HIP_TRY(hipEventRecord(lead->ev_gather[par], st));
+    }
+    ACAV_HIP_TRY(hipStreamSynchronize(sf));
+    for (int c = 0; c < nchunks; ++c) {
+        acav_mi *mi = mis[c];
+        const int64_t itc = iters[(size_t)c];
+        const int64_t nsel = itc * k < subset[c] ? itc * k : subset[c];
+        if (itc > 0) {
+            ACAV_HIP_TRY(hipMemcpyAsync(S_out[c], mi->S.p, sizeof(long long) * (size_t)nsel, hipMemcpyDeviceToHost, st));
+            ACAV_HIP_TRY(hipMemcpyAsync(GAIN_out[c], mi->G.p, sizeof(double) * (size_t)(itc * k), hipMemcpyDeviceToHost, st));
+        }
+        if (n_selected) n_selected[c] = nsel;
+        if (n_iters) n_iters[c] = itc;
+    }
+    ACAV_HIP_TRY(hipStreamSynchronize(st));
+    for (int c = 0; c < nchunks; ++c) {  // every generator continues on the host where its chunk stopped drawing
+        ACAV_HIP_TRY(hipStreamSynchronize(mis[c]->st_mt));
+        unsigned mtbuf[625];
+        int idx = 0;
+        ACAV_TRY(acav_rng_get_state(rngs[c], mtbuf, &idx));
+        ACAV_TRY(streams[(size_t)c].final_state(mtbuf, &idx));
+        ACAV_TRY(acav_rng_set_state(rngs[c], mtbuf, idx));
+        unsigned ferr = 0;
+        ACAV_HIP_TRY(hipMemcpy(&ferr, mis[c]->fy_err.p, sizeof(ferr), hipMemcpyDeviceToHost));
+        ACAV_REQUIRE(ferr == 0, ACAV_ESTATE, "tiled Fisher-Yates: a tile bucket of chunk %d overflowed (flags %u); re-run with "
+                                             "ACAV_FY_LEGACY=1", c, ferr);
+    }
+    return ACAV_OK;
+}
+
 ACAV_EXPORT int acav_mi_run_greedy_multi(acav_mi **mis, int nchunks, const int64_t *const *candidates, const int64_t *L,
                                          const int64_t *const *start, const int *ns, const int64_t *subset, int B, int k,
                                          int keep_unselected, acav_rng **rngs, int64_t *const *S_out,
@@ -1245,6 +1479,24 @@ ACAV_EXPORT int acav_mi_run_greedy_multi(acav_mi **mis, int nchunks, const int64
     acav_mi *lead = mis[0];
     ACAV_REQUIRE(lead, ACAV_EINVAL, "handle is NULL");
     ACAV_HIP_TRY(hipSetDevice(lead->ctx.device));
+    {   // validation common to both evaluations, then the tiled one unless a list is too long for it (or ACAV_FY_LEGACY=1)
+        const char *legacy = getenv("ACAV_FY_LEGACY");
+        bool tiled = !(legacy && legacy[0] == '1');
+        for (int c = 0; c < nchunks; ++c) {
+            acav_mi *mi = mis[c];
+            ACAV_REQUIRE(mi && candidates[c] && rngs[c] && S_out[c] && GAIN_out[c], ACAV_EINVAL, "chunk %d: NULL argument", c);
+            ACAV_REQUIRE(mi->ctx.device == lead->ctx.device, ACAV_EINVAL, "chunk %d lives on another device", c);
+            ACAV_REQUIRE(L[c] > 0 && L[c] <= mi->V && ns[c] >= 0 && (ns[c] == 0 || (start && start[c])) && subset[c] >= 0,
+                         ACAV_EINVAL, "chunk %d: bad sizes", c);
+            ACAV_REQUIRE((int64_t)B * mi->P <= SEL_MAXBP, ACAV_EINVAL, "chunk %d: B*P exceeds %d", c, SEL_MAXBP);
+            for (int e = 0; e < c; ++e)
+                ACAV_REQUIRE(mis[e] != mi && rngs[e] != rngs[c], ACAV_EINVAL, "chunks must not share a handle or a generator");
+            tiled = tiled && L[c] <= FY_TILED_MAX;
+        }
+        if (tiled)
+            return run_greedy_multi_tiled(mis, nchunks, candidates, L, start, ns, subset, B, k, keep_unselected, rngs, S_out,
+                                          GAIN_out, n_selected, n_iters);
+    }
     hipStream_t st = lead->ctx.stream, smt = lead->st_mt;
     const int64_t dl = B - (keep_unselected ? B - k : 0);
     std::vector<ChunkDesc> desc((size_t)nchunks);
@@ -1545,20 +1797,7 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
     const bool tiled = L <= FY_TILED_MAX && !(legacy && legacy[0] == '1');
     FyPlan fp;
     if (tiled) {
-        fp.build(L);
-        ACAV_TRY(mi->fy_table.ensure(sizeof(unsigned short) * fp.table.size()));
-        ACAV_TRY(mi->fy_bounds.ensure(sizeof(int) * fp.ebound.size()));
-        ACAV_TRY(mi->fy_bucket.ensure(sizeof(int2) * (size_t)fp.NT * FY_SHARDS * fp.capg));
-        ACAV_TRY(mi->fy_count.ensure(sizeof(int) * (size_t)fp.NT * FY_SHARDS));
-        ACAV_TRY(mi->fy_err.ensure(sizeof(unsigned)));
-        for (int q = 0; q < FY_NBUF; ++q) {
-            ACAV_TRY(mi->fy_src[q].ensure(sizeof(unsigned) * (size_t)L));
-            ACAV_TRY(mi->fy_g[q].ensure(sizeof(int) * (size_t)L));
-        }
-        ACAV_HIP_TRY(hipMemcpyAsync(mi->fy_table.p, fp.table.data(), sizeof(unsigned short) * fp.table.size(), hipMemcpyHostToDevice, st));
-        ACAV_HIP_TRY(hipMemcpyAsync(mi->fy_bounds.p, fp.ebound.data(), sizeof(int) * fp.ebound.size(), hipMemcpyHostToDevice, st));
-        ACAV_HIP_TRY(hipMemsetAsync(mi->fy_count.p, 0, sizeof(int) * (size_t)fp.NT * FY_SHARDS, st));
-        ACAV_HIP_TRY(hipMemsetAsync(mi->fy_err.p, 0, sizeof(unsigned), st));
+        ACAV_TRY(fy_setup(mi, L, fp, st));
         ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fy_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)fp.tile_smem()));
     } else {
