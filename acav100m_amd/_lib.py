@@ -50,7 +50,8 @@ SIGNATURES = {
     "acav_comm_allgather": [vp, vp, vp, i64],
     "acav_comm_broadcast": [vp, vp, i64, i32],
     "acav_kmeans_allreduce_init": [vp, vp],
-    "acav_kmeans_train_dp": [vp, vp, vp, i64, i64, f64, vp, i64, i64],
+    "acav_kmeans_train_dp": [vp, vp, vp, i64, i64, f64, vp, i64, i64, i32],
+    "acav_kmeans_broadcast_state": [vp, vp, i32],
     "acav_kmeans_timer_begin": [vp],
     "acav_kmeans_timer_end": [vp, C.POINTER(f32)],
     "acav_kmeans_stats": [vp, C.POINTER(i64), C.POINTER(i64)],

@@ -370,18 +370,27 @@ class KMeans:
         _lib.check(_lib._lib.acav_kmeans_train_multi(h_arr, cnt, x_arr, _lib.ptr(n_arr), int(batch_size), float(lr), w_arr,
                                                      _lib.ptr(nw_arr)))
 
-    def train_epoch_distributed(self, x_local, batch_size, lr=None, chunk_steps=1024):
+    def train_epoch_distributed(self, x_local, batch_size, lr=None, chunk_steps=1024, train_here=True, comm_slot=0, wait=True):
         """One epoch of the reference's multi-GPU add() loop (global batch = world * batch_size rows, rank-major)
         without a collective per step: see acav100m_amd/parallel/kmeans_dp.py:train_epoch_dp."""
         lr = self.lr if lr is None else lr
         from ..parallel.rccl_comm import default_comm
-        comm = default_comm() if hasattr(x_local, "is_cuda") and x_local.is_cuda else None
+        comm = default_comm(comm_slot) if hasattr(x_local, "is_cuda") and x_local.is_cuda else None
         if comm is None:  # gloo / host tensors (CPU tests): the same schedule through torch.distributed
             from ..parallel import train_epoch_dp
             return train_epoch_dp(self, x_local, int(batch_size), lr, chunk_steps=chunk_steps)
-        self.train_epoch_comm(comm, x_local, int(batch_size), lr, chunk_steps)
+        self.train_epoch_comm(comm, x_local, int(batch_size), lr, chunk_steps, train_here, wait)
 
-    def train_epoch_comm(self, comm, x_local, b_local, lr, chunk_steps=1024):
+    def broadcast_state_from(self, root, comm_slot=0):
+        """every rank's state <- rank `root`'s (RCCL through the C ABI; torch.distributed under gloo)"""
+        from ..parallel.rccl_comm import default_comm
+        comm = default_comm(comm_slot)
+        if comm is None:
+            from ..parallel import broadcast_state
+            return broadcast_state(self, int(root))
+        _lib.check(_lib._lib.acav_kmeans_broadcast_state(self._require_handle(), comm._h, int(root)))
+
+    def train_epoch_comm(self, comm, x_local, b_local, lr, chunk_steps=1024, train_here=True, wait=True):
         """acav_kmeans_train_dp: the DDP epoch with the bulk row exchange through RCCL inside the library -- no torch
         op between the collective and the SGD chain.  Only the warm-up labels (drawn per rank) are exchanged here, once."""
         import torch
@@ -402,7 +411,8 @@ class KMeans:
             else:
                 warm = np.ascontiguousarray(mine)
         _lib.check(_lib._lib.acav_kmeans_train_dp(self._require_handle(), comm._h, xp, n_local, int(b_local), float(lr),
-                                                  _lib.ptr(warm) if need else None, need, int(chunk_steps)))
+                                                  _lib.ptr(warm) if need else None, need, int(chunk_steps),
+                                                  (1 if train_here else 0) | (0 if wait else 2)))
 
     # ------------------------------------------------- state exchange (parallel/kmeans_dp.py:broadcast_state)
     def state_arrays(self):

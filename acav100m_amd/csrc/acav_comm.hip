@@ -229,9 +229,16 @@ ACAV_EXPORT int acav_kmeans_allreduce_init(acav_kmeans *km, acav_comm *c)
 // of chunk c), re-ordered into global batches by k_interleave_rows, and trained by acav_kmeans_train on every rank --
 // identical state everywhere, no collective on the step path.  warm_global [n_warm, world * b_local]: the labels of the
 // warm-up steps, already in global-batch order (drawn per rank, exchanged once by the caller).
+// flags: bit 0 (ACAV_DP_TRAIN) -- this rank trains; without it the rank only takes part in the row exchange (another
+// rank trains this clustering and broadcasts its state afterwards, acav_kmeans_broadcast_state): with several
+// clusterings over the same rows the replicated chains are dealt out over the ranks instead of every rank running all
+// of them.  bit 1 (ACAV_DP_NOWAIT) -- return once everything is enqueued (collectives on the communicator's stream,
+// training on the clustering's): with one communicator per clustering, different ranks then train different
+// clusterings AT THE SAME TIME while all of them keep feeding every exchange.
 ACAV_EXPORT int acav_kmeans_train_dp(acav_kmeans *km, acav_comm *c, const float *x_local_dev, int64_t n_local, int64_t b_local,
-                                     double lr, const int64_t *warm_global, int64_t n_warm, int64_t chunk_steps)
+                                     double lr, const int64_t *warm_global, int64_t n_warm, int64_t chunk_steps, int flags)
 {
+    const bool train_here = (flags & 1) != 0, nowait = (flags & 2) != 0;
     ACAV_REQUIRE(km && c && (x_local_dev || n_local == 0), ACAV_EINVAL, "NULL argument");
     ACAV_REQUIRE(n_local >= 0 && b_local > 0 && chunk_steps > 0 && n_warm >= 0, ACAV_EINVAL, "bad sizes");
     int K = 0, d = 0;
@@ -255,13 +262,15 @@ ACAV_EXPORT int acav_kmeans_train_dp(acav_kmeans *km, acav_comm *c, const float 
     auto gather = [&](int64_t c0, int par) -> int {  // rows of steps [c0, c0 + s) of every rank -> batches[par]
         const int64_t s = steps - c0 < chunk_steps ? steps - c0 : chunk_steps;
         const size_t bytes = sizeof(float) * (size_t)s * (size_t)b_local * (size_t)d;
-        ACAV_HIP_TRY(hipStreamWaitEvent(sc, c->ev_trained[par], 0));  // the chunk trained from this buffer is done
+        if (train_here) ACAV_HIP_TRY(hipStreamWaitEvent(sc, c->ev_trained[par], 0));  // the chunk trained from this buffer is done
         ACAV_NCCL_TRY(rccl().AllGather(x_local_dev + (size_t)c0 * b_local * d, c->gather[par].p, bytes, ncclInt8, c->comm, sc));
-        const int64_t total4 = (int64_t)w * s * b_local * (d / 4);
-        const unsigned grid = (unsigned)(total4 / 256 + 1 < 4096 ? total4 / 256 + 1 : 4096);
-        hipLaunchKernelGGL(k_interleave_rows, dim3(grid), dim3(256), 0, sc, c->gather[par].as<float4>(),
-                           c->batches[par].as<float4>(), w, (int)s, (int)b_local, d / 4);
-        ACAV_HIP_TRY(hipGetLastError());
+        if (train_here) {
+            const int64_t total4 = (int64_t)w * s * b_local * (d / 4);
+            const unsigned grid = (unsigned)(total4 / 256 + 1 < 4096 ? total4 / 256 + 1 : 4096);
+            hipLaunchKernelGGL(k_interleave_rows, dim3(grid), dim3(256), 0, sc, c->gather[par].as<float4>(),
+                               c->batches[par].as<float4>(), w, (int)s, (int)b_local, d / 4);
+            ACAV_HIP_TRY(hipGetLastError());
+        }
         ACAV_HIP_TRY(hipEventRecord(c->ev_gathered[par], sc));
         return ACAV_OK;
     };
@@ -271,13 +280,36 @@ ACAV_EXPORT int acav_kmeans_train_dp(acav_kmeans *km, acav_comm *c, const float 
     for (int64_t c0 = 0; c0 < steps; c0 += chunk_steps, par ^= 1) {
         const int64_t s = steps - c0 < chunk_steps ? steps - c0 : chunk_steps;
         if (c0 + s < steps) ACAV_TRY(gather(c0 + s, par ^ 1));  // next chunk travels while this one trains
-        ACAV_HIP_TRY(hipStreamWaitEvent((hipStream_t)st_train, c->ev_gathered[par], 0));
+        if (train_here) ACAV_HIP_TRY(hipStreamWaitEvent((hipStream_t)st_train, c->ev_gathered[par], 0));
         int64_t nw = n_warm - warm_done;
         nw = nw < 0 ? 0 : (nw > s ? s : nw);
-        ACAV_TRY(acav_kmeans_train(km, c->batches[par].as<float>(), s * bg, bg, lr, nw ? warm_global + warm_done * bg : nullptr, nw));
+        if (train_here)
+            ACAV_TRY(acav_kmeans_train(km, c->batches[par].as<float>(), s * bg, bg, lr, nw ? warm_global + warm_done * bg : nullptr, nw));
         warm_done += nw;
-        ACAV_HIP_TRY(hipEventRecord(c->ev_trained[par], (hipStream_t)st_train));
+        if (train_here) ACAV_HIP_TRY(hipEventRecord(c->ev_trained[par], (hipStream_t)st_train));
     }
+    if (nowait) return ACAV_OK;
     ACAV_HIP_TRY(hipStreamSynchronize(sc));
     return acav_kmeans_sync(km);
+}
+
+// every rank's clustering state <- rank `root`'s (centres, usage counts, count, fallback): one RCCL broadcast of
+// K d + K floats and 16 bytes
+ACAV_EXPORT int acav_kmeans_broadcast_state(acav_kmeans *km, acav_comm *c, int root)
+{
+    ACAV_REQUIRE(km && c && root >= 0 && root < c->world, ACAV_EINVAL, "bad argument");
+    int K = 0, d = 0;
+    ACAV_TRY(acav_kmeans_shape(km, &K, &d));
+    const int64_t nc = (int64_t)K * d, n = nc + K;
+    ACAV_HIP_TRY(hipSetDevice(c->ctx.device));
+    ACAV_TRY(c->flat.ensure(sizeof(float) * (size_t)(n + 4)));
+    float *flat = c->flat.as<float>();
+    int64_t sc[2] = {0, 0};
+    ACAV_TRY(acav_kmeans_get_state(km, flat, flat + nc, &sc[0], &sc[1]));  // device destination; synchronises km's stream
+    ACAV_HIP_TRY(hipMemcpyAsync(flat + n, sc, sizeof(sc), hipMemcpyHostToDevice, c->ctx.stream));
+    ACAV_TRY(acav_comm_broadcast(c, flat, (int64_t)sizeof(float) * (n + 4), root));
+    ACAV_HIP_TRY(hipMemcpyAsync(sc, flat + n, sizeof(sc), hipMemcpyDeviceToHost, c->ctx.stream));
+    ACAV_HIP_TRY(hipStreamSynchronize(c->ctx.stream));
+    if (c->rank == root) return ACAV_OK;
+    return acav_kmeans_set_state(km, flat, flat + nc, sc[0], sc[1]);
 }

@@ -66,13 +66,16 @@ class Comm:
         _lib.check(_lib._lib.acav_comm_sync(self._h))
 
 
-def default_comm():
-    """the process-wide communicator over the launcher's group, created on first use; None when RCCL is not the
-    backend in use (CPU tests under gloo keep the torch.distributed plumbing)"""
+def default_comm(slot=0):
+    """the process-wide communicator number `slot` over the launcher's group, created on first use (every rank must ask
+    for the slots in the same order); None when RCCL is not the backend in use (CPU tests under gloo keep the
+    torch.distributed plumbing).  One communicator per clustering lets their exchanges proceed independently."""
     global _default
     if _default is None:
+        _default = {}
+    if slot not in _default:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl":
             return None
-        _default = Comm.from_process_group()
-    return _default
+        _default[slot] = Comm.from_process_group()
+    return _default[slot]

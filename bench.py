@@ -20,9 +20,9 @@ value = N * n_gpus * steps / time with the features resident in HBM when the tim
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
            --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1 (weak scaling): every rank holds its own 1M-clip partition.  k-means training is one global clustering with the
-reference's DDP semantics (global batch = 32 N rows per step, rows all-gathered in bulk ahead of the SGD chain, no
-collective on the step path); assign is local; the MI selection runs per rank on its own partition -- the reference's
+N > 1 (weak scaling): every rank holds its own 1M-clip partition.  k-means training is one global clustering per view with
+the reference's DDP semantics (global batch = 32 N rows per step, rows all-gathered in bulk ahead of the SGD chain, no
+collective on the step path; the replicated chain of a view runs on one rank, which broadcasts its state); assign is local; the MI selection runs per rank on its own partition -- the reference's
 chunked mode with one chunk per GPU (chunk.py:21-53) -- no exchange.
 
 The JSON line also carries
@@ -202,9 +202,16 @@ def main():
             lr = 0.1 ** (2 + epoch // 5)
             if world == 1:  # the two views' SGD chains are independent: side by side on the GPU (run_clustering does the same)
                 KMeans.train_epoch_multi(kms, xs, b, lr=lr)
-            else:  # reference DDP semantics: global batch = world * b rows per step; rows all-gathered in bulk
-                for km, x in zip(kms, xs):
-                    km.train_epoch_distributed(x, b, lr=lr)
+            else:
+                # reference DDP semantics: global batch = world * b rows per step, rows all-gathered in bulk by every rank;
+                # the (replicated, device-resident) SGD chain of view v runs on rank v % world only, which then hands out
+                # its state -- instead of every rank running both chains one after the other
+                # (one communicator per view, nothing waits until all views are enqueued: the views train concurrently
+                # on different ranks while every rank keeps feeding both exchanges)
+                for v, (km, x) in enumerate(zip(kms, xs)):
+                    km.train_epoch_distributed(x, b, lr=lr, train_here=(rank == v % world), comm_slot=v, wait=False)
+                for v, km in enumerate(kms):
+                    km.broadcast_state_from(v % world, comm_slot=v)
         for km in kms:
             km.synchronize()
         t1 = time.perf_counter()

@@ -158,5 +158,16 @@ def test_comm_c_abi_world1():
     for epoch in range(2):
         km.train_epoch_comm(comm, xt, b, 0.01, chunk_steps=16)
         ref.train_epoch(x, b, 0.01)
+        _lib.check(_lib._lib.acav_kmeans_broadcast_state(km._h, comm._h, 0))  # the root keeps its state
         assert np.array_equal(km.centers.numpy(), ref.centers), f"epoch {epoch}"
         assert np.array_equal(km.counts.numpy(), ref.counts) and km.count == ref.count
+    # the multi-GPU bench's calls: a communicator per clustering, nothing waits until everything is enqueued, then the
+    # trainer hands out its state -- with one rank the result is one more plain epoch
+    km.train_epoch_distributed(xt, b, lr=0.01, train_here=True, comm_slot=1, wait=False)
+    km.broadcast_state_from(0, comm_slot=1)
+    ref.train_epoch(x, b, 0.01)
+    assert np.array_equal(km.centers.numpy(), ref.centers) and km.count == ref.count
+    # a rank that only takes part in the row exchange (train_here = 0) leaves its state alone
+    before = (km.centers.numpy().copy(), km.count)
+    km.train_epoch_comm(comm, xt, b, 0.01, chunk_steps=16, train_here=False)
+    assert np.array_equal(km.centers.numpy(), before[0]) and km.count == before[1]
