@@ -640,7 +640,8 @@ constexpr int FYA_CH = 4096;       // steps per k_fy_part workgroup
 constexpr int FYA_THREADS = 1024;
 constexpr int64_t FY_TILED_MAX = 16 << 20;
 constexpr unsigned FY_EREF = 0x80000000u;
-constexpr int FY_NBUF = 4;         // src / g buffers: k_fy_part + k_fy_tile may run this many iterations ahead of the gather
+constexpr int FY_GROUP = 8;        // iterations per cross-stream hand-off (one event pair per group, not per iteration)
+constexpr int FY_NBUF = 2 * FY_GROUP;  // src / g buffers: k_fy_part + k_fy_tile run one group ahead of the gathers
 constexpr int FY_SHARDS = 8;       // sub-buckets per tile (capg entries each), filled by workgroups b with b % 8 == shard
 constexpr int FYT_THREADS = 1024;  // k_fy_tile: the list walks are chains of dependent LDS reads -- many waves hide them
 
@@ -1415,29 +1416,35 @@ static int run_greedy_multi_tiled(acav_mi **mis, int nchunks, const int64_t *con
                                      (int)tile_smem));
     const TileChunk *dcd = lead->chunk_desc.as<TileChunk>();
     const size_t sel_smem = sizeof(double) * (size_t)B * (size_t)pmax;
-    for (int64_t it = 0; it < iters_max; ++it) {
-        const int par = (int)(it % FY_NBUF);
-        const int64_t lt = lmax - it * dl;  // the longest list still in play bounds the grids
-        for (int c = 0; c < nchunks; ++c) {
-            if (it >= iters[(size_t)c]) continue;
-            const int64_t Lc = L[c] - it * dl, nd = Lc > 1 ? Lc - 1 : 0;
-            const unsigned *unused = nullptr;
-            ACAV_TRY(streams[(size_t)c].acquire(r0[(size_t)c], nd, &unused));
-            r0[(size_t)c] += nd;
+    for (int64_t g0 = 0; g0 < iters_max; g0 += FY_GROUP) {  // groups of iterations, as in acav_mi_run_greedy
+        const int64_t g1 = g0 + FY_GROUP < iters_max ? g0 + FY_GROUP : iters_max;
+        const int ge = (int)((g0 / FY_GROUP) & 1);
+        if (g0 >= 2 * FY_GROUP) ACAV_HIP_TRY(hipStreamWaitEvent(sf, lead->ev_gather[ge], 0));
+        for (int64_t it = g0; it < g1; ++it) {
+            const int64_t lt = lmax - it * dl;  // the longest list still in play bounds the grids
+            for (int c = 0; c < nchunks; ++c) {
+                if (it >= iters[(size_t)c]) continue;
+                const int64_t Lc = L[c] - it * dl, nd = Lc > 1 ? Lc - 1 : 0;
+                const unsigned *unused = nullptr;
+                ACAV_TRY(streams[(size_t)c].acquire(r0[(size_t)c], nd, &unused));
+                r0[(size_t)c] += nd;
+            }
+            hipLaunchKernelGGL(k_fy_part_multi, dim3((unsigned)((lt + FYA_CH - 1) / FYA_CH), (unsigned)nchunks), dim3(FYA_THREADS),
+                               part_smem, sf, dcd, (int)it, (int)dl);
+            for (int c = 0; c < nchunks; ++c)
+                if (it < iters[(size_t)c]) ACAV_TRY(streams[(size_t)c].release(r0[(size_t)c]));  // k_fy_part is the only reader of the draws
+            hipLaunchKernelGGL(k_fy_tile_multi, dim3((unsigned)ntmax, (unsigned)nchunks), dim3(FYT_THREADS), tile_smem, sf, dcd, (int)it,
+                               (int)dl);
         }
-        if (it >= FY_NBUF) ACAV_HIP_TRY(hipStreamWaitEvent(sf, lead->ev_gather[par], 0));
-        hipLaunchKernelGGL(k_fy_part_multi, dim3((unsigned)((lt + FYA_CH - 1) / FYA_CH), (unsigned)nchunks), dim3(FYA_THREADS), part_smem,
-                           sf, dcd, (int)it, (int)dl);
-        for (int c = 0; c < nchunks; ++c)
-            if (it < iters[(size_t)c]) ACAV_TRY(streams[(size_t)c].release(r0[(size_t)c]));  // k_fy_part is the only reader of the draws
-        hipLaunchKernelGGL(k_fy_tile_multi, dim3((unsigned)ntmax, (unsigned)nchunks), dim3(FYT_THREADS), tile_smem, sf, dcd, (int)it,
-                           (int)dl);
-        ACAV_HIP_TRY(hipEventRecord(lead->ev_tile[par], sf));
-        ACAV_HIP_TRY(hipStreamWaitEvent(st, lead->ev_tile[par], 0));
-        hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((unsigned)((lt + 255) / 256), (unsigned)nchunks), dim3(256), sel_smem, st, dcd,
-                           (int)it, (int)dl, B, k, keep_unselected);
+        ACAV_HIP_TRY(hipEventRecord(lead->ev_tile[ge], sf));
+        ACAV_HIP_TRY(hipStreamWaitEvent(st, lead->ev_tile[ge], 0));
+        for (int64_t it = g0; it < g1; ++it) {
+            const int64_t lt = lmax - it * dl;
+            hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((unsigned)((lt + 255) / 256), (unsigned)nchunks), dim3(256), sel_smem, st,
+                               dcd, (int)it, (int)dl, B, k, keep_unselected);
+        }
         ACAV_HIP_TRY(hipGetLastError());
-        ACAV_HIP_TRY(hipEventRecord(lead->ev_gather[par], st));
+        ACAV_HIP_TRY(hipEventRecord(lead->ev_gather[ge], st));
     }
     ACAV_HIP_TRY(hipStreamSynchronize(sf));
     for (int c = 0; c < nchunks; ++c) {
@@ -1841,49 +1848,58 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
     int64_t l = L;
     int64_t r0 = 0;  // first draw of this iteration, counted from the first draw of the run
     if (tiled) {
-        // two streams: k_fy_part + k_fy_tile (positions only, no content) run on st_fy up to FY_NBUF iterations ahead of
-        // the gather + selection on st; src / g are multi-buffered, the streams meet through two events per iteration
-        // (a cross-stream hand-off costs ~20 us of latency: with only two buffers it sat on the critical cycle)
+        // two streams: k_fy_part + k_fy_tile (positions only, no content) run on st_fy one GROUP of iterations ahead of the
+        // gathers + selections on st; src / g are multi-buffered and the streams meet through one event pair per group
+        // (a cross-stream hand-off costs ~20 us of latency, an event record / wait a few us of queue time: per iteration they
+        // sat on the critical path -- 80 us with two buffers, 55 us with four, per-iteration events)
         hipStream_t sf = mi->st_fy;
         ACAV_HIP_TRY(hipStreamSynchronize(st));  // tables, counters and the candidate list are in place
         const bool timing = getenv("ACAV_MI_TIMING") != nullptr;
         const auto t_loop0 = std::chrono::steady_clock::now();
         const size_t smem_sel = sizeof(double) * (size_t)B * mi->P;
-        for (int64_t it = 0; it < iters; ++it) {
-            const int Li = (int)l, par = (int)(it % FY_NBUF);
-            const int64_t nd = Li > 1 ? Li - 1 : 0;
-            const unsigned *draws = nullptr;
-            ACAV_TRY(ms.acquire(r0, nd, &draws));
-            if (it >= FY_NBUF) ACAV_HIP_TRY(hipStreamWaitEvent(sf, mi->ev_gather[par], 0));  // src / g of iteration t - FY_NBUF are consumed
-            unsigned *src = mi->fy_src[par].as<unsigned>();
-            int *gq = mi->fy_g[par].as<int>();
-            hipLaunchKernelGGL(k_fy_part, dim3((unsigned)((Li + FYA_CH - 1) / FYA_CH)), dim3(FYA_THREADS),
-                               sizeof(int) * 2 * (size_t)fp.NT + sizeof(unsigned short) * fp.table.size(), sf, draws, Li,
-                               mi->fy_table.as<unsigned short>(), (int)fp.table.size(), fp.gsh, fp.NT, fp.capg,
-                               mi->fy_bucket.as<int2>(), mi->fy_count.as<int>(), src, mi->fy_err.as<unsigned>());
-            r0 += nd;
-            ACAV_TRY(ms.release(r0));  // k_fy_part is the only reader of the draws
-            hipLaunchKernelGGL(k_fy_tile, dim3((unsigned)fp.NT), dim3(FYT_THREADS), fp.tile_smem(), sf, Li, mi->fy_bounds.as<int>(), fp.capg,
-                               fp.ecap_lds, fp.wcap, mi->fy_bucket.as<int2>(), mi->fy_count.as<int>(), src, gq,
-                               mi->fy_err.as<unsigned>());
-            ACAV_HIP_TRY(hipEventRecord(mi->ev_tile[par], sf));
-            ACAV_HIP_TRY(hipStreamWaitEvent(st, mi->ev_tile[par], 0));
-            hipLaunchKernelGGL(k_fy_gather_select, dim3((unsigned)((Li + 255) / 256)), dim3(256), smem_sel, st, Acur, Li, src, gq, Anew,
-                               mi->asg.as<int>(), mi->D, mi->C, mi->P, mi->pairs.as<int>(), mi->batch.as<int>(), B, k,
-                               mi->Nc.as<int>(), mi->ac.as<int>(), mi->bc.as<int>(), mi->SN.as<double>(), mi->Sa.as<double>(),
-                               mi->Sb.as<double>(), mi->phi.as<double>(), mi->scalars.as<MiScalars>(),
-                               mi->S.as<long long>() + it * k, mi->G.as<double>() + it * k,
-                               forced_pos ? mi->forced.as<int>() + it * k : nullptr,
-                               trace_pos ? mi->tr_pos.as<int>() + it * k : nullptr,
-                               trace_ids ? mi->tr_ids.as<long long>() + it * B : nullptr,
-                               trace_scores ? mi->tr_sc.as<double>() + it * B : nullptr, keep_unselected);
+        for (int64_t g0 = 0; g0 < iters; g0 += FY_GROUP) {
+            const int64_t g1 = g0 + FY_GROUP < iters ? g0 + FY_GROUP : iters;
+            const int ge = (int)((g0 / FY_GROUP) & 1);  // event pair and buffer half of this group
+            // ---- st_fy: the positions of the group's iterations (the gathers of the group two back are done with this half)
+            if (g0 >= 2 * FY_GROUP) ACAV_HIP_TRY(hipStreamWaitEvent(sf, mi->ev_gather[ge], 0));
+            for (int64_t it = g0; it < g1; ++it) {
+                const int Li = (int)(L - it * dl), par = (int)(it % FY_NBUF);
+                const int64_t nd = Li > 1 ? Li - 1 : 0;
+                const unsigned *draws = nullptr;
+                ACAV_TRY(ms.acquire(r0, nd, &draws));
+                hipLaunchKernelGGL(k_fy_part, dim3((unsigned)((Li + FYA_CH - 1) / FYA_CH)), dim3(FYA_THREADS),
+                                   sizeof(int) * 2 * (size_t)fp.NT + sizeof(unsigned short) * fp.table.size(), sf, draws, Li,
+                                   mi->fy_table.as<unsigned short>(), (int)fp.table.size(), fp.gsh, fp.NT, fp.capg,
+                                   mi->fy_bucket.as<int2>(), mi->fy_count.as<int>(), mi->fy_src[par].as<unsigned>(),
+                                   mi->fy_err.as<unsigned>());
+                r0 += nd;
+                ACAV_TRY(ms.release(r0));  // k_fy_part is the only reader of the draws
+                hipLaunchKernelGGL(k_fy_tile, dim3((unsigned)fp.NT), dim3(FYT_THREADS), fp.tile_smem(), sf, Li, mi->fy_bounds.as<int>(),
+                                   fp.capg, fp.ecap_lds, fp.wcap, mi->fy_bucket.as<int2>(), mi->fy_count.as<int>(),
+                                   mi->fy_src[par].as<unsigned>(), mi->fy_g[par].as<int>(), mi->fy_err.as<unsigned>());
+            }
+            ACAV_HIP_TRY(hipEventRecord(mi->ev_tile[ge], sf));
+            // ---- st: the group's gathers + selections, back to back
+            ACAV_HIP_TRY(hipStreamWaitEvent(st, mi->ev_tile[ge], 0));
+            for (int64_t it = g0; it < g1; ++it) {
+                const int Li = (int)(L - it * dl), par = (int)(it % FY_NBUF);
+                hipLaunchKernelGGL(k_fy_gather_select, dim3((unsigned)((Li + 255) / 256)), dim3(256), smem_sel, st, Acur, Li,
+                                   mi->fy_src[par].as<unsigned>(), mi->fy_g[par].as<int>(), Anew, mi->asg.as<int>(), mi->D, mi->C, mi->P,
+                                   mi->pairs.as<int>(), mi->batch.as<int>(), B, k, mi->Nc.as<int>(), mi->ac.as<int>(), mi->bc.as<int>(),
+                                   mi->SN.as<double>(), mi->Sa.as<double>(), mi->Sb.as<double>(), mi->phi.as<double>(),
+                                   mi->scalars.as<MiScalars>(), mi->S.as<long long>() + it * k, mi->G.as<double>() + it * k,
+                                   forced_pos ? mi->forced.as<int>() + it * k : nullptr,
+                                   trace_pos ? mi->tr_pos.as<int>() + it * k : nullptr,
+                                   trace_ids ? mi->tr_ids.as<long long>() + it * B : nullptr,
+                                   trace_scores ? mi->tr_sc.as<double>() + it * B : nullptr, keep_unselected);
+                int *t = Acur;
+                Acur = Anew;
+                Anew = t;
+            }
             ACAV_HIP_TRY(hipGetLastError());
-            ACAV_HIP_TRY(hipEventRecord(mi->ev_gather[par], st));
-            l = l - B + (keep_unselected ? B - k : 0);
-            int *t = Acur;
-            Acur = Anew;
-            Anew = t;
+            ACAV_HIP_TRY(hipEventRecord(mi->ev_gather[ge], st));
         }
+        l = L - iters * dl;
         const auto t_loop1 = std::chrono::steady_clock::now();
         ACAV_HIP_TRY(hipStreamSynchronize(sf));
         if (timing) {
