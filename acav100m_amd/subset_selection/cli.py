@@ -7,7 +7,7 @@ import time
 from pathlib import Path
 
 from ..config import SUBSET_DEFAULTS, merge, parse_cli
-from .run import merge_all_csvs, run_chunks, run_single
+from .run import compare_measures, merge_all_csvs, reduce_all_pkls, run_chunks, run_single
 
 
 def get_args(**kwargs):
@@ -67,7 +67,21 @@ class Cli:
         print('done. total time elasped: {}'.format(datetime.timedelta(seconds=time.time() - start)))
         return out
 
-    reduce = reduce_csvs
+    def reduce_pkls(self, **kwargs):
+        start = time.time()
+        out = reduce_all_pkls(prepare(**kwargs))
+        print('done. total time elasped: {}'.format(datetime.timedelta(seconds=time.time() - start)))
+        return out
+
+    def reduce(self, **kwargs):
+        """cli.py:69-78: csv caches or pickle caches, whichever the run wrote"""
+        args = prepare(**kwargs)
+        return merge_all_csvs(args) if (args.save_cache_as_csvs or args.save_cache_as_csvs is None) else reduce_all_pkls(args)
+
+    def compare_measures(self, **kwargs):
+        out = compare_measures(prepare(**kwargs))
+        print('done')
+        return out
 
     def merge_contrastive(self, **kwargs):
         from .run_contrastive import merge_contrastive

@@ -11,6 +11,8 @@ import os
 from collections import defaultdict
 from pathlib import Path
 
+import numpy as np
+
 from .. import shards as io
 from ..parallel import world
 from .run_greedy import _prepare, run_greedy
@@ -113,12 +115,75 @@ def run_chunks(args):
             results, metas = _run(chunk_args, chunk)
         res = results[0] if results else []  # a chunk is assumed to be a single partition (chunk.py:152)
         name = "cache_{}_{}_{}".format(chunk_args.parent_pid, rank, i)
-        cache_out = Path(args.data.output.path).parent / 'caches' / Path(args.data.output.path).name
-        out_path, _ = io.append_output_csv(res, metas, cache_out, name + '_')
-        written.append(out_path)
+        written.append(_save_chunk(args, name, res, metas))
     if pool:
         pool.shutdown()
     return written
+
+
+def _save_chunk(args, name, res, metas):
+    """chunk.py:125-131: the chunk's selection as caches/{name}_output.csv, or -- save_cache_as_csvs=False -- as the
+    pickle caches/{name}.pkl = {'res', 'metas'} that `cli.py reduce_pkls` turns into the csv later"""
+    cache_dir = Path(args.data.output.path).parent / 'caches'
+    if args.save_cache_as_csvs or args.save_cache_as_csvs is None:
+        out_path, _ = io.append_output_csv(res, metas, cache_dir / Path(args.data.output.path).name, name + '_')
+        return out_path
+    cache_dir.mkdir(parents=True, exist_ok=True)
+    out_path = cache_dir / (name + '.pkl')
+    io.dump_pickle({'res': res, 'metas': metas}, out_path)
+    return out_path
+
+
+def reduce_all_pkls(args):
+    """chunk.py:56-92 (reduce_all_pkls / reduce_single_cache): caches/cache_*_*.pkl -> per-cache csv -> output.csv"""
+    cache_dir = Path(args.data.output.path).parent / 'caches'
+    groups = defaultdict(list)
+    for p in cache_dir.glob('cache_*_*.pkl'):
+        groups['_'.join(p.stem.split('_')[:2])].append(p)
+    total = 0
+    for key in sorted(groups):
+        print('processing cache set {}'.format(key))
+        outs = []
+        for p in sorted(groups[key]):
+            print("loading cache ({})".format(p.stem))
+            cache = io.load_pickle(p)
+            res = cache['res']
+            if isinstance(args.subset.size, int):
+                res = res[:args.subset.size]
+            print("saving cache ({}), subset size: {}".format(p.stem, len(res)))
+            out_path, _ = io.append_output_csv(res, cache['metas'], cache_dir / Path(args.data.output.path).name, p.stem + '_')
+            outs.append(out_path)
+        print("merging csvs")
+        total += io.merge_csvs(sorted(outs), args.data.output.path)
+    if args.verbose:
+        print("Saved Results: added {} lines to {}".format(total, args.data.output.path))
+    return total
+
+
+def compare_measures(args):
+    """tests.py:10-46: run several measures on every partition and report how far their selections agree (the
+    reference's version stops in a debugger; this one prints and returns the figures)."""
+    from .run_greedy import _run_greedy
+    names = args.measure_names or ['mem_mi', 'mi']
+    partitions, _ = load_data(args.data.path, args.data.meta.path, args.verbose)
+    report = []
+    for k in sorted(partitions):
+        assignments, clustering_types, _, _ = io.load_assignment_shards(partitions[k])
+        runs = {}
+        for name in names:
+            runs[name] = _run_greedy(args, assignments, clustering_types, args.subset.size, args.subset.ratio, measure_name=name,
+                                     cluster_pairing=args.clustering.pairing, shuffle_candidates=False, verbose=False)
+        keys = list(runs)
+        for a in range(len(keys)):
+            for b in range(a + 1, len(keys)):
+                (sa, ga, _), (sb, gb, _) = runs[keys[a]], runs[keys[b]]
+                same = float(np.mean([int(x == y) for x, y in zip(sa, sb)])) if sa and sb else float('nan')
+                gd = float(np.mean([abs(x - y) for x, y in zip(ga, gb)])) if ga and gb else float('nan')
+                print(keys[a], 'vs.', keys[b])
+                print('S equivalence: ', same)
+                print('GAIN diff mean: ', gd)
+                report.append((k, keys[a], keys[b], same, gd))
+    return report
 
 
 def _run_chunks_lockstep(args, chunk_args, mine, rank, width):

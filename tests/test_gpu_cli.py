@@ -124,6 +124,32 @@ def test_chunked_run_sync_and_async_prefetch(workdir):
         # each chunk (2 shards = 512 clips) selects round(0.2 * 512) = 102 clips
         assert len(outs[mode]) == 204
     assert outs[False] == outs[True]
+    # pickle caches (save_cache_as_csvs=False) + `reduce_pkls` (chunk.py:56-112,134-141) end in the same output.csv
+    out_dir = os.path.join(root, "chunked_pkl")
+    os.makedirs(out_dir, exist_ok=True)
+    out_csv = os.path.join(out_dir, "output.csv")
+    random.seed(1)
+    acav100m_amd.manual_seed(1)
+    kw = dict(shards_path=os.path.join(root, "clusters", "shard-{000000..000003}.pkl"), meta_path=os.path.join(root, "videos"),
+              out_path=out_csv, chunk_size=2, save_cache_as_csvs=False)
+    Cli().run(**kw)
+    caches = sorted(os.listdir(os.path.join(out_dir, "caches")))
+    assert len(caches) == 2 and all(c.startswith("cache_") and c.endswith(".pkl") for c in caches)
+    Cli().reduce_pkls(**kw)
+    assert open(out_csv).read().splitlines() == outs[False]
+
+
+def test_compare_measures_verb(workdir):
+    """`cli.py compare_measures` (tests.py:10-46): the exact-greedy `mem_mi` and `mi` share one canonical evaluation here,
+    so their selections agree completely (the reference's two formulations agree on 12-66 % of the picks)."""
+    from acav100m_amd.subset_selection.cli import Cli
+    root, glob = workdir
+    if not os.path.isfile(os.path.join(root, "clusters", "shard-000000.pkl")):
+        pytest.skip("clustering test did not run")
+    rep = Cli().compare_measures(shards_path=os.path.join(root, "clusters", "shard-{000000..000001}.pkl"),
+                                 meta_path=os.path.join(root, "videos"), out_path=os.path.join(root, "cmp", "output.csv"),
+                                 **{"subset.size": 40})
+    assert len(rep) == 1 and rep[0][1:3] == ("mem_mi", "mi") and rep[0][3] == 1.0 and rep[0][4] == 0.0
 
 
 def test_chunked_run_lockstep_chunks(workdir):
