@@ -70,8 +70,24 @@ def spawn_per_gpu(module, argv, nprocs, extra_env=None):
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "ACAV_PARENT_PID": str(os.getpid())})
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, "-m", module] + list(argv), env=env))
-    codes = [p.wait() for p in procs]
-    bad = [c for c in codes if c != 0]
-    if bad:
-        raise SystemExit(bad[0])
+    # a rank that dies would leave the others waiting in a collective for ever: watch them all, and take the rest down
+    # with the first failure (torch.multiprocessing.spawn does the same for the reference)
+    import time
+    codes = [None] * nprocs
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed:
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            raise SystemExit(failed[0])
+        time.sleep(0.05)
     return codes
