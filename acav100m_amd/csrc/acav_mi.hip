@@ -26,6 +26,15 @@ struct MiScalars {
     long long nc;  // n of the tables: number of samples added so far
 };
 
+#ifdef ACAV_FY_PROF  // tools/exp/fy_bench.hip: 100 MHz wall-clock ticks per phase, summed over workgroups
+__device__ unsigned long long fy_prof[16];
+#define FY_CLK(slot) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&fy_prof[slot], t_ - fy_t0); fy_t0 = t_; } } while (0)
+#define FY_CLK0() unsigned long long fy_t0 = wall_clock64()
+#else
+#define FY_CLK(slot) do { } while (0)
+#define FY_CLK0() do { } while (0)
+#endif
+
 // -------------------------------------------------------------------------- table kernels
 // cache += one-hots of ids (mi.py:127-148): thread p owns pair p, ids applied in order so the
 // running sums see the same sequence of float64 updates as the oracle.
@@ -83,23 +92,62 @@ constexpr int SEL_MAXBP = 8192;
 // (descending, ties -> lower batch position), commit them, emit S/GAIN, and append the
 // unselected ids in ascending order to the new candidate array (batch.py:132-171).
 // ids == batch_in when called for plain scoring (k = 0: nothing committed).
-// The kernel sits on the critical path of every iteration and is pure latency, so every phase issues all of its
-// independent loads before the first use: scoring is 4 dependent load levels (id -> row -> counts -> phi), the
-// top-k is k wave-wide argmax reductions, the commit of k <= SEL_FASTK picks is 3 levels per pair.
+// The kernel sits on the critical path of every iteration and is pure latency -- a chain of dependent memory round
+// trips (~1 us each on a busy chip) -- so the chain is kept short:
+//   * what does not depend on the batch (n, the pair list, the running sums) is staged in LDS by mi_select_stage BEFORE
+//     the caller produces the batch (the permutation gather), under that round trip
+//   * the batch ids come in registers when the caller has just produced them (no store -> fence -> load)
+//   * scoring is 3 dependent levels (id -> label row -> counts -> phi); every phase issues all of its independent loads
+//     before the first use
+//   * the top-k is a rank count over the B scores in LDS (no reduction rounds); barriers order LDS only
+//   * the commit of k <= SEL_FASTK picks re-uses the labels and counts the scoring read (LDS, B P <= SEL_FASTBP) and
+//     pays one level (phi of the adjusted counts); beyond those sizes it re-reads (3 levels per pick)
 constexpr int SEL_FASTK = 8;
+constexpr int SEL_LDSP = 256;     // pairs (and their running sums) staged in LDS
+constexpr int SEL_FASTBP = 2048;  // B * P up to which the scoring's labels / counts are kept for the commit
 
-__device__ __forceinline__ void sel_argmax_step(double &s, int &w, int lane_delta)
+struct SelShared {
+    double score[SEL_MAXB], key[SEL_MAXB];
+    double SN[SEL_LDSP], Sa[SEL_LDSP], Sb[SEL_LDSP];
+    long long nc;
+    unsigned long long used;
+    int id[SEL_MAXB], pos[SEL_MAXB], pick[SEL_MAXB];
+    int pairs[2 * SEL_LDSP];
+};
+
+// dynamic LDS of a selection launch: scores [B P] doubles (+ labels and counts, 5 ints per (candidate, pair))
+static inline bool sel_fast(int B, int P) { return (long long)B * P <= SEL_FASTBP; }
+static inline size_t sel_smem_bytes(int B, int P) { return (size_t)B * (size_t)P * (sel_fast(B, P) ? 28u : 8u); }
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global store to be
+// acknowledged (~1 us each time on the selection's critical path)
+__device__ __forceinline__ void lds_barrier()
 {
-    const double so = __shfl_xor(s, lane_delta);
-    const int wo = __shfl_xor(w, lane_delta);
-    const bool take = so > s || (so == s && wo < w);  // NaN scores never win; ties -> lower batch position
-    s = take ? so : s;
-    w = take ? wo : w;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 }
 
+// everything the selection needs that does not depend on the batch; a barrier must separate it from mi_select_body
+__device__ __forceinline__ void mi_select_stage(SelShared &ss, int P, const int *__restrict__ pairs,
+                                                const double *__restrict__ SN, const double *__restrict__ Sa,
+                                                const double *__restrict__ Sb, const MiScalars *__restrict__ sc)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) ss.nc = sc->nc;
+    for (int p = tid; p < P && p < SEL_LDSP; p += blockDim.x) {
+        ss.pairs[2 * p] = pairs[2 * p];
+        ss.pairs[2 * p + 1] = pairs[2 * p + 1];
+        ss.SN[p] = SN[p];
+        ss.Sa[p] = Sa[p];
+        ss.Sb[p] = Sb[p];
+    }
+}
+
+// batch == nullptr: the id of batch position tid (< B) is in reg_id.  fast: the launch carries sel_smem_bytes() of
+// dynamic LDS for a B * P within SEL_FASTBP (decided on the host, the same for every chunk of a launch).
 __device__ __forceinline__ void mi_select_body(
-    const int *__restrict__ asg, int D, int C, int P, const int *__restrict__ pairs,
-    const int *__restrict__ batch, int B, int k, int *__restrict__ Nc, int *__restrict__ ac,
+    SelShared &ss, const int *__restrict__ asg, int D, int C, int P, const int *__restrict__ pairs,
+    const int *__restrict__ batch, int reg_id, int B, int k, bool fast, int *__restrict__ Nc, int *__restrict__ ac,
     int *__restrict__ bc, double *__restrict__ SN, double *__restrict__ Sa, double *__restrict__ Sb,
     const double *__restrict__ phi, MiScalars *__restrict__ sc, double *__restrict__ scores_out,
     long long *__restrict__ S_out, double *__restrict__ G_out, const int *__restrict__ forced_pos,
@@ -108,100 +156,123 @@ __device__ __forceinline__ void mi_select_body(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double *sS = reinterpret_cast<double *>(smem_raw);  // [B*P]
-    __shared__ double sScore[SEL_MAXB];
-    __shared__ int sId[SEL_MAXB];
-    __shared__ int sPos[SEL_MAXB];
-    __shared__ int sPick[SEL_MAXB];
-    __shared__ unsigned long long sUsed;
+    int *sCi = reinterpret_cast<int *>(sS + (size_t)B * P), *sCj = sCi + (size_t)B * P, *sCN = sCj + (size_t)B * P;
+    int *sCa = sCN + (size_t)B * P, *sCb = sCa + (size_t)B * P;  // fast only
     const int tid = threadIdx.x;
-    const long long nc = sc->nc;
-    if (tid < B) sId[tid] = batch[tid];
-    __syncthreads();
+    FY_CLK0();
+    if (tid < B) ss.id[tid] = batch ? batch[tid] : reg_id;
+    lds_barrier();  // also: the staged constants are visible
+    FY_CLK(8);
+    const long long nc = ss.nc;
+    const double phin = phi[nc + 1];
     for (int t = tid; t < B * P; t += blockDim.x) {
+        // score of candidate w for pair p if it alone were added (canonical float64 closed form)
         const int w = t / P, p = t - w * P;
-        sS[t] = mi_pair_score(asg, D, C, p, pairs, sId[w], Nc, ac, bc, SN, Sa, Sb, phi, nc);
+        const bool lp = p < SEL_LDSP;
+        const int d0 = lp ? ss.pairs[2 * p] : pairs[2 * p], d1 = lp ? ss.pairs[2 * p + 1] : pairs[2 * p + 1];
+        const double sN0 = lp ? ss.SN[p] : SN[p], sa0 = lp ? ss.Sa[p] : Sa[p], sb0 = lp ? ss.Sb[p] : Sb[p];
+        const int *row = asg + (size_t)ss.id[w] * D;
+        const int i = row[d0], j = row[d1];
+        const int cN = Nc[((size_t)p * C + i) * C + j];
+        const int ca = ac[(size_t)p * C + j], cb = bc[(size_t)p * C + i];
+        const double sN = sN0 - phi[cN] + phi[cN + 1];
+        const double sa = sa0 - phi[ca] + phi[ca + 1];
+        const double sb = sb0 - phi[cb] + phi[cb + 1];
+        sS[t] = (((sN - sa) - sb) + phin) / (double)(nc + 1);
+        if (fast) sCi[t] = i, sCj[t] = j, sCN[t] = cN, sCa[t] = ca, sCb[t] = cb;
     }
-    __syncthreads();
-    if (tid < 64) {  // wave 0: means, then k argmax rounds over the B <= 64 lanes
-        double s = -INFINITY;
-        if (tid < B) {
-            double tot = 0.0;
-            for (int p = 0; p < P; ++p) tot = tot + sS[tid * P + p];
-            s = tot / (double)P;
-            sScore[tid] = s;
-            if (scores_out) scores_out[tid] = s;
-            if (trace_scores) trace_scores[tid] = s;
-            if (trace_ids) trace_ids[tid] = sId[tid];
-        }
-        if (k > 0) {
-            unsigned long long used = 0ull;
-            const bool nan_or_out = !(s == s) || tid >= B;
-            for (int r = 0; r < k; ++r) {
-                // candidates still in play; a NaN score compares false with everything: the serial scan this
-                // replaces would keep the first unused position in that case, so do the same
-                double sr = (nan_or_out || (used >> tid & 1ull)) ? -INFINITY : s;
-                int wr = tid < B && !(used >> tid & 1ull) ? tid : 0x7fffffff;
-                sel_argmax_step(sr, wr, 1);
-                sel_argmax_step(sr, wr, 2);
-                sel_argmax_step(sr, wr, 4);
-                sel_argmax_step(sr, wr, 8);
-                sel_argmax_step(sr, wr, 16);
-                sel_argmax_step(sr, wr, 32);
-                used |= 1ull << wr;
-                if (tid == 0) {
-                    sPos[r] = wr;
-                    if (trace_pos) trace_pos[r] = wr;
-                }
-            }
-            if (forced_pos) {
-                used = 0ull;
-                for (int r = 0; r < k; ++r) used |= 1ull << forced_pos[r];
-                if (tid < k) sPos[tid] = forced_pos[tid];
-            }
-            if (tid == 0) sUsed = used;
-        }
+    lds_barrier();
+    FY_CLK(9);
+    // means, then the top k by RANK: every lane counts the candidates that beat it -- no reduction rounds, no dependent chain
+    // (k rounds of a wave-wide argmax were 2.6 us of shuffles).  Order: score descending, ties -> lower batch position;
+    // a NaN score never wins against a number and ranks by position among its like (as the argmax rounds did).
+    if (tid < B) {
+        double tot = 0.0;
+        for (int p = 0; p < P; ++p) tot = tot + sS[tid * P + p];
+        const double s = tot / (double)P;
+        ss.score[tid] = s;
+        ss.key[tid] = s == s ? s : -INFINITY;
+        if (scores_out) scores_out[tid] = s;
+        if (trace_scores) trace_scores[tid] = s;
+        if (trace_ids) trace_ids[tid] = ss.id[tid];
     }
-    __syncthreads();
+    lds_barrier();
+    FY_CLK(10);
     if (k == 0) return;
-    if (tid < k) {
-        const int pos = sPos[tid];
-        sPick[tid] = sId[pos];
-        S_out[tid] = (long long)sId[pos];
-        G_out[tid] = sScore[pos];
-    }
-    if (keep_unselected && tid < B) {  // get_unselected: torch.unique -> ascending ids (batch.py:167-171)
-        const unsigned long long used = sUsed;
-        if (!(used >> tid & 1ull)) {
-            const int v = sId[tid];
+    if (tid < 64) {  // wave 0 (B <= 64)
+        bool picked = false;
+        if (tid < B) {
+            const double mine = ss.key[tid];
             int rank = 0;
             for (int w = 0; w < B; ++w) {
-                const int o = sId[w];
+                const double o = ss.key[w];
+                rank += (o > mine || (o == mine && w < tid)) ? 1 : 0;
+            }
+            picked = rank < k;
+            if (picked) {
+                if (!forced_pos) ss.pos[rank] = tid;
+                if (trace_pos) trace_pos[rank] = tid;  // the free-running choice, also under teacher forcing
+            }
+        }
+        unsigned long long used = __ballot(picked);
+        if (forced_pos) {
+            used = 0ull;
+            for (int r = 0; r < k; ++r) used |= 1ull << forced_pos[r];
+            if (tid < k) ss.pos[tid] = forced_pos[tid];
+        }
+        if (tid == 0) ss.used = used;
+    }
+    lds_barrier();
+    if (tid < k) {
+        const int pos = ss.pos[tid];
+        ss.pick[tid] = ss.id[pos];
+        S_out[tid] = (long long)ss.id[pos];
+        G_out[tid] = ss.score[pos];
+    }
+    if (keep_unselected && tid < B) {  // get_unselected: torch.unique -> ascending ids (batch.py:167-171)
+        const unsigned long long used = ss.used;
+        if (!(used >> tid & 1ull)) {
+            const int v = ss.id[tid];
+            int rank = 0;
+            for (int w = 0; w < B; ++w) {
+                const int o = ss.id[w];
                 rank += (!(used >> w & 1ull) && (o < v || (o == v && w < tid))) ? 1 : 0;
             }
             requeue_out[rank * requeue_stride] = v;
         }
     }
-    __syncthreads();
+    lds_barrier();  // ss.pick; the global stores above need not have landed
+    FY_CLK(11);
     // update_cache (batch.py:152-154): commit the k winners, pair-parallel, pick order preserved
     for (int p = tid; p < P; p += blockDim.x) {
-        const int d0 = pairs[2 * p], d1 = pairs[2 * p + 1];
-        double sN = SN[p], sa = Sa[p], sb = Sb[p];
+        const bool lp = p < SEL_LDSP;
+        double sN = lp ? ss.SN[p] : SN[p], sa = lp ? ss.Sa[p] : Sa[p], sb = lp ? ss.Sb[p] : Sb[p];
         if (k <= SEL_FASTK) {
             int ci[SEL_FASTK], cj[SEL_FASTK], cN[SEL_FASTK], ca[SEL_FASTK], cb[SEL_FASTK];
+            if (fast) {  // what the scoring read for (pick, pair)
 #pragma unroll
-            for (int r = 0; r < SEL_FASTK; ++r)
-                if (r < k) {
-                    const int *row = asg + (size_t)sPick[r] * D;
-                    ci[r] = row[d0];
-                    cj[r] = row[d1];
-                }
+                for (int r = 0; r < SEL_FASTK; ++r)
+                    if (r < k) {
+                        const int t = ss.pos[r] * P + p;
+                        ci[r] = sCi[t], cj[r] = sCj[t], cN[r] = sCN[t], ca[r] = sCa[t], cb[r] = sCb[t];
+                    }
+            } else {
+                const int d0 = lp ? ss.pairs[2 * p] : pairs[2 * p], d1 = lp ? ss.pairs[2 * p + 1] : pairs[2 * p + 1];
 #pragma unroll
-            for (int r = 0; r < SEL_FASTK; ++r)
-                if (r < k) {
-                    cN[r] = Nc[((size_t)p * C + ci[r]) * C + cj[r]];
-                    ca[r] = ac[(size_t)p * C + cj[r]];
-                    cb[r] = bc[(size_t)p * C + ci[r]];
-                }
+                for (int r = 0; r < SEL_FASTK; ++r)
+                    if (r < k) {
+                        const int *row = asg + (size_t)ss.pick[r] * D;
+                        ci[r] = row[d0];
+                        cj[r] = row[d1];
+                    }
+#pragma unroll
+                for (int r = 0; r < SEL_FASTK; ++r)
+                    if (r < k) {
+                        cN[r] = Nc[((size_t)p * C + ci[r]) * C + cj[r]];
+                        ca[r] = ac[(size_t)p * C + cj[r]];
+                        cb[r] = bc[(size_t)p * C + ci[r]];
+                    }
+            }
 #pragma unroll
             for (int r = 0; r < SEL_FASTK; ++r)  // counts as pick r sees them: earlier picks of this iteration included
                 if (r < k) {
@@ -232,8 +303,9 @@ __device__ __forceinline__ void mi_select_body(
                     sb = sb - f[r][4] + f[r][5];
                 }
         } else {
+            const int d0 = lp ? ss.pairs[2 * p] : pairs[2 * p], d1 = lp ? ss.pairs[2 * p + 1] : pairs[2 * p + 1];
             for (int r = 0; r < k; ++r) {
-                const int *row = asg + (size_t)sPick[r] * D;
+                const int *row = asg + (size_t)ss.pick[r] * D;
                 const int i = row[d0], j = row[d1];
                 const size_t cell = ((size_t)p * C + i) * C + j;
                 const int cN = Nc[cell], ca = ac[(size_t)p * C + j], cb = bc[(size_t)p * C + i];
@@ -250,19 +322,22 @@ __device__ __forceinline__ void mi_select_body(
         Sb[p] = sb;
     }
     if (tid == 0) sc->nc = nc + k;
+    FY_CLK(12);
 }
 
 __global__ __launch_bounds__(256) void k_mi_select(
     const int *__restrict__ asg, int D, int C, int P, const int *__restrict__ pairs,
-    const int *__restrict__ batch, int B, int k, int *__restrict__ Nc, int *__restrict__ ac,
+    const int *__restrict__ batch, int B, int k, int fast, int *__restrict__ Nc, int *__restrict__ ac,
     int *__restrict__ bc, double *__restrict__ SN, double *__restrict__ Sa, double *__restrict__ Sb,
     const double *__restrict__ phi, MiScalars *__restrict__ sc, double *__restrict__ scores_out,
     long long *__restrict__ S_out, double *__restrict__ G_out, const int *__restrict__ forced_pos,
     int *__restrict__ trace_pos, long long *__restrict__ trace_ids, double *__restrict__ trace_scores,
     int keep_unselected, int *__restrict__ requeue_out)
 {
-    mi_select_body(asg, D, C, P, pairs, batch, B, k, Nc, ac, bc, SN, Sa, Sb, phi, sc, scores_out, S_out, G_out, forced_pos,
-                   trace_pos, trace_ids, trace_scores, keep_unselected, requeue_out);
+    __shared__ SelShared ss;
+    mi_select_stage(ss, P, pairs, SN, Sa, Sb, sc);
+    mi_select_body(ss, asg, D, C, P, pairs, batch, 0, B, k, fast != 0, Nc, ac, bc, SN, Sa, Sb, phi, sc, scores_out, S_out, G_out,
+                   forced_pos, trace_pos, trace_ids, trace_scores, keep_unselected, requeue_out);
 }
 
 // ------------------------------------------------------------------- exact greedy (mi / mem_mi)
@@ -618,37 +693,49 @@ __global__ __launch_bounds__(256) void k_fy_apply(const int *__restrict__ A, int
     fy_apply_body(A, L, B, h, head, next, g, batch_out, A_new, head_next, g_next, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
-// ------------------------------------------------------------------- tiled Fisher-Yates (single chunk)
+// ------------------------------------------------------------------- tiled Fisher-Yates
 // The kernels above pay two device-scope atomics per candidate (list head exchange + max) -- at L = 10^6 that is the
 // whole iteration (k_fy_build 88 us of 165).  This evaluation of the SAME swap sequence keeps every atomic in LDS:
-//   k_fy_part    step j -> its target h_j; steps with h_j = j (and position L-1, which has no step) keep their own
-//                content reference; every other step is appended to the bucket of the TILE its target lies in
-//                (LDS histogram per workgroup, one global reservation per non-empty bin, unordered append)
-//   k_fy_tile    one workgroup per tile: the pull lists of the tile's positions are built in LDS (ds exchange / max),
-//                every entry finds its predecessor in its list, and the tile emits  src[j] = "content of position h_j
-//                as it was before any step" (A-ref) or "what step pred left behind" (E-ref pred),  g[q] = last step
-//                that pulled from q
-//   k_fy_gather_select   out[i] = A[src] with E-refs resolved through the g chains (expected length ~1), and -- in
-//                workgroup 0, which is the one that produces the B batch entries -- the scoring / top-k / commit of the
-//                greedy iteration (mi_select_body): the selection runs while the other workgroups still gather
+//   k_fy_part     step j -> its target h_j; steps with h_j = j (and position L-1, which has no step) keep their own
+//                 content reference; every other step is appended to the bucket of the TILE its target lies in
+//                 (LDS histogram per workgroup, one global reservation per non-empty bin, unordered append)
+//   k_fy_tile     one workgroup per tile: the pull lists of the tile's positions are built in LDS (ds exchange / max),
+//                 every entry finds its predecessor in its list, and the tile emits  src[j] = "content of position h_j
+//                 as it was before any step" (A-ref) or "what step pred left behind" (E-ref pred),  g[q] = last step
+//                 that pulled from q
+//   k_fy_resolve  perm[j] = the position whose ORIGINAL content output j receives: E-refs walk back through the last
+//                 pullers (g chains, expected length ~1.5)
+//   k_fy_gather_select   out[i] = A[perm[i]], and -- in workgroup 0, which is the one that produces the B batch entries --
+//                 the scoring / top-k / commit of the greedy iteration (mi_select_body): the selection runs while the
+//                 other workgroups still gather
+// Only the last kernel touches content: the first three depend on the draws alone, run a GROUP of iterations per launch
+// on a second stream, a group ahead.  Random 4-byte accesses are bound by the L2 request rate (one request per element,
+// ~100-160 G/s on the whole chip), not by bytes, and either stream alone saturates it: at L = 10^6 the iteration takes
+// what its kernels take one after the other (tools/exp/fy_bench.hip), so every request saved anywhere counts.
 // Tiles are defined on e = L - 1 - h, the distance from the END of the list: the expected number of pulls on a
 // position is ~ln(L / (e + 1)), it depends on e (not on L, which shrinks every iteration), so one tiling computed for
 // the first iteration bounds every later one.  A tile is closed when it is `wcap` positions wide or its expected load
 // reaches 70 % of the LDS entry capacity; a (never expected) overload is handled by sub-ranging the tile, a bucket or
 // sub-range overflow raises the error flag and the run is refused -- never a wrong permutation.
-constexpr int FYA_CH = 4096;       // steps per k_fy_part workgroup
+#ifndef ACAV_FYA_CH
+#define ACAV_FYA_CH 8192
+#endif
+#ifndef ACAV_FYT_THREADS
+#define ACAV_FYT_THREADS 1024
+#endif
+constexpr int FYA_CH = ACAV_FYA_CH;  // steps per k_fy_part workgroup
 constexpr int FYA_THREADS = 1024;
 constexpr int64_t FY_TILED_MAX = 16 << 20;
 constexpr unsigned FY_EREF = 0x80000000u;
-constexpr int FY_GROUP = 8;        // iterations per cross-stream hand-off (one event pair per group, not per iteration)
-constexpr int FY_NBUF = 2 * FY_GROUP;  // src / g buffers: k_fy_part + k_fy_tile run one group ahead of the gathers
+constexpr int FY_GROUP = 8;        // iterations per launch of the position kernels and per cross-stream hand-off
+constexpr int FY_NBUF = 2 * FY_GROUP;  // perm buffers: the position kernels run one group ahead of the gathers
 constexpr int FY_SHARDS = 8;       // sub-buckets per tile (capg entries each), filled by workgroups b with b % 8 == shard
-constexpr int FYT_THREADS = 1024;  // k_fy_tile: the list walks are chains of dependent LDS reads -- many waves hide them
+constexpr int FYT_THREADS = ACAV_FYT_THREADS;  // k_fy_tile: the list walks are chains of dependent LDS reads -- many waves hide them
 
 __device__ __forceinline__ void fy_part_body(const unsigned *__restrict__ draws, int L, const unsigned short *__restrict__ table,
                                              int ntab, int gsh, int NT, int capg, int2 *__restrict__ bucket,
                                              int *__restrict__ gcount, unsigned *__restrict__ src, unsigned *__restrict__ err,
-                                             int bx)
+                                             int bx, int shard)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fy_smem[];
     int *lhist = reinterpret_cast<int *>(fy_smem), *lbase = lhist + NT;
@@ -684,9 +771,8 @@ __device__ __forceinline__ void fy_part_body(const unsigned *__restrict__ draws,
         }
     }
     __syncthreads();
-    // one reservation per non-empty bin -- in the workgroup's SHARD of the tile's bucket (workgroup b lands on XCD
-    // b % 8: a shard is written through one L2 only)
-    const int shard = bx & (FY_SHARDS - 1);
+    // one reservation per non-empty bin -- in the workgroup's SHARD of the tile's bucket (the workgroup with linear id b
+    // lands on XCD b % 8: a shard is written through one L2 only)
     for (int t = tid; t < NT; t += FYA_THREADS) {
         const int c = lhist[t];
         lbase[t] = c ? atomicAdd(&gcount[t * FY_SHARDS + shard], c) : 0;
@@ -703,14 +789,6 @@ __device__ __forceinline__ void fy_part_body(const unsigned *__restrict__ draws,
         }
 }
 
-__global__ __launch_bounds__(FYA_THREADS) void k_fy_part(const unsigned *__restrict__ draws, int L,
-                                                         const unsigned short *__restrict__ table, int ntab, int gsh, int NT,
-                                                         int capg, int2 *__restrict__ bucket, int *__restrict__ gcount,
-                                                         unsigned *__restrict__ src, unsigned *__restrict__ err)
-{
-    fy_part_body(draws, L, table, ntab, gsh, NT, capg, bucket, gcount, src, err, (int)blockIdx.x);
-}
-
 __device__ __forceinline__ void fy_tile_body(int L, const int *__restrict__ ebound, int capg, int ecap, int wcap,
                                              const int2 *__restrict__ bucket, int *__restrict__ gcount, unsigned *__restrict__ src,
                                              int *__restrict__ g, unsigned *__restrict__ err, int tile)
@@ -724,6 +802,7 @@ __device__ __forceinline__ void fy_tile_body(int L, const int *__restrict__ ebou
     __shared__ int lcnt;
     __shared__ int soff[FY_SHARDS + 1];
     const int tid = threadIdx.x;
+    FY_CLK0();
     const int e_lo = ebound[tile], e_hi = ebound[tile + 1];
     if (e_lo > L - 1) return;  // the list no longer reaches this tile (no step targets it: its counts are 0)
     const int q_lo = L - e_hi, w = e_hi - e_lo;  // positions q_lo .. q_lo + w - 1 (q_lo may be negative)
@@ -731,7 +810,7 @@ __device__ __forceinline__ void fy_tile_body(int L, const int *__restrict__ ebou
         int tot = 0;
         for (int sh = 0; sh < FY_SHARDS; ++sh) {
             int c = gcount[tile * FY_SHARDS + sh];
-            gcount[tile * FY_SHARDS + sh] = 0;  // for the next iteration's k_fy_part
+            gcount[tile * FY_SHARDS + sh] = 0;  // for the next group's k_fy_part
             c = c > capg ? capg : c;           // k_fy_part has raised the error flag
             soff[sh] = tot;
             tot += c;
@@ -739,6 +818,7 @@ __device__ __forceinline__ void fy_tile_body(int L, const int *__restrict__ ebou
         soff[FY_SHARDS] = tot;
     }
     __syncthreads();
+    FY_CLK(0);
     const int count = soff[FY_SHARDS];
     const int2 *bk = bucket + (size_t)tile * FY_SHARDS * capg;
     const int nsub = count <= ecap ? 1 : (count + (ecap >> 2) - 1) / (ecap >> 2);
@@ -750,24 +830,38 @@ __device__ __forceinline__ void fy_tile_body(int L, const int *__restrict__ ebou
         }
         if (tid == 0) lcnt = 0;
         __syncthreads();
-        for (int x = tid; x < count; x += FYT_THREADS) {
-            int sh = 0;  // entry x of the concatenated shards
+        FY_CLK(1);
+        // entry x of the concatenated shards; every load of the thread is issued before the first one is used (a loop of
+        // load -> LDS update pays one memory round trip per entry: that was most of this kernel)
+        constexpr int TPF = 8;
+        for (int x0 = tid; x0 < count; x0 += TPF * FYT_THREADS) {
+            int2 jh[TPF];
 #pragma unroll
-            for (int q = 1; q < FY_SHARDS; ++q) sh += x >= soff[q] ? 1 : 0;
-            const int2 jh = bk[(size_t)sh * capg + (x - soff[sh])];
-            const int p = jh.y - q_lo;
-            if (nsub > 1 && (p < p0 || p >= p1)) continue;
-            const int e = nsub == 1 ? x : atomicAdd(&lcnt, 1);
-            if (e < ecap) {
-                ej[e] = jh.x;
-                ep[e] = (unsigned short)p;
-                enx[e] = (unsigned short)atomicExch(&lhead[p], e);  // -1 -> 0xFFFF
-                atomicMax(&lg[p], jh.x);
-            } else {
-                atomicOr(err, 2u);
+            for (int u = 0; u < TPF; ++u) {
+                const int x = x0 + u * FYT_THREADS;
+                int sh = 0;
+#pragma unroll
+                for (int q = 1; q < FY_SHARDS; ++q) sh += x >= soff[q] ? 1 : 0;
+                jh[u] = x < count ? bk[(size_t)sh * capg + (x - soff[sh])] : make_int2(0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < TPF; ++u) {
+                const int x = x0 + u * FYT_THREADS;
+                const int p = jh[u].y - q_lo;
+                if (x >= count || (nsub > 1 && (p < p0 || p >= p1))) continue;
+                const int e = nsub == 1 ? x : atomicAdd(&lcnt, 1);
+                if (e < ecap) {
+                    ej[e] = jh[u].x;
+                    ep[e] = (unsigned short)p;
+                    enx[e] = (unsigned short)atomicExch(&lhead[p], e);  // -1 -> 0xFFFF
+                    atomicMax(&lg[p], jh[u].x);
+                } else {
+                    atomicOr(err, 2u);
+                }
             }
         }
         __syncthreads();
+        FY_CLK(2);
         const int n = nsub == 1 ? count : (lcnt < ecap ? lcnt : ecap);
         for (int e = tid; e < n; e += FYT_THREADS) {
             const int p = ep[e], j = ej[e];
@@ -778,73 +872,30 @@ __device__ __forceinline__ void fy_tile_body(int L, const int *__restrict__ ebou
             }
             src[j] = pred >= 0 ? (FY_EREF | (unsigned)pred) : (unsigned)(q_lo + p);
         }
+        FY_CLK(3);
         for (int p = p0 + tid; p < p1; p += FYT_THREADS)
             if (q_lo + p >= 0) g[q_lo + p] = lg[p];
         __syncthreads();
+        FY_CLK(4);
     }
 }
 
-__global__ __launch_bounds__(FYT_THREADS) void k_fy_tile(int L, const int *__restrict__ ebound, int capg, int ecap, int wcap,
-                                                         const int2 *__restrict__ bucket, int *__restrict__ gcount,
-                                                         unsigned *__restrict__ src, int *__restrict__ g, unsigned *__restrict__ err)
-{
-    fy_tile_body(L, ebound, capg, ecap, wcap, bucket, gcount, src, g, err, (int)blockIdx.x);
-}
-
-__device__ __forceinline__ void fy_gather_select_body(
-    const int *__restrict__ A, int L, const unsigned *__restrict__ src, const int *__restrict__ g, int *__restrict__ A_new,
-    const int *__restrict__ asg, int D, int C, int P, const int *__restrict__ pairs, int *__restrict__ batch, int B, int k,
-    int *__restrict__ Nc, int *__restrict__ ac, int *__restrict__ bc, double *__restrict__ SN, double *__restrict__ Sa,
-    double *__restrict__ Sb, const double *__restrict__ phi, MiScalars *__restrict__ sc, long long *__restrict__ S_out,
-    double *__restrict__ G_out, const int *__restrict__ forced_pos, int *__restrict__ trace_pos,
-    long long *__restrict__ trace_ids, double *__restrict__ trace_scores, int keep_unselected, int bx)
-{
-    const int i = (int)(bx * 256 + threadIdx.x);
-    if (i < L) {
-        const unsigned s = src[i];
-        int a = (int)(s & 0x7fffffffu);
-        if (s & FY_EREF) {  // what step a left behind: walk back to the position whose original content that was
-            int ga;
-            while ((ga = g[a]) >= 0) a = ga;
-        }
-        const int v = A[a];
-        if (i < B)
-            batch[i] = v;
-        else
-            A_new[i - B] = v;
-    }
-    if (bx != 0) return;  // uniform
-    __threadfence_block();
-    __syncthreads();
-    mi_select_body(asg, D, C, P, pairs, batch, B, k, Nc, ac, bc, SN, Sa, Sb, phi, sc, nullptr, S_out, G_out, forced_pos,
-                   trace_pos, trace_ids, trace_scores, keep_unselected, A_new + (L - B));
-}
-
-__global__ __launch_bounds__(256) void k_fy_gather_select(
-    const int *__restrict__ A, int L, const unsigned *__restrict__ src, const int *__restrict__ g, int *__restrict__ A_new,
-    const int *__restrict__ asg, int D, int C, int P, const int *__restrict__ pairs, int *__restrict__ batch, int B, int k,
-    int *__restrict__ Nc, int *__restrict__ ac, int *__restrict__ bc, double *__restrict__ SN, double *__restrict__ Sa,
-    double *__restrict__ Sb, const double *__restrict__ phi, MiScalars *__restrict__ sc, long long *__restrict__ S_out,
-    double *__restrict__ G_out, const int *__restrict__ forced_pos, int *__restrict__ trace_pos,
-    long long *__restrict__ trace_ids, double *__restrict__ trace_scores, int keep_unselected)
-{
-    fy_gather_select_body(A, L, src, g, A_new, asg, D, C, P, pairs, batch, B, k, Nc, ac, bc, SN, Sa, Sb, phi, sc, S_out, G_out,
-                          forced_pos, trace_pos, trace_ids, trace_scores, keep_unselected, (int)blockIdx.x);
-}
-
-// Several independent chunks (chunk.py:21-53) through the same three kernels with ONE launch each per iteration:
-// blockIdx.y picks the chunk, everything per chunk comes from a descriptor, everything that changes per iteration is a
-// function of the iteration number (L_t = L0 - t dl, buffer parities, the position of the iteration's draws in the
-// chunk's generator ring: r0(t) = t (L0 - 1) - dl t (t - 1) / 2).  Same device functions: same results per chunk.
+// One chunk of a tiled run (chunk.py:21-53; a single-chunk run is the case of one descriptor).  The three position
+// kernels serve a GROUP of iterations of every chunk per launch (blockIdx.y = chunk, blockIdx.z = iteration within the
+// group): nothing they compute depends on what the greedy selects, only on the draws, so the iterations of a group are
+// independent.  Everything per chunk comes from the descriptor, everything that changes per iteration is a function of
+// the iteration number (L_t = L0 - t dl, buffer indices, the position of the iteration's draws in the chunk's generator
+// ring: r0(t) = t (L0 - 1) - dl t (t - 1) / 2).
 struct TileChunk {
     const unsigned *ring;  // draw r' (counted from the first GENERATED word) at ring[r' mod ring_words]; r < head: ring[r - head]
     long long head, ring_words;
     const unsigned short *table;
     const int *ebound;
-    int2 *bucket;
-    int *gcount;
-    unsigned *src[FY_NBUF];
-    int *g[FY_NBUF];
+    int2 *bucket;            // [FY_GROUP][NT][FY_SHARDS][capg]
+    int *gcount;             // [FY_GROUP][NT][FY_SHARDS]
+    unsigned *src[FY_GROUP]; // content references and last pullers, per iteration of the group in flight
+    int *g[FY_GROUP];
+    unsigned *perm[FY_NBUF]; // source position of every output position, per iteration (two groups deep)
     int *A[2];
     unsigned *err;
     const int *asg, *pairs;
@@ -854,6 +905,10 @@ struct TileChunk {
     MiScalars *sc;
     long long *S;
     double *G;
+    const int *forced;       // teacher forcing / traces of a single-chunk run (NULL otherwise)
+    int *tr_pos;
+    long long *tr_ids;
+    double *tr_sc;
     int L0, iters, ntab, gsh, NT, capg, ecap, wcap, D, C, P, pad;
 };
 
@@ -863,32 +918,70 @@ __device__ __forceinline__ const unsigned *chunk_draw_ptr(const TileChunk &c, in
     return r0 < c.head ? c.ring - (c.head - r0) : c.ring + (r0 - c.head) % c.ring_words;
 }
 
-__global__ __launch_bounds__(FYA_THREADS) void k_fy_part_multi(const TileChunk *__restrict__ cd, int it, int dl)
+__global__ __launch_bounds__(FYA_THREADS) void k_fy_part_multi(const TileChunk *__restrict__ cd, int it0, int dl)
 {
     const TileChunk &c = cd[blockIdx.y];
+    const int z = (int)blockIdx.z, it = it0 + z;
     const int L = c.L0 - it * dl;
     if (it >= c.iters || (int)blockIdx.x * FYA_CH >= L) return;
-    fy_part_body(chunk_draw_ptr(c, it, dl), L, c.table, c.ntab, c.gsh, c.NT, c.capg, c.bucket, c.gcount, c.src[it % FY_NBUF], c.err,
-                 (int)blockIdx.x);
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    fy_part_body(chunk_draw_ptr(c, it, dl), L, c.table, c.ntab, c.gsh, c.NT, c.capg, c.bucket + (size_t)z * c.NT * FY_SHARDS * c.capg,
+                 c.gcount + (size_t)z * c.NT * FY_SHARDS, c.src[z], c.err, (int)blockIdx.x, (int)(lin & (FY_SHARDS - 1)));
 }
 
-__global__ __launch_bounds__(FYT_THREADS) void k_fy_tile_multi(const TileChunk *__restrict__ cd, int it, int dl)
+__global__ __launch_bounds__(FYT_THREADS) void k_fy_tile_multi(const TileChunk *__restrict__ cd, int it0, int dl)
 {
     const TileChunk &c = cd[blockIdx.y];
+    const int z = (int)blockIdx.z, it = it0 + z;
     if (it >= c.iters || (int)blockIdx.x >= c.NT) return;
-    fy_tile_body(c.L0 - it * dl, c.ebound, c.capg, c.ecap, c.wcap, c.bucket, c.gcount, c.src[it % FY_NBUF], c.g[it % FY_NBUF], c.err,
-                 (int)blockIdx.x);
+    fy_tile_body(c.L0 - it * dl, c.ebound, c.capg, c.ecap, c.wcap, c.bucket + (size_t)z * c.NT * FY_SHARDS * c.capg,
+                 c.gcount + (size_t)z * c.NT * FY_SHARDS, c.src[z], c.g[z], c.err, (int)blockIdx.x);
 }
 
+// perm[i] = the position (before the iteration) whose content output position i receives: the E-ref chains are walked
+// here, beside the content path -- the gather that waits for the previous selection is then one indexed copy
+__global__ __launch_bounds__(256) void k_fy_resolve_multi(const TileChunk *__restrict__ cd, int it0, int dl)
+{
+    // one element per thread: a wave waits for the longest of its chains, and four elements per thread (256 chains per
+    // wave) made the kernel 1.5x slower
+    const TileChunk &c = cd[blockIdx.y];
+    const int z = (int)blockIdx.z, it = it0 + z;
+    const int L = c.L0 - it * dl;
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (it >= c.iters || i >= L) return;
+    const unsigned s = c.src[z][i];
+    int a = (int)(s & 0x7fffffffu);
+    if (s & FY_EREF) {  // what step a left behind: walk back to the position whose original content that was
+        const int *__restrict__ g = c.g[z];
+        int ga;
+        while ((ga = g[a]) >= 0) a = ga;
+    }
+    c.perm[it % FY_NBUF][i] = (unsigned)a;
+}
+
+// out[i] = A[perm[i]]; the first B outputs are the batch, the rest the head of the next list; workgroup 0 -- the one
+// that produces the batch -- then runs the scoring / top-k / commit of the greedy iteration (mi_select_body) while the
+// other workgroups still gather
 __global__ __launch_bounds__(256) void k_fy_gather_select_multi(const TileChunk *__restrict__ cd, int it, int dl, int B, int k,
-                                                                int keep_unselected)
+                                                                int fast, int keep_unselected)
 {
     const TileChunk &c = cd[blockIdx.y];
     const int L = c.L0 - it * dl;
     if (it >= c.iters || (int)blockIdx.x * 256 >= L) return;
-    fy_gather_select_body(c.A[it & 1], L, c.src[it % FY_NBUF], c.g[it % FY_NBUF], c.A[(it + 1) & 1], c.asg, c.D, c.C, c.P, c.pairs,
-                          c.batch, B, k, c.Nc, c.ac, c.bc, c.SN, c.Sa, c.Sb, c.phi, c.sc, c.S + (size_t)it * k,
-                          c.G + (size_t)it * k, nullptr, nullptr, nullptr, nullptr, keep_unselected, (int)blockIdx.x);
+    __shared__ SelShared ss;
+    if (blockIdx.x == 0) mi_select_stage(ss, c.P, c.pairs, c.SN, c.Sa, c.Sb, c.sc);  // under the gather's round trips
+    int *__restrict__ A_new = c.A[(it + 1) & 1];
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    int v = 0;
+    if (i < L) {
+        v = c.A[it & 1][c.perm[it % FY_NBUF][i]];
+        if (i >= B) A_new[i - B] = v;
+    }
+    if (blockIdx.x != 0) return;  // uniform
+    mi_select_body(ss, c.asg, c.D, c.C, c.P, c.pairs, nullptr, v, B, k, fast != 0, c.Nc, c.ac, c.bc, c.SN, c.Sa, c.Sb, c.phi, c.sc,
+                   nullptr, c.S + (size_t)it * k, c.G + (size_t)it * k, c.forced ? c.forced + (size_t)it * k : nullptr,
+                   c.tr_pos ? c.tr_pos + (size_t)it * k : nullptr, c.tr_ids ? c.tr_ids + (size_t)it * B : nullptr,
+                   c.tr_sc ? c.tr_sc + (size_t)it * B : nullptr, keep_unselected, A_new + (L - B));
 }
 
 // ------------------------------------------------------------------ several chunks in lockstep
@@ -950,11 +1043,13 @@ __global__ __launch_bounds__(256) void k_fy_apply_multi(const ChunkDesc *__restr
 }
 
 __global__ __launch_bounds__(256) void k_mi_select_multi(const ChunkDesc *__restrict__ cd, int it, int dl, int B, int k,
-                                                         int keep_unselected)
+                                                         int fast, int keep_unselected)
 {
     const ChunkDesc c = cd[blockIdx.x];
     if (it >= c.iters) return;
-    mi_select_body(c.asg, c.D, c.C, c.P, c.pairs, c.batch, B, k, c.Nc, c.ac, c.bc, c.SN, c.Sa, c.Sb, c.phi, c.sc, nullptr,
+    __shared__ SelShared ss;
+    mi_select_stage(ss, c.P, c.pairs, c.SN, c.Sa, c.Sb, c.sc);
+    mi_select_body(ss, c.asg, c.D, c.C, c.P, c.pairs, c.batch, 0, B, k, fast != 0, c.Nc, c.ac, c.bc, c.SN, c.Sa, c.Sb, c.phi, c.sc, nullptr,
                    c.S + (size_t)it * k, c.G + (size_t)it * k, nullptr, nullptr, nullptr, nullptr, keep_unselected,
                    c.A[(it + 1) & 1] + (c.L0 - it * dl - B));
 }
@@ -979,8 +1074,8 @@ struct acav_mi {
     DevBuf removed, blockbest, ticket, tr_am;  // exact greedy
     DevBuf chunk_desc;                         // descriptor array of a multi-chunk run (lead handle)
     DevBuf lane_states, ring, polys;           // MT19937 lanes of the single-chunk greedy (MtStream)
-    DevBuf fy_table, fy_bounds, fy_bucket, fy_count, fy_src[FY_NBUF], fy_g[FY_NBUF], fy_err;  // tiled Fisher-Yates
-    hipStream_t st_fy = nullptr;               // k_fy_part / k_fy_tile of iteration t+1 run beside the gather of t
+    DevBuf fy_table, fy_bounds, fy_bucket, fy_count, fy_src[FY_GROUP], fy_g[FY_GROUP], fy_perm[FY_NBUF], fy_err;  // tiled Fisher-Yates
+    hipStream_t st_fy = nullptr;               // the position kernels of group g+1 run beside the gathers of group g
     hipEvent_t ev_tile[FY_NBUF] = {}, ev_gather[FY_NBUF] = {};
     // the mt19937 stream does not depend on the selection state: it is generated one iteration ahead on
     // its own stream (double-buffered draws), overlapping the Fisher-Yates / select kernels
@@ -1013,7 +1108,8 @@ struct MtStream {
     int64_t waited = -1;   // highest superblock `st` has been told to wait for
     int64_t freed = 0;     // superblocks [0, freed) are no longer read by any iteration still to be enqueued
 
-    int plan(acav_mi *mi, hipStream_t consumer, const uint32_t *mtbuf, int idx, int64_t total_draws, int64_t L)
+    // L: the longest list (one iteration reads at most L - 1 contiguous draws); span: the most draws one acquire() covers
+    int plan(acav_mi *mi, hipStream_t consumer, const uint32_t *mtbuf, int idx, int64_t total_draws, int64_t L, int64_t span)
     {
         T = total_draws;
         p0 = idx;
@@ -1029,8 +1125,8 @@ struct MtStream {
             nblocks = (gen + blk - 1) / blk;
             W = 1;
             while (W < 32 && W < nblocks) W *= 2;
-            if ((nblocks + W - 1) / W > NSLOT && (int64_t)W * blk < 2 * L) {  // a slot must hold a whole iteration twice over
-                blk = 624 * ((2 * L + 624 * (int64_t)W - 1) / (624 * (int64_t)W));
+            if ((nblocks + W - 1) / W > NSLOT && (int64_t)W * blk < 2 * span) {  // a slot must hold what one acquire() covers twice over
+                blk = 624 * ((2 * span + 624 * (int64_t)W - 1) / (624 * (int64_t)W));
                 nblocks = (gen + blk - 1) / blk;
             }
         }
@@ -1146,8 +1242,12 @@ struct FyPlan {
     std::vector<int> ebound;            // tile t covers e in [ebound[t], ebound[t+1])
     void build(int64_t L0)
     {
-        int cap = 256;
-        while (cap < 8192 && (int64_t)cap * 128 < L0) cap *= 2;
+        int cap = 256, cap_max = 8192;
+        if (const char *v = getenv("ACAV_FY_CAP")) {  // experiments: smaller tiles (more workgroups per CU)
+            const int x = atoi(v);
+            if (x >= 256 && x <= 8192 && (x & (x - 1)) == 0) cap_max = x;
+        }
+        while (cap < cap_max && (int64_t)cap * 128 < L0) cap *= 2;
         wcap = ecap = cap;
         // capacity of ONE shard of a tile's bucket: with many k_fy_part workgroups the shards fill evenly (an eighth of
         // the tile's load each, 4x headroom); with few, one shard may receive everything
@@ -1186,23 +1286,25 @@ struct FyPlan {
 };
 
 // tiling of a list of (at most) L candidates and the handle's buffers for it: table, tile bounds, sharded buckets and their
-// counters (zeroed), error flag (cleared), FY_NBUF src / g buffers; uploads are stream-ordered on st (fp must stay alive
+// counters (one set per iteration of a group; zeroed), error flag (cleared), src / g (per iteration of a group) and perm
+// (two groups deep) buffers; uploads are stream-ordered on st (fp must stay alive
 // until st has been synchronised)
 static int fy_setup(acav_mi *mi, int64_t L, FyPlan &fp, hipStream_t st)
 {
     fp.build(L);
     ACAV_TRY(mi->fy_table.ensure(sizeof(unsigned short) * fp.table.size()));
     ACAV_TRY(mi->fy_bounds.ensure(sizeof(int) * fp.ebound.size()));
-    ACAV_TRY(mi->fy_bucket.ensure(sizeof(int2) * (size_t)fp.NT * FY_SHARDS * fp.capg));
-    ACAV_TRY(mi->fy_count.ensure(sizeof(int) * (size_t)fp.NT * FY_SHARDS));
+    ACAV_TRY(mi->fy_bucket.ensure(sizeof(int2) * (size_t)FY_GROUP * fp.NT * FY_SHARDS * fp.capg));
+    ACAV_TRY(mi->fy_count.ensure(sizeof(int) * (size_t)FY_GROUP * fp.NT * FY_SHARDS));
     ACAV_TRY(mi->fy_err.ensure(sizeof(unsigned)));
-    for (int q = 0; q < FY_NBUF; ++q) {
+    for (int q = 0; q < FY_GROUP; ++q) {
         ACAV_TRY(mi->fy_src[q].ensure(sizeof(unsigned) * (size_t)L));
         ACAV_TRY(mi->fy_g[q].ensure(sizeof(int) * (size_t)L));
     }
+    for (int q = 0; q < FY_NBUF; ++q) ACAV_TRY(mi->fy_perm[q].ensure(sizeof(unsigned) * (size_t)L));
     ACAV_HIP_TRY(hipMemcpyAsync(mi->fy_table.p, fp.table.data(), sizeof(unsigned short) * fp.table.size(), hipMemcpyHostToDevice, st));
     ACAV_HIP_TRY(hipMemcpyAsync(mi->fy_bounds.p, fp.ebound.data(), sizeof(int) * fp.ebound.size(), hipMemcpyHostToDevice, st));
-    ACAV_HIP_TRY(hipMemsetAsync(mi->fy_count.p, 0, sizeof(int) * (size_t)fp.NT * FY_SHARDS, st));
+    ACAV_HIP_TRY(hipMemsetAsync(mi->fy_count.p, 0, sizeof(int) * (size_t)FY_GROUP * fp.NT * FY_SHARDS, st));
     ACAV_HIP_TRY(hipMemsetAsync(mi->fy_err.p, 0, sizeof(unsigned), st));
     return ACAV_OK;
 }
@@ -1338,19 +1440,30 @@ ACAV_EXPORT int acav_mi_destroy(acav_mi *mi)
     delete mi;
     return ACAV_OK;
 }
-// Several independent chunks (one handle, candidate list, start set, subset size and generator each) selected in
-// lockstep: the same kernels as acav_mi_run_greedy, one launch serving every chunk (see ChunkDesc).  All handles
-// must live on the same device; the first handle's streams carry the work.  Results per chunk are exactly those
-// of acav_mi_run_greedy called with that chunk's arguments and generator.
-// the lockstep run on the lane generator + tiled Fisher-Yates kernels (every chunk's list within FY_TILED_MAX)
-static int run_greedy_multi_tiled(acav_mi **mis, int nchunks, const int64_t *const *candidates, const int64_t *L,
-                                  const int64_t *const *start, const int *ns, const int64_t *subset, int B, int k,
-                                  int keep_unselected, acav_rng **rngs, int64_t *const *S_out, double *const *GAIN_out,
-                                  int64_t *n_selected, int64_t *n_iters)
+// single-chunk options of acav_mi_run_greedy (teacher forcing, traces, an iteration cap)
+struct TiledExtras {
+    int64_t *trace_ids = nullptr;
+    double *trace_scores = nullptr;
+    int32_t *trace_pos = nullptr;
+    const int32_t *forced_pos = nullptr;
+    int64_t max_iters = -1;
+};
+
+// The greedy run on the lane generator + tiled Fisher-Yates kernels: one chunk (acav_mi_run_greedy) or several independent
+// chunks in lockstep (acav_mi_run_greedy_multi; one handle, candidate list, start set, subset size and generator each;
+// every list within FY_TILED_MAX).  All handles live on the same device; the first handle's streams carry the work.
+// Two streams: the position kernels (k_fy_part / k_fy_tile / k_fy_resolve: no content, one launch each per GROUP of
+// iterations) run on st_fy one group ahead of the gathers + selections on the main stream; perm is buffered two groups
+// deep and the streams meet through one event pair per group (a cross-stream hand-off costs ~20 us of latency,
+// an event record / wait a few us of queue time: per iteration they sat on the critical path).
+static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *candidates, const int64_t *L,
+                            const int64_t *const *start, const int *ns, const int64_t *subset, int B, int k,
+                            int keep_unselected, acav_rng **rngs, int64_t *const *S_out, double *const *GAIN_out,
+                            int64_t *n_selected, int64_t *n_iters, const TiledExtras &ex)
 {
     acav_mi *lead = mis[0];
     hipStream_t st = lead->ctx.stream, sf = lead->st_fy;
-    const int64_t dl = B - (keep_unselected ? B - k : 0);
+    const int64_t dl = B - (keep_unselected ? B - k : 0);  // candidates consumed per iteration
     std::vector<TileChunk> desc((size_t)nchunks);
     std::vector<int64_t> iters((size_t)nchunks, 0), r0((size_t)nchunks, 0);
     std::vector<FyPlan> plans((size_t)nchunks);
@@ -1361,11 +1474,13 @@ static int run_greedy_multi_tiled(acav_mi **mis, int nchunks, const int64_t *con
     for (int c = 0; c < nchunks; ++c) {
         acav_mi *mi = mis[c];
         ACAV_HIP_TRY(hipStreamSynchronize(mi->ctx.stream));  // whatever the handle was doing on its own stream is over
-        if (ns[c]) ACAV_TRY(acav_mi_add_samples(mi, start[c], ns[c]));
+        if (ns[c]) ACAV_TRY(acav_mi_add_samples(mi, start[c], ns[c]));  // batch.py:215
+        // plan: the number of iterations and every L_t are known on the host (no device feedback)
         int64_t nS = 0, l = L[c], itc = 0, draws = 0;
-        while (nS < subset[c]) {
-            ACAV_REQUIRE(l >= B, ACAV_ERANGE, "chunk %d: %lld candidates left < batch_size %d (batch.py:143-150)", c,
-                         (long long)l, B);
+        while (nS < subset[c] && (ex.max_iters < 0 || itc < ex.max_iters)) {
+            ACAV_REQUIRE(l >= B, ACAV_ERANGE,
+                         "chunk %d: %lld candidates left < batch_size %d: the reference's topk(k=floor(B/k*B')) raises here "
+                         "(batch.py:143-150)", c, (long long)l, B);
             draws += l > 1 ? l - 1 : 0;
             nS += k;
             l -= dl;
@@ -1376,77 +1491,112 @@ static int run_greedy_multi_tiled(acav_mi **mis, int nchunks, const int64_t *con
         lmax = L[c] > lmax ? L[c] : lmax;
         pmax = mi->P > pmax ? mi->P : pmax;
         const size_t Lc = (size_t)L[c];
-        ACAV_TRY(mi->A0.ensure(sizeof(int) * (Lc + B)));
+        ACAV_TRY(mi->A0.ensure(sizeof(int) * (Lc + B)));  // before the conversion: ensure() does not copy
         ACAV_TRY(ids_to_device32(mi, candidates[c], L[c], mi->stage, mi->A0));
         ACAV_TRY(mi->A1.ensure(sizeof(int) * (Lc + B)));
         ACAV_TRY(mi->batch.ensure(sizeof(int) * SEL_MAXB));
         ACAV_TRY(mi->S.ensure(sizeof(long long) * (size_t)(itc * k + 1)));
         ACAV_TRY(mi->G.ensure(sizeof(double) * (size_t)(itc * k + 1)));
+        if (ex.trace_pos) ACAV_TRY(mi->tr_pos.ensure(sizeof(int) * (size_t)(itc * k + 1)));
+        if (ex.trace_ids) ACAV_TRY(mi->tr_ids.ensure(sizeof(long long) * (size_t)(itc * B + 1)));
+        if (ex.trace_scores) ACAV_TRY(mi->tr_sc.ensure(sizeof(double) * (size_t)(itc * B + 1)));
+        if (ex.forced_pos) {
+            for (int64_t i = 0; i < itc * k; ++i)
+                ACAV_REQUIRE(ex.forced_pos[i] >= 0 && ex.forced_pos[i] < B, ACAV_EINVAL, "forced position out of range");
+            ACAV_TRY(mi->forced.ensure(sizeof(int) * (size_t)(itc * k + 1)));
+            ACAV_HIP_TRY(hipMemcpyAsync(mi->forced.p, ex.forced_pos, sizeof(int) * (size_t)(itc * k), hipMemcpyHostToDevice, st));
+        }
         FyPlan &fp = plans[(size_t)c];
         ACAV_TRY(fy_setup(mi, L[c], fp, st));
         ntmax = fp.NT > ntmax ? fp.NT : ntmax;
         const size_t ps = sizeof(int) * 2 * (size_t)fp.NT + sizeof(unsigned short) * fp.table.size();
         part_smem = ps > part_smem ? ps : part_smem;
         tile_smem = fp.tile_smem() > tile_smem ? fp.tile_smem() : tile_smem;
+        // hand the host MT19937 stream to the device: W lanes generate it superblock by superblock on their own stream
+        // (MtStream); nothing they do depends on what gets selected (L shrinks by a fixed amount per iteration)
         unsigned mtbuf[625];
         int idx = 0;
         ACAV_TRY(acav_rng_get_state(rngs[c], mtbuf, &idx));
         MtStream &ms = streams[(size_t)c];
-        ACAV_TRY(ms.plan(mi, sf, mtbuf, idx, draws, L[c]));
+        ACAV_TRY(ms.plan(mi, sf, mtbuf, idx, draws, L[c], (int64_t)FY_GROUP * L[c]));
         TileChunk &d = desc[(size_t)c];
         d.ring = ms.ring + MtStream::PAD;
         d.head = ms.head;
         d.ring_words = ms.wraps ? MtStream::NSLOT * ms.S : ((long long)1 << 62);
         d.table = mi->fy_table.as<unsigned short>(), d.ebound = mi->fy_bounds.as<int>();
         d.bucket = mi->fy_bucket.as<int2>(), d.gcount = mi->fy_count.as<int>(), d.err = mi->fy_err.as<unsigned>();
-        for (int q = 0; q < FY_NBUF; ++q) d.src[q] = mi->fy_src[q].as<unsigned>(), d.g[q] = mi->fy_g[q].as<int>();
+        for (int q = 0; q < FY_GROUP; ++q) d.src[q] = mi->fy_src[q].as<unsigned>(), d.g[q] = mi->fy_g[q].as<int>();
+        for (int q = 0; q < FY_NBUF; ++q) d.perm[q] = mi->fy_perm[q].as<unsigned>();
         d.A[0] = mi->A0.as<int>(), d.A[1] = mi->A1.as<int>();
         d.asg = mi->asg.as<int>(), d.pairs = mi->pairs.as<int>(), d.batch = mi->batch.as<int>();
         d.Nc = mi->Nc.as<int>(), d.ac = mi->ac.as<int>(), d.bc = mi->bc.as<int>();
         d.SN = mi->SN.as<double>(), d.Sa = mi->Sa.as<double>(), d.Sb = mi->Sb.as<double>();
         d.phi = mi->phi.as<double>(), d.sc = mi->scalars.as<MiScalars>();
         d.S = mi->S.as<long long>(), d.G = mi->G.as<double>();
+        d.forced = ex.forced_pos ? mi->forced.as<int>() : nullptr;
+        d.tr_pos = ex.trace_pos ? mi->tr_pos.as<int>() : nullptr;
+        d.tr_ids = ex.trace_ids ? mi->tr_ids.as<long long>() : nullptr;
+        d.tr_sc = ex.trace_scores ? mi->tr_sc.as<double>() : nullptr;
         d.L0 = (int)L[c], d.iters = (int)itc, d.ntab = (int)fp.table.size(), d.gsh = fp.gsh, d.NT = fp.NT, d.capg = fp.capg;
         d.ecap = fp.ecap_lds, d.wcap = fp.wcap, d.D = mi->D, d.C = mi->C, d.P = mi->P, d.pad = 0;
     }
     ACAV_TRY(lead->chunk_desc.ensure(sizeof(TileChunk) * (size_t)nchunks));
     ACAV_HIP_TRY(hipMemcpyAsync(lead->chunk_desc.p, desc.data(), sizeof(TileChunk) * (size_t)nchunks, hipMemcpyHostToDevice, st));
-    ACAV_HIP_TRY(hipStreamSynchronize(st));  // tables, counters, candidate lists and descriptors are in place
+    ACAV_HIP_TRY(hipStreamSynchronize(st));  // tables, counters, candidate lists, forced positions and descriptors are in place
     ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fy_tile_multi), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)tile_smem));
     const TileChunk *dcd = lead->chunk_desc.as<TileChunk>();
-    const size_t sel_smem = sizeof(double) * (size_t)B * (size_t)pmax;
-    for (int64_t g0 = 0; g0 < iters_max; g0 += FY_GROUP) {  // groups of iterations, as in acav_mi_run_greedy
+    const size_t sel_smem = sel_smem_bytes(B, pmax);
+    const int sel_f = sel_fast(B, pmax) ? 1 : 0;
+    const bool timing = getenv("ACAV_MI_TIMING") != nullptr;
+    const auto t_loop0 = std::chrono::steady_clock::now();
+    for (int64_t g0 = 0; g0 < iters_max; g0 += FY_GROUP) {
         const int64_t g1 = g0 + FY_GROUP < iters_max ? g0 + FY_GROUP : iters_max;
-        const int ge = (int)((g0 / FY_GROUP) & 1);
+        const unsigned gz = (unsigned)(g1 - g0);
+        const int ge = (int)((g0 / FY_GROUP) & 1);  // event pair and buffer half of this group
+        const int64_t lt = lmax - g0 * dl;           // the longest list still in play bounds the grids
+        // ---- st_fy: the positions of the group's iterations (the gathers of the group two back are done with this half)
         if (g0 >= 2 * FY_GROUP) ACAV_HIP_TRY(hipStreamWaitEvent(sf, lead->ev_gather[ge], 0));
-        for (int64_t it = g0; it < g1; ++it) {
-            const int64_t lt = lmax - it * dl;  // the longest list still in play bounds the grids
-            for (int c = 0; c < nchunks; ++c) {
-                if (it >= iters[(size_t)c]) continue;
-                const int64_t Lc = L[c] - it * dl, nd = Lc > 1 ? Lc - 1 : 0;
-                const unsigned *unused = nullptr;
-                ACAV_TRY(streams[(size_t)c].acquire(r0[(size_t)c], nd, &unused));
-                r0[(size_t)c] += nd;
+        for (int c = 0; c < nchunks; ++c) {
+            int64_t nd = 0;
+            for (int64_t it = g0; it < g1 && it < iters[(size_t)c]; ++it) {
+                const int64_t Lc = L[c] - it * dl;
+                nd += Lc > 1 ? Lc - 1 : 0;
             }
-            hipLaunchKernelGGL(k_fy_part_multi, dim3((unsigned)((lt + FYA_CH - 1) / FYA_CH), (unsigned)nchunks), dim3(FYA_THREADS),
-                               part_smem, sf, dcd, (int)it, (int)dl);
-            for (int c = 0; c < nchunks; ++c)
-                if (it < iters[(size_t)c]) ACAV_TRY(streams[(size_t)c].release(r0[(size_t)c]));  // k_fy_part is the only reader of the draws
-            hipLaunchKernelGGL(k_fy_tile_multi, dim3((unsigned)ntmax, (unsigned)nchunks), dim3(FYT_THREADS), tile_smem, sf, dcd, (int)it,
-                               (int)dl);
+            if (nd == 0) continue;
+            const unsigned *unused = nullptr;
+            ACAV_TRY(streams[(size_t)c].acquire(r0[(size_t)c], nd, &unused));
+            r0[(size_t)c] += nd;
         }
+        hipLaunchKernelGGL(k_fy_part_multi, dim3((unsigned)((lt + FYA_CH - 1) / FYA_CH), (unsigned)nchunks, gz), dim3(FYA_THREADS),
+                           part_smem, sf, dcd, (int)g0, (int)dl);
+        for (int c = 0; c < nchunks; ++c)
+            if (g0 < iters[(size_t)c]) ACAV_TRY(streams[(size_t)c].release(r0[(size_t)c]));  // k_fy_part is the only reader of the draws
+        hipLaunchKernelGGL(k_fy_tile_multi, dim3((unsigned)ntmax, (unsigned)nchunks, gz), dim3(FYT_THREADS), tile_smem, sf, dcd, (int)g0,
+                           (int)dl);
+        hipLaunchKernelGGL(k_fy_resolve_multi, dim3((unsigned)((lt + 255) / 256), (unsigned)nchunks, gz), dim3(256), 0, sf, dcd, (int)g0,
+                           (int)dl);
         ACAV_HIP_TRY(hipEventRecord(lead->ev_tile[ge], sf));
+        // ---- main stream: the group's gathers + selections, back to back
         ACAV_HIP_TRY(hipStreamWaitEvent(st, lead->ev_tile[ge], 0));
         for (int64_t it = g0; it < g1; ++it) {
-            const int64_t lt = lmax - it * dl;
-            hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((unsigned)((lt + 255) / 256), (unsigned)nchunks), dim3(256), sel_smem, st,
-                               dcd, (int)it, (int)dl, B, k, keep_unselected);
+            const dim3 grid((unsigned)((lmax - it * dl + 255) / 256), (unsigned)nchunks);
+            hipLaunchKernelGGL(k_fy_gather_select_multi, grid, dim3(256), sel_smem, st, dcd, (int)it, (int)dl, B, k, sel_f, keep_unselected);
         }
         ACAV_HIP_TRY(hipGetLastError());
         ACAV_HIP_TRY(hipEventRecord(lead->ev_gather[ge], st));
     }
+    const auto t_loop1 = std::chrono::steady_clock::now();
     ACAV_HIP_TRY(hipStreamSynchronize(sf));
+    if (timing) {
+        ACAV_HIP_TRY(hipStreamSynchronize(st));
+        const auto t_loop2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[acav] greedy loop: %d chunk(s), %lld iterations, host enqueue %.2f us/iteration, enqueue + drain %.2f "
+                        "us/iteration (tiles %d, cap %d, lanes %d)\n", nchunks, (long long)iters_max,
+                std::chrono::duration<double, std::micro>(t_loop1 - t_loop0).count() / (double)(iters_max ? iters_max : 1),
+                std::chrono::duration<double, std::micro>(t_loop2 - t_loop0).count() / (double)(iters_max ? iters_max : 1),
+                plans[0].NT, plans[0].ecap, streams[0].W);
+    }
     for (int c = 0; c < nchunks; ++c) {
         acav_mi *mi = mis[c];
         const int64_t itc = iters[(size_t)c];
@@ -1454,6 +1604,12 @@ static int run_greedy_multi_tiled(acav_mi **mis, int nchunks, const int64_t *con
         if (itc > 0) {
             ACAV_HIP_TRY(hipMemcpyAsync(S_out[c], mi->S.p, sizeof(long long) * (size_t)nsel, hipMemcpyDeviceToHost, st));
             ACAV_HIP_TRY(hipMemcpyAsync(GAIN_out[c], mi->G.p, sizeof(double) * (size_t)(itc * k), hipMemcpyDeviceToHost, st));
+            if (ex.trace_pos)
+                ACAV_HIP_TRY(hipMemcpyAsync(ex.trace_pos, mi->tr_pos.p, sizeof(int) * (size_t)(itc * k), hipMemcpyDeviceToHost, st));
+            if (ex.trace_ids)
+                ACAV_HIP_TRY(hipMemcpyAsync(ex.trace_ids, mi->tr_ids.p, sizeof(long long) * (size_t)(itc * B), hipMemcpyDeviceToHost, st));
+            if (ex.trace_scores)
+                ACAV_HIP_TRY(hipMemcpyAsync(ex.trace_scores, mi->tr_sc.p, sizeof(double) * (size_t)(itc * B), hipMemcpyDeviceToHost, st));
         }
         if (n_selected) n_selected[c] = nsel;
         if (n_iters) n_iters[c] = itc;
@@ -1501,8 +1657,8 @@ ACAV_EXPORT int acav_mi_run_greedy_multi(acav_mi **mis, int nchunks, const int64
             tiled = tiled && L[c] <= FY_TILED_MAX;
         }
         if (tiled)
-            return run_greedy_multi_tiled(mis, nchunks, candidates, L, start, ns, subset, B, k, keep_unselected, rngs, S_out,
-                                          GAIN_out, n_selected, n_iters);
+            return run_greedy_tiled(mis, nchunks, candidates, L, start, ns, subset, B, k, keep_unselected, rngs, S_out, GAIN_out,
+                                    n_selected, n_iters, TiledExtras());
     }
     hipStream_t st = lead->ctx.stream, smt = lead->st_mt;
     const int64_t dl = B - (keep_unselected ? B - k : 0);
@@ -1586,7 +1742,8 @@ ACAV_EXPORT int acav_mi_run_greedy_multi(acav_mi **mis, int nchunks, const int64
         return ACAV_OK;
     };
     if (iters_max > 0) ACAV_TRY(launch_mt(0));
-    const size_t smem = sizeof(double) * (size_t)B * (size_t)pmax;
+    const size_t smem = sel_smem_bytes(B, pmax);
+    const int sel_f = sel_fast(B, pmax) ? 1 : 0;
     for (int64_t it = 0; it < iters_max; ++it) {
         const int64_t grp = it / MT_GROUP;
         const int cur = (int)(grp & 1);
@@ -1599,7 +1756,7 @@ ACAV_EXPORT int acav_mi_run_greedy_multi(acav_mi **mis, int nchunks, const int64
         hipLaunchKernelGGL(k_fy_build_multi, grid, dim3(256), 0, st, dcd, (int)it, (int)dl);
         if (it % MT_GROUP == MT_GROUP - 1 || it + 1 == iters_max) ACAV_HIP_TRY(hipEventRecord(lead->ev_used[cur], st));
         hipLaunchKernelGGL(k_fy_apply_multi, grid, dim3(256), 0, st, dcd, (int)it, (int)dl, B);
-        hipLaunchKernelGGL(k_mi_select_multi, dim3((unsigned)nchunks), dim3(256), smem, st, dcd, (int)it, (int)dl, B, k,
+        hipLaunchKernelGGL(k_mi_select_multi, dim3((unsigned)nchunks), dim3(256), smem, st, dcd, (int)it, (int)dl, B, k, sel_f,
                            keep_unselected);
     }
     ACAV_HIP_TRY(hipGetLastError());
@@ -1725,9 +1882,9 @@ static int launch_select(acav_mi *mi, const int *batch, int B, int k, double *sc
                          double *G_out, const int *forced_pos, int *trace_pos, long long *trace_ids,
                          double *trace_scores, int keep, int *requeue_out)
 {
-    const size_t smem = sizeof(double) * (size_t)B * mi->P;
+    const size_t smem = sel_smem_bytes(B, mi->P);
     hipLaunchKernelGGL(k_mi_select, dim3(1), dim3(256), smem, mi->ctx.stream, mi->asg.as<int>(), mi->D, mi->C, mi->P,
-                       mi->pairs.as<int>(), batch, B, k, mi->Nc.as<int>(), mi->ac.as<int>(), mi->bc.as<int>(),
+                       mi->pairs.as<int>(), batch, B, k, sel_fast(B, mi->P) ? 1 : 0, mi->Nc.as<int>(), mi->ac.as<int>(), mi->bc.as<int>(),
                        mi->SN.as<double>(), mi->Sa.as<double>(), mi->Sb.as<double>(), mi->phi.as<double>(),
                        mi->scalars.as<MiScalars>(), scores_out, S_out, G_out, forced_pos, trace_pos, trace_ids,
                        trace_scores, keep, requeue_out);
@@ -1778,6 +1935,16 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
                  "batch_size %d / selection_size %d / pairs %d outside the supported range (B<=%d, B*P<=%d)", B, k,
                  mi->P, SEL_MAXB, SEL_MAXBP);
     ACAV_HIP_TRY(hipSetDevice(mi->ctx.device));
+    // the permutation of every iteration: tiled evaluation (all atomics in LDS; run_greedy_tiled) unless the list is too long
+    // for its tile table, or ACAV_FY_LEGACY=1 asks for the global-atomic kernels (k_fy_build / k_fy_apply) below
+    const char *legacy = getenv("ACAV_FY_LEGACY");
+    if (L <= FY_TILED_MAX && !(legacy && legacy[0] == '1')) {
+        TiledExtras ex;
+        ex.trace_ids = trace_ids, ex.trace_scores = trace_scores, ex.trace_pos = trace_pos, ex.forced_pos = forced_pos;
+        ex.max_iters = max_iters;
+        return run_greedy_tiled(&mi, 1, &candidates, &L, &start, &ns, &subset, B, k, keep_unselected, &rng, &S_out, &GAIN_out,
+                                n_selected, n_iters, ex);
+    }
     hipStream_t st = mi->ctx.stream;
     if (ns) ACAV_TRY(acav_mi_add_samples(mi, start, ns));  // batch.py:215
 
@@ -1798,25 +1965,14 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
     ACAV_TRY(mi->A0.ensure(sizeof(int) * (size_t)(L + B)));  // before the conversion: ensure() does not copy
     ACAV_TRY(ids_to_device32(mi, candidates, L, mi->stage, mi->A0));
     ACAV_TRY(mi->A1.ensure(sizeof(int) * (size_t)(L + B)));
-    // the permutation of every iteration: tiled evaluation (all atomics in LDS) unless the list is too long for its
-    // tile table, or ACAV_FY_LEGACY=1 asks for the global-atomic kernels (k_fy_build / k_fy_apply)
-    const char *legacy = getenv("ACAV_FY_LEGACY");
-    const bool tiled = L <= FY_TILED_MAX && !(legacy && legacy[0] == '1');
-    FyPlan fp;
-    if (tiled) {
-        ACAV_TRY(fy_setup(mi, L, fp, st));
-        ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fy_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)fp.tile_smem()));
-    } else {
-        ACAV_TRY(mi->h.ensure(sizeof(int) * (size_t)L));
-        ACAV_TRY(mi->head.ensure(sizeof(int) * (size_t)L));
-        ACAV_TRY(mi->next.ensure(sizeof(int) * (size_t)L));
-        ACAV_TRY(mi->g.ensure(sizeof(int) * (size_t)L));
-        ACAV_TRY(mi->head2.ensure(sizeof(int) * (size_t)L));
-        ACAV_TRY(mi->g2.ensure(sizeof(int) * (size_t)L));
-        ACAV_HIP_TRY(hipMemsetAsync(mi->head.p, 0xFF, sizeof(int) * (size_t)L, st));
-        ACAV_HIP_TRY(hipMemsetAsync(mi->g.p, 0xFF, sizeof(int) * (size_t)L, st));
-    }
+    ACAV_TRY(mi->h.ensure(sizeof(int) * (size_t)L));
+    ACAV_TRY(mi->head.ensure(sizeof(int) * (size_t)L));
+    ACAV_TRY(mi->next.ensure(sizeof(int) * (size_t)L));
+    ACAV_TRY(mi->g.ensure(sizeof(int) * (size_t)L));
+    ACAV_TRY(mi->head2.ensure(sizeof(int) * (size_t)L));
+    ACAV_TRY(mi->g2.ensure(sizeof(int) * (size_t)L));
+    ACAV_HIP_TRY(hipMemsetAsync(mi->head.p, 0xFF, sizeof(int) * (size_t)L, st));
+    ACAV_HIP_TRY(hipMemsetAsync(mi->g.p, 0xFF, sizeof(int) * (size_t)L, st));
     ACAV_TRY(mi->mt.ensure(sizeof(unsigned) * 625));
     ACAV_TRY(mi->batch.ensure(sizeof(int) * SEL_MAXB));
     ACAV_TRY(mi->S.ensure(sizeof(long long) * (size_t)cap));
@@ -1842,76 +1998,11 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
         total_draws += lt > 1 ? lt - 1 : 0;
     }
     MtStream ms;
-    ACAV_TRY(ms.plan(mi, tiled ? mi->st_fy : st, mtbuf, idx, total_draws, L));
+    ACAV_TRY(ms.plan(mi, st, mtbuf, idx, total_draws, L, L));
 
     int *Acur = mi->A0.as<int>(), *Anew = mi->A1.as<int>();
     int64_t l = L;
     int64_t r0 = 0;  // first draw of this iteration, counted from the first draw of the run
-    if (tiled) {
-        // two streams: k_fy_part + k_fy_tile (positions only, no content) run on st_fy one GROUP of iterations ahead of the
-        // gathers + selections on st; src / g are multi-buffered and the streams meet through one event pair per group
-        // (a cross-stream hand-off costs ~20 us of latency, an event record / wait a few us of queue time: per iteration they
-        // sat on the critical path -- 80 us with two buffers, 55 us with four, per-iteration events)
-        hipStream_t sf = mi->st_fy;
-        ACAV_HIP_TRY(hipStreamSynchronize(st));  // tables, counters and the candidate list are in place
-        const bool timing = getenv("ACAV_MI_TIMING") != nullptr;
-        const auto t_loop0 = std::chrono::steady_clock::now();
-        const size_t smem_sel = sizeof(double) * (size_t)B * mi->P;
-        for (int64_t g0 = 0; g0 < iters; g0 += FY_GROUP) {
-            const int64_t g1 = g0 + FY_GROUP < iters ? g0 + FY_GROUP : iters;
-            const int ge = (int)((g0 / FY_GROUP) & 1);  // event pair and buffer half of this group
-            // ---- st_fy: the positions of the group's iterations (the gathers of the group two back are done with this half)
-            if (g0 >= 2 * FY_GROUP) ACAV_HIP_TRY(hipStreamWaitEvent(sf, mi->ev_gather[ge], 0));
-            for (int64_t it = g0; it < g1; ++it) {
-                const int Li = (int)(L - it * dl), par = (int)(it % FY_NBUF);
-                const int64_t nd = Li > 1 ? Li - 1 : 0;
-                const unsigned *draws = nullptr;
-                ACAV_TRY(ms.acquire(r0, nd, &draws));
-                hipLaunchKernelGGL(k_fy_part, dim3((unsigned)((Li + FYA_CH - 1) / FYA_CH)), dim3(FYA_THREADS),
-                                   sizeof(int) * 2 * (size_t)fp.NT + sizeof(unsigned short) * fp.table.size(), sf, draws, Li,
-                                   mi->fy_table.as<unsigned short>(), (int)fp.table.size(), fp.gsh, fp.NT, fp.capg,
-                                   mi->fy_bucket.as<int2>(), mi->fy_count.as<int>(), mi->fy_src[par].as<unsigned>(),
-                                   mi->fy_err.as<unsigned>());
-                r0 += nd;
-                ACAV_TRY(ms.release(r0));  // k_fy_part is the only reader of the draws
-                hipLaunchKernelGGL(k_fy_tile, dim3((unsigned)fp.NT), dim3(FYT_THREADS), fp.tile_smem(), sf, Li, mi->fy_bounds.as<int>(),
-                                   fp.capg, fp.ecap_lds, fp.wcap, mi->fy_bucket.as<int2>(), mi->fy_count.as<int>(),
-                                   mi->fy_src[par].as<unsigned>(), mi->fy_g[par].as<int>(), mi->fy_err.as<unsigned>());
-            }
-            ACAV_HIP_TRY(hipEventRecord(mi->ev_tile[ge], sf));
-            // ---- st: the group's gathers + selections, back to back
-            ACAV_HIP_TRY(hipStreamWaitEvent(st, mi->ev_tile[ge], 0));
-            for (int64_t it = g0; it < g1; ++it) {
-                const int Li = (int)(L - it * dl), par = (int)(it % FY_NBUF);
-                hipLaunchKernelGGL(k_fy_gather_select, dim3((unsigned)((Li + 255) / 256)), dim3(256), smem_sel, st, Acur, Li,
-                                   mi->fy_src[par].as<unsigned>(), mi->fy_g[par].as<int>(), Anew, mi->asg.as<int>(), mi->D, mi->C, mi->P,
-                                   mi->pairs.as<int>(), mi->batch.as<int>(), B, k, mi->Nc.as<int>(), mi->ac.as<int>(), mi->bc.as<int>(),
-                                   mi->SN.as<double>(), mi->Sa.as<double>(), mi->Sb.as<double>(), mi->phi.as<double>(),
-                                   mi->scalars.as<MiScalars>(), mi->S.as<long long>() + it * k, mi->G.as<double>() + it * k,
-                                   forced_pos ? mi->forced.as<int>() + it * k : nullptr,
-                                   trace_pos ? mi->tr_pos.as<int>() + it * k : nullptr,
-                                   trace_ids ? mi->tr_ids.as<long long>() + it * B : nullptr,
-                                   trace_scores ? mi->tr_sc.as<double>() + it * B : nullptr, keep_unselected);
-                int *t = Acur;
-                Acur = Anew;
-                Anew = t;
-            }
-            ACAV_HIP_TRY(hipGetLastError());
-            ACAV_HIP_TRY(hipEventRecord(mi->ev_gather[ge], st));
-        }
-        l = L - iters * dl;
-        const auto t_loop1 = std::chrono::steady_clock::now();
-        ACAV_HIP_TRY(hipStreamSynchronize(sf));
-        if (timing) {
-            ACAV_HIP_TRY(hipStreamSynchronize(st));
-            const auto t_loop2 = std::chrono::steady_clock::now();
-            fprintf(stderr, "[acav] greedy loop: %lld iterations, host enqueue %.2f us/iteration, enqueue + drain %.2f us/iteration "
-                            "(tiles %d, cap %d, lanes %d)\n", (long long)iters,
-                    std::chrono::duration<double, std::micro>(t_loop1 - t_loop0).count() / (double)(iters ? iters : 1),
-                    std::chrono::duration<double, std::micro>(t_loop2 - t_loop0).count() / (double)(iters ? iters : 1), fp.NT,
-                    fp.ecap, ms.W);
-        }
-    } else
     for (int64_t it = 0; it < iters; ++it) {
         const int Li = (int)l;
         const int64_t nd = Li > 1 ? Li - 1 : 0;
@@ -1952,12 +2043,6 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
     ACAV_HIP_TRY(hipStreamSynchronize(st));
     ACAV_TRY(ms.final_state(mtbuf, &idx));
     ACAV_TRY(acav_rng_set_state(rng, mtbuf, idx));  // the stream continues on the host
-    if (tiled) {
-        unsigned ferr = 0;
-        ACAV_HIP_TRY(hipMemcpy(&ferr, mi->fy_err.p, sizeof(ferr), hipMemcpyDeviceToHost));
-        ACAV_REQUIRE(ferr == 0, ACAV_ESTATE,
-                     "tiled Fisher-Yates: a tile bucket overflowed (flags %u); re-run with ACAV_FY_LEGACY=1", ferr);
-    }
     if (n_selected) *n_selected = nsel;
     if (n_iters) *n_iters = iters;
     return ACAV_OK;

@@ -296,7 +296,7 @@ def main():
                          "sweep_ms": s_ms, "sweep_GBs": bytes_per_launch / (s_ms * 1e-3) / 1e9,
                          "sweep_frac": bytes_per_launch / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "rows_rechecked_exact": [int(f[2]) for f in filt_stats[-nviews:]], "rows": n},
-            "roofline_mi": {"kernel": "k_mt_generate_lanes + k_fy_part + k_fy_tile + k_fy_gather_select (one greedy iteration)",
+            "roofline_mi": {"kernel": "k_mt_generate_lanes + k_fy_part + k_fy_tile + k_fy_resolve + k_fy_gather_select (one greedy iteration)",
                             "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                             "algorithmic_bytes": perm_bytes, "achieved": perm_bytes / st["mi"] / 1e9,
                             "frac": perm_bytes / st["mi"] / 1e9 / HBM_PEAK_GBS,

@@ -1,0 +1,103 @@
+// Experiment harness (not product): the tiled Fisher-Yates kernels of acav_mi.hip, each timed ALONE on synthetic draws
+// (in the product they overlap on two streams and slow each other down).  Build: see tools/exp/build.sh.
+#include "../../acav100m_amd/csrc/acav_mi.hip"
+#include <random>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+int main(int argc, char **argv)
+{
+    const int L = argc > 1 ? atoi(argv[1]) : 1000000;
+    const int G = FY_GROUP, B = 20, k = 4, dl = 4, reps = 40;
+    FyPlan fp;
+    fp.build(L);
+    printf("L %d  tiles %d cap %d gsh %d capg %d  tile smem %zu\n", L, fp.NT, fp.ecap, fp.gsh, fp.capg, fp.tile_smem());
+    std::mt19937 rng(3);
+    const size_t ndraw = (size_t)G * L + 1024;
+    std::vector<unsigned> draws(ndraw);
+    for (auto &d : draws) d = rng();
+    TileChunk c{};
+    unsigned *dring; CK(hipMalloc(&dring, 4 * ndraw)); CK(hipMemcpy(dring, draws.data(), 4 * ndraw, hipMemcpyHostToDevice));
+    c.ring = dring; c.head = 0; c.ring_words = 1ll << 62;
+    unsigned short *dtab; CK(hipMalloc(&dtab, 2 * fp.table.size())); CK(hipMemcpy(dtab, fp.table.data(), 2 * fp.table.size(), hipMemcpyHostToDevice));
+    int *deb; CK(hipMalloc(&deb, 4 * fp.ebound.size())); CK(hipMemcpy(deb, fp.ebound.data(), 4 * fp.ebound.size(), hipMemcpyHostToDevice));
+    c.table = dtab; c.ebound = deb;
+    const size_t nb = (size_t)G * fp.NT * FY_SHARDS * fp.capg, nc = (size_t)G * fp.NT * FY_SHARDS;
+    CK(hipMalloc(&c.bucket, 8 * nb)); CK(hipMalloc(&c.gcount, 4 * nc)); CK(hipMemset(c.gcount, 0, 4 * nc));
+    for (int q = 0; q < FY_GROUP; ++q) { CK(hipMalloc(&c.g[q], 4 * (size_t)L)); CK(hipMalloc(&c.src[q], 4 * (size_t)L)); }
+    for (int q = 0; q < FY_NBUF; ++q) { CK(hipMalloc(&c.perm[q], 4 * (size_t)L)); CK(hipMemset(c.perm[q], 0, 4 * (size_t)L)); }
+    CK(hipMalloc(&c.A[0], 4 * (size_t)(L + B))); CK(hipMalloc(&c.A[1], 4 * (size_t)(L + B)));
+    CK(hipMemset(c.A[0], 0, 4 * (size_t)(L + B))); CK(hipMemset(c.A[1], 0, 4 * (size_t)(L + B)));
+    CK(hipMalloc(&c.err, 4)); CK(hipMemset(c.err, 0, 4));
+    // a tiny MI problem so that the selection in workgroup 0 runs as in the product (V = L ids, all label 0)
+    const int D = 2, C = 256, P = 1;
+    int *dasg, *dpairs, *dbatch, *dNc, *dac, *dbc; double *dS3, *dphi, *dG; MiScalars *dsc; long long *dS;
+    CK(hipMalloc(&dasg, 4 * (size_t)L * D));
+    { std::vector<int> a((size_t)L * D); for (auto &v : a) v = rng() % C; CK(hipMemcpy(dasg, a.data(), 4 * a.size(), hipMemcpyHostToDevice)); }
+    int hp[2] = {0, 1}; CK(hipMalloc(&dpairs, 8)); CK(hipMemcpy(dpairs, hp, 8, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dbatch, 4 * 1024)); CK(hipMalloc(&dNc, 4 * C * C)); CK(hipMalloc(&dac, 4 * C)); CK(hipMalloc(&dbc, 4 * C));
+    CK(hipMemset(dNc, 0, 4 * C * C)); CK(hipMemset(dac, 0, 4 * C)); CK(hipMemset(dbc, 0, 4 * C));
+    CK(hipMalloc(&dS3, 8 * 3)); CK(hipMemset(dS3, 0, 24));
+    { std::vector<double> phi((size_t)L + 2, 0.0); for (size_t i = 1; i < phi.size(); ++i) phi[i] = (double)i * log((double)i);
+      CK(hipMalloc(&dphi, 8 * phi.size())); CK(hipMemcpy(dphi, phi.data(), 8 * phi.size(), hipMemcpyHostToDevice)); }
+    CK(hipMalloc(&dsc, sizeof(MiScalars))); CK(hipMemset(dsc, 0, sizeof(MiScalars)));
+    const int iters = 64;
+    CK(hipMalloc(&dS, 8 * iters * k)); CK(hipMalloc(&dG, 8 * iters * k));
+    c.asg = dasg; c.pairs = dpairs; c.batch = dbatch; c.Nc = dNc; c.ac = dac; c.bc = dbc; c.SN = dS3; c.Sa = dS3 + 1; c.Sb = dS3 + 2;
+    c.phi = dphi; c.sc = dsc; c.S = dS; c.G = dG;
+    c.L0 = L; c.iters = iters; c.ntab = (int)fp.table.size(); c.gsh = fp.gsh; c.NT = fp.NT; c.capg = fp.capg; c.ecap = fp.ecap_lds; c.wcap = fp.wcap;
+    c.D = D; c.C = C; c.P = P;
+    TileChunk *dcd; CK(hipMalloc(&dcd, sizeof(c))); CK(hipMemcpy(dcd, &c, sizeof(c), hipMemcpyHostToDevice));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fy_tile_multi), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.tile_smem()));
+    const size_t part_smem = sizeof(int) * 2 * (size_t)fp.NT + sizeof(unsigned short) * fp.table.size();
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto part = [&]() { hipLaunchKernelGGL(k_fy_part_multi, dim3((L + FYA_CH - 1) / FYA_CH, 1, G), dim3(FYA_THREADS), part_smem, 0, dcd, 0, dl); };
+    auto tile = [&]() { hipLaunchKernelGGL(k_fy_tile_multi, dim3(fp.NT, 1, G), dim3(FYT_THREADS), fp.tile_smem(), 0, dcd, 0, dl); };
+    auto resolve = [&]() { hipLaunchKernelGGL(k_fy_resolve_multi, dim3((L + 255) / 256, 1, G), dim3(256), 0, 0, dcd, 0, dl); };
+    auto timeit = [&](const char *name, auto fn, double base_us) {
+        for (int i = 0; i < 3; ++i) fn();
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < reps; ++i) fn();
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1000.0 / reps;
+        printf("%-34s %8.2f us per group  (%.2f us per iteration; minus previous: %.2f)\n", name, us, us / G, (us - base_us) / G);
+        return us;
+    };
+    const double t_ms = timeit("memset counters", [&]() { CK(hipMemsetAsync(c.gcount, 0, 4 * nc, 0)); }, 0);
+    const double t_p = timeit("memset + part", [&]() { CK(hipMemsetAsync(c.gcount, 0, 4 * nc, 0)); part(); }, t_ms);
+    const double t_pt = timeit("memset + part + tile", [&]() { CK(hipMemsetAsync(c.gcount, 0, 4 * nc, 0)); part(); tile(); }, t_p);
+    timeit("part + tile + resolve", [&]() { part(); tile(); resolve(); }, t_pt - t_ms);
+    (void)t_ms;
+#ifdef ACAV_FY_PROF
+    {   // phase ticks of k_fy_tile, one group
+        unsigned long long z16[16] = {0}, pr[16];
+        CK(hipMemsetAsync(c.gcount, 0, 4 * nc, 0)); part(); CK(hipDeviceSynchronize());
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(fy_prof), z16, sizeof(z16)));
+        tile(); CK(hipDeviceSynchronize());
+        CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(fy_prof), sizeof(pr)));
+        const double wgs = (double)fp.NT * G;
+        const char *nm[5] = {"prologue (bounds, counters)", "LDS init", "entries: bucket -> lists", "walk + src scatter", "g store"};
+        for (int q = 0; q < 5; ++q) printf("   tile phase %-28s %7.2f us per workgroup\n", nm[q], pr[q] / wgs / 100.0);
+    }
+#endif
+    unsigned err; CK(hipMemcpy(&err, c.err, 4, hipMemcpyDeviceToHost)); printf("err flags %u\n", err);
+    // gathers of iterations 0..G-1, alone (perm / src / g of the last group are in place)
+    const size_t sel_smem = sel_smem_bytes(B, P);
+    int itg = 0;
+    auto g_sc = [&]() { hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 255) / 256, 1), dim3(256), sel_smem, 0, dcd, itg, dl, B, k, 1, 1); itg = (itg + 1) % G; };
+    timeit("8 x gather+select", [&]() { for (int i = 0; i < G; ++i) g_sc(); }, 0);
+#ifdef ACAV_FY_PROF
+    {   // phase ticks of the selection in workgroup 0 of the gather kernel
+        unsigned long long z16[16] = {0}, pr[16];
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(fy_prof), z16, sizeof(z16)));
+        for (int i = 0; i < G; ++i) g_sc();
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(fy_prof), sizeof(pr)));
+        const char *nm[5] = {"ids -> LDS (after the gather)", "scoring", "means + top-k", "picks + requeue", "commit"};
+        for (int q = 0; q < 5; ++q) printf("   select phase %-30s %7.2f us\n", nm[q], pr[8 + q] / (double)G / 100.0);
+    }
+#endif
+    return 0;
+}
