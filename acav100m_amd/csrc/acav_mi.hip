@@ -727,8 +727,17 @@ constexpr int FYA_CH = ACAV_FYA_CH;  // steps per k_fy_part workgroup
 constexpr int FYA_THREADS = 1024;
 constexpr int64_t FY_TILED_MAX = 16 << 20;
 constexpr unsigned FY_EREF = 0x80000000u;
-constexpr int FY_GROUP = 8;        // iterations per launch of the position kernels and per cross-stream hand-off
-constexpr int FY_NBUF = 2 * FY_GROUP;  // perm buffers: the position kernels run one group ahead of the gathers
+#ifndef ACAV_FY_GROUP
+#define ACAV_FY_GROUP 16
+#endif
+constexpr int FY_GROUP = ACAV_FY_GROUP;  // iterations per launch of the position kernels and per cross-stream hand-off (an event
+                                         // wait + record on the content stream costs it ~10 us per group even when long satisfied)
+#ifndef ACAV_FY_DEPTH
+#define ACAV_FY_DEPTH 3
+#endif
+constexpr int FY_DEPTH = ACAV_FY_DEPTH;     // groups of perm buffers in flight: the position kernels run up to FY_DEPTH - 1 groups ahead
+constexpr int FY_NBUF = FY_DEPTH * FY_GROUP;  // of the gathers (a cross-stream hand-off costs 15-45 us: two deep, both hand-offs
+                                              // of a group sat on the critical cycle and left a ~30 us bubble per group)
 constexpr int FY_SHARDS = 8;       // sub-buckets per tile (capg entries each), filled by workgroups b with b % 8 == shard
 constexpr int FYT_THREADS = ACAV_FYT_THREADS;  // k_fy_tile: the list walks are chains of dependent LDS reads -- many waves hide them
 
@@ -895,7 +904,7 @@ struct TileChunk {
     int *gcount;             // [FY_GROUP][NT][FY_SHARDS]
     unsigned *src[FY_GROUP]; // content references and last pullers, per iteration of the group in flight
     int *g[FY_GROUP];
-    unsigned *perm[FY_NBUF]; // source position of every output position, per iteration (two groups deep)
+    unsigned *perm[FY_NBUF]; // source position of every output position, per iteration (FY_DEPTH groups deep)
     int *A[2];
     unsigned *err;
     const int *asg, *pairs;
@@ -1453,7 +1462,7 @@ struct TiledExtras {
 // chunks in lockstep (acav_mi_run_greedy_multi; one handle, candidate list, start set, subset size and generator each;
 // every list within FY_TILED_MAX).  All handles live on the same device; the first handle's streams carry the work.
 // Two streams: the position kernels (k_fy_part / k_fy_tile / k_fy_resolve: no content, one launch each per GROUP of
-// iterations) run on st_fy one group ahead of the gathers + selections on the main stream; perm is buffered two groups
+// iterations) run on st_fy ahead of the gathers + selections on the main stream; perm is buffered FY_DEPTH groups
 // deep and the streams meet through one event pair per group (a cross-stream hand-off costs ~20 us of latency,
 // an event record / wait a few us of queue time: per iteration they sat on the critical path).
 static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *candidates, const int64_t *L,
@@ -1553,10 +1562,10 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
     for (int64_t g0 = 0; g0 < iters_max; g0 += FY_GROUP) {
         const int64_t g1 = g0 + FY_GROUP < iters_max ? g0 + FY_GROUP : iters_max;
         const unsigned gz = (unsigned)(g1 - g0);
-        const int ge = (int)((g0 / FY_GROUP) & 1);  // event pair and buffer half of this group
+        const int ge = (int)((g0 / FY_GROUP) % FY_DEPTH);  // event pair and buffer set of this group
         const int64_t lt = lmax - g0 * dl;           // the longest list still in play bounds the grids
-        // ---- st_fy: the positions of the group's iterations (the gathers of the group two back are done with this half)
-        if (g0 >= 2 * FY_GROUP) ACAV_HIP_TRY(hipStreamWaitEvent(sf, lead->ev_gather[ge], 0));
+        // ---- st_fy: the positions of the group's iterations (the gathers of the group FY_DEPTH back are done with this buffer set)
+        if (g0 >= FY_DEPTH * FY_GROUP) ACAV_HIP_TRY(hipStreamWaitEvent(sf, lead->ev_gather[ge], 0));
         for (int c = 0; c < nchunks; ++c) {
             int64_t nd = 0;
             for (int64_t it = g0; it < g1 && it < iters[(size_t)c]; ++it) {

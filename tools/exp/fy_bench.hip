@@ -12,7 +12,7 @@ int main(int argc, char **argv)
     fp.build(L);
     printf("L %d  tiles %d cap %d gsh %d capg %d  tile smem %zu\n", L, fp.NT, fp.ecap, fp.gsh, fp.capg, fp.tile_smem());
     std::mt19937 rng(3);
-    const size_t ndraw = (size_t)G * L + 1024;
+    const size_t ndraw = (size_t)2 * G * L + 1024;
     std::vector<unsigned> draws(ndraw);
     for (auto &d : draws) d = rng();
     TileChunk c{};
@@ -87,6 +87,43 @@ int main(int argc, char **argv)
     int itg = 0;
     auto g_sc = [&]() { hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 255) / 256, 1), dim3(256), sel_smem, 0, dcd, itg, dl, B, k, 1, 1); itg = (itg + 1) % G; };
     timeit("8 x gather+select", [&]() { for (int i = 0; i < G; ++i) g_sc(); }, 0);
+    {   // do the two streams of the product overlap?  side group (iterations 8..15) on one stream, 8 gathers (0..7) on another
+        const char *pri = getenv("FYB_PRIORITY"), *mask = getenv("FYB_CUMASK");
+        hipStream_t sa, sb;
+        int lo = 0, hi = 0;
+        CK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = least priority (largest number)
+        if (mask) {
+            const int ncu = atoi(mask);  // side stream restricted to the first ncu CUs of every XCD-interleaved mask word
+            uint32_t m[8];
+            for (int q = 0; q < 8; ++q) m[q] = 0;
+            for (int cu = 0; cu < ncu; ++cu) m[cu / 32] |= 1u << (cu % 32);
+            CK(hipExtStreamCreateWithCUMask(&sa, 8, m));
+        } else {
+            CK(hipStreamCreateWithPriority(&sa, hipStreamNonBlocking, pri ? lo : 0));
+        }
+        CK(hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, pri ? hi : 0));
+        auto side = [&](hipStream_t st) {
+            hipLaunchKernelGGL(k_fy_part_multi, dim3((L + FYA_CH - 1) / FYA_CH, 1, G), dim3(FYA_THREADS), part_smem, st, dcd, 8, dl);
+            hipLaunchKernelGGL(k_fy_tile_multi, dim3(fp.NT, 1, G), dim3(FYT_THREADS), fp.tile_smem(), st, dcd, 8, dl);
+            hipLaunchKernelGGL(k_fy_resolve_multi, dim3((L + 255) / 256, 1, G), dim3(256), 0, st, dcd, 8, dl);
+        };
+        auto gath = [&](hipStream_t st) {
+            for (int i = 0; i < G; ++i)
+                hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 255) / 256, 1), dim3(256), sel_smem, st, dcd, i, dl, B, k, 1, 1);
+        };
+        auto wall = [&](const char *name, auto fn) {
+            fn(); CK(hipDeviceSynchronize());
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < reps; ++r) fn();
+            CK(hipDeviceSynchronize());
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+            printf("%-44s %8.2f us per group (%.2f us per iteration)\n", name, us, us / G);
+        };
+        printf("priority range %d (low) .. %d (high)%s%s\n", lo, hi, pri ? "  [side low, gathers high]" : "", mask ? "  [side CU-masked]" : "");
+        wall("side group alone (stream a)", [&]() { side(sa); });
+        wall("8 gathers alone (stream b)", [&]() { gath(sb); });
+        wall("both, two streams", [&]() { side(sa); gath(sb); });
+    }
 #ifdef ACAV_FY_PROF
     {   // phase ticks of the selection in workgroup 0 of the gather kernel
         unsigned long long z16[16] = {0}, pr[16];
