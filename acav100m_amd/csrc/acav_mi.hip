@@ -93,21 +93,25 @@ constexpr int SEL_MAXBP = 8192;
 // unselected ids in ascending order to the new candidate array (batch.py:132-171).
 // ids == batch_in when called for plain scoring (k = 0: nothing committed).
 // The kernel sits on the critical path of every iteration and is pure latency -- a chain of dependent memory round
-// trips (~1 us each on a busy chip) -- so the chain is kept short:
-//   * what does not depend on the batch (n, the pair list, the running sums) is staged in LDS by mi_select_stage BEFORE
-//     the caller produces the batch (the permutation gather), under that round trip
-//   * the batch ids come in registers when the caller has just produced them (no store -> fence -> load)
-//   * scoring is 3 dependent levels (id -> label row -> counts -> phi); every phase issues all of its independent loads
+// trips (~1 us each, ~2 us beside a gather in full flight) -- so the chain is kept short:
+//   * what does not depend on the batch (n, the pair list, the running sums) is staged in LDS by mi_select_stage before
+//     anything else
+//   * the batch arrives with its label rows (the gather that produced it fetched them: lab_in), or in registers
+//   * scoring is then 2 dependent levels (labels -> counts -> phi); every phase issues all of its independent loads
 //     before the first use
 //   * the top-k is a rank count over the B scores in LDS (no reduction rounds); barriers order LDS only
-//   * the commit of k <= SEL_FASTK picks re-uses the labels and counts the scoring read (LDS, B P <= SEL_FASTBP) and
-//     pays one level (phi of the adjusted counts); beyond those sizes it re-reads (3 levels per pick)
-constexpr int SEL_FASTK = 8;
+//   * the commit re-uses the labels, counts and phi values the scoring read (LDS); only a pick whose cell an earlier pick
+//     of the same iteration touched pays a level for the phi of its adjusted counts.  Beyond the staged sizes (SEL_FAST*)
+//     it re-reads (3 levels per pick)
+//   * few registers: the gather workgroups of the same launch inherit the kernel's allocation
 constexpr int SEL_LDSP = 256;     // pairs (and their running sums) staged in LDS
-constexpr int SEL_FASTBP = 2048;  // B * P up to which the scoring's labels / counts are kept for the commit
+constexpr int SEL_FASTBP = 2048;  // B * P up to which the scoring's labels / counts are kept for the commit ...
+constexpr int SEL_FASTKP = 512;   // ... and k * P up to which the commit's phi values are staged (both: SEL_FAST)
+constexpr int SEL_PHIBP = 256;    // B * P up to which the scoring's phi values are kept too (SEL_KEEPPHI)
+constexpr int SEL_FAST = 1, SEL_KEEPPHI = 2;
 
 struct SelShared {
-    double score[SEL_MAXB], key[SEL_MAXB];
+    double score[SEL_MAXB];
     double SN[SEL_LDSP], Sa[SEL_LDSP], Sb[SEL_LDSP];
     long long nc;
     unsigned long long used;
@@ -115,9 +119,29 @@ struct SelShared {
     int pairs[2 * SEL_LDSP];
 };
 
-// dynamic LDS of a selection launch: scores [B P] doubles (+ labels and counts, 5 ints per (candidate, pair))
-static inline bool sel_fast(int B, int P) { return (long long)B * P <= SEL_FASTBP; }
-static inline size_t sel_smem_bytes(int B, int P) { return (size_t)B * (size_t)P * (sel_fast(B, P) ? 28u : 8u); }
+// Dynamic LDS of a selection launch:  scores [B P] f64 | labels + counts 5 x [B P] i32 (SEL_FAST) | scoring's phi [B P][6] f64
+// (SEL_KEEPPHI) | commit's phi [k P][6] f64 (SEL_FAST) | label rows [B D] i32.  The mode is decided on the host for the
+// largest P and D of the launch; every chunk lays its own sizes out in the same order.
+struct SelLayout {
+    unsigned off_c, off_phi, off_phik, off_lab, total;
+};
+__host__ __device__ inline int sel_mode(int B, int P, int k)
+{
+    const long long bp = (long long)B * P, kp = (long long)k * P;
+    const int fast = bp <= SEL_FASTBP && kp <= SEL_FASTKP ? SEL_FAST : 0;
+    return fast | (fast && bp <= SEL_PHIBP ? SEL_KEEPPHI : 0);
+}
+__host__ __device__ inline SelLayout sel_layout(int B, int P, int D, int k, int mode)
+{
+    const unsigned bp = (unsigned)B * (unsigned)P, kp = (unsigned)k * (unsigned)P;
+    SelLayout l;
+    l.off_c = 8u * bp;
+    l.off_phi = l.off_c + ((mode & SEL_FAST) ? 20u * bp + 4u * (bp & 1u) : 0u);
+    l.off_phik = l.off_phi + ((mode & SEL_KEEPPHI) ? 48u * bp : 0u);
+    l.off_lab = l.off_phik + ((mode & SEL_FAST) ? 48u * kp : 0u);
+    l.total = l.off_lab + 4u * (unsigned)B * (unsigned)D;
+    return l;
+}
 
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global store to be
 // acknowledged (~1 us each time on the selection's critical path)
@@ -143,25 +167,39 @@ __device__ __forceinline__ void mi_select_stage(SelShared &ss, int P, const int 
     }
 }
 
-// batch == nullptr: the id of batch position tid (< B) is in reg_id.  fast: the launch carries sel_smem_bytes() of
-// dynamic LDS for a B * P within SEL_FASTBP (decided on the host, the same for every chunk of a launch).
+// batch == nullptr: the id of batch position tid (< B) is in reg_id.  lab_in: the B label rows [B][D] when the caller has
+// them (else they are read from asg: one more level).  mode: sel_mode() for the launch (decided on the host).
 __device__ __forceinline__ void mi_select_body(
     SelShared &ss, const int *__restrict__ asg, int D, int C, int P, const int *__restrict__ pairs,
-    const int *__restrict__ batch, int reg_id, int B, int k, bool fast, int *__restrict__ Nc, int *__restrict__ ac,
-    int *__restrict__ bc, double *__restrict__ SN, double *__restrict__ Sa, double *__restrict__ Sb,
+    const int *__restrict__ batch, int reg_id, const int *__restrict__ lab_in, int B, int k, int mode, int *__restrict__ Nc,
+    int *__restrict__ ac, int *__restrict__ bc, double *__restrict__ SN, double *__restrict__ Sa, double *__restrict__ Sb,
     const double *__restrict__ phi, MiScalars *__restrict__ sc, double *__restrict__ scores_out,
     long long *__restrict__ S_out, double *__restrict__ G_out, const int *__restrict__ forced_pos,
     int *__restrict__ trace_pos, long long *__restrict__ trace_ids, double *__restrict__ trace_scores,
     int keep_unselected, int *__restrict__ requeue_out, int requeue_stride = 1)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const bool fast = (mode & SEL_FAST) != 0, keepphi = (mode & SEL_KEEPPHI) != 0;
+    const SelLayout lay = sel_layout(B, P, D, k, mode);
+    const size_t BP = (size_t)B * P;
     double *sS = reinterpret_cast<double *>(smem_raw);  // [B*P]
-    int *sCi = reinterpret_cast<int *>(sS + (size_t)B * P), *sCj = sCi + (size_t)B * P, *sCN = sCj + (size_t)B * P;
-    int *sCa = sCN + (size_t)B * P, *sCb = sCa + (size_t)B * P;  // fast only
+    int *sCi = reinterpret_cast<int *>(smem_raw + lay.off_c), *sCj = sCi + BP, *sCN = sCj + BP, *sCa = sCN + BP, *sCb = sCa + BP;
+    double *sPhiAll = reinterpret_cast<double *>(smem_raw + lay.off_phi);  // [B*P][6]  (keepphi)
+    double *sPhiK = reinterpret_cast<double *>(smem_raw + lay.off_phik);   // [k*P][6]  (fast)
+    int *sLab = reinterpret_cast<int *>(smem_raw + lay.off_lab);           // [B][D]
     const int tid = threadIdx.x;
     FY_CLK0();
     if (tid < B) ss.id[tid] = batch ? batch[tid] : reg_id;
+    if (lab_in)
+        for (int t = tid; t < B * D; t += blockDim.x) sLab[t] = lab_in[t];
     lds_barrier();  // also: the staged constants are visible
+    if (!lab_in) {
+        for (int t = tid; t < B * D; t += blockDim.x) {
+            const int w = t / D;
+            sLab[t] = asg[(size_t)ss.id[w] * D + (t - w * D)];
+        }
+        lds_barrier();
+    }
     FY_CLK(8);
     const long long nc = ss.nc;
     const double phin = phi[nc + 1];
@@ -171,141 +209,140 @@ __device__ __forceinline__ void mi_select_body(
         const bool lp = p < SEL_LDSP;
         const int d0 = lp ? ss.pairs[2 * p] : pairs[2 * p], d1 = lp ? ss.pairs[2 * p + 1] : pairs[2 * p + 1];
         const double sN0 = lp ? ss.SN[p] : SN[p], sa0 = lp ? ss.Sa[p] : Sa[p], sb0 = lp ? ss.Sb[p] : Sb[p];
-        const int *row = asg + (size_t)ss.id[w] * D;
-        const int i = row[d0], j = row[d1];
+        const int i = sLab[w * D + d0], j = sLab[w * D + d1];
         const int cN = Nc[((size_t)p * C + i) * C + j];
         const int ca = ac[(size_t)p * C + j], cb = bc[(size_t)p * C + i];
-        const double sN = sN0 - phi[cN] + phi[cN + 1];
-        const double sa = sa0 - phi[ca] + phi[ca + 1];
-        const double sb = sb0 - phi[cb] + phi[cb + 1];
+        const double f0 = phi[cN], f1 = phi[cN + 1], f2 = phi[ca], f3 = phi[ca + 1], f4 = phi[cb], f5 = phi[cb + 1];
+        const double sN = sN0 - f0 + f1;
+        const double sa = sa0 - f2 + f3;
+        const double sb = sb0 - f4 + f5;
         sS[t] = (((sN - sa) - sb) + phin) / (double)(nc + 1);
         if (fast) sCi[t] = i, sCj[t] = j, sCN[t] = cN, sCa[t] = ca, sCb[t] = cb;
+        if (keepphi) {
+            double *o6 = sPhiAll + (size_t)t * 6;
+            o6[0] = f0, o6[1] = f1, o6[2] = f2, o6[3] = f3, o6[4] = f4, o6[5] = f5;
+        }
     }
     lds_barrier();
     FY_CLK(9);
-    // means, then the top k by RANK: every lane counts the candidates that beat it -- no reduction rounds, no dependent chain
-    // (k rounds of a wave-wide argmax were 2.6 us of shuffles).  Order: score descending, ties -> lower batch position;
-    // a NaN score never wins against a number and ranks by position among its like (as the argmax rounds did).
-    if (tid < B) {
-        double tot = 0.0;
-        for (int p = 0; p < P; ++p) tot = tot + sS[tid * P + p];
-        const double s = tot / (double)P;
-        ss.score[tid] = s;
-        ss.key[tid] = s == s ? s : -INFINITY;
-        if (scores_out) scores_out[tid] = s;
-        if (trace_scores) trace_scores[tid] = s;
-        if (trace_ids) trace_ids[tid] = ss.id[tid];
-    }
-    lds_barrier();
-    FY_CLK(10);
-    if (k == 0) return;
-    if (tid < 64) {  // wave 0 (B <= 64)
-        bool picked = false;
+    // Wave 0 (B <= 64), lane = batch position: mean score, then the top k by RANK -- every lane counts the candidates that
+    // beat it, their keys broadcast lane by lane (v_readlane; k rounds of a wave-wide argmax were 2.6 us of shuffles, a
+    // loop of LDS reads 1 us).  Order: score descending, ties -> lower batch position; a NaN score never wins against a
+    // number and ranks by position among its like (as the argmax rounds did).  The un-selected ids are ranked the same way.
+    if (tid < 64) {
+        double s = 0.0, key = -INFINITY;
+        const int myid = tid < B ? ss.id[tid] : 0;
         if (tid < B) {
-            const double mine = ss.key[tid];
+            double tot = 0.0;
+            for (int p = 0; p < P; ++p) tot = tot + sS[tid * P + p];
+            s = tot / (double)P;
+            key = s == s ? s : -INFINITY;
+            ss.score[tid] = s;
+            if (scores_out) scores_out[tid] = s;
+            if (trace_scores) trace_scores[tid] = s;
+            if (trace_ids) trace_ids[tid] = myid;
+        }
+        if (k > 0) {
+            const int khi = __double2hiint(key), klo = __double2loint(key);
             int rank = 0;
             for (int w = 0; w < B; ++w) {
-                const double o = ss.key[w];
-                rank += (o > mine || (o == mine && w < tid)) ? 1 : 0;
+                const double o = __hiloint2double(__builtin_amdgcn_readlane(khi, w), __builtin_amdgcn_readlane(klo, w));
+                rank += (o > key || (o == key && w < tid)) ? 1 : 0;
             }
-            picked = rank < k;
+            const bool picked = tid < B && rank < k;
             if (picked) {
                 if (!forced_pos) ss.pos[rank] = tid;
                 if (trace_pos) trace_pos[rank] = tid;  // the free-running choice, also under teacher forcing
             }
-        }
-        unsigned long long used = __ballot(picked);
-        if (forced_pos) {
-            used = 0ull;
-            for (int r = 0; r < k; ++r) used |= 1ull << forced_pos[r];
-            if (tid < k) ss.pos[tid] = forced_pos[tid];
-        }
-        if (tid == 0) ss.used = used;
-    }
-    lds_barrier();
-    if (tid < k) {
-        const int pos = ss.pos[tid];
-        ss.pick[tid] = ss.id[pos];
-        S_out[tid] = (long long)ss.id[pos];
-        G_out[tid] = ss.score[pos];
-    }
-    if (keep_unselected && tid < B) {  // get_unselected: torch.unique -> ascending ids (batch.py:167-171)
-        const unsigned long long used = ss.used;
-        if (!(used >> tid & 1ull)) {
-            const int v = ss.id[tid];
-            int rank = 0;
-            for (int w = 0; w < B; ++w) {
-                const int o = ss.id[w];
-                rank += (!(used >> w & 1ull) && (o < v || (o == v && w < tid))) ? 1 : 0;
+            unsigned long long used = __ballot(picked);
+            if (forced_pos) {
+                used = 0ull;
+                for (int r = 0; r < k; ++r) used |= 1ull << forced_pos[r];
+                if (tid < k) ss.pos[tid] = forced_pos[tid];
             }
-            requeue_out[rank * requeue_stride] = v;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ss.pos / ss.score: written and read by this wave, in order
+            if (tid < k) {
+                const int pos = ss.pos[tid];
+                ss.pick[tid] = ss.id[pos];
+                S_out[tid] = (long long)ss.id[pos];
+                G_out[tid] = ss.score[pos];
+            }
+            if (keep_unselected) {  // get_unselected: torch.unique -> ascending ids (batch.py:167-171)
+                int rq = 0;
+                for (int w = 0; w < B; ++w) {
+                    const int o = __builtin_amdgcn_readlane(myid, w);
+                    rq += (!(used >> w & 1ull) && (o < myid || (o == myid && w < tid))) ? 1 : 0;
+                }
+                if (tid < B && !(used >> tid & 1ull)) requeue_out[rq * requeue_stride] = myid;
+            }
         }
     }
-    lds_barrier();  // ss.pick; the global stores above need not have landed
+    FY_CLK(10);
+    if (k == 0) return;
+    lds_barrier();  // ss.pos, ss.pick; the global stores above need not have landed
     FY_CLK(11);
-    // update_cache (batch.py:152-154): commit the k winners, pair-parallel, pick order preserved
-    for (int p = tid; p < P; p += blockDim.x) {
-        const bool lp = p < SEL_LDSP;
-        double sN = lp ? ss.SN[p] : SN[p], sa = lp ? ss.Sa[p] : Sa[p], sb = lp ? ss.Sb[p] : Sb[p];
-        if (k <= SEL_FASTK) {
-            int ci[SEL_FASTK], cj[SEL_FASTK], cN[SEL_FASTK], ca[SEL_FASTK], cb[SEL_FASTK];
-            if (fast) {  // what the scoring read for (pick, pair)
-#pragma unroll
-                for (int r = 0; r < SEL_FASTK; ++r)
-                    if (r < k) {
-                        const int t = ss.pos[r] * P + p;
-                        ci[r] = sCi[t], cj[r] = sCj[t], cN[r] = sCN[t], ca[r] = sCa[t], cb[r] = sCb[t];
-                    }
-            } else {
-                const int d0 = lp ? ss.pairs[2 * p] : pairs[2 * p], d1 = lp ? ss.pairs[2 * p + 1] : pairs[2 * p + 1];
-#pragma unroll
-                for (int r = 0; r < SEL_FASTK; ++r)
-                    if (r < k) {
-                        const int *row = asg + (size_t)ss.pick[r] * D;
-                        ci[r] = row[d0];
-                        cj[r] = row[d1];
-                    }
-#pragma unroll
-                for (int r = 0; r < SEL_FASTK; ++r)
-                    if (r < k) {
-                        cN[r] = Nc[((size_t)p * C + ci[r]) * C + cj[r]];
-                        ca[r] = ac[(size_t)p * C + cj[r]];
-                        cb[r] = bc[(size_t)p * C + ci[r]];
-                    }
+    // update_cache (batch.py:152-154): commit the k winners; per pair the picks are applied in pick order (the float64
+    // running sums see the oracle's sequence of updates)
+    if (fast) {
+        // (pick, pair)-parallel: the labels and counts are the ones the scoring read (LDS), adjusted by the earlier picks
+        // of this iteration; the phi values too unless the adjustment moved the count (then one round of loads); staged in
+        // LDS, then one thread per pair applies them in order.  (Registers: an unrolled per-pair loop over the picks took
+        // the kernel to 253 VGPRs -- 2 waves per SIMD for every gather workgroup of the same launch.)
+        for (int t = tid; t < k * P; t += blockDim.x) {
+            const int r = t / P, p = t - r * P;
+            const int me = ss.pos[r] * P + p;
+            const int ci = sCi[me], cj = sCj[me];
+            const int bN = sCN[me], ba = sCa[me], bb = sCb[me];
+            int cN = bN, ca = ba, cb = bb;
+            bool lastN = true, lasta = true, lastb = true;  // no later pick of this iteration touches the same cell
+#pragma unroll 4
+            for (int e = 0; e < k; ++e) {
+                if (e == r) continue;
+                const int o = ss.pos[e] * P + p;
+                const bool mi_ = sCi[o] == ci, mj = sCj[o] == cj;
+                if (e < r) {
+                    cN += (mi_ && mj) ? 1 : 0;
+                    ca += mj ? 1 : 0;
+                    cb += mi_ ? 1 : 0;
+                } else {
+                    lastN = lastN && !(mi_ && mj);
+                    lasta = lasta && !mj;
+                    lastb = lastb && !mi_;
+                }
             }
-#pragma unroll
-            for (int r = 0; r < SEL_FASTK; ++r)  // counts as pick r sees them: earlier picks of this iteration included
-                if (r < k) {
-#pragma unroll
-                    for (int e = 0; e < SEL_FASTK; ++e)
-                        if (e < r) {
-                            cN[r] += (ci[e] == ci[r] && cj[e] == cj[r]) ? 1 : 0;
-                            ca[r] += (cj[e] == cj[r]) ? 1 : 0;
-                            cb[r] += (ci[e] == ci[r]) ? 1 : 0;
-                        }
-                }
-            double f[SEL_FASTK][6];
-#pragma unroll
-            for (int r = 0; r < SEL_FASTK; ++r)
-                if (r < k) {
-                    f[r][0] = phi[cN[r]], f[r][1] = phi[cN[r] + 1];
-                    f[r][2] = phi[ca[r]], f[r][3] = phi[ca[r] + 1];
-                    f[r][4] = phi[cb[r]], f[r][5] = phi[cb[r] + 1];
-                }
-#pragma unroll
-            for (int r = 0; r < SEL_FASTK; ++r)
-                if (r < k) {
-                    Nc[((size_t)p * C + ci[r]) * C + cj[r]] = cN[r] + 1;  // same-thread stores: the last pick's count stays
-                    ac[(size_t)p * C + cj[r]] = ca[r] + 1;
-                    bc[(size_t)p * C + ci[r]] = cb[r] + 1;
-                    sN = sN - f[r][0] + f[r][1];
-                    sa = sa - f[r][2] + f[r][3];
-                    sb = sb - f[r][4] + f[r][5];
-                }
-        } else {
+            const double *q6 = sPhiAll + (size_t)me * 6;
+            const bool hN = keepphi && cN == bN, ha = keepphi && ca == ba, hb = keepphi && cb == bb;
+            const double f0 = hN ? q6[0] : phi[cN], f1 = hN ? q6[1] : phi[cN + 1];
+            const double f2 = ha ? q6[2] : phi[ca], f3 = ha ? q6[3] : phi[ca + 1];
+            const double f4 = hb ? q6[4] : phi[cb], f5 = hb ? q6[5] : phi[cb + 1];
+            if (lastN) Nc[((size_t)p * C + ci) * C + cj] = cN + 1;
+            if (lasta) ac[(size_t)p * C + cj] = ca + 1;
+            if (lastb) bc[(size_t)p * C + ci] = cb + 1;
+            double *o6 = sPhiK + (size_t)t * 6;
+            o6[0] = f0, o6[1] = f1, o6[2] = f2, o6[3] = f3, o6[4] = f4, o6[5] = f5;
+        }
+        lds_barrier();
+        for (int p = tid; p < P; p += blockDim.x) {
+            const bool lp = p < SEL_LDSP;
+            double sN = lp ? ss.SN[p] : SN[p], sa = lp ? ss.Sa[p] : Sa[p], sb = lp ? ss.Sb[p] : Sb[p];
+#pragma unroll 4
+            for (int r = 0; r < k; ++r) {
+                const double *f = sPhiK + ((size_t)r * P + p) * 6;
+                sN = sN - f[0] + f[1];
+                sa = sa - f[2] + f[3];
+                sb = sb - f[4] + f[5];
+            }
+            SN[p] = sN;
+            Sa[p] = sa;
+            Sb[p] = sb;
+        }
+    } else {
+        for (int p = tid; p < P; p += blockDim.x) {  // one thread per pair, pick by pick
+            const bool lp = p < SEL_LDSP;
+            double sN = lp ? ss.SN[p] : SN[p], sa = lp ? ss.Sa[p] : Sa[p], sb = lp ? ss.Sb[p] : Sb[p];
             const int d0 = lp ? ss.pairs[2 * p] : pairs[2 * p], d1 = lp ? ss.pairs[2 * p + 1] : pairs[2 * p + 1];
             for (int r = 0; r < k; ++r) {
-                const int *row = asg + (size_t)ss.pick[r] * D;
+                const int *row = sLab + (size_t)ss.pos[r] * D;
                 const int i = row[d0], j = row[d1];
                 const size_t cell = ((size_t)p * C + i) * C + j;
                 const int cN = Nc[cell], ca = ac[(size_t)p * C + j], cb = bc[(size_t)p * C + i];
@@ -316,10 +353,10 @@ __device__ __forceinline__ void mi_select_body(
                 sa = sa - phi[ca] + phi[ca + 1];
                 sb = sb - phi[cb] + phi[cb + 1];
             }
+            SN[p] = sN;
+            Sa[p] = sa;
+            Sb[p] = sb;
         }
-        SN[p] = sN;
-        Sa[p] = sa;
-        Sb[p] = sb;
     }
     if (tid == 0) sc->nc = nc + k;
     FY_CLK(12);
@@ -327,7 +364,7 @@ __device__ __forceinline__ void mi_select_body(
 
 __global__ __launch_bounds__(256) void k_mi_select(
     const int *__restrict__ asg, int D, int C, int P, const int *__restrict__ pairs,
-    const int *__restrict__ batch, int B, int k, int fast, int *__restrict__ Nc, int *__restrict__ ac,
+    const int *__restrict__ batch, int B, int k, int mode, int *__restrict__ Nc, int *__restrict__ ac,
     int *__restrict__ bc, double *__restrict__ SN, double *__restrict__ Sa, double *__restrict__ Sb,
     const double *__restrict__ phi, MiScalars *__restrict__ sc, double *__restrict__ scores_out,
     long long *__restrict__ S_out, double *__restrict__ G_out, const int *__restrict__ forced_pos,
@@ -336,7 +373,7 @@ __global__ __launch_bounds__(256) void k_mi_select(
 {
     __shared__ SelShared ss;
     mi_select_stage(ss, P, pairs, SN, Sa, Sb, sc);
-    mi_select_body(ss, asg, D, C, P, pairs, batch, 0, B, k, fast != 0, Nc, ac, bc, SN, Sa, Sb, phi, sc, scores_out, S_out, G_out,
+    mi_select_body(ss, asg, D, C, P, pairs, batch, 0, nullptr, B, k, mode, Nc, ac, bc, SN, Sa, Sb, phi, sc, scores_out, S_out, G_out,
                    forced_pos, trace_pos, trace_ids, trace_scores, keep_unselected, requeue_out);
 }
 
@@ -905,10 +942,11 @@ struct TileChunk {
     unsigned *src[FY_GROUP]; // content references and last pullers, per iteration of the group in flight
     int *g[FY_GROUP];
     unsigned *perm[FY_NBUF]; // source position of every output position, per iteration (FY_DEPTH groups deep)
+    int *tailinv;            // [FY_NBUF][SEL_MAXB] the output position that reads the r-th of the last `nreq` list positions
     int *A[2];
     unsigned *err;
     const int *asg, *pairs;
-    int *batch, *Nc, *ac, *bc;
+    int *batch, *Nc, *ac, *bc;  // batch: [2][SEL_MAXB (1 + D)]: ids and label rows of the batch of iteration t in half t & 1
     double *SN, *Sa, *Sb;
     const double *phi;
     MiScalars *sc;
@@ -949,7 +987,7 @@ __global__ __launch_bounds__(FYT_THREADS) void k_fy_tile_multi(const TileChunk *
 
 // perm[i] = the position (before the iteration) whose content output position i receives: the E-ref chains are walked
 // here, beside the content path -- the gather that waits for the previous selection is then one indexed copy
-__global__ __launch_bounds__(256) void k_fy_resolve_multi(const TileChunk *__restrict__ cd, int it0, int dl)
+__global__ __launch_bounds__(256) void k_fy_resolve_multi(const TileChunk *__restrict__ cd, int it0, int dl, int nreq)
 {
     // one element per thread: a wave waits for the longest of its chains, and four elements per thread (256 chains per
     // wave) made the kernel 1.5x slower
@@ -966,31 +1004,68 @@ __global__ __launch_bounds__(256) void k_fy_resolve_multi(const TileChunk *__res
         while ((ga = g[a]) >= 0) a = ga;
     }
     c.perm[it % FY_NBUF][i] = (unsigned)a;
+    // the last nreq positions of the list hold what the PREVIOUS iteration's selection re-queues (see
+    // k_fy_gather_select_multi): who reads them
+    if (a >= L - nreq) c.tailinv[(size_t)(it % FY_NBUF) * SEL_MAXB + (a - (L - nreq))] = i;
 }
 
-// out[i] = A[perm[i]]; the first B outputs are the batch, the rest the head of the next list; workgroup 0 -- the one
-// that produces the batch -- then runs the scoring / top-k / commit of the greedy iteration (mi_select_body) while the
-// other workgroups still gather
-__global__ __launch_bounds__(256) void k_fy_gather_select_multi(const TileChunk *__restrict__ cd, int it, int dl, int B, int k,
-                                                                int fast, int keep_unselected)
+// Launch `it` of the content stream, two things that do not depend on each other (software pipelining: the selection is a
+// latency chain of ~5 us, the gather a bandwidth burst of ~6 us; in one dependent sequence they cost their sum, and the
+// selection's round trips were slowed further by the gather's traffic):
+//   workgroups 1..   GATHER of iteration `it`: out[i] = A_it[perm_it[i]]; outputs i < B are the batch of iteration `it` (kept
+//                    for the next launch), the rest the head of list it+1.  The last nreq = B - k positions of A_it are what
+//                    the selection of iteration it-1 re-queues -- which runs in THIS launch: an output that reads one of
+//                    them is left to workgroup 0 (exactly one output per position: tailinv, from k_fy_resolve).
+//   workgroup 0      SELECTION of iteration it-1 (mi_select_body: scoring / top-k / commit on the batch gathered by the
+//                    previous launch), then the nreq re-queued ids go straight to the outputs of iteration `it` that read them.
+// Launches run it = 0 .. iters (the first has no selection, the last no gather).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fy_gather_select_multi(
+    const TileChunk *__restrict__ cd, int it, int dl, int B, int k, int mode, int keep_unselected)
 {
     const TileChunk &c = cd[blockIdx.y];
-    const int L = c.L0 - it * dl;
-    if (it >= c.iters || (int)blockIdx.x * 256 >= L) return;
-    __shared__ SelShared ss;
-    if (blockIdx.x == 0) mi_select_stage(ss, c.P, c.pairs, c.SN, c.Sa, c.Sb, c.sc);  // under the gather's round trips
-    int *__restrict__ A_new = c.A[(it + 1) & 1];
-    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
-    int v = 0;
-    if (i < L) {
-        v = c.A[it & 1][c.perm[it % FY_NBUF][i]];
-        if (i >= B) A_new[i - B] = v;
+    const int L = c.L0 - it * dl;  // list length of iteration `it`
+    const int nreq = keep_unselected ? B - k : 0;
+    const int bstride = SEL_MAXB * (1 + c.D);  // one half of the batch buffer: ids [SEL_MAXB], label rows [SEL_MAXB][D]
+    if (blockIdx.x != 0) {
+        const int i = (int)((blockIdx.x - 1) * 256 + threadIdx.x);
+        if (it >= c.iters || i >= L) return;
+        const int a = (int)c.perm[it % FY_NBUF][i];
+        if (it > 0 && a >= L - nreq) return;  // not there yet: workgroup 0 delivers it
+        const int v = c.A[it & 1][a];
+        if (i < B) {  // a batch entry travels with its label row: the next launch's selection starts one level further on
+            int *bb = c.batch + (it & 1) * bstride;
+            bb[i] = v;
+            for (int d = 0; d < c.D; ++d) bb[SEL_MAXB + i * c.D + d] = c.asg[(size_t)v * c.D + d];
+        } else {
+            c.A[(it + 1) & 1][i - B] = v;
+        }
+        return;
     }
-    if (blockIdx.x != 0) return;  // uniform
-    mi_select_body(ss, c.asg, c.D, c.C, c.P, c.pairs, nullptr, v, B, k, fast != 0, c.Nc, c.ac, c.bc, c.SN, c.Sa, c.Sb, c.phi, c.sc,
-                   nullptr, c.S + (size_t)it * k, c.G + (size_t)it * k, c.forced ? c.forced + (size_t)it * k : nullptr,
-                   c.tr_pos ? c.tr_pos + (size_t)it * k : nullptr, c.tr_ids ? c.tr_ids + (size_t)it * B : nullptr,
-                   c.tr_sc ? c.tr_sc + (size_t)it * B : nullptr, keep_unselected, A_new + (L - B));
+    if (it < 1 || it > c.iters) return;
+    const int ps = it - 1;  // the iteration whose selection this is
+    __shared__ SelShared ss;
+    __shared__ int sReq[SEL_MAXB];
+    const int *bprev = c.batch + (ps & 1) * bstride;
+    mi_select_stage(ss, c.P, c.pairs, c.SN, c.Sa, c.Sb, c.sc);
+    const int id = (int)threadIdx.x < B ? bprev[threadIdx.x] : 0;
+    const bool feeds = it < c.iters && (int)threadIdx.x < nreq;  // this thread delivers a re-queued id to the gather of `it`
+    const int dest = feeds ? c.tailinv[(size_t)(it % FY_NBUF) * SEL_MAXB + threadIdx.x] : 0;
+    mi_select_body(ss, c.asg, c.D, c.C, c.P, c.pairs, nullptr, id, bprev + SEL_MAXB, B, k, mode, c.Nc, c.ac, c.bc, c.SN, c.Sa, c.Sb,
+                   c.phi, c.sc, nullptr, c.S + (size_t)ps * k, c.G + (size_t)ps * k, c.forced ? c.forced + (size_t)ps * k : nullptr,
+                   c.tr_pos ? c.tr_pos + (size_t)ps * k : nullptr, c.tr_ids ? c.tr_ids + (size_t)ps * B : nullptr,
+                   c.tr_sc ? c.tr_sc + (size_t)ps * B : nullptr, keep_unselected, sReq);
+    if (it >= c.iters || nreq == 0) return;  // no gather left to feed
+    lds_barrier();
+    if (feeds) {
+        const int v = sReq[threadIdx.x];
+        if (dest < B) {
+            int *bb = c.batch + (it & 1) * bstride;
+            bb[dest] = v;
+            for (int d = 0; d < c.D; ++d) bb[SEL_MAXB + dest * c.D + d] = c.asg[(size_t)v * c.D + d];
+        } else {
+            c.A[(it + 1) & 1][dest - B] = v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ several chunks in lockstep
@@ -1052,13 +1127,13 @@ __global__ __launch_bounds__(256) void k_fy_apply_multi(const ChunkDesc *__restr
 }
 
 __global__ __launch_bounds__(256) void k_mi_select_multi(const ChunkDesc *__restrict__ cd, int it, int dl, int B, int k,
-                                                         int fast, int keep_unselected)
+                                                         int mode, int keep_unselected)
 {
     const ChunkDesc c = cd[blockIdx.x];
     if (it >= c.iters) return;
     __shared__ SelShared ss;
     mi_select_stage(ss, c.P, c.pairs, c.SN, c.Sa, c.Sb, c.sc);
-    mi_select_body(ss, c.asg, c.D, c.C, c.P, c.pairs, c.batch, 0, B, k, fast != 0, c.Nc, c.ac, c.bc, c.SN, c.Sa, c.Sb, c.phi, c.sc, nullptr,
+    mi_select_body(ss, c.asg, c.D, c.C, c.P, c.pairs, c.batch, 0, nullptr, B, k, mode, c.Nc, c.ac, c.bc, c.SN, c.Sa, c.Sb, c.phi, c.sc, nullptr,
                    c.S + (size_t)it * k, c.G + (size_t)it * k, nullptr, nullptr, nullptr, nullptr, keep_unselected,
                    c.A[(it + 1) & 1] + (c.L0 - it * dl - B));
 }
@@ -1083,7 +1158,7 @@ struct acav_mi {
     DevBuf removed, blockbest, ticket, tr_am;  // exact greedy
     DevBuf chunk_desc;                         // descriptor array of a multi-chunk run (lead handle)
     DevBuf lane_states, ring, polys;           // MT19937 lanes of the single-chunk greedy (MtStream)
-    DevBuf fy_table, fy_bounds, fy_bucket, fy_count, fy_src[FY_GROUP], fy_g[FY_GROUP], fy_perm[FY_NBUF], fy_err;  // tiled Fisher-Yates
+    DevBuf fy_table, fy_bounds, fy_bucket, fy_count, fy_src[FY_GROUP], fy_g[FY_GROUP], fy_perm[FY_NBUF], fy_tail, fy_err;  // tiled Fisher-Yates
     hipStream_t st_fy = nullptr;               // the position kernels of group g+1 run beside the gathers of group g
     hipEvent_t ev_tile[FY_NBUF] = {}, ev_gather[FY_NBUF] = {};
     // the mt19937 stream does not depend on the selection state: it is generated one iteration ahead on
@@ -1311,6 +1386,7 @@ static int fy_setup(acav_mi *mi, int64_t L, FyPlan &fp, hipStream_t st)
         ACAV_TRY(mi->fy_g[q].ensure(sizeof(int) * (size_t)L));
     }
     for (int q = 0; q < FY_NBUF; ++q) ACAV_TRY(mi->fy_perm[q].ensure(sizeof(unsigned) * (size_t)L));
+    ACAV_TRY(mi->fy_tail.ensure(sizeof(int) * (size_t)FY_NBUF * SEL_MAXB));
     ACAV_HIP_TRY(hipMemcpyAsync(mi->fy_table.p, fp.table.data(), sizeof(unsigned short) * fp.table.size(), hipMemcpyHostToDevice, st));
     ACAV_HIP_TRY(hipMemcpyAsync(mi->fy_bounds.p, fp.ebound.data(), sizeof(int) * fp.ebound.size(), hipMemcpyHostToDevice, st));
     ACAV_HIP_TRY(hipMemsetAsync(mi->fy_count.p, 0, sizeof(int) * (size_t)FY_GROUP * fp.NT * FY_SHARDS, st));
@@ -1478,7 +1554,7 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
     std::vector<FyPlan> plans((size_t)nchunks);
     std::vector<MtStream> streams((size_t)nchunks);
     int64_t iters_max = 0, lmax = 0;
-    int pmax = 1, ntmax = 1;
+    int pmax = 1, dmax = 1, ntmax = 1;
     size_t part_smem = 0, tile_smem = 0;
     for (int c = 0; c < nchunks; ++c) {
         acav_mi *mi = mis[c];
@@ -1499,11 +1575,12 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
         iters_max = itc > iters_max ? itc : iters_max;
         lmax = L[c] > lmax ? L[c] : lmax;
         pmax = mi->P > pmax ? mi->P : pmax;
+        dmax = mi->D > dmax ? mi->D : dmax;
         const size_t Lc = (size_t)L[c];
         ACAV_TRY(mi->A0.ensure(sizeof(int) * (Lc + B)));  // before the conversion: ensure() does not copy
         ACAV_TRY(ids_to_device32(mi, candidates[c], L[c], mi->stage, mi->A0));
         ACAV_TRY(mi->A1.ensure(sizeof(int) * (Lc + B)));
-        ACAV_TRY(mi->batch.ensure(sizeof(int) * SEL_MAXB));
+        ACAV_TRY(mi->batch.ensure(sizeof(int) * 2 * SEL_MAXB * (size_t)(1 + mi->D)));
         ACAV_TRY(mi->S.ensure(sizeof(long long) * (size_t)(itc * k + 1)));
         ACAV_TRY(mi->G.ensure(sizeof(double) * (size_t)(itc * k + 1)));
         if (ex.trace_pos) ACAV_TRY(mi->tr_pos.ensure(sizeof(int) * (size_t)(itc * k + 1)));
@@ -1536,6 +1613,7 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
         d.bucket = mi->fy_bucket.as<int2>(), d.gcount = mi->fy_count.as<int>(), d.err = mi->fy_err.as<unsigned>();
         for (int q = 0; q < FY_GROUP; ++q) d.src[q] = mi->fy_src[q].as<unsigned>(), d.g[q] = mi->fy_g[q].as<int>();
         for (int q = 0; q < FY_NBUF; ++q) d.perm[q] = mi->fy_perm[q].as<unsigned>();
+        d.tailinv = mi->fy_tail.as<int>();
         d.A[0] = mi->A0.as<int>(), d.A[1] = mi->A1.as<int>();
         d.asg = mi->asg.as<int>(), d.pairs = mi->pairs.as<int>(), d.batch = mi->batch.as<int>();
         d.Nc = mi->Nc.as<int>(), d.ac = mi->ac.as<int>(), d.bc = mi->bc.as<int>();
@@ -1555,8 +1633,11 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
     ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fy_tile_multi), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)tile_smem));
     const TileChunk *dcd = lead->chunk_desc.as<TileChunk>();
-    const size_t sel_smem = sel_smem_bytes(B, pmax);
-    const int sel_f = sel_fast(B, pmax) ? 1 : 0;
+    const int sel_f = sel_mode(B, pmax, k);  // one mode for every chunk of the launch: sized for the largest P and D
+    const size_t sel_smem = sel_layout(B, pmax, dmax, k, sel_f).total;
+    if (sel_smem > 48 * 1024)
+        ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fy_gather_select_multi),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_smem));
     const bool timing = getenv("ACAV_MI_TIMING") != nullptr;
     const auto t_loop0 = std::chrono::steady_clock::now();
     for (int64_t g0 = 0; g0 < iters_max; g0 += FY_GROUP) {
@@ -1584,17 +1665,21 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
         hipLaunchKernelGGL(k_fy_tile_multi, dim3((unsigned)ntmax, (unsigned)nchunks, gz), dim3(FYT_THREADS), tile_smem, sf, dcd, (int)g0,
                            (int)dl);
         hipLaunchKernelGGL(k_fy_resolve_multi, dim3((unsigned)((lt + 255) / 256), (unsigned)nchunks, gz), dim3(256), 0, sf, dcd, (int)g0,
-                           (int)dl);
+                           (int)dl, keep_unselected ? B - k : 0);
         ACAV_HIP_TRY(hipEventRecord(lead->ev_tile[ge], sf));
-        // ---- main stream: the group's gathers + selections, back to back
+        // ---- main stream: the group's gathers (each with the selection of the iteration before it), back to back
         ACAV_HIP_TRY(hipStreamWaitEvent(st, lead->ev_tile[ge], 0));
         for (int64_t it = g0; it < g1; ++it) {
-            const dim3 grid((unsigned)((lmax - it * dl + 255) / 256), (unsigned)nchunks);
+            const dim3 grid((unsigned)((lmax - it * dl + 255) / 256) + 1u, (unsigned)nchunks);
             hipLaunchKernelGGL(k_fy_gather_select_multi, grid, dim3(256), sel_smem, st, dcd, (int)it, (int)dl, B, k, sel_f, keep_unselected);
         }
         ACAV_HIP_TRY(hipGetLastError());
         ACAV_HIP_TRY(hipEventRecord(lead->ev_gather[ge], st));
     }
+    if (iters_max > 0)  // the selection of the last iteration
+        hipLaunchKernelGGL(k_fy_gather_select_multi, dim3(1u, (unsigned)nchunks), dim3(256), sel_smem, st, dcd, (int)iters_max, (int)dl, B, k,
+                           sel_f, keep_unselected);
+    ACAV_HIP_TRY(hipGetLastError());
     const auto t_loop1 = std::chrono::steady_clock::now();
     ACAV_HIP_TRY(hipStreamSynchronize(sf));
     if (timing) {
@@ -1674,7 +1759,7 @@ ACAV_EXPORT int acav_mi_run_greedy_multi(acav_mi **mis, int nchunks, const int64
     std::vector<ChunkDesc> desc((size_t)nchunks);
     std::vector<int64_t> iters((size_t)nchunks, 0);
     int64_t iters_max = 0, lmax = 0;
-    int pmax = 1;
+    int pmax = 1, dmax = 1;
     for (int c = 0; c < nchunks; ++c) {
         acav_mi *mi = mis[c];
         ACAV_REQUIRE(mi && candidates[c] && rngs[c] && S_out[c] && GAIN_out[c], ACAV_EINVAL, "chunk %d: NULL argument", c);
@@ -1697,6 +1782,7 @@ ACAV_EXPORT int acav_mi_run_greedy_multi(acav_mi **mis, int nchunks, const int64
         iters_max = itc > iters_max ? itc : iters_max;
         lmax = L[c] > lmax ? L[c] : lmax;
         pmax = mi->P > pmax ? mi->P : pmax;
+        dmax = mi->D > dmax ? mi->D : dmax;
         const size_t Lc = (size_t)L[c];
         hipStream_t sc = mi->ctx.stream;
         ACAV_TRY(mi->A0.ensure(sizeof(int) * (Lc + B)));
@@ -1751,8 +1837,11 @@ ACAV_EXPORT int acav_mi_run_greedy_multi(acav_mi **mis, int nchunks, const int64
         return ACAV_OK;
     };
     if (iters_max > 0) ACAV_TRY(launch_mt(0));
-    const size_t smem = sel_smem_bytes(B, pmax);
-    const int sel_f = sel_fast(B, pmax) ? 1 : 0;
+    const int sel_f = sel_mode(B, pmax, k);
+    const size_t smem = sel_layout(B, pmax, dmax, k, sel_f).total;
+    if (smem > 48 * 1024)
+        ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mi_select_multi), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)smem));
     for (int64_t it = 0; it < iters_max; ++it) {
         const int64_t grp = it / MT_GROUP;
         const int cur = (int)(grp & 1);
@@ -1891,9 +1980,13 @@ static int launch_select(acav_mi *mi, const int *batch, int B, int k, double *sc
                          double *G_out, const int *forced_pos, int *trace_pos, long long *trace_ids,
                          double *trace_scores, int keep, int *requeue_out)
 {
-    const size_t smem = sel_smem_bytes(B, mi->P);
+    const int mode = sel_mode(B, mi->P, k);
+    const size_t smem = sel_layout(B, mi->P, mi->D, k, mode).total;
+    if (smem > 48 * 1024)
+        ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mi_select), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)smem));
     hipLaunchKernelGGL(k_mi_select, dim3(1), dim3(256), smem, mi->ctx.stream, mi->asg.as<int>(), mi->D, mi->C, mi->P,
-                       mi->pairs.as<int>(), batch, B, k, sel_fast(B, mi->P) ? 1 : 0, mi->Nc.as<int>(), mi->ac.as<int>(), mi->bc.as<int>(),
+                       mi->pairs.as<int>(), batch, B, k, mode, mi->Nc.as<int>(), mi->ac.as<int>(), mi->bc.as<int>(),
                        mi->SN.as<double>(), mi->Sa.as<double>(), mi->Sb.as<double>(), mi->phi.as<double>(),
                        mi->scalars.as<MiScalars>(), scores_out, S_out, G_out, forced_pos, trace_pos, trace_ids,
                        trace_scores, keep, requeue_out);

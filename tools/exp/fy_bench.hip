@@ -34,7 +34,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&dasg, 4 * (size_t)L * D));
     { std::vector<int> a((size_t)L * D); for (auto &v : a) v = rng() % C; CK(hipMemcpy(dasg, a.data(), 4 * a.size(), hipMemcpyHostToDevice)); }
     int hp[2] = {0, 1}; CK(hipMalloc(&dpairs, 8)); CK(hipMemcpy(dpairs, hp, 8, hipMemcpyHostToDevice));
-    CK(hipMalloc(&dbatch, 4 * 1024)); CK(hipMalloc(&dNc, 4 * C * C)); CK(hipMalloc(&dac, 4 * C)); CK(hipMalloc(&dbc, 4 * C));
+    CK(hipMalloc(&dbatch, 4 * 1024)); CK(hipMemset(dbatch, 0, 4 * 1024)); CK(hipMalloc(&c.tailinv, 4 * FY_NBUF * SEL_MAXB)); CK(hipMemset(c.tailinv, 0, 4 * FY_NBUF * SEL_MAXB)); CK(hipMalloc(&dNc, 4 * C * C)); CK(hipMalloc(&dac, 4 * C)); CK(hipMalloc(&dbc, 4 * C));
     CK(hipMemset(dNc, 0, 4 * C * C)); CK(hipMemset(dac, 0, 4 * C)); CK(hipMemset(dbc, 0, 4 * C));
     CK(hipMalloc(&dS3, 8 * 3)); CK(hipMemset(dS3, 0, 24));
     { std::vector<double> phi((size_t)L + 2, 0.0); for (size_t i = 1; i < phi.size(); ++i) phi[i] = (double)i * log((double)i);
@@ -52,7 +52,7 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto part = [&]() { hipLaunchKernelGGL(k_fy_part_multi, dim3((L + FYA_CH - 1) / FYA_CH, 1, G), dim3(FYA_THREADS), part_smem, 0, dcd, 0, dl); };
     auto tile = [&]() { hipLaunchKernelGGL(k_fy_tile_multi, dim3(fp.NT, 1, G), dim3(FYT_THREADS), fp.tile_smem(), 0, dcd, 0, dl); };
-    auto resolve = [&]() { hipLaunchKernelGGL(k_fy_resolve_multi, dim3((L + 255) / 256, 1, G), dim3(256), 0, 0, dcd, 0, dl); };
+    auto resolve = [&]() { hipLaunchKernelGGL(k_fy_resolve_multi, dim3((L + 255) / 256, 1, G), dim3(256), 0, 0, dcd, 0, dl, B - k); };
     auto timeit = [&](const char *name, auto fn, double base_us) {
         for (int i = 0; i < 3; ++i) fn();
         CK(hipDeviceSynchronize());
@@ -83,10 +83,22 @@ int main(int argc, char **argv)
 #endif
     unsigned err; CK(hipMemcpy(&err, c.err, 4, hipMemcpyDeviceToHost)); printf("err flags %u\n", err);
     // gathers of iterations 0..G-1, alone (perm / src / g of the last group are in place)
-    const size_t sel_smem = sel_smem_bytes(B, P);
+    const int sel_m = sel_mode(B, P, k);
+    const size_t sel_smem = sel_layout(B, P, D, k, sel_m).total;
     int itg = 0;
-    auto g_sc = [&]() { hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 255) / 256, 1), dim3(256), sel_smem, 0, dcd, itg, dl, B, k, 1, 1); itg = (itg + 1) % G; };
-    timeit("8 x gather+select", [&]() { for (int i = 0; i < G; ++i) g_sc(); }, 0);
+    auto g_sc = [&]() { hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 255) / 256 + 1, 1), dim3(256), sel_smem, 0, dcd, itg, dl, B, k, sel_m, 1); itg = (itg + 1) % G; };
+    timeit("G x gather+select", [&]() { for (int i = 0; i < G; ++i) g_sc(); }, 0);
+    {   // iteration 0 only: no selection in workgroup 0 -- the gather alone
+        auto g0only = [&]() { hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 255) / 256 + 1, 1), dim3(256), sel_smem, 0, dcd, 0, dl, B, k, sel_m, 1); };
+        timeit("G x gather (launch 0: no selection)", [&]() { for (int i = 0; i < G; ++i) g0only(); }, 0);
+    }
+    {   // the same with ONE perm buffer for every iteration (stays in cache) -- how much of the gather is the first touch of perm?
+        TileChunk c2 = c;
+        for (int q = 0; q < FY_NBUF; ++q) c2.perm[q] = c.perm[0];
+        CK(hipMemcpy(dcd, &c2, sizeof(c2), hipMemcpyHostToDevice));
+        timeit("G x gather+select, one perm buffer", [&]() { for (int i = 0; i < G; ++i) g_sc(); }, 0);
+        CK(hipMemcpy(dcd, &c, sizeof(c), hipMemcpyHostToDevice));
+    }
     {   // do the two streams of the product overlap?  side group (iterations 8..15) on one stream, 8 gathers (0..7) on another
         const char *pri = getenv("FYB_PRIORITY"), *mask = getenv("FYB_CUMASK");
         hipStream_t sa, sb;
@@ -105,11 +117,11 @@ int main(int argc, char **argv)
         auto side = [&](hipStream_t st) {
             hipLaunchKernelGGL(k_fy_part_multi, dim3((L + FYA_CH - 1) / FYA_CH, 1, G), dim3(FYA_THREADS), part_smem, st, dcd, 8, dl);
             hipLaunchKernelGGL(k_fy_tile_multi, dim3(fp.NT, 1, G), dim3(FYT_THREADS), fp.tile_smem(), st, dcd, 8, dl);
-            hipLaunchKernelGGL(k_fy_resolve_multi, dim3((L + 255) / 256, 1, G), dim3(256), 0, st, dcd, 8, dl);
+            hipLaunchKernelGGL(k_fy_resolve_multi, dim3((L + 255) / 256, 1, G), dim3(256), 0, st, dcd, 8, dl, B - k);
         };
         auto gath = [&](hipStream_t st) {
             for (int i = 0; i < G; ++i)
-                hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 255) / 256, 1), dim3(256), sel_smem, st, dcd, i, dl, B, k, 1, 1);
+                hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 255) / 256 + 1, 1), dim3(256), sel_smem, st, dcd, i, dl, B, k, sel_m, 1);
         };
         auto wall = [&](const char *name, auto fn) {
             fn(); CK(hipDeviceSynchronize());

@@ -13,6 +13,28 @@ __global__ __launch_bounds__(256) void g1(const int *__restrict__ A, const unsig
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i < L) out[i] = A[perm[i]];
 }
+__global__ __launch_bounds__(256) void g1s(const int *__restrict__ A, const unsigned *__restrict__ perm, int *__restrict__ out, int L)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < L) { int v = A[perm[i]]; if (i >= 20) out[i - 20] = v; }
+}
+struct Desc { long long pad[8]; const int *A[2]; const unsigned *perm[48]; int *out[2]; int L0, iters; };
+__global__ __launch_bounds__(256) void g1d(const Desc *__restrict__ cd, int it)
+{
+    const Desc &c = cd[blockIdx.y];
+    const int L = c.L0 - it * 4;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (it >= c.iters || i >= L) return;
+    int v = c.A[it & 1][c.perm[it % 48][i]];
+    if (i >= 20) c.out[(it + 1) & 1][i - 20] = v;
+}
+__global__ __launch_bounds__(256) void g1l(const int *__restrict__ A, const unsigned *__restrict__ perm, int *__restrict__ out, int L)
+{
+    __shared__ int pad[2560];  // 10 KB of static LDS per workgroup, as the product kernel carries
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0x7fffffff) pad[threadIdx.x] = i;
+    if (i < L) out[i] = A[perm[i]] + (i == 0x7ffffffe ? pad[5] : 0);
+}
 // the current form: 37 % E-refs resolved through g
 __global__ __launch_bounds__(256) void g0(const int *__restrict__ A, const unsigned *__restrict__ src, const int *__restrict__ g,
                                           int *__restrict__ out, int L)
@@ -122,6 +144,11 @@ int main(int argc, char **argv)
     };
     run("g0 current (src+g chains)", [&](int i) { hipLaunchKernelGGL(g0, nb, 256, 0, 0, (i & 1) ? dB : dA, dsrc, dg, (i & 1) ? dA : dB, L); });
     run("g1 out[i]=A[perm[i]]", [&](int i) { hipLaunchKernelGGL(g1, nb, 256, 0, 0, (i & 1) ? dB : dA, dperm, (i & 1) ? dA : dB, L); });
+    run("g1s shifted store (i-20)", [&](int i) { hipLaunchKernelGGL(g1s, nb, 256, 0, 0, (i & 1) ? dB : dA, dperm, (i & 1) ? dA : dB, L); });
+    run("g1l +10 KB static LDS", [&](int i) { hipLaunchKernelGGL(g1l, nb, 256, 0, 0, (i & 1) ? dB : dA, dperm, (i & 1) ? dA : dB, L); });
+    { Desc d{}; d.A[0] = dA; d.A[1] = dB; d.out[0] = dA; d.out[1] = dB; for (int q = 0; q < 48; ++q) d.perm[q] = dperm; d.L0 = L; d.iters = 1 << 30;
+      Desc *dd; CK(hipMalloc(&dd, sizeof(d))); CK(hipMemcpy(dd, &d, sizeof(d), hipMemcpyHostToDevice));
+      run("g1d descriptor + shifted store", [&](int i) { hipLaunchKernelGGL(g1d, dim3(nb, 1), 256, 0, 0, dd, i & 1); }); }
     run("g4 x4", [&](int i) { hipLaunchKernelGGL(g4<0>, nb4, 256, 0, 0, (i & 1) ? dB : dA, dperm, (i & 1) ? dA : dB, L); });
     run("g4 x4 nontemporal", [&](int i) { hipLaunchKernelGGL(g4<1>, nb4, 256, 0, 0, (i & 1) ? dB : dA, dperm, (i & 1) ? dA : dB, L); });
     run("sc1 out[inv[i]]=A[i]", [&](int i) { hipLaunchKernelGGL(sc1, nb, 256, 0, 0, (i & 1) ? dB : dA, dinv, (i & 1) ? dA : dB, L); });
