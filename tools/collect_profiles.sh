@@ -43,6 +43,11 @@ ACAV_FY_LEGACY=1 stats mi_1m_legacy python tools/bench_mi.py 1000000 256 2 0 300
 stats mi_100k python tools/bench_mi.py 100000 256 2
 stats mi_lockstep8 python tools/bench_mi_lockstep.py 100000 256 2 8
 ACAV_MI_TIMING=1 timeout 300 python tools/bench_mi.py 1000000 256 2 0 20000 > "$OUT/${P}_mi_1m_steady.txt" 2>&1
+ACAV_MI_TIMING=1 timeout 300 python tools/bench_mi.py 100000 256 2 > "$OUT/${P}_mi_100k_steady.txt" 2>&1
+# the kernels of one iteration, each ALONE on the product's code (tools/exp/build.sh fy_bench cross-compiles the harness)
+if [ -x tools/exp/fy_bench ]; then
+    (tools/exp/fy_bench 1000000; tools/exp/fy_bench 100000) > "$OUT/${P}_mi_kernels_alone.txt" 2>&1
+fi
 # 4. SGD step per shape (persistent / wide persistent / per-step launches)
 : > "$OUT/${P}_train_shapes.txt"
 for shape in "1024 256" "512 64" "1024 1024" "128 1024" "2048 1024" "2048 256"; do
