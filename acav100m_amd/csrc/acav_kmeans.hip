@@ -787,6 +787,10 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict_
 // DMA cursors running across tile boundaries, one workgroup per CU) halves that traffic and was SLOWER (0.94 vs 0.90 ms):
 // eight waves in lockstep on one barrier lose more than the centre traffic costs; two independent 128-row workgroups
 // per CU interleave their phases.  (round 2, measured and rejected)
+// Same-box ablations of the compute side (full 0.87-0.93 ms): half of the centre fragment reads 0.82, one centre tile's
+// fragments only 0.81, half of the MFMAs 0.80, both halved 0.80 -- neither the LDS reads nor the matrix pipe is the floor:
+// the two DMA streams are (rows from HBM + as many bytes of centres from L2: 8.2 GB through the LDS-DMA path per launch,
+// DMA only 0.78 ms), against a chip that copies at 6.3 TB/s (0.65 ms for the rows alone, MI355X_MICROARCH.md).
 template <bool NT>
 __global__ __launch_bounds__(256, 2) void k_assign_bf16_rw(const float *__restrict__ x, int64_t n, int d,
                                                             const __bf16 *__restrict__ cb, const float *__restrict__ cn,

@@ -77,5 +77,10 @@ def default_comm(slot=0):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl":
             return None
-        _default[slot] = Comm.from_process_group()
+        try:
+            _default[slot] = Comm.from_process_group()
+        except _lib.AcavError as exc:  # e.g. librccl not loadable: every rank fails alike and takes the torch.distributed route
+            import warnings
+            warnings.warn(f"acav_comm unavailable ({exc}); the collectives of this run go through torch.distributed")
+            _default[slot] = None
     return _default[slot]
