@@ -791,6 +791,9 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict_
 // fragments only 0.81, half of the MFMAs 0.80, both halved 0.80 -- neither the LDS reads nor the matrix pipe is the floor:
 // the two DMA streams are (rows from HBM + as many bytes of centres from L2: 8.2 GB through the LDS-DMA path per launch,
 // DMA only 0.78 ms), against a chip that copies at 6.3 TB/s (0.65 ms for the rows alone, MI355X_MICROARCH.md).
+// Halving the centre stream the other way -- a wave owning 64 rows (two accumulator sets = 256 registers, 512 with the
+// fragments, 7 spills), 256 rows per workgroup against one centre stage, 128 KB of LDS, one wave per SIMD -- was correct
+// and SLOWER too (0.97-0.98 vs 0.91-0.94 ms same box): with one wave per SIMD every barrier and LDS wait idles the SIMD.
 template <bool NT>
 __global__ __launch_bounds__(256, 2) void k_assign_bf16_rw(const float *__restrict__ x, int64_t n, int d,
                                                             const __bf16 *__restrict__ cb, const float *__restrict__ cn,
