@@ -381,6 +381,62 @@ class KMeans:
             return train_epoch_dp(self, x_local, int(batch_size), lr, chunk_steps=chunk_steps)
         self.train_epoch_comm(comm, x_local, int(batch_size), lr, chunk_steps, train_here, wait)
 
+    @staticmethod
+    def train_epoch_distributed_multi(clusterings, xs_local, batch_size, lr=None, chunk_steps=1024, trainers=None):
+        """train_epoch_distributed for several clusterings over the same local rows, chunk by chunk across all of them
+        (acav_kmeans_train_dp_multi): every rank feeds every clustering's row exchange (communicator slot = position in
+        the list), the replicated chain of clustering v runs on rank trainers[v] only (default v % world) -- different
+        ranks train different clusterings at the same time.  Follow with broadcast_state_from(trainers[v], comm_slot=v).
+        Without RCCL (gloo / host tensors: CPU tests) the clusterings go one after the other through torch.distributed."""
+        kms = list(clusterings)
+        if not kms:
+            return []
+        from ..parallel.collectives import world as _world
+        from ..parallel.rccl_comm import default_comm
+        rank, w = _world()
+        trainers = [v % w for v in range(len(kms))] if trainers is None else [int(t) for t in trainers]
+        lr = kms[0].lr if lr is None else lr
+        on_gpu = all(hasattr(x, "is_cuda") and x.is_cuda for x in xs_local)
+        comms = [default_comm(v) for v in range(len(kms))] if on_gpu else [None] * len(kms)
+        if any(c is None for c in comms):
+            from ..parallel import train_epoch_dp
+            for km, x in zip(kms, xs_local):
+                train_epoch_dp(km, x, int(batch_size), lr, chunk_steps=chunk_steps)
+            return trainers
+        import torch
+        keep, ptrs, warms, needs = [], [], [], []
+        n_local = None
+        for v, (km, x, comm) in enumerate(zip(kms, xs_local, comms)):
+            k, xp, n, _ = _as_f32_2d(x, km._shape[1])
+            assert n_local is None or n == n_local, "the clusterings of one call share the local rows"
+            n_local = n
+            need = km.warmup_steps(w * int(batch_size), n // int(batch_size))
+            warm = None
+            if need:  # drawn per rank (every rank: the shared generator must advance alike), exchanged once
+                mine = np.stack([km.draw_warmup(int(batch_size)) for _ in range(need)]).astype(np.int64)
+                if w > 1:
+                    send = torch.from_numpy(mine).to(x.device)
+                    recv = torch.empty((w, need, int(batch_size)), dtype=torch.long, device=x.device)
+                    comm.allgather(send, recv)
+                    comm.synchronize()
+                    warm = np.ascontiguousarray(recv.cpu().numpy().transpose(1, 0, 2).reshape(need, w * int(batch_size)))
+                else:
+                    warm = np.ascontiguousarray(mine)
+            keep.append((k, warm))
+            ptrs.append(xp.value)
+            warms.append(warm.ctypes.data if need else None)
+            needs.append(need)
+        cnt = len(kms)
+        h_arr = (C.c_void_p * cnt)(*[km._require_handle().value for km in kms])
+        c_arr = (C.c_void_p * cnt)(*[c._h.value for c in comms])
+        x_arr = (C.c_void_p * cnt)(*ptrs)
+        w_arr = (C.c_void_p * cnt)(*warms)
+        nw_arr = np.asarray(needs, np.int64)
+        here = np.asarray([1 if t == rank else 0 for t in trainers], np.int32)
+        _lib.check(_lib._lib.acav_kmeans_train_dp_multi(h_arr, c_arr, cnt, x_arr, int(n_local), int(batch_size), float(lr), w_arr,
+                                                        _lib.ptr(nw_arr), int(chunk_steps), _lib.ptr(here)))
+        return trainers
+
     def broadcast_state_from(self, root, comm_slot=0):
         """every rank's state <- rank `root`'s (RCCL through the C ABI; torch.distributed under gloo)"""
         from ..parallel.rccl_comm import default_comm

@@ -11,6 +11,7 @@
 // RCCL is resolved at run time (dlopen of the librccl the process already has -- torch's -- else the ROCm one): the
 // library loads and every other entry point works on a box without RCCL; only acav_comm_* report ACAV_ESTATE there.
 #include <dlfcn.h>
+#include <vector>
 #include <rccl/rccl.h>
 
 #include "acav_common.h"
@@ -291,6 +292,102 @@ ACAV_EXPORT int acav_kmeans_train_dp(acav_kmeans *km, acav_comm *c, const float 
     if (nowait) return ACAV_OK;
     ACAV_HIP_TRY(hipStreamSynchronize(sc));
     return acav_kmeans_sync(km);
+}
+
+// The same epoch for SEVERAL clusterings over the same local rows (the views of one batch stream), chunk by chunk across
+// all of them: per chunk every rank first enqueues the NEXT chunk's row exchange of every clustering (one communicator --
+// and stream -- per clustering; the same order on every rank), then trains the current chunk of the clusterings dealt to
+// it (train_here[v] != 0) side by side (acav_kmeans_train_multi).  A rank that blocks in its own clustering's chunk has
+// therefore already fed every other clustering's exchange: different ranks train different clusterings at the same time.
+// (Calling acav_kmeans_train_dp once per clustering serialises them: the training call of a chunk is synchronous, so the
+// trainer of clustering 0 joins the exchanges of clustering 1 only after its whole epoch.)
+ACAV_EXPORT int acav_kmeans_train_dp_multi(acav_kmeans *const *kms, acav_comm *const *comms, int count,
+                                           const float *const *x_local_dev, int64_t n_local, int64_t b_local, double lr,
+                                           const int64_t *const *warm_global, const int64_t *n_warm, int64_t chunk_steps,
+                                           const int *train_here)
+{
+    ACAV_REQUIRE(kms && comms && x_local_dev && train_here && count > 0 && count <= 64, ACAV_EINVAL, "bad argument");
+    ACAV_REQUIRE(n_local >= 0 && b_local > 0 && chunk_steps > 0, ACAV_EINVAL, "bad sizes");
+    const int64_t steps = n_local / b_local;
+    if (steps == 0) return ACAV_OK;
+    std::vector<int> dv((size_t)count, 0);
+    std::vector<void *> st_train((size_t)count, nullptr);
+    const int w = comms[0] ? comms[0]->world : 1;
+    const int64_t bg = (int64_t)w * b_local;
+    for (int v = 0; v < count; ++v) {
+        ACAV_REQUIRE(kms[v] && comms[v] && x_local_dev[v], ACAV_EINVAL, "clustering %d: NULL argument", v);
+        ACAV_REQUIRE(comms[v]->world == w, ACAV_EINVAL, "communicators of different sizes");
+        ACAV_REQUIRE(is_device_ptr(x_local_dev[v]), ACAV_EINVAL, "x_local must be device memory");
+        ACAV_REQUIRE(!n_warm || n_warm[v] == 0 || (warm_global && warm_global[v]), ACAV_EINVAL, "clustering %d: warm-up labels missing", v);
+        for (int e = 0; e < v; ++e) ACAV_REQUIRE(comms[e] != comms[v] && kms[e] != kms[v], ACAV_EINVAL, "one communicator and one handle per clustering");
+        int K = 0;
+        ACAV_TRY(acav_kmeans_shape(kms[v], &K, &dv[(size_t)v]));
+        ACAV_REQUIRE((dv[(size_t)v] & 3) == 0, ACAV_EINVAL, "d = %d must be a multiple of 4 for the bulk exchange", dv[(size_t)v]);
+        ACAV_TRY(acav_kmeans_stream(kms[v], &st_train[(size_t)v]));
+        const size_t chunk_bytes = sizeof(float) * (size_t)chunk_steps * (size_t)bg * (size_t)dv[(size_t)v];
+        ACAV_HIP_TRY(hipSetDevice(comms[v]->ctx.device));
+        for (int q = 0; q < 2; ++q) {
+            ACAV_TRY(comms[v]->gather[q].ensure(chunk_bytes));
+            if (train_here[v]) ACAV_TRY(comms[v]->batches[q].ensure(chunk_bytes));
+        }
+    }
+    auto gather = [&](int v, int64_t c0, int par) -> int {  // rows of steps [c0, c0 + s) of every rank -> batches[par] of clustering v
+        acav_comm *c = comms[v];
+        const int d = dv[(size_t)v];
+        hipStream_t sc = c->ctx.stream;
+        const int64_t s = steps - c0 < chunk_steps ? steps - c0 : chunk_steps;
+        const size_t bytes = sizeof(float) * (size_t)s * (size_t)b_local * (size_t)d;
+        if (train_here[v]) ACAV_HIP_TRY(hipStreamWaitEvent(sc, c->ev_trained[par], 0));  // the chunk trained from this buffer is done
+        ACAV_NCCL_TRY(rccl().AllGather(x_local_dev[v] + (size_t)c0 * b_local * d, c->gather[par].p, bytes, ncclInt8, c->comm, sc));
+        if (train_here[v]) {
+            const int64_t total4 = (int64_t)w * s * b_local * (d / 4);
+            const unsigned grid = (unsigned)(total4 / 256 + 1 < 4096 ? total4 / 256 + 1 : 4096);
+            hipLaunchKernelGGL(k_interleave_rows, dim3(grid), dim3(256), 0, sc, c->gather[par].as<float4>(),
+                               c->batches[par].as<float4>(), w, (int)s, (int)b_local, d / 4);
+            ACAV_HIP_TRY(hipGetLastError());
+        }
+        ACAV_HIP_TRY(hipEventRecord(c->ev_gathered[par], sc));
+        return ACAV_OK;
+    };
+    for (int v = 0; v < count; ++v) {
+        if (train_here[v])
+            for (int q = 0; q < 2; ++q) ACAV_HIP_TRY(hipEventRecord(comms[v]->ev_trained[q], (hipStream_t)st_train[(size_t)v]));  // both buffers free
+        ACAV_TRY(gather(v, 0, 0));
+    }
+    std::vector<int64_t> warm_done((size_t)count, 0);
+    std::vector<acav_kmeans *> lk;
+    std::vector<const float *> lx;
+    std::vector<int64_t> ln, lnw;
+    std::vector<const int64_t *> lw;
+    int par = 0;
+    for (int64_t c0 = 0; c0 < steps; c0 += chunk_steps, par ^= 1) {
+        const int64_t s = steps - c0 < chunk_steps ? steps - c0 : chunk_steps;
+        if (c0 + s < steps)
+            for (int v = 0; v < count; ++v) ACAV_TRY(gather(v, c0 + s, par ^ 1));  // next chunk travels while this one trains
+        lk.clear(), lx.clear(), ln.clear(), lnw.clear(), lw.clear();
+        for (int v = 0; v < count; ++v) {
+            if (!train_here[v]) continue;
+            ACAV_HIP_TRY(hipStreamWaitEvent((hipStream_t)st_train[(size_t)v], comms[v]->ev_gathered[par], 0));
+            int64_t nw = (n_warm ? n_warm[v] : 0) - warm_done[(size_t)v];
+            nw = nw < 0 ? 0 : (nw > s ? s : nw);
+            lk.push_back(kms[v]);
+            lx.push_back(comms[v]->batches[par].as<float>());
+            ln.push_back(s * bg);
+            lnw.push_back(nw);
+            lw.push_back(nw ? warm_global[v] + warm_done[(size_t)v] * bg : nullptr);
+            warm_done[(size_t)v] += nw;
+        }
+        if (!lk.empty()) {
+            ACAV_TRY(acav_kmeans_train_multi(lk.data(), (int)lk.size(), lx.data(), ln.data(), bg, lr, lw.data(), lnw.data()));
+            for (int v = 0; v < count; ++v)
+                if (train_here[v]) ACAV_HIP_TRY(hipEventRecord(comms[v]->ev_trained[par], (hipStream_t)st_train[(size_t)v]));
+        }
+    }
+    for (int v = 0; v < count; ++v) {
+        ACAV_HIP_TRY(hipStreamSynchronize(comms[v]->ctx.stream));
+        ACAV_TRY(acav_kmeans_sync(kms[v]));
+    }
+    return ACAV_OK;
 }
 
 // every rank's clustering state <- rank `root`'s (centres, usage counts, count, fallback): one RCCL broadcast of

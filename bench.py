@@ -206,13 +206,12 @@ def main():
             else:
                 # reference DDP semantics: global batch = world * b rows per step, rows all-gathered in bulk by every rank;
                 # the (replicated, device-resident) SGD chain of view v runs on rank v % world only, which then hands out
-                # its state -- instead of every rank running both chains one after the other
-                # (one communicator per view, nothing waits until all views are enqueued: the views train concurrently
-                # on different ranks while every rank keeps feeding both exchanges)
-                for v, (km, x) in enumerate(zip(kms, xs)):
-                    km.train_epoch_distributed(x, b, lr=lr, train_here=(rank == v % world), comm_slot=v, wait=False)
+                # its state -- instead of every rank running both chains one after the other.  Chunk by chunk across the
+                # views (acav_kmeans_train_dp_multi: one communicator per view, every rank feeds every exchange before it
+                # blocks in its own chain): the views train on different ranks at the same time
+                trainers = KMeans.train_epoch_distributed_multi(kms, xs, b, lr=lr)
                 for v, km in enumerate(kms):
-                    km.broadcast_state_from(v % world, comm_slot=v)
+                    km.broadcast_state_from(trainers[v], comm_slot=v)
         for km in kms:
             km.synchronize()
         t1 = time.perf_counter()

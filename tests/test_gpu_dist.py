@@ -171,3 +171,24 @@ def test_comm_c_abi_world1():
     before = (km.centers.numpy().copy(), km.count)
     km.train_epoch_comm(comm, xt, b, 0.01, chunk_steps=16, train_here=False)
     assert np.array_equal(km.centers.numpy(), before[0]) and km.count == before[1]
+    # several clusterings chunk by chunk (acav_kmeans_train_dp_multi, what bench.py --gpus N calls): with one rank == one
+    # plain epoch each; a clustering dealt to another rank (trainer 1 in a world of one: nobody) only feeds its exchange
+    d2 = 128
+    x2 = (rs.randn(k, d2)[rs.randint(0, k, steps * b)] * 3 + rs.randn(steps * b, d2)).astype(np.float32)
+    x2t = torch.from_numpy(x2).cuda()
+    acav100m_amd.manual_seed(11)
+    ka, kb = KMeans(None, d, k).to("cuda:0"), KMeans(None, d2, k).to("cuda:0")
+    ra, rb = O.KMeans(d, k, O.Rng(11)), None
+    rb = O.KMeans(d2, k, ra.rng)  # the two clusterings share the generator, as ka / kb share the library's
+    for epoch in range(2):
+        tr = KMeans.train_epoch_distributed_multi([ka, kb], [xt, x2t], b, lr=0.01, chunk_steps=16)
+        assert tr == [0, 0]
+        for v, kmv in enumerate((ka, kb)):
+            kmv.broadcast_state_from(tr[v], comm_slot=v)
+        ra.train_epoch(x, b, 0.01)
+        rb.train_epoch(x2, b, 0.01)
+        assert np.array_equal(ka.centers.numpy(), ra.centers) and ka.count == ra.count, f"epoch {epoch}"
+        assert np.array_equal(kb.centers.numpy(), rb.centers) and kb.count == rb.count, f"epoch {epoch}"
+    before = (kb.centers.numpy().copy(), kb.count, ka.count)
+    KMeans.train_epoch_distributed_multi([ka, kb], [xt, x2t], b, lr=0.01, chunk_steps=16, trainers=[0, 1])
+    assert np.array_equal(kb.centers.numpy(), before[0]) and kb.count == before[1] and ka.count == before[2] + steps * b
