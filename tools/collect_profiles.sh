@@ -56,6 +56,8 @@ for shape in "1024 256" "512 64" "1024 1024" "128 1024" "2048 1024" "2048 256"; 
     BENCH_D=$1 BENCH_K=$2 timeout 300 python tools/bench_train_b.py 32 2> /dev/null | tail -1 >> "$OUT/${P}_train_shapes.txt"
     ACAV_NO_PERSISTENT=1 BENCH_D=$1 BENCH_K=$2 timeout 300 python tools/bench_train_b.py 32 2> /dev/null | tail -1 | sed 's/^/   per-step launches: /' >> "$OUT/${P}_train_shapes.txt"
 done
+echo "d=1024 K=256, larger batches (the DDP path trains on global batches of 32 W rows; SURVEY 8(d): a large-batch point)" >> "$OUT/${P}_train_shapes.txt"
+BENCH_D=1024 BENCH_K=256 timeout 600 python tools/bench_train_b.py 64 128 256 1024 2> /dev/null | sed 's/^/   /' >> "$OUT/${P}_train_shapes.txt"
 ACAV_PROFILE_STEPS=1 BENCH_D=1024 BENCH_K=256 timeout 300 python tools/bench_train_b.py 32 > "$OUT/${P}_train_phase_cycles.txt" 2>&1
 for f in "$OUT"/${P}_*.txt; do sed -i '/amdgpu.ids/d' "$f"; done
 for f in "$OUT/${P}_mi_1m.txt" "$OUT/${P}_mi_1m_legacy.txt" "$OUT/${P}_mi_100k.txt" "$OUT/${P}_mi_lockstep8.txt" "$OUT/${P}_bench_under_rocprof.txt"; do grep "^{" "$f" | tail -1 > "$f.tmp" && mv "$f.tmp" "${f%.txt}.json" && rm -f "$f"; done
