@@ -101,6 +101,30 @@ def test_free_running_equals_oracle(env, v, dd, c, keep, subset):
     assert idx_o == idx_p and np.array_equal(mt_o, mt_p)
 
 
+@pytest.mark.parametrize("switch", [("ACAV_FY_LEGACY", "1"), ("ACAV_FY_ECAP", "64"), ("ACAV_FY_CAP", "256")])
+def test_permutation_variants_equal_oracle(env, switch, monkeypatch):
+    """The other evaluations of the same swap sequence give the same selection: the global-atomic Fisher-Yates kernels
+    (ACAV_FY_LEGACY=1, also the path of lists beyond the tile table), the tiled kernels with the tile's LDS capacity cut
+    so that every loaded tile takes the sub-ranged overload path (ACAV_FY_ECAP), and smaller tiles (ACAV_FY_CAP)."""
+    torch, acav, O = env
+    monkeypatch.setenv(*switch)
+    v, dd, c, subset = 20000, 2, 32, 1200
+    a = _correlated(77, v, dd, c)
+    pairs = list(itertools.combinations(range(dd), 2))
+    cand = [int(i) for i in np.random.RandomState(5).permutation(v)]
+    start, cand = [cand[0]], cand[1:]
+    acav.manual_seed(21)
+    m = _measure(a, c, pairs, cand)
+    S, GAIN, _, _ = m.run_greedy(subset, start, None, record_trace=True)
+    rng = O.Rng(21)
+    ref = O.BatchMI(a, c, pairs).run_greedy(cand, start, subset, 20, m.k, rng, keep_unselected=True, trace=True)
+    assert np.array_equal(m.trace["ids"], ref["ids"]) and S == list(ref["S"])
+    assert np.array_equal(np.array(GAIN), ref["GAIN"])
+    mt_o, idx_o = rng.get_state()
+    mt_p, idx_p = acav.default_generator.get_state()
+    assert idx_o == idx_p and np.array_equal(mt_o, mt_p)
+
+
 def test_scores_vs_oracle_and_sklearn(env):
     torch, acav, O = env
     from sklearn.metrics import mutual_info_score
