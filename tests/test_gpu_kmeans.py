@@ -222,6 +222,29 @@ def test_bf16_filter_path_is_bit_identical(env, case):
         assert rechecked < n // 20  # centred centres: the common component costs nothing
 
 
+@pytest.mark.parametrize("switch", [("ACAV_FILTER_V1", "1"), ("ACAV_FILTER_NT", "0"), ("ACAV_ASSIGN_EXACT_ONLY", "1"),
+                                    ("ACAV_NO_PERSISTENT", "1")])
+def test_diagnostic_switches_keep_the_results(env, switch, monkeypatch):
+    """The A/B switches select other kernels, never other results: the round-1 wave layout of the filter, the default
+    cache policy on its row DMA, the exact sweep alone, and per-step launches instead of the persistent epoch kernel."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    monkeypatch.setenv(*switch)
+    n, d, K, b = 4096, 256, 64, 32
+    x = _mixture(21, n, d, 40)
+    acav.manual_seed(4)
+    km = KMeans(None, d, K).to("cuda:0")
+    ref = O.KMeans(d, K, O.Rng(4))
+    xt = torch.from_numpy(x).cuda()
+    for epoch in range(2):
+        km.train_epoch(xt, b, lr=0.01)
+        ref.train_epoch(x, b, 0.01)
+    assert np.array_equal(km.centers.numpy(), ref.centers) and np.array_equal(km.counts.numpy(), ref.counts)
+    lab, mean = km.calc_best(xt, need_mean=False)
+    lab_ref, _ = ref.calc_best(x)
+    assert np.array_equal(lab.cpu().numpy(), lab_ref)
+
+
 def test_exact_ties_take_first_index(env):
     torch, acav, O = env
     from acav100m_amd.clustering import KMeans
