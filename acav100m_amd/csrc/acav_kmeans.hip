@@ -1482,6 +1482,82 @@ __device__ __forceinline__ void tp_refresh_norms(unsigned pend, const float *sC,
     if (q == 0 && mine) sCn[c8] = norm2_from_sumsq(p);
 }
 
+// k_step_dist_dma for LARGE batches (the DDP path steps global batches of 32 W rows; d <= 1024): one workgroup keeps its 8
+// centres in LDS and walks RG groups of 8 batch rows against them, the next group's rows in flight (LDS-DMA, double
+// buffered) while the current one runs its FMA chains.  The one-group-per-workgroup kernel re-loads the centres for every
+// 8 rows and needs b / 8 x K / 8 workgroups (1024 at b = 256, K = 256: two rounds of ~8 us of mostly DMA latency); here
+// the grid is K / 8 x b / (8 RG) and a round costs ~1.5 + 2 RG us.  Same arithmetic per (centre, row) pair: bit-identical.
+template <int RG, bool RAGGED>
+__global__ __launch_bounds__(256) void k_step_dist_dma_rg(const float *__restrict__ x, int b, int d, const float *__restrict__ centers,
+                                                          const float *__restrict__ cn, const float *__restrict__ counts,
+                                                          const float *__restrict__ xn, int K, float thr, float r,
+                                                          unsigned long long *__restrict__ keys)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdrg_smem[];
+    float *sC = reinterpret_cast<float *>(sdrg_smem);        // [8][TP_DS]
+    float *sX = sC + TP_NC * TP_DS;                           // [2][8][TP_DS]
+    __shared__ float sPart[2][4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // wave w owns column block w
+    const int kk = lane >> 3, ii = lane & 7;
+    const int kbase = blockIdx.x * TP_NC, rbase0 = blockIdx.y * (TP_NR * RG);
+    const int nck = min(TP_NC, K - kbase);
+    const int nblk = (d + 255) >> 8;
+    const bool active = wave < nblk;
+    if (RAGGED && active) {  // ragged last block: columns d .. 256 nblk - 1 must read as zero for good
+        for (int row = 0; row < TP_NC; ++row) {
+            *reinterpret_cast<float4 *>(sC + row * TP_DS + wave * 256 + (lane << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(sX + row * TP_DS + wave * 256 + (lane << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(sX + (TP_NR + row) * TP_DS + wave * 256 + (lane << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // before the DMA below writes the same rows
+    }
+    // what the epilogue needs is loaded BEFORE the DMA it would otherwise queue behind (vmcnt retires in order)
+    float my_cn = 0.f;
+    bool my_disc = false;
+    if (wave == 0 && kk < nck) {
+        my_cn = cn[kbase + kk];
+        my_disc = counts[kbase + kk] < thr;
+    }
+    if (active) {
+        tp_dma_block<RAGGED>(sC, centers, kbase, nck, d, wave, lane);
+        tp_dma_block<RAGGED>(sX, x, rbase0, min(TP_NR, b - rbase0), d, wave, lane);
+    }
+#pragma unroll
+    for (int gi = 0; gi < RG; ++gi) {
+        const int rb = rbase0 + gi * TP_NR;
+        if (rb >= b) break;  // uniform
+        const int nrv = min(TP_NR, b - rb);
+        const bool more = gi + 1 < RG && rb + TP_NR < b;
+        float xn_r = 0.f;
+        if (wave == 0 && ii < nrv) xn_r = xn[rb + ii];
+        if (active) {
+            // a wave re-fills only the block it alone reads, and it is done with the buffer the group before last used
+            if (more) tp_dma_block<RAGGED>(sX + ((gi + 1) & 1) * TP_NR * TP_DS, x, rb + TP_NR, min(TP_NR, b - rb - TP_NR), d, wave, lane);
+            if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // everything but the newest group (8 DMA instructions)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sPart[gi & 1][wave][lane] = dot_blocks<1>(sC + kk * TP_DS + wave * 256, sX + ((gi & 1) * TP_NR + ii) * TP_DS + wave * 256,
+                                                      kk << 2, ii << 2, 0.f, true);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float acc = sPart[gi & 1][0][lane];
+            for (int w = 1; w < nblk; ++w) acc = acc + sPart[gi & 1][w][lane];  // canonical left fold of the segments
+            const int k = kbase + kk;
+            unsigned long long key = ~0ull;
+            if (kk < nck && ii < nrv) key = pack_key(dist_epilogue(acc, xn_r, my_cn, my_disc, r), k);
+            unsigned long long o = __shfl_xor(key, 8);
+            key = o < key ? o : key;
+            o = __shfl_xor(key, 16);
+            key = o < key ? o : key;
+            o = __shfl_xor(key, 32);
+            key = o < key ? o : key;
+            if (lane < nrv) atomicMin(&keys[rb + lane], key);
+        }
+        // the next group writes the other sPart buffer
+    }
+}
+
 // 4 waves per workgroup; wave w owns column block (= canonical segment) w of every LDS row: it DMAs it,
 // runs the segment's FMA chain for all 64 (centre, row) pairs, and applies the centre update to it.
 // One wave can only issue ~1 ds_read_b128 per 20+ cycles, so the 4 waves quadruple the LDS read rate;
@@ -2025,6 +2101,7 @@ struct acav_kmeans {
     DevBuf cb16, caux, cmu, recheck_list, recheck_count, backup;
     hipEvent_t ev_f0 = nullptr, ev_f1 = nullptr;  // around the last k_assign_bf16 launch (acav_kmeans_filter_time)
     bool cb16_valid = false;  // bf16 copy of the centres matches `centers`
+    bool rg_attr_set = false; // dynamic-LDS attribute of the large-batch distance kernels set
     int64_t n_filter_launches = 0;
     uint64_t last_recheck = 0, last_rows = 0;
     int64_t n_persistent_launches = 0, n_persistent_fallbacks = 0;
@@ -2357,7 +2434,31 @@ static int step_device(acav_kmeans *km, const float *dx, int64_t b, double lr, c
             xn_dev = km->xn.as<float>();
         }
         const bool dma_ok = (km->d & 3) == 0 && ((uintptr_t)dx & 15) == 0;
-        if (dma_ok) {
+        // large batches (DDP global batches): row groups per workgroup so that the grid is about one round of workgroups
+        int rg = 1;
+        if (dma_ok && km->d <= TP_DS && b >= 128) {
+            const int64_t cgs = (km->K + TP_NC - 1) / TP_NC;
+            while (rg < 8 && cgs * ((b + TP_NR * rg - 1) / (TP_NR * rg)) > 256) rg *= 2;
+        }
+        if (rg > 1) {
+            const bool ragged = (km->d & 255) != 0;
+            auto kern = rg == 2 ? (ragged ? k_step_dist_dma_rg<2, true> : k_step_dist_dma_rg<2, false>)
+                      : rg == 4 ? (ragged ? k_step_dist_dma_rg<4, true> : k_step_dist_dma_rg<4, false>)
+                                : (ragged ? k_step_dist_dma_rg<8, true> : k_step_dist_dma_rg<8, false>);
+            const int smem = (int)sizeof(float) * (TP_NC + 2 * TP_NR) * TP_DS;
+            if (!km->rg_attr_set) {
+                ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_dist_dma_rg<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_dist_dma_rg<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_dist_dma_rg<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_dist_dma_rg<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_dist_dma_rg<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_dist_dma_rg<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                km->rg_attr_set = true;
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)((km->K + TP_NC - 1) / TP_NC), (unsigned)((b + TP_NR * rg - 1) / (TP_NR * rg))), dim3(256),
+                               smem, st, dx, (int)b, km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), xn_dev,
+                               km->K, km->threshold(), (float)km->reinit_r, kcur);
+        } else if (dma_ok) {
             hipLaunchKernelGGL(k_step_dist_dma, dim3((km->K + SD_NC - 1) / SD_NC, (unsigned)((b + SD_NR - 1) / SD_NR)),
                                dim3(256), 0, st, dx, (int)b, km->d, km->centers.as<float>(), km->cn.as<float>(),
                                km->counts.as<float>(), xn_dev, km->K, km->threshold(), (float)km->reinit_r, kcur);

@@ -263,14 +263,18 @@ def test_exact_ties_take_first_index(env):
 
 @pytest.mark.parametrize("b,lr,d,K", [(32, 0.01, 96, 24), (16, 0.01, 96, 24), (48, 0.01, 256, 40),
                                       (32, 0.2, 96, 24), (7, 0.5, 96, 24), (32, 0.01, 130, 24),
-                                      (32, 0.01, 2304, 20), (20, 0.01, 200, 70), (256, 0.01, 64, 33)])
+                                      (32, 0.01, 2304, 20), (20, 0.01, 200, 70), (256, 0.01, 64, 33),
+                                      # large (DDP global) batches: several row groups per workgroup (2 / 4 / 8), ragged
+                                      # column blocks, centre groups and row groups
+                                      (128, 0.01, 1024, 256), (256, 0.01, 256, 256), (250, 0.01, 132, 300),
+                                      (1024, 0.0005, 512, 64)])
 def test_step_matches_oracle(env, b, lr, d, K):
     """add() at several batch sizes / shapes: DMA path (d % 4 == 0, incl. d > 1024 = two LDS stages and
     ragged 256-column blocks), MFMA fallback (d = 130), ragged centre / row groups; lr large enough to
     trigger the fallback (sgd_clustering.py:116-119)."""
     torch, acav, O = env
     from acav100m_amd.clustering import KMeans
-    steps = 40 if d < 1000 else 16
+    steps = (40 if d < 1000 else 16) if b < 128 else 12
     x = _mixture(b, b * steps, d, K)
     acav.manual_seed(2)
     km = KMeans(None, d, K).to("cuda:0")
