@@ -1331,7 +1331,12 @@ struct FyPlan {
             const int x = atoi(v);
             if (x >= 256 && x <= 8192 && (x & (x - 1)) == 0) cap_max = x;
         }
-        while (cap < cap_max && (int64_t)cap * 128 < L0) cap *= 2;
+        // at least ~32 tiles per iteration (the kernels take FY_GROUP iterations per launch: hundreds of workgroups); smaller
+        // tiles only multiply 1024-thread workgroups with a few hundred entries each (8 x 100k chunks in lockstep: 4.85 us per
+        // chunk-iteration at 128 tiles, 4.0 at 32)
+        int tiles_min = 32;
+        if (const char *v = getenv("ACAV_FY_TILES_MIN")) tiles_min = atoi(v) > 0 ? atoi(v) : tiles_min;
+        while (cap < cap_max && (int64_t)cap * tiles_min < L0) cap *= 2;
         wcap = ecap = cap;
         // capacity of ONE shard of a tile's bucket: with many k_fy_part workgroups the shards fill evenly (an eighth of
         // the tile's load each, 4x headroom); with few, one shard may receive everything
