@@ -199,6 +199,26 @@ def test_k1024_train_and_assign(env, d):
     assert np.array_equal(km.calc_best(xt, need_mean=True)[0].cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("v", [16_777_216, 17_000_000])
+def test_longest_lists_first_iterations_vs_oracle(env, v):
+    """Maximum sizes of the permutation: the longest list the tiled Fisher-Yates takes (16 Mi candidates: ~3 700 tiles,
+    the largest tile table and buckets) and the first size beyond it (global-atomic kernels, chosen automatically) --
+    the first iterations of a selection equal the oracle's, ids and float64 gains."""
+    torch, acav, O = env
+    from acav100m_amd.subset_selection import get_measure
+    c, iters = 64, 10
+    rs = np.random.RandomState(1)
+    a = rs.randint(0, c, (v, 2)).astype(np.int64)
+    a[0] = c - 1
+    cand = np.arange(v, dtype=np.int64)
+    acav.manual_seed(3)
+    m = get_measure("batch_mi")(a, ncentroids=c, batch_size=20, selection_size=4, device="cuda:0", keep_unselected=True)
+    m.init([(0, 1)], cand[1:])
+    S, G, _, _ = m.run_greedy(4 * iters, [0], None, max_iters=iters)
+    ref = O.BatchMI(a, c, [(0, 1)]).run_greedy(cand[1:], cand[:1], 4 * iters, 20, 4, O.Rng(3), max_iters=iters)
+    assert S == list(ref["S"]) and np.array_equal(np.array(G), ref["GAIN"])
+
+
 def test_stress_parity_fixed_seed_slice(env):
     """tools/stress_parity.py with a fixed seed: random shapes (d 8..2304, K 2..600, b 7..128, ragged everything) for
     both assign paths, persistent and per-step training, batch and exact greedy -- every case bit-identical."""
