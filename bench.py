@@ -145,6 +145,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     args = ap.parse_args()
+    # the contract is ONE JSON line on stdout: whatever the libraries print there (RCCL's version banner at communicator
+    # creation, for one) goes to stderr instead -- fd 1 is parked and handed back for the result line only
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -312,7 +317,8 @@ def main():
             out["variants"] = {"chunked_lockstep": chunked_variant(last["a"], types, n, st)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, d, k, b, nviews, 1234)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 
