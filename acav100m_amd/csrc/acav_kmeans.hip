@@ -2588,12 +2588,15 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
     const int room = budget ? *budget : occ * km->num_cus;
     const bool shape_ok = steps > 0 && !(nop && nop[0] == '1') && (km->d % 4) == 0 && km->d <= TP_DS && b <= TP_MAXB &&
                           ((uintptr_t)fx & 15) == 0;
-    bool persistent = shape_ok && nwg <= room && nwg <= occ * km->num_cus;
+    // the exchange sweep of k_train_persistent reads 2 x TP_SW = 32 centre groups per row: K <= 256; more groups go to the
+    // wide kernel (64 groups of NCP x 8 centres)
+    const bool narrow_ok = (km->K + TP_NC - 1) / TP_NC <= 32;
+    bool persistent = shape_ok && narrow_ok && nwg <= room && nwg <= occ * km->num_cus;
     // more 8-centre groups than CUs (K = 1024): NCP x 8 centres per workgroup (k_train_persistent_wide) -- the smallest
     // NCP whose grid fits 3/4 of the device, else the whole device, within the LDS of a CU
     int ncp = 1, ds = 0, wide_wg = 0;
     size_t wide_smem = 0;
-    if (shape_ok && !persistent && nwg > occ * km->num_cus) {
+    if (shape_ok && !persistent && (nwg > occ * km->num_cus || !narrow_ok)) {
         ds = ((km->d + 255) / 256) * 256;
         const int rgroups = (int)((b + TP_NR - 1) / TP_NR);
         int best_ncp = 0;

@@ -87,7 +87,9 @@ def test_bulk_train_equals_stepwise_and_oracle(env):
 @pytest.mark.parametrize("n,d,K,b", [(2048, 256, 40, 32), (4096, 1024, 256, 32), (1536, 512, 20, 24),
                                      (2048, 768, 64, 32), (4096, 256, 40, 64), (8192, 1024, 256, 256),
                                      (2048, 88, 40, 32), (2048, 704, 64, 32), (1024, 64, 16, 32), (1536, 352, 24, 32),
-                                     (2048, 128, 32, 32), (1024, 1000, 24, 32)])
+                                     (2048, 128, 32, 32), (1024, 1000, 24, 32),
+                                     # more than 32 centre groups (256 < K): the wide kernel's exchange, not the narrow one's
+                                     (4096, 256, 264, 32), (4096, 256, 300, 32), (8192, 64, 512, 32)])
 def test_persistent_epoch_kernel(env, n, d, K, b):
     """acav_kmeans_train takes the persistent one-launch path for d % 4 == 0, d <= 1024, b <= 32:
     centres resident in LDS, per-step device-scope key exchange.  Must equal the oracle bit for bit

@@ -51,9 +51,9 @@ def stress(seed=0, budget=60.0, max_cases=None):
             counts["assign"] += 1
         elif which == 1:  # bulk training
             d = int(rs.choice([8, 64, 88, 128, 256, 352, 704, 1000, 1024, 1408]))
-            k = int(rs.choice([3, 16, 40, 64, 100, 256]))
-            b = int(rs.choice([7, 16, 24, 32, 48, 64, 128]))
-            steps = int(rs.randint(3, 60))
+            k = int(rs.choice([3, 16, 40, 64, 100, 256, 300, 600]))
+            b = int(rs.choice([7, 16, 24, 32, 48, 64, 128, 200, 256, 512]))  # >= 128: several row groups per workgroup
+            steps = int(rs.randint(3, 60)) if b <= 128 else int(rs.randint(3, 12))
             lr = float(rs.choice([0.01, 0.01, 0.3]))
             x = mixture(steps * b + int(rs.randint(0, b)), d, k, 3.0)
             s = int(rs.randint(1 << 30))
@@ -68,7 +68,7 @@ def stress(seed=0, budget=60.0, max_cases=None):
             assert km.count == ref.count and km.fallback == ref.fallback
             counts["train"] += 1
         else:
-            v = int(rs.choice([60, 300, 1000, 5000]))
+            v = int(rs.choice([60, 300, 1000, 5000, 5000, 30000]))
             dd = int(rs.choice([2, 3, 5, 10]))
             c = int(rs.choice([2, 8, 40, 256]))
             comp = rs.randint(0, c, v)
@@ -77,11 +77,12 @@ def stress(seed=0, budget=60.0, max_cases=None):
             pairs = list(itertools.combinations(range(dd), 2))
             cand = rs.permutation(v)
             if which == 2:
-                B = int(rs.choice([4, 20, 33])); kk = int(rs.randint(1, B + 1)); keep = bool(rs.randint(0, 2))
+                B = int(rs.choice([4, 20, 33, 64])); kk = int(rs.randint(1, B + 1)); keep = bool(rs.randint(0, 2))
                 B = min(B, v - 1); kk = min(kk, B)
                 subset = int(rs.randint(1, max(2, v // 5)))
-                if not keep and (subset + kk - 1) // kk * B > v - 1:
-                    continue
+                iters = (subset + kk - 1) // kk
+                if (v - 1) - (iters - 1) * (kk if keep else B) < B:
+                    continue  # the list would run out of candidates (the reference raises there too: tests/test_gpu_mi.py)
                 s = int(rs.randint(1 << 30))
                 m = get_measure("batch_mi")(a, ncentroids=c, batch_size=B, selection_size=kk, device="cuda:0",
                                             keep_unselected=keep, generator=Generator(s))
@@ -91,6 +92,8 @@ def stress(seed=0, budget=60.0, max_cases=None):
                 assert S == r["S"].tolist() and np.array_equal(np.array(G), r["GAIN"]), ("mi", v, dd, c, B, kk, keep, subset, s)
                 counts["mi"] += 1
             else:
+                if v > 5000:
+                    continue  # the exact greedy scores every remaining candidate per pick: small lists only
                 subset = int(rs.randint(2, max(3, v // 4)))
                 m = get_measure("mi")(a, ncentroids=c, device="cuda:0")
                 m.init(pairs, [int(i) for i in cand[1:]])
