@@ -30,8 +30,10 @@ def stress(seed=0, budget=60.0, max_cases=None):
         which = rs.randint(0, 4)
         if which == 0:  # assign, filter and exact paths
             d = int(rs.choice([8, 32, 64, 88, 96, 128, 160, 352, 512, 704, 1024, 1056, 2304]))
-            k = int(rs.choice([2, 3, 17, 64, 255, 256, 257, 300, 600]))
+            k = int(rs.choice([2, 3, 17, 64, 255, 256, 257, 300, 600, 1024, 1500]))
             n = int(rs.choice([1, 63, 128, 129, 1000, 4097, 20000]))
+            if k > 600 and (n > 4097 or d > 1056):
+                n, d = min(n, 4097), min(d, 1056)  # keep the oracle's share of a case short
             x = mixture(n, d, k, float(rs.choice([0.05, 1.0, 4.0])))
             offset = float(rs.choice([0.0, 0.0, 3.0, 40.0]))  # a large common component: the centred filter's case
             x = (x + offset).astype(np.float32)
@@ -51,9 +53,12 @@ def stress(seed=0, budget=60.0, max_cases=None):
             counts["assign"] += 1
         elif which == 1:  # bulk training
             d = int(rs.choice([8, 64, 88, 128, 256, 352, 704, 1000, 1024, 1408]))
-            k = int(rs.choice([3, 16, 40, 64, 100, 256, 300, 600]))
+            k = int(rs.choice([3, 16, 40, 64, 100, 256, 300, 600, 1000, 1024, 1030, 2048]))
             b = int(rs.choice([7, 16, 24, 32, 48, 64, 128, 200, 256, 512]))  # >= 128: several row groups per workgroup
             steps = int(rs.randint(3, 60)) if b <= 128 else int(rs.randint(3, 12))
+            if k >= 1000:  # the warm-up alone is 10 K rows: a few real steps beyond it, no more
+                steps = (10 * k) // b + int(rs.randint(2, 10))
+                d = min(d, 256) if rs.rand() < 0.7 else d
             lr = float(rs.choice([0.01, 0.01, 0.3]))
             x = mixture(steps * b + int(rs.randint(0, b)), d, k, 3.0)
             s = int(rs.randint(1 << 30))
@@ -69,8 +74,10 @@ def stress(seed=0, budget=60.0, max_cases=None):
             counts["train"] += 1
         else:
             v = int(rs.choice([60, 300, 1000, 5000, 5000, 30000]))
-            dd = int(rs.choice([2, 3, 5, 10]))
-            c = int(rs.choice([2, 8, 40, 256]))
+            dd = int(rs.choice([2, 3, 5, 10, 13]))
+            c = int(rs.choice([2, 8, 40, 256, 700]))
+            if c > 256 and dd > 5:
+                dd = 3  # P C^2 table cells
             comp = rs.randint(0, c, v)
             a = np.stack([np.where(rs.rand(v) < 0.5, comp, rs.randint(0, c, v)) for _ in range(dd)], 1).astype(np.int64)
             a[0] = c - 1
