@@ -78,6 +78,35 @@ def test_contrastive_vs_reference_and_oracle(env, golden_dir, name):
     np.testing.assert_allclose(lo, want, rtol=5e-5, atol=1e-6)  # the third loss is ~2e-3: a difference of logsumexp and logit
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_contrastive_random_shapes_vs_oracle(env, seed):
+    """Random feature widths (not multiples of the 64 x 64 GEMM tile), projection sizes and ragged batch lists, a few
+    accumulating steps each: losses 1e-4 relative (+1e-6), parameters 2e-4 relative, scores (cosines) 2e-4 relative + 1e-5
+    vs the numpy oracle."""
+    torch, acav = env
+    from acav100m_amd.rng import Generator
+    from acav100m_amd.subset_selection.measures import get_measure
+    from acav100m_amd.subset_selection.measures.contrastive import PARAM_NAMES
+    from oracle import contrastive_ref as CR
+    rs = np.random.RandomState(100 + seed)
+    vis, aud = int(rs.choice([5, 37, 64, 130, 513, 1000])), int(rs.choice([3, 64, 100, 257]))
+    out = int(rs.choice([2, 19, 64, 128, 200]))
+    sizes = [int(rs.choice([1, 2, 7, 33, 64, 65, 150])) for _ in range(int(rs.randint(2, 6)))]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    visual, audio = _data(seed, int(off[-1]), vis, aud)
+    m = get_measure("contrastive")(2, "cuda:0", 1e-3, 1, sizes=(vis, aud), out_size=out, generator=Generator(seed))
+    orc = CR.Contrastive(*[m.state_dict()[k] for k in PARAM_NAMES])
+    for lr in (5e-4, 1e-3):
+        lo, ac = m.train_batches(visual, audio, off, lr)
+        want = [orc.train_batch(visual[off[i]:off[i + 1]], audio[off[i]:off[i + 1]], lr) for i in range(len(sizes))]
+        np.testing.assert_allclose(lo, [w[0] for w in want], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(ac, [w[1] for w in want], atol=1e-3)
+    sd = m.state_dict()
+    for k, op in zip(PARAM_NAMES, orc.p):
+        np.testing.assert_allclose(sd[k], op, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(m.infer_scores(visual, audio), orc.infer(visual, audio), rtol=2e-4, atol=1e-5)  # cosines in [-1, 1]
+
+
 def test_contrastive_cli_end_to_end(env, tmp_path_factory, golden_dir):
     """`cli.py run --measure_name=contrastive` + `cli.py merge_contrastive` on synthetic feature shards (the real
     2304-d / 128-d penultimate layers): model caches per epoch in the reference's torch.save layout, one inference cache
