@@ -181,7 +181,8 @@ def test_comm_c_abi_world1():
     ra, rb = O.KMeans(d, k, O.Rng(11)), None
     rb = O.KMeans(d2, k, ra.rng)  # the two clusterings share the generator, as ka / kb share the library's
     for epoch in range(2):
-        tr = KMeans.train_epoch_distributed_multi([ka, kb], [xt, x2t], b, lr=0.01, chunk_steps=16)
+        # chunks of 8 steps: the 13 warm-up steps of the first epoch span two of them
+        tr = KMeans.train_epoch_distributed_multi([ka, kb], [xt, x2t], b, lr=0.01, chunk_steps=8)
         assert tr == [0, 0]
         for v, kmv in enumerate((ka, kb)):
             kmv.broadcast_state_from(tr[v], comm_slot=v)
