@@ -85,18 +85,22 @@ def stress(seed=0, budget=60.0, max_cases=None):
             cand = rs.permutation(v)
             if which == 2:
                 B = int(rs.choice([4, 20, 33, 64])); kk = int(rs.randint(1, B + 1)); keep = bool(rs.randint(0, 2))
-                B = min(B, v - 1); kk = min(kk, B)
-                subset = int(rs.randint(1, max(2, v // 5)))
+                ns = int(rs.choice([1, 1, 3]))                       # start set (seeds the tables, never selected)
+                L = v - ns if rs.rand() < 0.6 else max(2, int((v - ns) * rs.uniform(0.3, 1.0)))  # not every clip is a candidate
+                B = min(B, L - 1); kk = min(kk, B)
+                if B < 1:
+                    continue
+                subset = int(rs.randint(1, max(2, L // 5)))
                 iters = (subset + kk - 1) // kk
-                if (v - 1) - (iters - 1) * (kk if keep else B) < B:
+                if L - (iters - 1) * (kk if keep else B) < B:
                     continue  # the list would run out of candidates (the reference raises there too: tests/test_gpu_mi.py)
                 s = int(rs.randint(1 << 30))
                 m = get_measure("batch_mi")(a, ncentroids=c, batch_size=B, selection_size=kk, device="cuda:0",
                                             keep_unselected=keep, generator=Generator(s))
-                m.init(pairs, [int(i) for i in cand[1:]])
-                S, G, _, _ = m.run_greedy(subset, [int(cand[0])], None)
-                r = O.BatchMI(a, c, pairs).run_greedy(cand[1:], cand[:1], subset, B, m.k, O.Rng(s), keep_unselected=keep)
-                assert S == r["S"].tolist() and np.array_equal(np.array(G), r["GAIN"]), ("mi", v, dd, c, B, kk, keep, subset, s)
+                m.init(pairs, [int(i) for i in cand[ns:ns + L]])
+                S, G, _, _ = m.run_greedy(subset, [int(i) for i in cand[:ns]], None)
+                r = O.BatchMI(a, c, pairs).run_greedy(cand[ns:ns + L], cand[:ns], subset, B, m.k, O.Rng(s), keep_unselected=keep)
+                assert S == r["S"].tolist() and np.array_equal(np.array(G), r["GAIN"]), ("mi", v, dd, c, B, kk, keep, subset, ns, L, s)
                 counts["mi"] += 1
             else:
                 if v > 5000:
