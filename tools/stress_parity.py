@@ -1,5 +1,6 @@
 """Randomised parity stress (GPU vs oracle, bit-exact): random shapes for assign (both paths), bulk training
-(persistent + per-step kernels), MI batch greedy and exact greedy.  usage: stress_parity.py [seconds] [seed]
+(persistent, wide persistent and per-step kernels, batches up to 512), several clusterings side by side, MI batch greedy
+(start sets, partial candidate lists, B up to 64), several chunks in lockstep, and exact greedy.  usage: stress_parity.py [seconds] [seed]
 tests/test_gpu_configs.py runs a fixed-seed slice of it (stress(seed, budget, max_cases)) inside `pytest -m gpu`."""
 import itertools
 import os
@@ -20,14 +21,14 @@ def stress(seed=0, budget=60.0, max_cases=None):
     from oracle import oracle as O
     rs = np.random.RandomState(seed)
     t_end = time.time() + budget
-    counts = dict(assign=0, train=0, mi=0, exact=0)
+    counts = dict(assign=0, train=0, mi=0, exact=0, lockstep=0, train_multi=0)
 
     def mixture(n, d, k, spread):
         cen = rs.randn(k, d).astype(np.float32) * spread
         return (cen[rs.randint(0, k, n)] + rs.randn(n, d).astype(np.float32)).astype(np.float32)
 
     while time.time() < t_end and (max_cases is None or sum(counts.values()) < max_cases):
-        which = rs.randint(0, 4)
+        which = rs.randint(0, 6)
         if which == 0:  # assign, filter and exact paths
             d = int(rs.choice([8, 32, 64, 88, 96, 128, 160, 352, 512, 704, 1024, 1056, 2304]))
             k = int(rs.choice([2, 3, 17, 64, 255, 256, 257, 300, 600, 1024, 1500]))
@@ -72,6 +73,51 @@ def stress(seed=0, budget=60.0, max_cases=None):
             assert np.array_equal(km.centers.numpy(), ref.centers) and np.array_equal(km.counts.numpy(), ref.counts), ("train", d, k, b, steps, lr, s)
             assert km.count == ref.count and km.fallback == ref.fallback
             counts["train"] += 1
+        elif which == 4:  # several chunks in lockstep (own sizes, tables and generators) == each chunk alone == the oracle
+            from acav100m_amd.subset_selection.measures.batch import EfficientBatchMI
+            nch = int(rs.randint(2, 6))
+            B = int(rs.choice([4, 20, 33])); kk = int(rs.randint(1, B + 1))
+            ms, want, subsets, starts = [], [], [], []
+            for i in range(nch):
+                v = int(rs.choice([200, 1000, 3000, 12000]))
+                dd = int(rs.choice([2, 3, 5])); c = int(rs.choice([4, 40, 256]))
+                a = rs.randint(0, c, (v, dd)).astype(np.int64)
+                a[0] = c - 1
+                pairs = list(itertools.combinations(range(dd), 2))
+                cand = rs.permutation(v)
+                subset = int(rs.randint(1, max(2, v // 8)))
+                iters = (subset + kk - 1) // kk
+                if (v - 1) - (iters - 1) * kk < B:
+                    subset = kk
+                s = int(rs.randint(1 << 30))
+                m = get_measure("batch_mi")(a, ncentroids=c, batch_size=B, selection_size=kk, device="cuda:0",
+                                            keep_unselected=True, generator=Generator(s))
+                m.init(pairs, [int(j) for j in cand[1:]])
+                ms.append(m); subsets.append(subset); starts.append([int(cand[0])])
+                want.append(O.BatchMI(a, c, pairs).run_greedy(cand[1:], cand[:1], subset, B, m.k, O.Rng(s)))
+            got = EfficientBatchMI.run_greedy_multi(ms, subsets, starts)
+            for i in range(nch):
+                assert got[i][0] == want[i]["S"].tolist() and np.array_equal(np.array(got[i][1]), want[i]["GAIN"]), ("lockstep", nch, i, B, kk)
+            counts["lockstep"] += 1
+        elif which == 5:  # several clusterings side by side (acav_kmeans_train_multi)
+            ncl = int(rs.randint(2, 5))
+            b = int(rs.choice([16, 32, 32, 64]))
+            steps = int(rs.randint(20, 80))
+            shapes = [(int(rs.choice([64, 128, 352, 704, 1024, 2048])), int(rs.choice([16, 64, 256, 300]))) for _ in range(ncl)]
+            xs = [mixture(steps * b, d, k, 3.0) for d, k in shapes]
+            s = int(rs.randint(1 << 30))
+            acav100m_amd.manual_seed(s)
+            kms = [KMeans(None, d, k).to("cuda:0") for d, k in shapes]
+            rng = O.Rng(s)
+            refs = [O.KMeans(d, k, rng) for d, k in shapes]  # one generator: centres drawn clustering by clustering, as above
+            xts = [torch.from_numpy(x).cuda() for x in xs]
+            for _ in range(2):
+                KMeans.train_epoch_multi(kms, xts, b, lr=0.01)  # warm-up labels drawn clustering by clustering
+                for ref, x in zip(refs, xs):
+                    ref.train_epoch(x, b, lr=0.01)
+            for km, ref, sh in zip(kms, refs, shapes):
+                assert np.array_equal(km.centers.numpy(), ref.centers) and np.array_equal(km.counts.numpy(), ref.counts), ("train_multi", shapes, b, steps, s, sh)
+            counts["train_multi"] += 1
         else:
             v = int(rs.choice([60, 300, 1000, 5000, 5000, 30000]))
             dd = int(rs.choice([2, 3, 5, 10, 13]))
