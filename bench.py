@@ -92,7 +92,7 @@ def cpu_baseline(n, d, k, b, views, seed):
     from oracle import oracle as O
     rs = np.random.RandomState(seed)
     cen = rs.randn(k, d).astype(np.float32)
-    n_steps, n_assign_rows, mi_iters = 48, 16384, 150
+    n_steps, n_assign_rows, mi_iters = 256, 65536, 1500  # ~15 s of CPU work on this sample
     xs = (cen[rs.randint(0, k, n_steps * b + n_assign_rows)] +
           0.3 * rs.randn(n_steps * b + n_assign_rows, d)).astype(np.float32)
     cores = os.cpu_count() or 1
