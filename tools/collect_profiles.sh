@@ -37,6 +37,8 @@ ACAV_FILTER_V1=1 timeout 300 python tools/run_assign_only.py 1000000 20 filter >
 python tools/summarize_counters.py "$OUT" "$P" > "$OUT/${P}_assign_pipe_counters.json"
 stats assign_exact python tools/run_assign_only.py 1000000 3 exact
 stats assign_k1024 python tools/run_assign_only.py 1000000 3 filter 1024 1024
+# cfg4's per-GPU partition (10M clips over 8 GPUs): 1.25M rows, 2048-d visual / 128-d audio, K = 1024
+(python tools/run_assign_only.py 1250000 3 filter 2048 1024; python tools/run_assign_only.py 1250000 3 filter 128 1024) > "$OUT/${P}_assign_cfg4.txt" 2> /dev/null
 # 3. MI greedy: one chunk at V = 1M (3000 iterations) and V = 100k, legacy global-atomic kernels for the A/B, 8 chunks in lockstep
 stats mi_1m python tools/bench_mi.py 1000000 256 2 0 3000
 ACAV_FY_LEGACY=1 stats mi_1m_legacy python tools/bench_mi.py 1000000 256 2 0 3000
