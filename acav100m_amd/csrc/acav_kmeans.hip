@@ -2600,8 +2600,13 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
         ds = ((km->d + 255) / 256) * 256;
         const int rgroups = (int)((b + TP_NR - 1) / TP_NR);
         int best_ncp = 0;
-        for (int pass = 0; pass < 2 && !best_ncp; ++pass)
+        const char *fncp = getenv("ACAV_WIDE_NCP");  // experiments: force the centres per workgroup (2, 4, 8)
+        // a call for one clustering takes the smallest NCP that fits the device (K = 1024, d = 128: 9.8 us per step on 256
+        // workgroups, 11.4 on 128); with several clusterings in one call (budget) the grids stay within 3/4 of it first,
+        // so that two of them run side by side
+        for (int pass = (fncp || !budget) ? 1 : 0; pass < 2 && !best_ncp; ++pass)
             for (int c : {2, 4, 8}) {
+                if (fncp && atoi(fncp) != c) continue;
                 const int groups = (km->K + 8 * c - 1) / (8 * c);
                 const size_t smem = sizeof(float) * ((size_t)(8 * c + 16) * ds + 2 * 8 * c + 256 * c + 32);
                 const int lim = pass == 0 ? (3 * km->num_cus) / 4 : km->num_cus;
