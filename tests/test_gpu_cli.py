@@ -275,7 +275,9 @@ def test_streamed_clustering_equals_resident(tmp_path_factory, golden_dir):
     root = str(tmp_path_factory.mktemp("acav_stream"))
     glob = synth.write_feature_shards(root, n_shards=5, rows=250, seed=3)
     outs = {}
-    for mode, budget in (("resident", None), ("streamed", str(10_000_000))):
+    # budgets: about one shard per row group, two, and most of the data
+    modes = [("resident", None), ("streamed", str(10_000_000)), ("streamed_small", str(4_000_000)), ("streamed_big", str(30_000_000))]
+    for mode, budget in modes:
         if budget is None:
             os.environ.pop("ACAV_RESIDENT_BYTES", None)
         else:
@@ -288,21 +290,22 @@ def test_streamed_clustering_equals_resident(tmp_path_factory, golden_dir):
             outs[mode] = out
         finally:
             os.environ.pop("ACAV_RESIDENT_BYTES", None)
-    for s in range(5):
-        name = "shard-%06d.pkl" % s
-        a = pickle.load(open(os.path.join(outs["resident"], name), "rb"))
-        b = pickle.load(open(os.path.join(outs["streamed"], name), "rb"))
-        assert len(a) == len(b) == 250
-        for ra, rb in zip(a, b):
-            assert ra["filename"] == rb["filename"]
-            for key in ("audio_assignments", "video_assignments"):
-                assert {k: int(v) for k, v in ra[key][0]["array"].items()} == {k: int(v) for k, v in rb[key][0]["array"].items()}
-    for e in (0, 1):
-        ca = [f for f in os.listdir(outs["resident"]) if f.startswith("cache_epoch_%d_" % e)][0]
-        c1 = torch.load(os.path.join(outs["resident"], ca), weights_only=False)
-        c2 = torch.load(os.path.join(outs["streamed"], ca), weights_only=False)
-        for mk in c1:
-            for layer in c1[mk]:
-                assert np.array_equal(c1[mk][layer]["centers"], c2[mk][layer]["centers"]), (e, mk, layer)
-                assert np.array_equal(c1[mk][layer]["counts"], c2[mk][layer]["counts"])
-                assert c1[mk][layer]["count"] == c2[mk][layer]["count"]
+    for streamed in [m for m, b in modes if b is not None]:
+        for s in range(5):
+            name = "shard-%06d.pkl" % s
+            a = pickle.load(open(os.path.join(outs["resident"], name), "rb"))
+            b = pickle.load(open(os.path.join(outs[streamed], name), "rb"))
+            assert len(a) == len(b) == 250
+            for ra, rb in zip(a, b):
+                assert ra["filename"] == rb["filename"]
+                for key in ("audio_assignments", "video_assignments"):
+                    assert {k: int(v) for k, v in ra[key][0]["array"].items()} == {k: int(v) for k, v in rb[key][0]["array"].items()}
+        for e in (0, 1):
+            ca = [f for f in os.listdir(outs["resident"]) if f.startswith("cache_epoch_%d_" % e)][0]
+            c1 = torch.load(os.path.join(outs["resident"], ca), weights_only=False)
+            c2 = torch.load(os.path.join(outs[streamed], ca), weights_only=False)
+            for mk in c1:
+                for layer in c1[mk]:
+                    assert np.array_equal(c1[mk][layer]["centers"], c2[mk][layer]["centers"]), (streamed, e, mk, layer)
+                    assert np.array_equal(c1[mk][layer]["counts"], c2[mk][layer]["counts"])
+                    assert c1[mk][layer]["count"] == c2[mk][layer]["count"]
