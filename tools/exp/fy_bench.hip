@@ -86,10 +86,10 @@ int main(int argc, char **argv)
     const int sel_m = sel_mode(B, P, k);
     const size_t sel_smem = sel_layout(B, P, D, k, sel_m).total;
     int itg = 0;
-    auto g_sc = [&]() { hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 255) / 256 + 1, 1), dim3(256), sel_smem, 0, dcd, itg, dl, B, k, sel_m, 1); itg = (itg + 1) % G; };
+    auto g_sc = [&]() { hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 256 * GS_EPT - 1) / (256 * GS_EPT) + 1, 1), dim3(256), sel_smem, 0, dcd, itg, dl, B, k, sel_m, 1); itg = (itg + 1) % G; };
     timeit("G x gather+select", [&]() { for (int i = 0; i < G; ++i) g_sc(); }, 0);
     {   // iteration 0 only: no selection in workgroup 0 -- the gather alone
-        auto g0only = [&]() { hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 255) / 256 + 1, 1), dim3(256), sel_smem, 0, dcd, 0, dl, B, k, sel_m, 1); };
+        auto g0only = [&]() { hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 256 * GS_EPT - 1) / (256 * GS_EPT) + 1, 1), dim3(256), sel_smem, 0, dcd, 0, dl, B, k, sel_m, 1); };
         timeit("G x gather (launch 0: no selection)", [&]() { for (int i = 0; i < G; ++i) g0only(); }, 0);
     }
     {   // the same with ONE perm buffer for every iteration (stays in cache) -- how much of the gather is the first touch of perm?
@@ -121,7 +121,7 @@ int main(int argc, char **argv)
         };
         auto gath = [&](hipStream_t st) {
             for (int i = 0; i < G; ++i)
-                hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 255) / 256 + 1, 1), dim3(256), sel_smem, st, dcd, i, dl, B, k, sel_m, 1);
+                hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 256 * GS_EPT - 1) / (256 * GS_EPT) + 1, 1), dim3(256), sel_smem, st, dcd, i, dl, B, k, sel_m, 1);
         };
         auto wall = [&](const char *name, auto fn) {
             fn(); CK(hipDeviceSynchronize());
