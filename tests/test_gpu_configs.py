@@ -222,7 +222,7 @@ def test_longest_lists_first_iterations_vs_oracle(env, v):
 def test_stress_parity_fixed_seed_slice(env):
     """tools/stress_parity.py with a fixed seed: random shapes (d 8..2304, K 2..2048, b 7..512, ragged everything) for
     both assign paths, persistent / wide / per-step training alone and side by side, batch greedy alone and in
-    lockstep, exact greedy -- every case bit-identical.  (The tool run longer is what found the 257..500-centre
+    lockstep, exact greedy, the DDP epoch through the C-ABI communicator (a world of one) -- every case bit-identical.  (The tool run longer is what found the 257..500-centre
     clusterings on the wrong persistent kernel.)"""
     spec = importlib.util.spec_from_file_location("stress_parity", os.path.join(ROOT, "tools", "stress_parity.py"))
     mod = importlib.util.module_from_spec(spec)

@@ -1,6 +1,7 @@
 """Randomised parity stress (GPU vs oracle, bit-exact): random shapes for assign (both paths), bulk training
 (persistent, wide persistent and per-step kernels, batches up to 512), several clusterings side by side, MI batch greedy
-(start sets, partial candidate lists, B up to 64), several chunks in lockstep, and exact greedy.  usage: stress_parity.py [seconds] [seed]
+(start sets, partial candidate lists, B up to 64), several chunks in lockstep, exact greedy, and the multi-clustering DDP
+epoch through the C-ABI communicator with a world of one.  usage: stress_parity.py [seconds] [seed]
 tests/test_gpu_configs.py runs a fixed-seed slice of it (stress(seed, budget, max_cases)) inside `pytest -m gpu`."""
 import itertools
 import os
@@ -21,14 +22,14 @@ def stress(seed=0, budget=60.0, max_cases=None):
     from oracle import oracle as O
     rs = np.random.RandomState(seed)
     t_end = time.time() + budget
-    counts = dict(assign=0, train=0, mi=0, exact=0, lockstep=0, train_multi=0)
+    counts = dict(assign=0, train=0, mi=0, exact=0, lockstep=0, train_multi=0, ddp=0)
 
     def mixture(n, d, k, spread):
         cen = rs.randn(k, d).astype(np.float32) * spread
         return (cen[rs.randint(0, k, n)] + rs.randn(n, d).astype(np.float32)).astype(np.float32)
 
     while time.time() < t_end and (max_cases is None or sum(counts.values()) < max_cases):
-        which = rs.randint(0, 6)
+        which = rs.randint(0, 7)
         if which == 0:  # assign, filter and exact paths
             d = int(rs.choice([8, 32, 64, 88, 96, 128, 160, 352, 512, 704, 1024, 1056, 2304]))
             k = int(rs.choice([2, 3, 17, 64, 255, 256, 257, 300, 600, 1024, 1500]))
@@ -118,6 +119,31 @@ def stress(seed=0, budget=60.0, max_cases=None):
             for km, ref, sh in zip(kms, refs, shapes):
                 assert np.array_equal(km.centers.numpy(), ref.centers) and np.array_equal(km.counts.numpy(), ref.counts), ("train_multi", shapes, b, steps, s, sh)
             counts["train_multi"] += 1
+        elif which == 6:  # the DDP epoch of several clusterings through the C-ABI communicator (a world of one: the row exchange,
+            # the interleave kernel, chunking and warm-up hand-over are all on the path; == plain epochs == the oracle)
+            ncl = int(rs.randint(1, 4))
+            b = int(rs.choice([16, 32, 32, 64]))
+            steps = int(rs.randint(10, 40))
+            chunk = int(rs.choice([8, 1024]))
+            shapes = [(int(rs.choice([64, 128, 352, 1024])), int(rs.choice([16, 40, 64, 256]))) for _ in range(ncl)]
+            xs = [mixture(steps * b + int(rs.randint(0, b)), d, k, 3.0) for d, k in shapes]
+            n0 = min(len(x) for x in xs)
+            xs = [x[:n0] for x in xs]
+            s = int(rs.randint(1 << 30))
+            acav100m_amd.manual_seed(s)
+            kms = [KMeans(None, d, k).to("cuda:0") for d, k in shapes]
+            rng = O.Rng(s)
+            refs = [O.KMeans(d, k, rng) for d, k in shapes]
+            xts = [torch.from_numpy(x).cuda() for x in xs]
+            for _ in range(2):
+                tr = KMeans.train_epoch_distributed_multi(kms, xts, b, lr=0.01, chunk_steps=chunk)
+                for v, km in enumerate(kms):
+                    km.broadcast_state_from(tr[v], comm_slot=v)
+                for ref, x in zip(refs, xs):
+                    ref.train_epoch(x, b, lr=0.01)
+            for km, ref, sh in zip(kms, refs, shapes):
+                assert np.array_equal(km.centers.numpy(), ref.centers) and km.count == ref.count, ("ddp", shapes, b, steps, chunk, s, sh)
+            counts["ddp"] += 1
         else:
             v = int(rs.choice([60, 300, 1000, 5000, 5000, 30000]))
             dd = int(rs.choice([2, 3, 5, 10, 13]))
