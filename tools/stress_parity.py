@@ -31,7 +31,7 @@ def stress(seed=0, budget=60.0, max_cases=None):
     while time.time() < t_end and (max_cases is None or sum(counts.values()) < max_cases):
         which = rs.randint(0, 7)
         if which == 0:  # assign, filter and exact paths
-            d = int(rs.choice([8, 32, 64, 88, 96, 128, 160, 352, 512, 704, 1024, 1056, 2304]))
+            d = int(rs.choice([8, 10, 32, 64, 88, 96, 128, 130, 160, 352, 512, 704, 1001, 1024, 1056, 2304]))
             k = int(rs.choice([2, 3, 17, 64, 255, 256, 257, 300, 600, 1024, 1500]))
             n = int(rs.choice([1, 63, 128, 129, 1000, 4097, 20000]))
             if k > 600 and (n > 4097 or d > 1056):
@@ -54,9 +54,9 @@ def stress(seed=0, budget=60.0, max_cases=None):
             assert np.array_equal(a.cpu().numpy(), want) and np.array_equal(b.cpu().numpy(), want), ("assign", n, d, k, s)
             counts["assign"] += 1
         elif which == 1:  # bulk training
-            d = int(rs.choice([8, 64, 88, 128, 256, 352, 704, 1000, 1024, 1408]))
+            d = int(rs.choice([8, 30, 64, 88, 128, 130, 256, 352, 704, 1000, 1024, 1408]))
             k = int(rs.choice([3, 16, 40, 64, 100, 256, 300, 600, 1000, 1024, 1030, 2048]))
-            b = int(rs.choice([7, 16, 24, 32, 48, 64, 128, 200, 256, 512]))  # >= 128: several row groups per workgroup
+            b = int(rs.choice([1, 7, 16, 24, 32, 48, 64, 128, 200, 256, 512, 1024]))  # >= 128: several row groups per workgroup
             steps = int(rs.randint(3, 60)) if b <= 128 else int(rs.randint(3, 12))
             if k >= 1000:  # the warm-up alone is 10 K rows: a few real steps beyond it, no more
                 steps = (10 * k) // b + int(rs.randint(2, 10))
@@ -156,7 +156,7 @@ def stress(seed=0, budget=60.0, max_cases=None):
             pairs = list(itertools.combinations(range(dd), 2))
             cand = rs.permutation(v)
             if which == 2:
-                B = int(rs.choice([4, 20, 33, 64])); kk = int(rs.randint(1, B + 1)); keep = bool(rs.randint(0, 2))
+                B = int(rs.choice([1, 2, 4, 20, 33, 64])); kk = int(rs.randint(1, B + 1)); keep = bool(rs.randint(0, 2))
                 ns = int(rs.choice([1, 1, 3]))                       # start set (seeds the tables, never selected)
                 L = v - ns if rs.rand() < 0.6 else max(2, int((v - ns) * rs.uniform(0.3, 1.0)))  # not every clip is a candidate
                 B = min(B, L - 1); kk = min(kk, B)
