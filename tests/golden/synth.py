@@ -47,3 +47,25 @@ def write_feature_shards(root, n_shards=4, rows=256, seed=0, comps=24, audio_dim
             json.dump(meta, f)
     last = "%06d" % (n_shards - 1)
     return os.path.join(feat_dir, "shard-{000000..%s}.pkl" % last)
+
+
+def overlapping_rows(seed, n, d, comps, spread, noise=0.3):
+    """Rows of the BASELINE-shape assign goldens (gen_golden.py `kmeans_big`): mixture components whose centres are only
+    `spread` apart per coordinate (centre distance ~ spread*sqrt(2d)) under noise of radius noise*sqrt(d), so that
+    neighbouring clusters OVERLAP and a trained clustering leaves rows near the bisector of two centres.  Regenerated
+    from the seed by the generator and by the tests (128 / 256 MB of rows are not committed)."""
+    rs = np.random.RandomState(seed)
+    cen = (spread * rs.randn(comps, d)).astype(np.float32)
+    comp = rs.randint(0, comps, n)
+    x = np.empty((n, d), np.float32)
+    for s in range(0, n, 4096):  # chunked: the float64 draw of the whole matrix would be 0.5 GB at d = 2048
+        e = min(n, s + 4096)
+        x[s:e] = cen[comp[s:e]] + (noise * rs.randn(e - s, d)).astype(np.float32)
+    return x
+
+
+def bisector_rows(x, centers, idx, i, j, t):
+    """x[idx] + t * (centers[j] - centers[i]) evaluated in fp32 element by element (two IEEE roundings per element:
+    the product, then the sum) -- the near-tie rows of the `kmeans_big` goldens, rebuilt from the fixture's (idx, i, j, t)."""
+    u = centers[j.astype(np.int64)] - centers[i.astype(np.int64)]
+    return (x[idx] + (t.astype(np.float32)[:, None] * u).astype(np.float32)).astype(np.float32)

@@ -199,6 +199,54 @@ def test_k1024_train_and_assign(env, d):
     assert np.array_equal(km.calc_best(xt, need_mean=True)[0].cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("name", ["d1024_k256", "d2048_k1024"])
+def test_reference_goldens_at_baseline_shapes(env, name):
+    """The REFERENCE's own results at BASELINE's shapes (tests/golden/kmeans_big_*.npz, recorded by gen_golden.py
+    `kmeans_big`; 32 768 rows of overlapping clusters): GPU training from the reference's seed ends in the reference's
+    centres bit for bit (sha256), both assign paths give the reference's label on every natural row (also under the
+    doctored /5 discount), and on the 4 096 bisector rows the GPU equals the oracle exactly while every difference from
+    the reference is an exact-arithmetic tie (census printed; tests/_census.py)."""
+    import hashlib
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    from tests import _census as Z
+    g, x, n, d, K = Z.load_case(name)
+    b = int(g["b"])
+    acav.manual_seed(int(g["seed"]))
+    km = KMeans(None, d, K).to("cuda:0")
+    xt = torch.from_numpy(x).cuda()
+    for e in range(int(g["epochs"])):
+        km.train_epoch(xt, b, lr=0.1 ** (2 + e // 5))
+    c, cnt = km.centers.numpy(), km.counts.numpy()
+    assert hashlib.sha256(c.tobytes()).hexdigest() == str(g["centers_sha256"]), "trained centres differ from the reference's"
+    assert np.array_equal(cnt, g["counts"]) and km.count == int(g["count"]) and km.fallback == int(g["fallback"])
+    reinit = (0.7, 5.0)
+    fast = km.calc_best(xt, need_mean=False)[0].cpu().numpy()
+    exact = km.calc_best(xt, need_mean=True)[0].cpu().numpy()
+    assert np.array_equal(fast, exact)
+    nm, _ = Z.census(x, c, cnt, km.count, reinit, fast, g["labels"], f"GPU, {name}, natural rows")
+    assert nm == 0
+    ref = O.KMeans(d, K, O.Rng(0))
+    ref.set_state(c, cnt, km.count)
+    xb = Z.bisector(g, x, c)
+    xbt = torch.from_numpy(xb).cuda()
+    want = ref.calc_best(xb)[0]
+    fastb = km.calc_best(xbt, need_mean=False)[0].cpu().numpy()
+    _, rows, rechecked = km.filter_stats()
+    exactb = km.calc_best(xbt, need_mean=True)[0].cpu().numpy()
+    assert np.array_equal(fastb, want) and np.array_equal(exactb, want)  # GPU == oracle bit for bit ON the ties
+    print(f"{name}: {rechecked} of {rows} bisector rows went to the exact re-check")
+    assert rechecked >= len(xb) // 2
+    nb, _ = Z.census(xb, c, cnt, km.count, reinit, fastb, g["bis_labels"], f"GPU, {name}, bisector rows", max_ulps=8)
+    assert nb > 0
+    cnt2 = cnt.copy()
+    cnt2[::3] = 1.0
+    km.counts = torch.from_numpy(cnt2)
+    doc = km.calc_best(xt, need_mean=False)[0].cpu().numpy()
+    assert np.array_equal(doc, km.calc_best(xt, need_mean=True)[0].cpu().numpy())
+    Z.census(x, c, cnt2, km.count, reinit, doc, g["labels_doctored"], f"GPU, {name}, doctored discount")
+
+
 @pytest.mark.parametrize("v", [16_777_216, 17_000_000])
 def test_longest_lists_first_iterations_vs_oracle(env, v):
     """Maximum sizes of the permutation: the longest list the tiled Fisher-Yates takes (16 Mi candidates: ~3 700 tiles,
