@@ -1,0 +1,243 @@
+// Experiment (not product): the READ ceiling of the assign filter's access pattern on one MI355X.
+// The filter (k_assign_bf16_rw) streams 1M x 1024 fp32 rows (4.1 GB) from HBM exactly once, a workgroup taking 128 rows x
+// 32 columns (16 KB) per stage, and beside it the same number of bf16-centre bytes from L2.  VERDICT r2 item 2(a): measure
+// the read rate of that pattern instead of quoting the guide's copy rate.  Variants, all read-only (no MFMA, no LDS reads):
+//   dma     LDS-DMA (global_load_lds_dwordx4) of 128-row x 32-column stages into a ring of S slots, nt or default policy,
+//           with / without the per-stage workgroup barrier; workgroups per CU follow from the ring's LDS
+//   dma+c   the same plus an equal stream of "centre" bytes from a 512 KB L2-resident buffer (ring of 2)
+//   l2      only the L2-resident stream (what the L2 -> LDS path delivers)
+//   flat    plain global_load_dwordx4, lanes contiguous (the guide's copy pattern, read half), U loads in flight
+//   rowlane global_load_dwordx4 in the MFMA B-fragment pattern: lane l reads 16 B of row (l % 32), half (l / 32) -- rows
+//           straight into VGPRs, U stages of 4 loads in flight
+// Build: hipcc --offload-arch=gfx950 -O3 -o stream_bench stream_bench.hip ; run: ./stream_bench [rows] [d]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return __builtin_amdgcn_readfirstlane((unsigned)(__SIZE_TYPE__)(const __attribute__((address_space(3))) void *)(p));
+}
+template <bool NT>
+__device__ __forceinline__ void dma16(const void *gbase_uniform, unsigned voff, unsigned lds)
+{
+    if (NT) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(gbase_uniform), "s"(lds) : "memory", "m0");
+    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gbase_uniform), "s"(lds) : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// S-slot ring of 16 KB stages (128 rows x 32 fp32 columns); CEN: also a 2-slot ring of 16 KB "centre" stages from cb.
+template <int S, bool NT, bool BAR, bool ROWS, bool CEN>
+__global__ __launch_bounds__(256) void k_dma(const float *__restrict__ x, int64_t n, int d, const char *__restrict__ cb, int *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    const int nchunks = d / 32;
+    unsigned voffx[4], voffc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rr = (wq * 4 + q) * 8 + (lane >> 3);
+        voffx[q] = (unsigned)rr * (unsigned)d * 4u + ((lane & 7) << 4);
+        const int rc = (wq * 4 + q) * 16 + (lane >> 2);
+        voffc[q] = (unsigned)rc * (unsigned)d * 2u + ((lane & 3) << 4);
+    }
+    const unsigned xring = lds_addr(smem) + wq * 4096;
+    const unsigned cring = lds_addr(smem) + (ROWS ? S : 0) * 16384 + wq * 4096;
+    const char *gx = reinterpret_cast<const char *>(x + (size_t)row0 * d);
+    const char *gc = cb;
+    int wx = 0, wc = 0;
+    auto issue_x = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma16<NT>(gx, voffx[q], xring + wx * 16384 + q * 1024);
+        gx += 128;
+        wx = wx + 1 == S ? 0 : wx + 1;
+    };
+    auto issue_c = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma16<false>(gc, voffc[q], cring + wc * 16384 + q * 1024);
+        gc += 64;
+        wc ^= 1;
+    };
+    // prologue: S-1 row stages (and one centre stage) in flight
+    // with both streams the order is the product's: x0, c0, x1 | per stage: centres c+1 THEN rows c+2 -- vmcnt retires in
+    // order, so the wait for centres c leaves only the 4 row pieces issued after them in flight (S = 3 in that case)
+    if (ROWS) issue_x();
+    if (CEN) issue_c();
+    if (ROWS)
+        for (int s = 1; s < S - 1 && s < nchunks; ++s) issue_x();
+    for (int c = 0; c < nchunks; ++c) {
+        // retire stage c (the oldest): everything issued after it may stay in flight
+        constexpr int AHEAD = ROWS ? (CEN ? 4 : (S - 2) * 4) : 0;
+        if (c + (ROWS ? S - 1 : 1) <= nchunks) wait_vm<AHEAD>();
+        else wait_vm<0>();
+        if (BAR) __builtin_amdgcn_s_barrier();
+        if (CEN && c + 1 < nchunks) issue_c();
+        if (ROWS && c + S - 1 < nchunks) issue_x();
+    }
+    wait_vm<0>();
+    if (tid == 0x7fffffff) sink[0] = smem[tid];
+}
+
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_flat(const f4 *__restrict__ x, int64_t n4, int *sink)
+{
+    // a workgroup takes a contiguous 128-row x d slab like the filter does; lanes contiguous inside it
+    const int64_t per = n4 / gridDim.x;
+    const f4 *p = x + (int64_t)blockIdx.x * per + threadIdx.x;
+    float acc = 0.f;
+    for (int64_t i = 0; i + 256 * U <= per; i += 256 * U) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(p + i + u * 256) : p[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+    }
+    if (acc == 1.2345e-30f) sink[0] = 1;
+}
+
+// rows straight into VGPRs in the B-fragment pattern of v_mfma_f32_32x32x16_bf16: wave = 32 rows, lane (r = l % 32, h = l / 32)
+// takes 16 fp32 (64 B) of its row per 32-column stage = 4 x dwordx4; U stages in flight.  HALF: which 64 B a lane takes:
+// 0 = [h*16, h*16+16) floats (64 B contiguous per lane), 1 = interleaved 16-B pieces (h + 2 q): both legal K permutations.
+template <int U, bool NT, int PAT>
+__global__ __launch_bounds__(256) void k_rowlane(const float *__restrict__ x, int64_t n, int d, int *sink)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t row = (int64_t)blockIdx.x * 128 + wq * 32 + r;
+    const f4 *p = reinterpret_cast<const f4 *>(x + row * d) + (PAT == 0 ? h * 4 : h);
+    constexpr int QS = PAT == 0 ? 1 : 2;
+    const int nchunks = d / 32;
+    float acc = 0.f;
+    for (int c = 0; c + U <= nchunks; c += U) {
+        f4 v[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                v[u][q] = NT ? __builtin_nontemporal_load(p + (c + u) * 8 + q * QS) : p[(c + u) * 8 + q * QS];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += v[u][q].x + v[u][q].y + v[u][q].z + v[u][q].w;
+    }
+    if (acc == 1.2345e-30f) sink[0] = 1;
+}
+
+static float run(const char *name, int lds, int grid, void (*launch)(int grid, int lds), double bytes, int reps = 7)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    launch(grid, lds);
+    CK(hipDeviceSynchronize());
+    std::vector<float> ms;
+    for (int i = 0; i < reps; ++i) {
+        CK(hipEventRecord(e0));
+        launch(grid, lds);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float t;
+        CK(hipEventElapsedTime(&t, e0, e1));
+        ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    const float med = ms[ms.size() / 2];
+    printf("%-44s lds %6d  min %.3f med %.3f ms  %.2f TB/s (med)  = %.3f of 8 TB/s\n", name, lds, ms[0], med, bytes / med * 1e-9, bytes / med * 1e-9 / 8.0);
+    fflush(stdout);
+    return med;
+}
+
+static const float *g_x;
+static int64_t g_n;
+static int g_d;
+static char *g_cb;
+static int *g_sink;
+
+#define DMA_CASE(S, NT, BAR, ROWS, CEN, LDS)                                                                                 \
+    {                                                                                                                        \
+        auto fn = [](int grid, int lds) {                                                                                    \
+            hipLaunchKernelGGL((k_dma<S, NT, BAR, ROWS, CEN>), dim3(grid), dim3(256), lds, 0, g_x, g_n, g_d, g_cb, g_sink);   \
+        };                                                                                                                   \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dma<S, NT, BAR, ROWS, CEN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+        char nm[96];                                                                                                         \
+        snprintf(nm, sizeof nm, "dma S=%d %s %s %s%s", S, NT ? "nt" : "dflt", BAR ? "bar" : "nobar", ROWS ? "rows" : "", CEN ? "+centres(L2)" : ""); \
+        run(nm, LDS, (int)(g_n / 128), fn, (ROWS ? 1.0 : 0.0) * g_n * g_d * 4.0 + 0.0);                                       \
+    }
+#define L2_CASE(LDS)                                                                                                         \
+    {                                                                                                                        \
+        auto fn = [](int grid, int lds) {                                                                                    \
+            hipLaunchKernelGGL((k_dma<2, false, true, false, true>), dim3(grid), dim3(256), lds, 0, g_x, g_n, g_d, g_cb, g_sink); \
+        };                                                                                                                   \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dma<2, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+        run("l2 only: centre stream, ring of 2, bar", LDS, (int)(g_n / 128), fn, (double)g_n / 128 * g_d * 512.0);            \
+    }
+#define FLAT_CASE(U, NT, WGPC)                                                                                               \
+    {                                                                                                                        \
+        auto fn = [](int grid, int) { hipLaunchKernelGGL((k_flat<U, NT>), dim3(grid), dim3(256), 0, 0, reinterpret_cast<const f4 *>(g_x), g_n * g_d / 4, g_sink); }; \
+        char nm[96];                                                                                                         \
+        snprintf(nm, sizeof nm, "flat U=%d %s grid %d", U, NT ? "nt" : "dflt", WGPC);                                        \
+        run(nm, 0, WGPC, fn, (double)g_n * g_d * 4.0);                                                                        \
+    }
+#define ROWLANE_CASE(U, NT, PAT)                                                                                             \
+    {                                                                                                                        \
+        auto fn = [](int grid, int) { hipLaunchKernelGGL((k_rowlane<U, NT, PAT>), dim3(grid), dim3(256), 0, 0, g_x, g_n, g_d, g_sink); }; \
+        char nm[96];                                                                                                         \
+        snprintf(nm, sizeof nm, "rowlane U=%d %s pattern %d", U, NT ? "nt" : "dflt", PAT);                                   \
+        run(nm, 0, (int)(g_n / 128), fn, (double)g_n * g_d * 4.0);                                                            \
+    }
+
+int main(int argc, char **argv)
+{
+    g_n = argc > 1 ? atoll(argv[1]) : 1000000;
+    g_d = argc > 2 ? atoi(argv[2]) : 1024;
+    g_n = g_n / 128 * 128;
+    float *x;
+    CK(hipMalloc(&x, (size_t)g_n * g_d * 4));
+    CK(hipMemset(x, 0x3c, (size_t)g_n * g_d * 4));
+    CK(hipMalloc(&g_cb, 256 * (size_t)g_d * 2 + 65536));
+    CK(hipMemset(g_cb, 0x3c, 256 * (size_t)g_d * 2 + 65536));
+    CK(hipMalloc(&g_sink, 64));
+    g_x = x;
+    printf("rows %lld x d %d fp32 = %.3f GB\n", (long long)g_n, g_d, g_n * (double)g_d * 4e-9);
+    // ring depth / workgroups per CU (LDS decides): 48 KB -> 3 per CU, 80 KB -> 2, 160 KB -> 1
+    DMA_CASE(3, true, true, true, false, 3 * 16384)
+    DMA_CASE(3, true, true, true, false, 80 * 1024)
+    DMA_CASE(3, false, true, true, false, 80 * 1024)
+    DMA_CASE(3, true, false, true, false, 80 * 1024)
+    DMA_CASE(5, true, true, true, false, 80 * 1024)
+    DMA_CASE(5, true, false, true, false, 80 * 1024)
+    DMA_CASE(4, true, true, true, false, 64 * 1024)
+    DMA_CASE(2, true, true, true, false, 32 * 1024)
+    DMA_CASE(2, true, true, true, false, 40 * 1024)
+    DMA_CASE(10, true, true, true, false, 160 * 1024)
+    DMA_CASE(8, true, true, true, false, 128 * 1024)
+    // the product's shape: rows ring 3 + centre ring 2 = 80 KB
+    DMA_CASE(3, true, true, true, true, 80 * 1024)
+    DMA_CASE(3, false, true, true, true, 80 * 1024)
+    DMA_CASE(3, true, false, true, true, 80 * 1024)
+    L2_CASE(32 * 1024)
+    L2_CASE(80 * 1024)
+    FLAT_CASE(4, true, 7812)
+    FLAT_CASE(8, true, 7812)
+    FLAT_CASE(8, false, 7812)
+    FLAT_CASE(8, true, 2048)
+    FLAT_CASE(16, true, 2048)
+    FLAT_CASE(8, true, 1024)
+    ROWLANE_CASE(1, true, 0)
+    ROWLANE_CASE(2, true, 0)
+    ROWLANE_CASE(2, false, 0)
+    ROWLANE_CASE(4, true, 0)
+    ROWLANE_CASE(2, true, 1)
+    ROWLANE_CASE(4, true, 1)
+    ROWLANE_CASE(4, false, 1)
+    return 0;
+}
