@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int FB_ROWS = 128;  // rows per workgroup (4 MFMA row tiles)
+constexpr int FILTER_NW_DEFAULT = 4, FILTER_SCHED_DEFAULT = 0;  // K <= 256 defaults of k_assign_bf16_rw (see acav_kmeans_assign)
 
 struct CentersAux {
     unsigned cmax_bits;   // bits of max_k ||c_k||^2 (non-negative floats order like unsigned)
@@ -466,6 +467,12 @@ __device__ __forceinline__ bf16x8 cvt_bf16x8(float4 lo, float4 hi)
     return r;
 }
 
+#ifdef ACAV_RW_PROF  // tools/exp/assign_bench.hip only: per-stage phase cycles of k_assign_bf16_rw (s_memtime)
+__device__ unsigned long long g_rw_prof[16];
+#define RW_T(v) const long long v = clock64()
+#else
+#define RW_T(v)
+#endif
 #ifdef ACAV_FD_PROF
 __device__ unsigned long long g_fd_prof[20];
 #define FD_T(v) const long long v = clock64()
@@ -794,17 +801,38 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict_
 // Halving the centre stream the other way -- a wave owning 64 rows (two accumulator sets = 256 registers, 512 with the
 // fragments, 7 spills), 256 rows per workgroup against one centre stage, 128 KB of LDS, one wave per SIMD -- was correct
 // and SLOWER too (0.97-0.98 vs 0.91-0.94 ms same box): with one wave per SIMD every barrier and LDS wait idles the SIMD.
-template <bool NT>
-__global__ __launch_bounds__(256, 2) void k_assign_bf16_rw(const float *__restrict__ x, int64_t n, int d,
+//
+// Template parameters (round 3):
+//   NW   waves per workgroup = 32-row tiles per workgroup: 4 (128 rows, 80 KB of LDS, two workgroups per CU) or 8 (256 rows
+//        against ONE centre stage, 128 KB, one workgroup per CU: half the centre bytes per row)
+//   GS   "group split" for K > 256: one workgroup = one (row tile, group of 256 centres) PAIR instead of a loop over the
+//        groups that re-streams the tile's rows from HBM once per group.  The pairs of a tile are consecutive in dispatch
+//        order on ONE XCD (block b runs on XCD b % 8): the tile's rows come from HBM once and from that XCD's L2 for the
+//        other groups.  Each pair leaves a (d1, k1, d2, ||x||^2) record per row; k_assign_merge folds the groups in
+//        ascending order (the order of the loop) and applies the acceptance test.
+//   DCR  centre ring depth.  2: a centre stage is issued one stage ahead (rows two).  With the rows L2-resident (GS) the
+//        stage time is no longer set by HBM but by how long a DMA piece takes to land under load (~1 us, L2 hit or not)
+//        over the stages of look-ahead: 3 gives the centre stream two stages like the rows (order per stage: centres
+//        c+2 THEN rows c+2, counted wait leaves one stage of both in flight).
+struct Top2Rec {
+    float d1;
+    int k1;
+    float d2;
+    float xn;
+};
+template <bool NT, int NW, bool GS, int DCR = FD_DC, int SCHED = 0>
+__global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__restrict__ x, int64_t n, int d,
                                                             const __bf16 *__restrict__ cb, const float *__restrict__ cn,
                                                             const float *__restrict__ counts, int K, float thr, float r,
                                                             const CentersAux *__restrict__ aux, float e1c, float e1r, float e2coef,
                                                             int64_t *__restrict__ labels, int *__restrict__ recheck_list,
-                                                            unsigned *__restrict__ recheck_count)
+                                                            unsigned *__restrict__ recheck_count, Top2Rec *__restrict__ grec)
 {
+    constexpr int XSLOT = NW * 4096;  // bytes per row-ring slot: NW x 32 rows x 32 fp32
+    constexpr int CQ = 16 / NW;       // centre-stage DMA pieces (1 KB = 16 centres x 64 B) per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
-    float *sXr = reinterpret_cast<float *>(fd_smem);                        // [FD_DX][128][32] fp32
-    __bf16 *sCb = reinterpret_cast<__bf16 *>(fd_smem + FD_DX * FD_SLOT);    // [FD_DC][256][32] bf16
+    float *sXr = reinterpret_cast<float *>(fd_smem);                        // [FD_DX][NW * 32][32] fp32
+    __bf16 *sCb = reinterpret_cast<__bf16 *>(fd_smem + FD_DX * XSLOT);      // [FD_DC][256][32] bf16
     float *sCn = reinterpret_cast<float *>(fd_smem);  // [256] epilogue scratch, aliases the (idle) row ring
     float *sSc = sCn + 256;                           // [256] 1, or 1/r for a discounted centre
 
@@ -812,9 +840,18 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16_rw(const float *__restri
     const int lane = tid & 63;
     const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = row tile (32 rows)
     const int l31 = lane & 31, h = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * 128;
     const int nchunks = d / FD_BK;
     const int ngroups = (K + 255) / 256;
+    int64_t tile = blockIdx.x;
+    int cg0 = 0, cg1 = ngroups;
+    if (GS) {
+        const int j = blockIdx.x >> 3;  // sequence number on XCD (blockIdx.x & 7)
+        tile = (int64_t)(j / ngroups) * 8 + (blockIdx.x & 7);
+        cg0 = j % ngroups;
+        cg1 = cg0 + 1;
+        if (tile * (NW * 32) >= n) return;  // the grid is rounded up to whole rounds of 8 tiles
+    }
+    const int64_t row0 = tile * (NW * 32);
     const float inv_r = 1.0f / r;
     // Centred mode (no centre is under-used: the filter multiplies by c - mu): every distance of a row carries the same
     // constant ||x||^2 + M - 2 x.mu, M = any number.  It is left out of the compared values -- ||x||^2 is not added and
@@ -824,26 +861,30 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16_rw(const float *__restri
     const bool centred = aux->any_disc == 0u;
     const float cn_shift = centred ? cn[0] : 0.0f;
 
-    unsigned voffx[4], voffc[4];
+    unsigned voffx[4], voffc[CQ];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int rr = (wq * 4 + q) * 8 + (lane >> 3);
         const int rc = row0 + rr < n ? rr : (int)(n - 1 - row0);  // ragged tail: re-read the last row
         voffx[q] = (unsigned)rc * (unsigned)d * 4u + (((lane & 7) ^ ((rr >> 1) & 7)) << 4);
     }
-    const unsigned xring = lds_addr(sXr) + wq * 4096, cring = lds_addr(sCb) + wq * 4096;
+    const unsigned xring = lds_addr(sXr) + wq * 4096, cring = lds_addr(sCb) + wq * (CQ * 1024);
 
     float ssq[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) ssq[e] = 0.f;
     Top2 run = {INFINITY, 0x7fffffff, INFINITY};
     float xn = 0.f;  // ||x||^2 of this lane's row
+#ifdef ACAV_RW_PROF
+    long long rwp[6] = {0, 0, 0, 0, 0, 0};
+    const long long rw_tstart = clock64(), rw_wstart = wall_clock64();
+#endif
 
-    for (int cg = 0; cg < ngroups; ++cg) {
+    for (int cg = cg0; cg < cg1; ++cg) {
         const int kbase = cg * 256;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int rr = (wq * 4 + q) * 16 + (lane >> 2);
+        for (int q = 0; q < CQ; ++q) {
+            const int rr = (wq * CQ + q) * 16 + (lane >> 2);
             const int rc = kbase + rr < K ? rr : K - 1 - kbase;
             voffc[q] = (unsigned)rc * (unsigned)d * 2u + (((lane & 3) ^ ((rr >> 2) & 3)) << 4);
         }
@@ -853,17 +894,17 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16_rw(const float *__restri
         auto issue_x = [&]() {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (NT) dma16_asm_nt(gx, voffx[q], xring + wx * FD_SLOT + q * 1024);
-                else dma16_asm(gx, voffx[q], xring + wx * FD_SLOT + q * 1024);
+                if (NT) dma16_asm_nt(gx, voffx[q], xring + wx * XSLOT + q * 1024);
+                else dma16_asm(gx, voffx[q], xring + wx * XSLOT + q * 1024);
             }
             gx += FD_BK * 4;
             wx = wx + 1 == FD_DX ? 0 : wx + 1;
         };
         auto issue_c = [&]() {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dma16_asm(gc, voffc[q], cring + wc * FD_SLOT + q * 1024);
+            for (int q = 0; q < CQ; ++q) dma16_asm(gc, voffc[q], cring + wc * FD_SLOT + q * 1024);
             gc += FD_BK * 2;
-            wc = wc + 1 == FD_DC ? 0 : wc + 1;
+            wc = wc + 1 == DCR ? 0 : wc + 1;
         };
 
         f32x16 acc[8];
@@ -874,41 +915,121 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16_rw(const float *__restri
 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave is done with the previous centre group's epilogue scratch
-        issue_x();
-        issue_c();
-        if (nchunks > 1) issue_x();
+        if (DCR == 2) {
+            issue_x();
+            issue_c();
+            if (nchunks > 1) issue_x();
+        } else {
+            issue_c();
+            issue_x();
+            if (nchunks > 1) {
+                issue_c();
+                issue_x();
+            }
+        }
         int rx = 0, rcs = 0;
         const int swz = (l31 >> 1) & 7, swa = (l31 >> 2) & 3;
         for (int c = 0; c < nchunks; ++c) {
-            if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            RW_T(t0);
+#if defined(ACAV_ABL_NOXDMA)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+            // what stays in flight behind stage c: DCR 2 -- the 4 row pieces of stage c+1 (issued last, after the
+            // centres of stage c); DCR 3 -- the CQ centre + 4 row pieces of stage c+1
+            if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DCR == 2 ? 4 : CQ + 4) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            RW_T(t1);
             __builtin_amdgcn_s_barrier();
-            const float *pxl = sXr + rx * (128 * 32) + wq * 1024 + l31 * 32;  // this lane's row of the wave's own tile
+            RW_T(t2);
+            const float *pxl = sXr + rx * (XSLOT / 4) + wq * 1024 + l31 * 32;  // this lane's row of the wave's own tile
             const __bf16 *pcl = sCb + rcs * (256 * 32) + l31 * 32;            // row l31 of centre tile 0 (+ 1024 per tile)
             rx = rx + 1 == FD_DX ? 0 : rx + 1;
-            rcs = rcs + 1 == FD_DC ? 0 : rcs + 1;
+            rcs = rcs + 1 == DCR ? 0 : rcs + 1;
 #define RW_LDB(ks, F0, F1)                                                                         \
     const float4 F0 = *reinterpret_cast<const float4 *>(pxl + (((4 * (ks) + 2 * h) ^ swz) << 2));  \
     const float4 F1 = *reinterpret_cast<const float4 *>(pxl + (((4 * (ks) + 2 * h + 1) ^ swz) << 2));
 #define RW_LDA(ks, ct) (*reinterpret_cast<const bf16x8 *>(pcl + (ct) * 1024 + (((2 * (ks) + h) ^ swa) << 3)))
+            // ACAV_ABL_*: timing-only ablations for tools/exp/assign_bench.hip (never defined in the product build)
+#ifdef ACAV_ABL_NOAFRAG
+#define RW_CT(ct) 0
+#else
+#define RW_CT(ct) (ct)
+#endif
+#ifdef ACAV_ABL_NOMFMA
+#define RW_MFMA(a, b, cc) cc[0] += (float)(a)[0] + (float)(b)[0]
+#else
+#define RW_MFMA(a, b, cc) cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, cc, 0, 0, 0)
+#endif
+            // SCHED: when a wave issues its CQ + 4 DMA pieces of the stage (an issue costs the wave 60-120 cycles while the
+            // path is busy: tools/exp/assign_bench.hip -DACAV_RW_PROF).  0: all of them in one burst before the MFMAs.
+            // 1 (512-thread workgroups): the second half of the waves shares its SIMDs with the first half and issues its
+            // burst AFTER its MFMAs.  2: one piece after every second MFMA -- the DMA path sees a steady stream instead of
+            // a burst per barrier, and while one wave of a SIMD sits in an issue the other one feeds the matrix pipe.
+            const bool dma_first = SCHED == 0 || (SCHED == 1 && (NW == 4 || wq < 4));
+            const bool dma_last = SCHED == 1 && !dma_first;
+            constexpr int NP = CQ + 4, NP1 = NP / 2;
+            auto piece = [&](int i) {
+                if (i < CQ) {
+#ifndef ACAV_ABL_NOCDMA
+                    if (c + DCR - 1 < nchunks) dma16_asm(gc, voffc[i], cring + wc * FD_SLOT + i * 1024);
+#endif
+                    if (i == CQ - 1) {
+                        gc += FD_BK * 2;
+                        wc = wc + 1 == DCR ? 0 : wc + 1;
+                    }
+                } else {
+                    const int q = i - CQ;
+#ifndef ACAV_ABL_NOXDMA
+                    if (c + 2 < nchunks) {
+                        if (NT) dma16_asm_nt(gx, voffx[q], xring + wx * XSLOT + q * 1024);
+                        else dma16_asm(gx, voffx[q], xring + wx * XSLOT + q * 1024);
+                    }
+#endif
+                    if (q == 3) {
+                        gx += FD_BK * 4;
+                        wx = wx + 1 == FD_DX ? 0 : wx + 1;
+                    }
+                }
+            };
             RW_LDB(0, p0, p1)
             bf16x8 a0[8], a1[8];
 #pragma unroll
-            for (int ct = 0; ct < 8; ++ct) a0[ct] = RW_LDA(0, ct);
-            if (c + 1 < nchunks) issue_c();  // into the slots stage c-1 just vacated
-            if (c + 2 < nchunks) issue_x();
+            for (int ct = 0; ct < 8; ++ct) a0[ct] = RW_LDA(0, RW_CT(ct));
+            RW_T(t3);
+            if (dma_first) {  // into the slots stage c-1 just vacated
+#pragma unroll
+                for (int i = 0; i < NP; ++i) piece(i);
+            }
+            RW_T(t4);
             RW_LDB(1, q0, q1)
             const bf16x8 b0 = cvt_bf16x8(p0, p1);
 #pragma unroll
             for (int ct = 0; ct < 8; ++ct) {
-                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ct], b0, acc[ct], 0, 0, 0);
-                a1[ct] = RW_LDA(1, ct);
+                RW_MFMA(a0[ct], b0, acc[ct]);
+                a1[ct] = RW_LDA(1, RW_CT(ct));
+                if (SCHED == 2 && (ct & 1) == 0 && ct / 2 < NP1) piece(ct / 2);
             }
             const bf16x8 b1 = cvt_bf16x8(q0, q1);
 #pragma unroll
-            for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ct], b1, acc[ct], 0, 0, 0);
-            if (cg == 0) {  // uniform: canonical ||x||^2 of the lane's row, classes 16 ks + 8 h + e
+            for (int ct = 0; ct < 8; ++ct) {
+                RW_MFMA(a1[ct], b1, acc[ct]);
+                if (SCHED == 2 && (ct & 1) == 0 && NP1 + ct / 2 < NP) piece(NP1 + ct / 2);
+            }
+            if (dma_last) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i) piece(i);
+            }
+#undef RW_MFMA
+#undef RW_CT
+#ifdef ACAV_RW_PROF
+            {
+                RW_T(t5);
+                rwp[0] += t1 - t0, rwp[1] += t2 - t1, rwp[2] += t3 - t2, rwp[3] += t4 - t3, rwp[4] += t5 - t4, rwp[5] += 1;
+            }
+#endif
+            if (cg == cg0) {  // uniform: canonical ||x||^2 of the lane's row, classes 16 ks + 8 h + e
                 ssq[0] = __builtin_fmaf(p0.x, p0.x, ssq[0]), ssq[1] = __builtin_fmaf(p0.y, p0.y, ssq[1]);
                 ssq[2] = __builtin_fmaf(p0.z, p0.z, ssq[2]), ssq[3] = __builtin_fmaf(p0.w, p0.w, ssq[3]);
                 ssq[4] = __builtin_fmaf(p1.x, p1.x, ssq[4]), ssq[5] = __builtin_fmaf(p1.y, p1.y, ssq[5]);
@@ -925,14 +1046,16 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16_rw(const float *__restri
         // into a NaN under the position tag, and fmaxf(s1, NaN) = s1 makes the runner-up collapse onto the minimum: every
         // lane that mixes real and padding centres would send its row to the re-check.)
         float my_cn = 3.0e38f, my_sc = 1.0f;
-        if (kbase + tid < K) {
+        if (kbase + tid < K && tid < 256) {
             my_cn = cn[kbase + tid] - cn_shift;
             my_sc = counts[kbase + tid] < thr ? inv_r : 1.0f;
         }
         __syncthreads();  // every wave has read its last fragments: the row ring becomes epilogue scratch
-        sCn[tid] = my_cn;
-        sSc[tid] = my_sc;
-        if (cg == 0) {
+        if (NW == 4 || tid < 256) {
+            sCn[tid] = my_cn;
+            sSc[tid] = my_sc;
+        }
+        if (cg == cg0) {
             // canonical tree: (p0+p1)+(p2+p3) per group of 4 classes, then ((g0+g1)+(g2+g3)) + ((g4+g5)+(g6+g7)):
             // g0,g1 = (ks 0, h 0), g2,g3 = (ks 0, h 1), g4,g5 = (ks 1, h 0), g6,g7 = (ks 1, h 1); fp32 + commutes bitwise
             float ta = ((ssq[0] + ssq[1]) + (ssq[2] + ssq[3])) + ((ssq[4] + ssq[5]) + (ssq[6] + ssq[7]));
@@ -973,7 +1096,22 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16_rw(const float *__restri
         o.d2 = __shfl_xor(t.d2, 32);
         run = top2_merge(run, top2_merge(t, o));
     }
+#ifdef ACAV_RW_PROF
+    if (lane == 0 && (blockIdx.x & 15) == 3 && (wq == 0 || wq == NW - 1)) {
+        const int o = wq == 0 ? 0 : 8;
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_rw_prof[o + i], (unsigned long long)rwp[i]);
+        atomicAdd(&g_rw_prof[o + 6], (unsigned long long)(clock64() - rw_tstart));
+        atomicAdd(&g_rw_prof[o + 7], (unsigned long long)(wall_clock64() - rw_wstart));
+    }
+#endif
     const int64_t row = row0 + wq * 32 + l31;
+    if (GS) {
+        if (h == 0 && row < n) {
+            const Top2Rec rec = {run.d1, run.k1, run.d2, xn};
+            grec[(size_t)cg0 * (size_t)n + (size_t)row] = rec;
+        }
+        return;
+    }
     if (h == 0 && row < n) {
         const float xnorm = __builtin_sqrtf(xn);
         const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
@@ -989,6 +1127,36 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16_rw(const float *__restri
             const unsigned slot = atomicAdd(recheck_count, 1u);
             recheck_list[slot] = (int)row;
         }
+    }
+}
+
+// Folds the per-group records of the group-split filter (ascending group order = the order of the single-workgroup loop;
+// top2_merge breaks distance ties towards the lower centre index, so the fold is order-independent anyway) and applies
+// k_assign_bf16_rw's acceptance test.  One thread per row; 16-byte records, coalesced.
+__global__ __launch_bounds__(256) void k_assign_merge(const Top2Rec *__restrict__ grec, int ngroups, int64_t n,
+                                                      const CentersAux *__restrict__ aux, float e1c, float e1r, float e2coef,
+                                                      int64_t *__restrict__ labels, int *__restrict__ recheck_list,
+                                                      unsigned *__restrict__ recheck_count)
+{
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    Top2Rec r0 = grec[row];
+    Top2 run = {r0.d1, r0.k1, r0.d2};
+    for (int g = 1; g < ngroups; ++g) {
+        const Top2Rec rg = grec[(size_t)g * (size_t)n + (size_t)row];
+        const Top2 o = {rg.d1, rg.k1, rg.d2};
+        run = top2_merge(run, o);
+    }
+    const float xnorm = __builtin_sqrtf(r0.xn);
+    const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
+    const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
+    const float s = xnorm + cmax;
+    const float E = (e1c * cmaxc + e1r * cmax) * xnorm + e2coef * s * s;
+    labels[row] = (int64_t)run.k1;
+    const float tagged = 1.6e-5f * (fabsf(run.d1) + fabsf(run.d2));
+    if (!((run.d2 - run.d1) > 2.0f * E + tagged)) {
+        const unsigned slot = atomicAdd(recheck_count, 1u);
+        recheck_list[slot] = (int)row;
     }
 }
 
@@ -2098,7 +2266,7 @@ struct acav_kmeans {
     int64_t count = 0;  // python int self.count (deterministic on the host)
     DevBuf centers, cn, counts, scalars;
     DevBuf stage_x, stage_lab, stage_forced, keys, xn, wg_sum, minval, thr, ctl;
-    DevBuf cb16, caux, cmu, recheck_list, recheck_count, backup;
+    DevBuf cb16, caux, cmu, recheck_list, recheck_count, backup, grec;
     hipEvent_t ev_f0 = nullptr, ev_f1 = nullptr;  // around the last k_assign_bf16 launch (acav_kmeans_filter_time)
     bool cb16_valid = false;  // bf16 copy of the centres matches `centers`
     bool rg_attr_set = false; // dynamic-LDS attribute of the large-batch distance kernels set
@@ -2338,18 +2506,56 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         const char *vnt = getenv("ACAV_FILTER_NT"), *v1 = getenv("ACAV_FILTER_V1");
         const bool nt = !(vnt && vnt[0] == '0'), rw = !(v1 && v1[0] == '1');
         const float e2 = (float)ldexp(1.0, rw ? -20 : -17);  // row waves: epilogue roundings only, the tag is charged separately
-        auto kern = rw ? (nt ? k_assign_bf16_rw<true> : k_assign_bf16_rw<false>) : (nt ? k_assign_bf16<true> : k_assign_bf16<false>);
-        ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, FD_SMEM));
+        // Tile shape and DMA schedule of k_assign_bf16_rw (template parameters there).  K > 256: one workgroup per (row tile,
+        // centre group) pair, the pairs of a tile side by side on one XCD, 256-row tiles (8 waves), centre ring of 3, DMA
+        // pieces spread between the MFMAs -- rows from HBM once.  Knobs for A/B runs: ACAV_FILTER_GS=0 (loop over the groups
+        // inside one workgroup), ACAV_FILTER_NW=4|8, ACAV_FILTER_SCHED=0|2.
+        const int ngroups = (km->K + 255) / 256;
+        const char *vgs = getenv("ACAV_FILTER_GS"), *vnw = getenv("ACAV_FILTER_NW"), *vsc = getenv("ACAV_FILTER_SCHED");
+        const bool gs = rw && ngroups > 1 && !(vgs && vgs[0] == '0');
+        const int nw = !rw ? 4 : (vnw && vnw[0] == '8') ? 8 : (vnw && vnw[0] == '4') ? 4 : (gs ? 8 : FILTER_NW_DEFAULT);
+        const bool nt_eff = gs ? !(vnt && vnt[0] == '0') : nt;  // nt rows are still found in L2 by the tile's other groups (PMC)
+        const int dcr = nw == 8 ? 3 : 2;  // centre ring depth (3 only fits the one-workgroup-per-CU tile)
+        const int sched = nw == 8 ? 2 : (vsc ? (vsc[0] == '2' ? 2 : 0) : FILTER_SCHED_DEFAULT);
+        typedef void (*FilterKern)(const float *, int64_t, int, const __bf16 *, const float *, const float *, int, float, float,
+                                   const CentersAux *, float, float, float, int64_t *, int *, unsigned *, Top2Rec *);
+        FilterKern rwk = nullptr;
+        if (rw) {
+            if (nw == 8) rwk = gs ? (nt_eff ? k_assign_bf16_rw<true, 8, true, 3, 2> : k_assign_bf16_rw<false, 8, true, 3, 2>)
+                                  : (nt_eff ? k_assign_bf16_rw<true, 8, false, 3, 2> : k_assign_bf16_rw<false, 8, false, 3, 2>);
+            else if (gs) rwk = nt_eff ? k_assign_bf16_rw<true, 4, true, 2, 0> : k_assign_bf16_rw<false, 4, true, 2, 0>;
+            else if (sched == 2) rwk = nt_eff ? k_assign_bf16_rw<true, 4, false, 2, 2> : k_assign_bf16_rw<false, 4, false, 2, 2>;
+            else rwk = nt_eff ? k_assign_bf16_rw<true, 4, false, 2, 0> : k_assign_bf16_rw<false, 4, false, 2, 0>;
+        }
+        const int fsmem = FD_DX * nw * 4096 + dcr * FD_SLOT;
+        const int64_t tile_rows = (int64_t)nw * 32, ntiles = (n + tile_rows - 1) / tile_rows;
+        const int64_t fgrid = gs ? (ntiles + 7) / 8 * 8 * ngroups : ntiles;
+        ACAV_REQUIRE(fgrid <= 0x7fffffff, ACAV_EINVAL, "n too large for one launch");
+        if (gs) ACAV_TRY(km->grec.ensure(sizeof(Top2Rec) * (size_t)ngroups * (size_t)n));
         if (!km->ev_f0) {
             ACAV_HIP_TRY(hipEventCreate(&km->ev_f0));
             ACAV_HIP_TRY(hipEventCreate(&km->ev_f1));
         }
-        ACAV_HIP_TRY(hipEventRecord(km->ev_f0, st));
-        hipLaunchKernelGGL(kern, dim3((unsigned)((n + FB_ROWS - 1) / FB_ROWS)), dim3(256), FD_SMEM, st,
-                           static_cast<const float *>(dx), n, km->d, km->cb16.as<__bf16>(), km->cn.as<float>(),
-                           km->counts.as<float>(), km->K, km->threshold(), (float)km->reinit_r, km->caux.as<CentersAux>(), e1c,
-                           e1r, e2, dlab, km->recheck_list.as<int>(), km->recheck_count.as<unsigned>());
+        if (rw) {
+            ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rwk), hipFuncAttributeMaxDynamicSharedMemorySize, fsmem));
+            ACAV_HIP_TRY(hipEventRecord(km->ev_f0, st));
+            hipLaunchKernelGGL(rwk, dim3((unsigned)fgrid), dim3(nw * 64), fsmem, st, static_cast<const float *>(dx), n, km->d,
+                               km->cb16.as<__bf16>(), km->cn.as<float>(), km->counts.as<float>(), km->K, km->threshold(),
+                               (float)km->reinit_r, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, km->recheck_list.as<int>(),
+                               km->recheck_count.as<unsigned>(), gs ? km->grec.as<Top2Rec>() : (Top2Rec *)nullptr);
+            if (gs)
+                hipLaunchKernelGGL(k_assign_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, km->grec.as<Top2Rec>(),
+                                   ngroups, n, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, km->recheck_list.as<int>(),
+                                   km->recheck_count.as<unsigned>());
+        } else {
+            auto kern = nt ? k_assign_bf16<true> : k_assign_bf16<false>;
+            ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FD_SMEM));
+            ACAV_HIP_TRY(hipEventRecord(km->ev_f0, st));
+            hipLaunchKernelGGL(kern, dim3((unsigned)((n + FB_ROWS - 1) / FB_ROWS)), dim3(256), FD_SMEM, st,
+                               static_cast<const float *>(dx), n, km->d, km->cb16.as<__bf16>(), km->cn.as<float>(),
+                               km->counts.as<float>(), km->K, km->threshold(), (float)km->reinit_r, km->caux.as<CentersAux>(), e1c,
+                               e1r, e2, dlab, km->recheck_list.as<int>(), km->recheck_count.as<unsigned>());
+        }
         ACAV_HIP_TRY(hipGetLastError());
         ACAV_HIP_TRY(hipEventRecord(km->ev_f1, st));
 #ifdef ACAV_FD_PROF

@@ -132,6 +132,222 @@ __global__ __launch_bounds__(256) void k_rowlane(const float *__restrict__ x, in
     if (acc == 1.2345e-30f) sink[0] = 1;
 }
 
+
+// The candidate structure for the filter: rows by PLAIN coalesced nt loads into VGPRs (wave w takes its own 32 rows: instruction
+// q covers rows 8 q + l / 8, 16-byte chunk l % 8 of the stage's 128-byte row piece), U stage-sets of 4 loads in flight per wave,
+// two workgroups per CU (80 KB of dynamic LDS requested to pin that); CEN: the bf16 centre stages by LDS-DMA from L2 into a ring
+// of 3 with one barrier per stage; WR: the retired set is rounded to bf16 and written to a wave-private LDS slot (ds_write_b64).
+template <int U, bool CEN, bool WR, bool NT>
+__global__ __launch_bounds__(256, 2) void k_mix(const float *__restrict__ x, int64_t n, int d, const char *__restrict__ cb, int *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunks = d / 32;
+    const f4 *p = reinterpret_cast<const f4 *>(x + ((int64_t)blockIdx.x * 128 + wq * 32 + (lane >> 3)) * d) + (lane & 7);
+    const int rstride = 8 * d / 4;  // 8 rows further, in f4 units
+    unsigned voffc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rc = (wq * 4 + q) * 16 + (lane >> 2);
+        voffc[q] = (unsigned)rc * (unsigned)d * 2u + ((lane & 3) << 4);
+    }
+    const unsigned cring = lds_addr(smem) + wq * 4096;
+    unsigned long long *rowslot = reinterpret_cast<unsigned long long *>(smem + 3 * 16384 + wq * 4096) + lane;  // 2 x 2 KB per wave
+    const char *gc = cb;
+    int wc = 0;
+    auto issue_c = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma16<false>(gc, voffc[q], cring + wc * 16384 + q * 1024);
+        gc += 64;
+        wc = wc + 1 == 3 ? 0 : wc + 1;
+    };
+    f4 v[U][4];
+    float acc = 0.f;
+    // prologue: sets 0 .. U-1 in flight, centre stages 0 and 1 behind set U-2 / U-1 (issue order of the steady state: c then x)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (CEN && u >= U - 2) issue_c();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[u][q] = NT ? __builtin_nontemporal_load(p + u * 8 + q * rstride) : p[u * 8 + q * rstride];
+    }
+    for (int c = 0; c < nchunks; c += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // oldest set = stage c + u; behind it in the queue: (U-1) row sets and, with CEN, the newer centre stages
+            if (CEN) wait_vm<(U - 1) * 4 + 4>();   // leaves the last-issued centre stage + U-1 row sets... see DESIGN
+            else wait_vm<(U - 1) * 4>();
+            if (WR) {
+                typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bf4 b = {(__bf16)v[u][q].x, (__bf16)v[u][q].y, (__bf16)v[u][q].z, (__bf16)v[u][q].w};
+                    rowslot[((c + u) & 1) * 256 + q * 64] = *reinterpret_cast<unsigned long long *>(&b);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc += v[u][q].x + v[u][q].y + v[u][q].z + v[u][q].w;
+            }
+            if (CEN) {
+                __builtin_amdgcn_s_barrier();
+                if (c + u + 2 < nchunks) issue_c();
+            }
+            if (c + u + U < nchunks) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    v[u][q] = NT ? __builtin_nontemporal_load(p + (c + u + U) * 8 + q * rstride) : p[(c + u + U) * 8 + q * rstride];
+            }
+        }
+    }
+    wait_vm<0>();
+    if (acc == 1.2345e-30f || tid == 0x7fffffff) sink[0] = smem[tid & 1023];
+}
+
+
+// DRAM locality: the same 16 KB stage cut as (4096 / COLS) rows x COLS fp32 columns -- COLS*4 contiguous bytes per row piece.
+// The workgroup then owns 4096/COLS rows... the filter would need a different tile; here only the read rate is measured.
+template <int S, int COLS>
+__global__ __launch_bounds__(256) void k_dma_cols(const float *__restrict__ x, int64_t n, int d, int *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int ROWS = 4096 / COLS, LPR = COLS / 4, RPP = 64 / LPR;  // lanes per row, rows per 1 KB piece
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    const int nchunks = d / COLS;
+    unsigned voffx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rr = (wq * 4 + q) * RPP + lane / LPR;
+        voffx[q] = (unsigned)rr * (unsigned)d * 4u + ((lane % LPR) << 4);
+    }
+    const unsigned xring = lds_addr(smem) + wq * 4096;
+    const char *gx = reinterpret_cast<const char *>(x + (size_t)row0 * d);
+    int wx = 0;
+    auto issue_x = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma16<true>(gx, voffx[q], xring + wx * 16384 + q * 1024);
+        gx += COLS * 4;
+        wx = wx + 1 == S ? 0 : wx + 1;
+    };
+    for (int s = 0; s < S - 1 && s < nchunks; ++s) issue_x();
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + S - 1 <= nchunks) wait_vm<(S - 2) * 4>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (c + S - 1 < nchunks) issue_x();
+    }
+    wait_vm<0>();
+    if (tid == 0x7fffffff) sink[0] = smem[tid];
+}
+
+
+// "Design X" skeleton: ONE 512-thread workgroup per CU, 256 rows x 32 columns of fp32 rows (32 KB) + ONE 256-centre x 32-column
+// bf16 stage (16 KB) per step -- the centre stream is shared by twice the rows.  Wave w DMAs its own 32 rows (4 pieces) and an
+// eighth of the centre stage (2 pieces); order per step: centres c+SC-1 then rows c+SX-1; one barrier per step.
+template <int SX, int SC, bool CEN>
+__global__ __launch_bounds__(512) void k_dma_x(const float *__restrict__ x, int64_t n, int d, const char *__restrict__ cb, int *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    const int nchunks = d / 32;
+    unsigned voffx[4], voffc[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rr = (wq * 4 + q) * 8 + (lane >> 3);
+        voffx[q] = (unsigned)rr * (unsigned)d * 4u + ((lane & 7) << 4);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int rc = (wq * 2 + q) * 16 + (lane >> 2);
+        voffc[q] = (unsigned)rc * (unsigned)d * 2u + ((lane & 3) << 4);
+    }
+    const unsigned xring = lds_addr(smem) + wq * 4096;
+    const unsigned cring = lds_addr(smem) + SX * 32768 + wq * 2048;
+    const char *gx = reinterpret_cast<const char *>(x + (size_t)row0 * d);
+    const char *gc = cb;
+    int wx = 0, wc = 0;
+    auto issue_x = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma16<true>(gx, voffx[q], xring + wx * 32768 + q * 1024);
+        gx += 128;
+        wx = wx + 1 == SX ? 0 : wx + 1;
+    };
+    auto issue_c = [&]() {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) dma16<false>(gc, voffc[q], cring + wc * 16384 + q * 1024);
+        gc += 64;
+        wc = wc + 1 == SC ? 0 : wc + 1;
+    };
+    // steady state per step c: [wait stage c] [barrier] [issue centres c+SC-1] [issue rows c+SX-1]; SX-1 >= SC-1.
+    // queue behind rows c / centres c at the wait: steps c-SC+2 .. c-1 issued (centres 2 + rows 4) each -> (SC-2)*6 ... and the
+    // rows of the steps before that are older than centres c: they are waited for too (in-order vmcnt).
+    for (int s = 0; s < SX - 1; ++s) {
+        if (CEN && s >= SX - SC) issue_c();
+        issue_x();
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        constexpr int AHEAD = CEN ? (SC - 2) * 6 + 4 : (SX - 2) * 4;
+        wait_vm<AHEAD>();
+        __builtin_amdgcn_s_barrier();
+        if (CEN && c + SC - 1 < nchunks) issue_c();
+        if (c + SX - 1 < nchunks) issue_x();
+    }
+    wait_vm<0>();
+    if (tid == 0x7fffffff) sink[0] = smem[tid];
+}
+
+
+// What one CU can pull out of L2: every workgroup streams the SAME 2 MB buffer `reps` times (L2-resident after the first touch).
+//   MODE 0: LDS-DMA, the centre pattern (a 1 KB piece = 16 rows x 64 B, rows 2 KB apart: half cache lines)
+//   MODE 1: LDS-DMA, contiguous 1 KB pieces (8 full lines)
+//   MODE 2: plain global_load_dwordx4, lanes contiguous, 4 loads in flight per wave (data to VGPRs)
+//   MODE 3: MODE 1 and MODE 2 together: per step a wave issues 2 DMA pieces AND 4 plain loads
+template <int MODE, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_l2rate(const char *__restrict__ buf, int steps, int *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned ring = lds_addr(smem) + wq * 4096;  // 2 slots x 2 KB per wave
+    const f4 *pf = reinterpret_cast<const f4 *>(buf) + tid;
+    float acc = 0.f;
+    unsigned voffc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) voffc[q] = (unsigned)((wq * 2 + q) * 16 + (lane >> 2)) * 2048u + ((lane & 3) << 4);
+    const unsigned voffl = lane * 16 + wq * 2048;
+    for (int s = 0; s < steps; ++s) {
+        const unsigned off = (unsigned)(s & 31) * 65536u;  // walk 2 MB
+        if (MODE == 0) {
+            dma16<false>(buf + (s & 31) * 64, voffc[0], ring + (s & 1) * 2048);
+            dma16<false>(buf + (s & 31) * 64, voffc[1], ring + (s & 1) * 2048 + 1024);
+            wait_vm<2>();
+        } else if (MODE == 1) {
+            dma16<false>(buf + off, voffl, ring + (s & 1) * 2048);
+            dma16<false>(buf + off, voffl + 1024, ring + (s & 1) * 2048 + 1024);
+            wait_vm<2>();
+        } else if (MODE == 2) {
+            f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = pf[(off >> 4) + u * NWAVES * 64];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+        } else {
+            f4 v[4];
+            dma16<false>(buf + off, voffl, ring + (s & 1) * 2048);
+            dma16<false>(buf + off, voffl + 1024, ring + (s & 1) * 2048 + 1024);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = pf[((off + 1048576u) >> 4) + u * NWAVES * 64];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+        }
+    }
+    wait_vm<0>();
+    if (acc == 1.2345e-30f || tid == 0x7fffffff) sink[0] = smem[tid & 1023];
+}
+
 static float run(const char *name, int lds, int grid, void (*launch)(int grid, int lds), double bytes, int reps = 7)
 {
     hipEvent_t e0, e1;
@@ -195,6 +411,57 @@ static int *g_sink;
         run(nm, 0, (int)(g_n / 128), fn, (double)g_n * g_d * 4.0);                                                            \
     }
 
+
+#define MIX_CASE(U, CEN, WR, NT)                                                                                              \
+    {                                                                                                                        \
+        auto fn = [](int grid, int lds) {                                                                                    \
+            hipLaunchKernelGGL((k_mix<U, CEN, WR, NT>), dim3(grid), dim3(256), lds, 0, g_x, g_n, g_d, g_cb, g_sink);          \
+        };                                                                                                                   \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mix<U, CEN, WR, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
+        char nm[96];                                                                                                         \
+        snprintf(nm, sizeof nm, "mix rows->VGPR U=%d %s%s%s", U, NT ? "nt" : "dflt", CEN ? " +centres(L2 DMA)" : "", WR ? " +bf16 ds_write" : ""); \
+        run(nm, 80 * 1024, (int)(g_n / 128), fn, (double)g_n * g_d * 4.0);                                                    \
+    }
+
+
+#define COLS_CASE(S, COLS, LDS)                                                                                              \
+    {                                                                                                                        \
+        auto fn = [](int grid, int lds) {                                                                                    \
+            hipLaunchKernelGGL((k_dma_cols<S, COLS>), dim3(grid), dim3(256), lds, 0, g_x, g_n, g_d, g_sink);                  \
+        };                                                                                                                   \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dma_cols<S, COLS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+        char nm[96];                                                                                                         \
+        snprintf(nm, sizeof nm, "dma S=%d nt bar, stage = %d rows x %d cols", S, 4096 / COLS, COLS);                         \
+        run(nm, LDS, (int)(g_n / (4096 / COLS)), fn, (double)g_n * g_d * 4.0);                                                \
+    }
+
+
+#define X_CASE(SX, SC, CEN)                                                                                                  \
+    {                                                                                                                        \
+        auto fn = [](int grid, int lds) {                                                                                    \
+            hipLaunchKernelGGL((k_dma_x<SX, SC, CEN>), dim3(grid), dim3(512), lds, 0, g_x, g_n, g_d, g_cb, g_sink);           \
+        };                                                                                                                   \
+        constexpr int LDS = SX * 32768 + SC * 16384;                                                                          \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dma_x<SX, SC, CEN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+        char nm[96];                                                                                                         \
+        snprintf(nm, sizeof nm, "X: 512 thr, 256 rows, rows ring %d%s", SX, CEN ? (SC == 2 ? " + centres ring 2" : " + centres ring 3") : ""); \
+        run(nm, LDS, (int)(g_n / 256), fn, (double)g_n * g_d * 4.0);                                                          \
+    }
+
+static char *g_cb2;
+
+#define L2RATE_CASE(MODE, NWAVES, WGPC, BYTES_PER_STEP_PER_WAVE)                                                              \
+    {                                                                                                                        \
+        auto fn = [](int grid, int lds) {                                                                                    \
+            hipLaunchKernelGGL((k_l2rate<MODE, NWAVES>), dim3(grid), dim3(NWAVES * 64), lds, 0, g_cb2, 2048, g_sink);         \
+        };                                                                                                                   \
+        constexpr int LDS = 160 * 1024 / WGPC;                                                                                \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_l2rate<MODE, NWAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+        char nm[96];                                                                                                         \
+        snprintf(nm, sizeof nm, "L2 rate mode %d, %d waves x %d WG/CU", MODE, NWAVES, WGPC);                                  \
+        run(nm, LDS, 256 * WGPC * 4, fn, 256.0 * WGPC * 4 * NWAVES * 2048.0 * BYTES_PER_STEP_PER_WAVE);                       \
+    }
+
 int main(int argc, char **argv)
 {
     g_n = argc > 1 ? atoll(argv[1]) : 1000000;
@@ -239,5 +506,43 @@ int main(int argc, char **argv)
     ROWLANE_CASE(2, true, 1)
     ROWLANE_CASE(4, true, 1)
     ROWLANE_CASE(4, false, 1)
+    CK(hipMalloc(&g_cb2, 4 << 20));
+    CK(hipMemset(g_cb2, 0x3c, 4 << 20));
+    if (argc > 3) {
+        L2RATE_CASE(0, 4, 2, 2048)
+        L2RATE_CASE(1, 4, 2, 2048)
+        L2RATE_CASE(2, 4, 2, 4096)
+        L2RATE_CASE(3, 4, 2, 6144)
+        L2RATE_CASE(0, 8, 1, 2048)
+        L2RATE_CASE(1, 8, 1, 2048)
+        L2RATE_CASE(2, 8, 1, 4096)
+        L2RATE_CASE(3, 8, 1, 6144)
+        L2RATE_CASE(1, 4, 4, 2048)
+        L2RATE_CASE(2, 4, 4, 4096)
+        return 0;
+    }
+    X_CASE(3, 2, false)
+    X_CASE(4, 2, false)
+    X_CASE(3, 2, true)
+    X_CASE(4, 2, true)
+    X_CASE(3, 3, true)
+    COLS_CASE(3, 32, 80 * 1024)
+    COLS_CASE(3, 64, 80 * 1024)
+    COLS_CASE(3, 128, 80 * 1024)
+    COLS_CASE(3, 256, 80 * 1024)
+    COLS_CASE(3, 1024, 80 * 1024)
+    COLS_CASE(4, 64, 64 * 1024)
+    COLS_CASE(4, 128, 64 * 1024)
+    COLS_CASE(4, 256, 64 * 1024)
+    MIX_CASE(2, false, false, true)
+    MIX_CASE(3, false, false, true)
+    MIX_CASE(4, false, false, true)
+    MIX_CASE(4, false, false, false)
+    MIX_CASE(2, true, false, true)
+    MIX_CASE(3, true, false, true)
+    MIX_CASE(4, true, false, true)
+    MIX_CASE(2, true, true, true)
+    MIX_CASE(3, true, true, true)
+    MIX_CASE(4, true, true, true)
     return 0;
 }
