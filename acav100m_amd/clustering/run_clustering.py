@@ -186,23 +186,56 @@ class _RowGroups:
         return io.load_feature_shards(group, model_order=self.model_order, audio_models=self.audio_models)
 
     def __iter__(self):
-        """-> (index, table, {view: device tensor [rows, d]})"""
+        return self.iterate()
+
+    def iterate(self, views=None, shards=None):
+        """-> (index, table, {view: device tensor [rows, d]}).
+
+        views:  the views this rank needs ON THE DEVICE (None: all).  The others come back as zero-width host tensors with
+                the right number of rows -- a rank that trains 1 of 10 clusterings uploads 1 of 10 matrices.
+        shards: only these shard stems (None: all).  Streamed: a group without any of them is skipped WITHOUT being read,
+                and only the wanted shards of a group are unpickled.  Resident: the rows of the wanted shards are gathered
+                on the host and uploaded (N / world rows); `table` stays the full table, and the third item carries
+                '_rows' -> the table row indices the gathered rows correspond to."""
         import torch
         dev = _device(self.args)
+
+        def up(v, m):
+            if views is not None and v not in views:
+                return torch.empty((m.shape[0], 0))
+            return torch.from_numpy(np.ascontiguousarray(m)).to(dev)
+
         if not self.streamed:
             if self._resident is None:
-                table = self._load(self.groups[0])
-                self._resident = (table, OrderedDict((v, torch.from_numpy(m).to(dev)) for v, m in table.views.items()))
-            yield (0,) + self._resident
+                self._resident = (self._load(self.groups[0]), OrderedDict())
+            table, on_dev = self._resident
+            if shards is not None and set(shards) < set(table.shard_rows):
+                idx = np.array(sorted(i for s in shards for i in (table.shard_rows.get(s) or ())), np.int64)
+                rows = OrderedDict((v, up(v, m[idx])) for v, m in table.views.items())
+                rows['_rows'] = idx
+                yield 0, table, rows
+                return
+            rows = OrderedDict()
+            for v, m in table.views.items():
+                if views is not None and v not in views:
+                    rows[v] = torch.empty((m.shape[0], 0))
+                    continue
+                if v not in on_dev:
+                    on_dev[v] = up(v, m)  # stays resident across epochs and the assign sweep
+                rows[v] = on_dev[v]
+            yield 0, table, rows
             return
+        want = None if shards is None else set(shards)
+        todo = [(gi, g if want is None else [p for p in g if p.stem in want]) for gi, g in enumerate(self.groups)]
+        todo = [(gi, g) for gi, g in todo if g]
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=1) as pool:
-            pending = pool.submit(self._load, self.groups[0])
-            for gi in range(len(self.groups)):
+            pending = pool.submit(self._load, todo[0][1]) if todo else None
+            for k, (gi, _g) in enumerate(todo):
                 table = pending.result()
-                if gi + 1 < len(self.groups):
-                    pending = pool.submit(self._load, self.groups[gi + 1])  # host work beside the GPU's
-                yield gi, table, OrderedDict((v, torch.from_numpy(np.ascontiguousarray(m)).to(dev)) for v, m in table.views.items())
+                if k + 1 < len(todo):
+                    pending = pool.submit(self._load, todo[k + 1][1])  # host work beside the GPU's
+                yield gi, table, OrderedDict((v, up(v, m)) for v, m in table.views.items())
 
 
 def _device_budget(args):
@@ -244,7 +277,9 @@ def train_clusters(args, probe, groups):
         gen.u32()
         carry = None  # rows of the previous group that did not fill a batch: the batch stream runs across groups
         last = len(groups.groups) - 1
-        for gi, table, rows in groups:
+        # several GPUs: a rank only trains (hence only uploads) its share of the views -- view i -> rank i % world
+        own = None if w == 1 else {v for i, v in enumerate(cl) if i % w == rank}
+        for gi, table, rows in groups.iterate(views=own):
             if carry is not None:
                 rows = OrderedDict((v, torch.cat([carry[v], rows[v]])) for v in rows)
             n = next(iter(rows.values())).shape[0] if rows else 0
@@ -280,16 +315,25 @@ def assign_clusters(args, groups, cl, shard_names):
     out_dir = Path(args.data.output.path)
     prefix = '' if args.clustering.cached_epoch is None else 'epoch_{}_'.format(args.clustering.cached_epoch)
     print("extracting clustering for views: {}".format([v[1:] for v in cl]))
-    mine = set(shard_names)
+    # this rank's shards that still have to be written (:248-250), decided from the NAMES: a group without any of them
+    # is never read, and only their rows are labelled (every rank sweeping every row would repeat the HBM-bound sweep,
+    # the unpickling and the upload `world` times over)
+    mine = [s for s in shard_names if not (out_dir / (s + '.pkl')).is_file()]
     saved = []
-    for gi, table, rows in groups:
-        todo = [s for s in table.shard_rows if s in mine and not (out_dir / (s + '.pkl')).is_file()]  # :248-250
+    for gi, table, rows in groups.iterate(shards=mine):
+        todo = [s for s in table.shard_rows if s in set(mine)]
         if not todo:
             continue
+        sel = rows.pop('_rows', None)  # resident table, several ranks: the rows of this rank's shards, gathered
         labels = OrderedDict()
         for v, km in cl.items():
             best, _ = km.calc_best(rows[v], need_mean=False)
-            labels[v] = best.cpu().numpy()
+            best = best.cpu().numpy()
+            if sel is not None:  # back into table row order (rows of other ranks' shards: never read)
+                full = np.full(len(table), -1, np.int64)
+                full[sel] = best
+                best = full
+            labels[v] = best
         for shard in todo:
             ids = table.shard_rows.get(shard)
             if not ids:  # unreadable (reported and skipped by the loader) or empty shard: nothing to write
@@ -310,17 +354,24 @@ def assign_clusters(args, groups, cl, shard_names):
 def run_clustering(args):
     paths = [Path(p) for p in sorted(io.brace_expand(args.data.path))]
     sizes = io.shard_sizes_from_meta(paths, args.data.meta.path)
-    if args.data.meta.path is not None:  # side effect of the reference: meta_cache.pkl in the meta dir
+    rank, w = world()
+    if args.data.meta.path is not None and rank == 0:  # side effect of the reference: meta_cache.pkl in the meta dir
         io.dump_pickle(dict(sizes), Path(args.data.meta.path) / 'meta_cache.pkl')
     paths = [p for p in paths if p.stem in sizes]
     if not paths:
         print(f"All shards of {args.data.path} processing already done!")
         return []
     print(f"processing {len(paths)} shards")
-    rank, w = world()
-    # the first shard tells the views and their widths (the order KMeans objects are created in, and the row size)
-    probe = io.load_feature_shards(paths[:1], model_order=list(args.models or []),
-                                   audio_models=tuple(args.model_types.audio or ()))
+    # the first shard THAT LOADS tells the views and their widths (the order KMeans objects are created in, and the row
+    # size): the loader reports and skips an unreadable shard, and an empty probe would create no clustering at all
+    for first in paths:
+        probe = io.load_feature_shards([first], model_order=list(args.models or []),
+                                       audio_models=tuple(args.model_types.audio or ()))
+        if probe.views:
+            break
+    else:
+        print(f"None of the {len(paths)} shards of {args.data.path} could be read")
+        return []
     row_bytes = 4 * sum(m.shape[1] for m in probe.views.values())
     groups = _RowGroups(args, paths, sizes, row_bytes, _device_budget(args))
     cl = train_clusters(args, probe, groups)

@@ -370,7 +370,8 @@ class KMeans:
         _lib.check(_lib._lib.acav_kmeans_train_multi(h_arr, cnt, x_arr, _lib.ptr(n_arr), int(batch_size), float(lr), w_arr,
                                                      _lib.ptr(nw_arr)))
 
-    def train_epoch_distributed(self, x_local, batch_size, lr=None, chunk_steps=1024, train_here=True, comm_slot=0, wait=True):
+    def train_epoch_distributed(self, x_local, batch_size, lr=None, chunk_steps=1024, train_here=True, comm_slot=0, wait=True,
+                                trainer=None):
         """One epoch of the reference's multi-GPU add() loop (global batch = world * batch_size rows, rank-major)
         without a collective per step: see acav100m_amd/parallel/kmeans_dp.py:train_epoch_dp."""
         lr = self.lr if lr is None else lr
@@ -379,7 +380,7 @@ class KMeans:
         if comm is None:  # gloo / host tensors (CPU tests): the same schedule through torch.distributed
             from ..parallel import train_epoch_dp
             return train_epoch_dp(self, x_local, int(batch_size), lr, chunk_steps=chunk_steps)
-        self.train_epoch_comm(comm, x_local, int(batch_size), lr, chunk_steps, train_here, wait)
+        self.train_epoch_comm(comm, x_local, int(batch_size), lr, chunk_steps, train_here, wait, trainer)
 
     @staticmethod
     def train_epoch_distributed_multi(clusterings, xs_local, batch_size, lr=None, chunk_steps=1024, trainers=None):
@@ -432,7 +433,8 @@ class KMeans:
         x_arr = (C.c_void_p * cnt)(*ptrs)
         w_arr = (C.c_void_p * cnt)(*warms)
         nw_arr = np.asarray(needs, np.int64)
-        here = np.asarray([1 if t == rank else 0 for t in trainers], np.int32)
+        # ACAV_DP_TRAIN | ACAV_DP_ROOTED | root << 8: the rows of clustering v are sent to rank trainers[v] only
+        here = np.asarray([(1 if t == rank else 0) | 4 | (t << 8) for t in trainers], np.int32)
         _lib.check(_lib._lib.acav_kmeans_train_dp_multi(h_arr, c_arr, cnt, x_arr, int(n_local), int(batch_size), float(lr), w_arr,
                                                         _lib.ptr(nw_arr), int(chunk_steps), _lib.ptr(here)))
         return trainers
@@ -446,9 +448,11 @@ class KMeans:
             return broadcast_state(self, int(root))
         _lib.check(_lib._lib.acav_kmeans_broadcast_state(self._require_handle(), comm._h, int(root)))
 
-    def train_epoch_comm(self, comm, x_local, b_local, lr, chunk_steps=1024, train_here=True, wait=True):
+    def train_epoch_comm(self, comm, x_local, b_local, lr, chunk_steps=1024, train_here=True, wait=True, trainer=None):
         """acav_kmeans_train_dp: the DDP epoch with the bulk row exchange through RCCL inside the library -- no torch
-        op between the collective and the SGD chain.  Only the warm-up labels (drawn per rank) are exchanged here, once."""
+        op between the collective and the SGD chain.  Only the warm-up labels (drawn per rank) are exchanged here, once.
+        trainer: the ONE rank that runs the chain (every rank passes the same number, train_here == (rank == trainer)):
+        the rows are sent to it instead of all-gathered."""
         import torch
         keep, xp, n_local, on_gpu = _as_f32_2d(x_local, self._shape[1])
         w = comm.world
@@ -468,7 +472,8 @@ class KMeans:
                 warm = np.ascontiguousarray(mine)
         _lib.check(_lib._lib.acav_kmeans_train_dp(self._require_handle(), comm._h, xp, n_local, int(b_local), float(lr),
                                                   _lib.ptr(warm) if need else None, need, int(chunk_steps),
-                                                  (1 if train_here else 0) | (0 if wait else 2)))
+                                                  (1 if train_here else 0) | (0 if wait else 2) |
+                                                  (0 if trainer is None else 4 | (int(trainer) << 8))))  # ACAV_DP_ROOTED
 
     # ------------------------------------------------- state exchange (parallel/kmeans_dp.py:broadcast_state)
     def state_arrays(self):

@@ -28,6 +28,11 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    bool p2p = false;  // Send / Recv / Group* resolved: rows can be gathered to the one rank that consumes them
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -56,8 +61,13 @@ Rccl &rccl()
     ACAV_SYM(AllGather, "ncclAllGather");
     ACAV_SYM(Broadcast, "ncclBroadcast");
     ACAV_SYM(GetErrorString, "ncclGetErrorString");
+    ACAV_SYM(Send, "ncclSend");
+    ACAV_SYM(Recv, "ncclRecv");
+    ACAV_SYM(GroupStart, "ncclGroupStart");
+    ACAV_SYM(GroupEnd, "ncclGroupEnd");
 #undef ACAV_SYM
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.AllGather && r.Broadcast;
+    r.p2p = r.Send && r.Recv && r.GroupStart && r.GroupEnd;
     return r;
 }
 
@@ -83,6 +93,29 @@ __global__ __launch_bounds__(256) void k_interleave_rows(const float4 *__restric
         const int rank = (int)(r % world), t = (int)(r / world);
         out[i] = in[(((int64_t)rank * steps + t) * bl + row) * d4 + c];
     }
+}
+
+// The rows of a chunk reach the rank(s) that consume them: with a known trainer (`root` >= 0) every rank SENDS its rows
+// to it and only it receives (one grouped send / receive round: (W-1)/W of the all-gather's bytes arrive at ONE rank
+// instead of at every rank -- at W = 8 an eighth of the xGMI traffic); root < 0: every rank trains, all-gather.
+static int rows_to_trainers(const Rccl &R, const void *send, void *recv, size_t bytes, int root, int rank, int world,
+                            ncclComm_t comm, hipStream_t st)
+{
+    if (root >= world) return ACAV_OK;  // the trainer is outside this communicator (single-rank tests): nothing to move
+    if (root < 0 || !R.p2p) {
+        ACAV_NCCL_TRY(R.AllGather(send, recv, bytes, ncclInt8, comm, st));
+        return ACAV_OK;
+    }
+    ACAV_NCCL_TRY(R.GroupStart());
+    ncclResult_t r1 = R.Send(send, bytes, ncclInt8, root, comm, st), r2 = ncclSuccess;
+    if (rank == root)
+        for (int r = 0; r < world && r2 == ncclSuccess; ++r)
+            r2 = R.Recv(static_cast<char *>(recv) + (size_t)r * bytes, bytes, ncclInt8, r, comm, st);
+    ncclResult_t r3 = R.GroupEnd();
+    ACAV_NCCL_TRY(r1);
+    ACAV_NCCL_TRY(r2);
+    ACAV_NCCL_TRY(r3);
+    return ACAV_OK;
 }
 
 __global__ void k_scale_f32(float *__restrict__ v, int64_t n, float s)
@@ -240,6 +273,9 @@ ACAV_EXPORT int acav_kmeans_train_dp(acav_kmeans *km, acav_comm *c, const float 
                                      double lr, const int64_t *warm_global, int64_t n_warm, int64_t chunk_steps, int flags)
 {
     const bool train_here = (flags & 1) != 0, nowait = (flags & 2) != 0;
+    const int root = (flags & 4) ? (flags >> 8) : -1;  // ACAV_DP_ROOTED: the one rank that trains (the same on every rank)
+    ACAV_REQUIRE(root < 0 || (c && train_here == (c->rank == root)), ACAV_EINVAL,
+                 "ACAV_DP_ROOTED: root %d does not match ACAV_DP_TRAIN on rank %d", root, c ? c->rank : -1);
     ACAV_REQUIRE(km && c && (x_local_dev || n_local == 0), ACAV_EINVAL, "NULL argument");
     ACAV_REQUIRE(n_local >= 0 && b_local > 0 && chunk_steps > 0 && n_warm >= 0, ACAV_EINVAL, "bad sizes");
     int K = 0, d = 0;
@@ -255,16 +291,16 @@ ACAV_EXPORT int acav_kmeans_train_dp(acav_kmeans *km, acav_comm *c, const float 
     void *st_train = nullptr;
     ACAV_TRY(acav_kmeans_stream(km, &st_train));
     const size_t chunk_bytes = sizeof(float) * (size_t)chunk_steps * (size_t)bg * (size_t)d;
-    for (int q = 0; q < 2; ++q) {
-        ACAV_TRY(c->gather[q].ensure(chunk_bytes));
-        ACAV_TRY(c->batches[q].ensure(chunk_bytes));
+    for (int q = 0; q < 2; ++q) {  // a rank that only sends needs no landing buffers
+        if (train_here || root < 0 || !rccl().p2p) ACAV_TRY(c->gather[q].ensure(chunk_bytes));
+        if (train_here) ACAV_TRY(c->batches[q].ensure(chunk_bytes));
     }
     int64_t warm_done = 0;
     auto gather = [&](int64_t c0, int par) -> int {  // rows of steps [c0, c0 + s) of every rank -> batches[par]
         const int64_t s = steps - c0 < chunk_steps ? steps - c0 : chunk_steps;
         const size_t bytes = sizeof(float) * (size_t)s * (size_t)b_local * (size_t)d;
         if (train_here) ACAV_HIP_TRY(hipStreamWaitEvent(sc, c->ev_trained[par], 0));  // the chunk trained from this buffer is done
-        ACAV_NCCL_TRY(rccl().AllGather(x_local_dev + (size_t)c0 * b_local * d, c->gather[par].p, bytes, ncclInt8, c->comm, sc));
+        ACAV_TRY(rows_to_trainers(rccl(), x_local_dev + (size_t)c0 * b_local * d, c->gather[par].p, bytes, root, c->rank, w, c->comm, sc));
         if (train_here) {
             const int64_t total4 = (int64_t)w * s * b_local * (d / 4);
             const unsigned grid = (unsigned)(total4 / 256 + 1 < 4096 ? total4 / 256 + 1 : 4096);
@@ -310,13 +346,19 @@ ACAV_EXPORT int acav_kmeans_train_dp_multi(acav_kmeans *const *kms, acav_comm *c
     ACAV_REQUIRE(n_local >= 0 && b_local > 0 && chunk_steps > 0, ACAV_EINVAL, "bad sizes");
     const int64_t steps = n_local / b_local;
     if (steps == 0) return ACAV_OK;
-    std::vector<int> dv((size_t)count, 0);
+    std::vector<int> dv((size_t)count, 0), here((size_t)count, 0), roots((size_t)count, -1);
     std::vector<void *> st_train((size_t)count, nullptr);
+    for (int v = 0; v < count; ++v) {  // train_here[v]: ACAV_DP_TRAIN | ACAV_DP_ROOTED | root << 8 (as `flags` of train_dp)
+        here[(size_t)v] = (train_here[v] & 1) != 0;
+        roots[(size_t)v] = (train_here[v] & 4) ? (train_here[v] >> 8) : -1;
+    }
     const int w = comms[0] ? comms[0]->world : 1;
     const int64_t bg = (int64_t)w * b_local;
     for (int v = 0; v < count; ++v) {
         ACAV_REQUIRE(kms[v] && comms[v] && x_local_dev[v], ACAV_EINVAL, "clustering %d: NULL argument", v);
         ACAV_REQUIRE(comms[v]->world == w, ACAV_EINVAL, "communicators of different sizes");
+        ACAV_REQUIRE(roots[(size_t)v] < 0 || here[(size_t)v] == (comms[v]->rank == roots[(size_t)v]), ACAV_EINVAL,
+                     "clustering %d: ACAV_DP_ROOTED root %d does not match ACAV_DP_TRAIN on rank %d", v, roots[(size_t)v], comms[v]->rank);
         ACAV_REQUIRE(is_device_ptr(x_local_dev[v]), ACAV_EINVAL, "x_local must be device memory");
         ACAV_REQUIRE(!n_warm || n_warm[v] == 0 || (warm_global && warm_global[v]), ACAV_EINVAL, "clustering %d: warm-up labels missing", v);
         for (int e = 0; e < v; ++e) ACAV_REQUIRE(comms[e] != comms[v] && kms[e] != kms[v], ACAV_EINVAL, "one communicator and one handle per clustering");
@@ -326,9 +368,9 @@ ACAV_EXPORT int acav_kmeans_train_dp_multi(acav_kmeans *const *kms, acav_comm *c
         ACAV_TRY(acav_kmeans_stream(kms[v], &st_train[(size_t)v]));
         const size_t chunk_bytes = sizeof(float) * (size_t)chunk_steps * (size_t)bg * (size_t)dv[(size_t)v];
         ACAV_HIP_TRY(hipSetDevice(comms[v]->ctx.device));
-        for (int q = 0; q < 2; ++q) {
-            ACAV_TRY(comms[v]->gather[q].ensure(chunk_bytes));
-            if (train_here[v]) ACAV_TRY(comms[v]->batches[q].ensure(chunk_bytes));
+        for (int q = 0; q < 2; ++q) {  // a rank that only sends needs no landing buffers
+            if (here[(size_t)v] || roots[(size_t)v] < 0 || !rccl().p2p) ACAV_TRY(comms[v]->gather[q].ensure(chunk_bytes));
+            if (here[(size_t)v]) ACAV_TRY(comms[v]->batches[q].ensure(chunk_bytes));
         }
     }
     auto gather = [&](int v, int64_t c0, int par) -> int {  // rows of steps [c0, c0 + s) of every rank -> batches[par] of clustering v
@@ -337,9 +379,9 @@ ACAV_EXPORT int acav_kmeans_train_dp_multi(acav_kmeans *const *kms, acav_comm *c
         hipStream_t sc = c->ctx.stream;
         const int64_t s = steps - c0 < chunk_steps ? steps - c0 : chunk_steps;
         const size_t bytes = sizeof(float) * (size_t)s * (size_t)b_local * (size_t)d;
-        if (train_here[v]) ACAV_HIP_TRY(hipStreamWaitEvent(sc, c->ev_trained[par], 0));  // the chunk trained from this buffer is done
-        ACAV_NCCL_TRY(rccl().AllGather(x_local_dev[v] + (size_t)c0 * b_local * d, c->gather[par].p, bytes, ncclInt8, c->comm, sc));
-        if (train_here[v]) {
+        if (here[(size_t)v]) ACAV_HIP_TRY(hipStreamWaitEvent(sc, c->ev_trained[par], 0));  // the chunk trained from this buffer is done
+        ACAV_TRY(rows_to_trainers(rccl(), x_local_dev[v] + (size_t)c0 * b_local * d, c->gather[par].p, bytes, roots[(size_t)v], c->rank, w, c->comm, sc));
+        if (here[(size_t)v]) {
             const int64_t total4 = (int64_t)w * s * b_local * (d / 4);
             const unsigned grid = (unsigned)(total4 / 256 + 1 < 4096 ? total4 / 256 + 1 : 4096);
             hipLaunchKernelGGL(k_interleave_rows, dim3(grid), dim3(256), 0, sc, c->gather[par].as<float4>(),
@@ -350,7 +392,7 @@ ACAV_EXPORT int acav_kmeans_train_dp_multi(acav_kmeans *const *kms, acav_comm *c
         return ACAV_OK;
     };
     for (int v = 0; v < count; ++v) {
-        if (train_here[v])
+        if (here[(size_t)v])
             for (int q = 0; q < 2; ++q) ACAV_HIP_TRY(hipEventRecord(comms[v]->ev_trained[q], (hipStream_t)st_train[(size_t)v]));  // both buffers free
         ACAV_TRY(gather(v, 0, 0));
     }
@@ -366,7 +408,7 @@ ACAV_EXPORT int acav_kmeans_train_dp_multi(acav_kmeans *const *kms, acav_comm *c
             for (int v = 0; v < count; ++v) ACAV_TRY(gather(v, c0 + s, par ^ 1));  // next chunk travels while this one trains
         lk.clear(), lx.clear(), ln.clear(), lnw.clear(), lw.clear();
         for (int v = 0; v < count; ++v) {
-            if (!train_here[v]) continue;
+            if (!here[(size_t)v]) continue;
             ACAV_HIP_TRY(hipStreamWaitEvent((hipStream_t)st_train[(size_t)v], comms[v]->ev_gathered[par], 0));
             int64_t nw = (n_warm ? n_warm[v] : 0) - warm_done[(size_t)v];
             nw = nw < 0 ? 0 : (nw > s ? s : nw);
@@ -380,7 +422,7 @@ ACAV_EXPORT int acav_kmeans_train_dp_multi(acav_kmeans *const *kms, acav_comm *c
         if (!lk.empty()) {
             ACAV_TRY(acav_kmeans_train_multi(lk.data(), (int)lk.size(), lx.data(), ln.data(), bg, lr, lw.data(), lnw.data()));
             for (int v = 0; v < count; ++v)
-                if (train_here[v]) ACAV_HIP_TRY(hipEventRecord(comms[v]->ev_trained[par], (hipStream_t)st_train[(size_t)v]));
+                if (here[(size_t)v]) ACAV_HIP_TRY(hipEventRecord(comms[v]->ev_trained[par], (hipStream_t)st_train[(size_t)v]));
         }
     }
     for (int v = 0; v < count; ++v) {

@@ -41,13 +41,38 @@ class Comm:
         import torch.distributed as dist
         rank, w = world()
         device = torch.cuda.current_device() if device is None else device
-        ident = cls.unique_id() if rank == 0 else np.zeros(128, np.uint8)
+        # Every rank must take the SAME route (acav_comm or the torch.distributed fallback), or the next collectives do
+        # not match and the run hangs: the id travels with a status byte (rank 0 could not create it -> everybody raises),
+        # and the outcome of the init is agreed on with one MIN all-reduce before anybody uses the communicator.
+        msg = np.zeros(129, np.uint8)
+        err = None
+        if rank == 0:
+            try:
+                msg[1:] = cls.unique_id()
+                msg[0] = 1
+            except _lib.AcavError as exc:
+                err = exc
         if w > 1:
             on = torch.device("cuda", device) if dist.get_backend() == "nccl" else torch.device("cpu")
-            t = torch.from_numpy(ident).to(on)
+            t = torch.from_numpy(msg).to(on)
             dist.broadcast(t, 0)
-            ident = t.cpu().numpy()
-        return cls(rank, w, ident, device)
+            msg = t.cpu().numpy()
+        if msg[0] != 1:
+            raise err if err is not None else _lib.AcavError("rank 0 could not create the RCCL id")
+        comm, err = None, None
+        try:
+            comm = cls(rank, w, msg[1:].copy(), device)
+        except _lib.AcavError as exc:
+            err = exc
+        if w > 1:
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=on)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                comm = None  # dropped here: __del__ releases a handle that other ranks could not match
+                raise err if err is not None else _lib.AcavError("acav_comm_init failed on another rank")
+        elif comm is None:
+            raise err
+        return comm
 
     # thin wrappers over device tensors (anything with data_ptr())
     def allreduce_(self, t):
@@ -79,7 +104,7 @@ def default_comm(slot=0):
             return None
         try:
             _default[slot] = Comm.from_process_group()
-        except _lib.AcavError as exc:  # e.g. librccl not loadable: every rank fails alike and takes the torch.distributed route
+        except _lib.AcavError as exc:  # e.g. librccl not loadable: from_process_group makes every rank fail alike -> torch.distributed route
             import warnings
             warnings.warn(f"acav_comm unavailable ({exc}); the collectives of this run go through torch.distributed")
             _default[slot] = None

@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--n", "--rows", dest="n", type=int, default=1_000_000)  # --rows: torchrun's own parser trips over "--n"
     ap.add_argument("--d", type=int, default=1024)
     ap.add_argument("--k", type=int, default=256)
     ap.add_argument("--batch", type=int, default=32)

@@ -4,6 +4,8 @@ all_gather of rows + labels on device tensors, apply_update on the gathered batc
 executed on a real GPU here.  With world = 1 the result must equal the plain add()."""
 import os
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 import numpy as np
 import pytest
 
@@ -167,6 +169,10 @@ def test_comm_c_abi_world1():
     km.broadcast_state_from(0, comm_slot=1)
     ref.train_epoch(x, b, 0.01)
     assert np.array_equal(km.centers.numpy(), ref.centers) and km.count == ref.count
+    # the rows SENT to the one trainer (ACAV_DP_ROOTED: grouped ncclSend / ncclRecv instead of the all-gather)
+    km.train_epoch_comm(comm, xt, b, 0.01, chunk_steps=16, train_here=True, trainer=0)
+    ref.train_epoch(x, b, 0.01)
+    assert np.array_equal(km.centers.numpy(), ref.centers) and km.count == ref.count
     # a rank that only takes part in the row exchange (train_here = 0) leaves its state alone
     before = (km.centers.numpy().copy(), km.count)
     km.train_epoch_comm(comm, xt, b, 0.01, chunk_steps=16, train_here=False)
@@ -193,3 +199,33 @@ def test_comm_c_abi_world1():
     before = (kb.centers.numpy().copy(), kb.count, ka.count)
     KMeans.train_epoch_distributed_multi([ka, kb], [xt, x2t], b, lr=0.01, chunk_steps=16, trainers=[0, 1])
     assert np.array_equal(kb.centers.numpy(), before[0]) and kb.count == before[1] and ka.count == before[2] + steps * b
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path end to end, launched the way the driver launches it (torch.distributed.run, one process per
+    rank) with two ranks sharing the one GPU of this box (ACAV_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device):
+    DDP training epochs with the bulk row exchange, the state hand-out, per-rank assign and selection, the MAX-over-ranks
+    timing and ONE JSON line from rank 0."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ACAV_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--rows", "65536", "--no-cpu-baseline", "--no-variants"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["scaling"] == "weak" and out["unit"] == "clips/s"
+    assert out["config"]["global_batch"] == 64 and out["config"]["rows_per_gpu"] == 65536
+    assert out["value"] > 0 and abs(out["value"] - 2 * 65536 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["rows"] == 65536
