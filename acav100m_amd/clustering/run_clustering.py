@@ -156,10 +156,17 @@ class _RowGroups:
     when everything fits there is ONE group and its device tensors stay resident across epochs and the assign sweep.
     Nothing holds [N, d] for all N unless N fits."""
 
-    def __init__(self, args, paths, sizes, row_bytes, budget):
+    def __init__(self, args, paths, sizes, row_bytes, budget, view_dims=None):
+        import os
         self.args = args
         self.model_order = list(args.models or [])
         self.audio_models = tuple(args.model_types.audio or ())
+        # the reference's `computation.num_workers` DataLoader workers (default 40) -> shard-reading worker processes
+        # (shards.py: straight into shared memory); ACAV_LOAD_WORKERS overrides, 0 / 1 = read in this process
+        nw = os.environ.get('ACAV_LOAD_WORKERS')
+        nw = int(nw) if nw is not None else int(args.computation.num_workers or 0)
+        self.workers = max(0, min(nw, os.cpu_count() or 1))
+        self.sizes, self.view_dims = sizes, view_dims
         total = sum(sizes[p.stem] for p in paths) * row_bytes
         if total <= budget:
             self.groups = [list(paths)]
@@ -177,13 +184,15 @@ class _RowGroups:
             print("streaming {} shards in {} groups (device budget {:.1f} MB, data {:.1f} MB)".format(
                 len(paths), len(self.groups), budget / 1e6, total / 1e6))
         self._resident = None
+        self.t_wait = self.t_upload = 0.0  # main-thread seconds waiting for the loader / copying host -> device (tools/bench_streamed.py)
 
     @property
     def streamed(self):
         return len(self.groups) > 1
 
     def _load(self, group):
-        return io.load_feature_shards(group, model_order=self.model_order, audio_models=self.audio_models)
+        return io.load_feature_shards(group, model_order=self.model_order, audio_models=self.audio_models,
+                                      workers=self.workers, expect_rows=self.sizes, expect_views=self.view_dims)
 
     def __iter__(self):
         return self.iterate()
@@ -203,7 +212,11 @@ class _RowGroups:
         def up(v, m):
             if views is not None and v not in views:
                 return torch.empty((m.shape[0], 0))
-            return torch.from_numpy(np.ascontiguousarray(m)).to(dev)
+            import time
+            t0 = time.perf_counter()
+            t = torch.from_numpy(np.ascontiguousarray(m)).to(dev)
+            self.t_upload += time.perf_counter() - t0
+            return t
 
         if not self.streamed:
             if self._resident is None:
@@ -232,7 +245,10 @@ class _RowGroups:
         with ThreadPoolExecutor(max_workers=1) as pool:
             pending = pool.submit(self._load, todo[0][1]) if todo else None
             for k, (gi, _g) in enumerate(todo):
+                import time
+                t0 = time.perf_counter()
                 table = pending.result()
+                self.t_wait += time.perf_counter() - t0
                 if k + 1 < len(todo):
                     pending = pool.submit(self._load, todo[k + 1][1])  # host work beside the GPU's
                 yield gi, table, OrderedDict((v, up(v, m)) for v, m in table.views.items())
@@ -320,6 +336,7 @@ def assign_clusters(args, groups, cl, shard_names):
     # the unpickling and the upload `world` times over)
     mine = [s for s in shard_names if not (out_dir / (s + '.pkl')).is_file()]
     saved = []
+    writer = io.AssignmentWriter(groups.workers if len(mine) >= 16 else 0)
     for gi, table, rows in groups.iterate(shards=mine):
         todo = [s for s in table.shard_rows if s in set(mine)]
         if not todo:
@@ -342,11 +359,10 @@ def assign_clusters(args, groups, cl, shard_names):
             if len(ids) < round(size * args.data.output.shard_ok_ratio):
                 continue  # too incomplete to save (:261-268)
             out_path = out_dir / (prefix + shard + '.pkl')
-            out_rows = io.assignment_rows(table, labels, ids)
-            io.dump_pickle(out_rows, out_path)
-            if io.sidecar_mode() == 'write':  # columnar twin for our own subset-selection loader (opt-in: extra files)
-                io.write_assignment_sidecar(out_path, out_rows)
+            # (sidecar: columnar twin for our own subset-selection loader, opt-in: extra files)
+            writer.submit(table, labels, ids, out_path, sidecar=io.sidecar_mode() == 'write')
             saved.append(out_path)
+    writer.finish()
     order = {s: i for i, s in enumerate(shard_names)}
     return sorted(saved, key=lambda p: order.get(p.name[len(prefix):-4], 0))
 
@@ -373,7 +389,8 @@ def run_clustering(args):
         print(f"None of the {len(paths)} shards of {args.data.path} could be read")
         return []
     row_bytes = 4 * sum(m.shape[1] for m in probe.views.values())
-    groups = _RowGroups(args, paths, sizes, row_bytes, _device_budget(args))
+    view_dims = OrderedDict((v, m.shape[1]) for v, m in probe.views.items())
+    groups = _RowGroups(args, paths, sizes, row_bytes, _device_budget(args), view_dims)
     cl = train_clusters(args, probe, groups)
     mine = [p.stem for p in paths][rank::w]  # assign: shards strided over ranks (mps/distributed.py:439)
     return assign_clusters(args, groups, cl, mine)

@@ -210,12 +210,186 @@ def read_feature_sidecar(path):
         return None
 
 
-def load_feature_shards(paths, model_order=None, audio_models=(), sidecar=None):
+# ---- parallel shard loading (the reference spreads its shard reading over `computation.num_workers` DataLoader workers,
+# clustering/code/data/clustering.py:17-66).  Unpickling a shard is ~45 us per row and view of pure Python: one loader thread
+# delivers 58 k rows/s against 2-4 M rows/s of GPU training per epoch (profiles/r03_streamed.txt).  Worker PROCESSES read
+# the shards and write their rows straight into ONE shared-memory matrix per view -- the table the parent hands to the GPU
+# upload -- and send back only the per-row metadata; nothing is pickled, piped or concatenated in the parent.
+_POOL = None
+
+
+def _pool(workers):
+    global _POOL
+    if _POOL is None or _POOL[0] < workers:
+        import atexit
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        if _POOL is not None:
+            _POOL[1].shutdown(wait=False)
+        ex = ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context('spawn'))  # never fork a process that holds a GPU
+        atexit.register(ex.shutdown, wait=False)
+        _POOL = (workers, ex)
+    return _POOL[1]
+
+
+def _worker_load(job):
+    """(path, mode, row offset, expected rows, [(view, d, shm name, total rows)]) -> per-row metadata, or a reason string"""
+    from multiprocessing import shared_memory
+    path, mode, base, n_expect, views = job
+    path = Path(path)
+    columns = read_feature_sidecar(path) if mode != 'off' else None
+    if columns is None:
+        try:
+            rows = load_pickle(path)
+        except Exception as exc:
+            return 'unreadable: {}'.format(exc)
+        columns = _shard_columns_from_rows(rows, path.stem)
+        if mode == 'write':
+            try:
+                write_feature_sidecar(path, columns)
+            except OSError:
+                pass
+    n = len(columns['filename'])
+    if n != n_expect or {v for v, _, _, _ in views} != {tuple(v) for v in columns['views']}:
+        return 'layout'
+    for view, d, name, total in views:
+        mat = columns['views'][tuple(view)]
+        if mat.shape != (n, d):
+            return 'layout'
+        shm = shared_memory.SharedMemory(name=name)
+        try:
+            np.ndarray((total, d), np.float32, buffer=shm.buf)[base:base + n] = mat
+        finally:
+            shm.close()
+    return {'filename': list(columns['filename']), 'shard_name': list(columns['shard_name']),
+            'shard_size': list(columns['shard_size']), 'tags': list(columns['tags'].items())}
+
+
+class _ShmCache:
+    """Shared-memory blocks are REUSED from one row group to the next: a fresh block costs a page fault per 4 KB when the
+    workers first write it (0.3 s per GB -- more than the unpickling it carries), and a reused block can stay registered
+    with the GPU runtime (pinned: the upload runs at the link rate instead of the pageable-copy rate)."""
+
+    def __init__(self, keep=8):
+        self.free, self.keep, self.pinned = [], keep, {}
+
+    def acquire(self, size):
+        from multiprocessing import shared_memory
+        best = None
+        for b in self.free:
+            if b.size >= size and (best is None or b.size < best.size):
+                best = b
+        if best is not None:
+            self.free.remove(best)
+            return best
+        b = shared_memory.SharedMemory(create=True, size=max(size + size // 8, 1))  # slack: groups differ by a shard or two
+        self._pin(b)
+        return b
+
+    def _pin(self, b):
+        if os.environ.get('ACAV_PIN_SHM', '1') == '0':
+            return
+        try:  # only when torch and a GPU are already in the process (the clustering CLI): never imports torch itself
+            import sys
+            torch = sys.modules.get('torch')
+            if torch is None or not torch.cuda.is_available():
+                return
+            import ctypes
+            addr = ctypes.addressof(ctypes.c_char.from_buffer(b.buf))
+            if int(torch.cuda.cudart().cudaHostRegister(addr, b.size, 0)) == 0:
+                self.pinned[b.name] = addr
+        except Exception:
+            pass
+
+    def release(self, blocks):
+        for b in blocks:
+            if len(self.free) < self.keep:
+                self.free.append(b)
+            else:
+                self._drop(b)
+
+    def _drop(self, b):
+        try:
+            addr = self.pinned.pop(b.name, None)
+            if addr is not None:
+                import sys
+                sys.modules['torch'].cuda.cudart().cudaHostUnregister(addr)
+            b.close()
+            b.unlink()
+        except Exception:
+            pass
+
+    def clear(self):
+        for b in self.free:
+            self._drop(b)
+        self.free = []
+
+
+_SHM = _ShmCache()
+import atexit as _atexit  # noqa: E402
+_atexit.register(_SHM.clear)
+
+
+def _load_parallel(paths, mode, expect_rows, expect_views, workers):
+    """-> FeatureTable whose views live in shared memory, or None (a shard did not have the expected layout: the caller
+    reads the group the plain way).  expect_rows: path stem -> rows; expect_views: OrderedDict view -> d."""
+    import weakref
+    paths = [Path(p) for p in paths]
+    try:
+        counts = [int(expect_rows[p.stem]) for p in paths]
+    except KeyError:
+        return None
+    total = sum(counts)
+    if total == 0:
+        return None
+    shms = []
+    try:
+        for view, d in expect_views.items():
+            shms.append(_SHM.acquire(max(total * int(d) * 4, 1)))
+        views = [(tuple(v), int(d), shm.name, total) for (v, d), shm in zip(expect_views.items(), shms)]
+        base, jobs = 0, []
+        for p, n in zip(paths, counts):
+            jobs.append((str(p), mode, base, n, views))
+            base += n
+        results = list(_pool(workers).map(_worker_load, jobs, chunksize=max(1, len(jobs) // (workers * 4))))
+    except Exception as exc:  # no /dev/shm, worker start-up failure ...: the plain path still works
+        print('parallel shard loading unavailable ({}); reading in this process'.format(exc))
+        results = None
+    if results is None or any(not isinstance(r, dict) for r in results):
+        _SHM.release(shms)
+        return None
+    table = FeatureTable()
+    base = 0
+    for p, n, r in zip(paths, counts, results):
+        table.filename.extend(r['filename'])
+        table.shard_name.extend(r['shard_name'])
+        table.shard_size.extend(r['shard_size'])
+        for key, tag in r['tags']:
+            table.tags.setdefault(tuple(key), tuple(tag))
+        table.shard_rows[p.stem] = list(range(base, base + n))
+        base += n
+    for (view, d), shm in zip(expect_views.items(), shms):
+        table.views[view] = np.ndarray((total, int(d)), np.float32, buffer=shm.buf)
+
+    table._shm = shms
+    weakref.finalize(table, _SHM.release, shms)  # back to the cache when the table goes away
+    return table
+
+
+def load_feature_shards(paths, model_order=None, audio_models=(), sidecar=None, workers=0, expect_rows=None, expect_views=None):
     """Read shards in the given order (training order of a single-stream loader: sorted shards,
     rows in file order -- clustering data/clustering.py:153-186 with num_workers=0).
     Corrupt shards are reported and skipped like the reference does (:167-182).
-    sidecar: see sidecar_mode(); a valid columnar twin of a shard replaces its unpickling."""
+    sidecar: see sidecar_mode(); a valid columnar twin of a shard replaces its unpickling.
+    workers > 1 with expect_rows (stem -> rows, from the metadata) and expect_views (view -> d, in table order, from a
+    probe shard): the shards are read by that many worker processes into shared memory (above); any surprise -- a short
+    or unreadable shard, another view set -- falls back to the plain loop below, which reports and skips as ever."""
     mode = sidecar_mode(sidecar)
+    paths = list(paths)
+    if workers and workers > 1 and len(paths) >= 16 and expect_rows is not None and expect_views:  # worker start-up ~1 s
+        table = _load_parallel(paths, mode, expect_rows, expect_views, min(int(workers), len(paths)))
+        if table is not None:
+            return table
     table = FeatureTable()
     parts = OrderedDict()
     for path in paths:
@@ -268,22 +442,64 @@ def _view_rank(view, model_order, audio_models):
 
 def assignment_rows(table, labels, row_ids):
     """labels: {view: int64 [N]} -> the reference's per-row dict schema (clustering save.py:48-74)."""
-    out = []
+    row_ids = list(row_ids)
+    return _assignment_rows_from_columns(
+        [table.filename[r] for r in row_ids], [table.shard_size[r] for r in row_ids], [table.shard_name[r] for r in row_ids],
+        list(table.tags.items()), [(view, np.asarray(lab)[row_ids]) for view, lab in labels.items()])
+
+
+def _assignment_rows_from_columns(filenames, shard_sizes, shard_names, tags, label_columns):
+    """the same from plain columns (what a writer process receives): label_columns = [((kind, mk, layer), int64 [n])]"""
+    tags = {tuple(k): tuple(v) for k, v in tags}
     by_model = OrderedDict()
-    for (kind, mk, layer) in labels:
-        by_model.setdefault((kind, mk), []).append(layer)
-    for r in row_ids:
+    for (kind, mk, layer), col in label_columns:
+        by_model.setdefault((kind, mk), []).append((layer, col))
+    out = []
+    for i in range(len(filenames)):
         row = {'video_assignments': [], 'audio_assignments': []}
         for (kind, mk), layers in by_model.items():
-            name, dataset = table.tags[(kind, mk)]
+            name, dataset = tags[(kind, mk)]
             entry = {'model_key': mk, 'extractor_name': name, 'dataset': dataset,
-                     'array': {layer: np.int64(labels[(kind, mk, layer)][r]) for layer in layers}}
+                     'array': {layer: np.int64(col[i]) for layer, col in layers}}
             row[f'{kind}_assignments'].append(entry)
-        row['filename'] = table.filename[r]
-        row['shard_size'] = table.shard_size[r]
-        row['shard_name'] = table.shard_name[r]
+        row['filename'] = filenames[i]
+        row['shard_size'] = shard_sizes[i]
+        row['shard_name'] = shard_names[i]
         out.append(row)
     return out
+
+
+def _worker_write_assignments(job):
+    out_path, filenames, shard_sizes, shard_names, tags, label_columns, sidecar = job
+    rows = _assignment_rows_from_columns(filenames, shard_sizes, shard_names, tags, label_columns)
+    dump_pickle(rows, out_path)
+    if sidecar:
+        write_assignment_sidecar(out_path, rows)
+    return str(out_path)
+
+
+class AssignmentWriter:
+    """Writes assignment shards ({out}/{shard}.pkl, the reference's per-row dict schema).  Building a million small dicts
+    and pickling them is ~10 us per row of pure Python -- more than the GPU spends on the whole clustering -- so with
+    workers > 1 the shards are written by the loader's worker processes while the caller goes on labelling."""
+
+    def __init__(self, workers=0):
+        self.workers, self.pending = int(workers or 0), []
+
+    def submit(self, table, labels, ids, out_path, sidecar=False):
+        ids = list(ids)
+        job = (str(out_path), [table.filename[r] for r in ids], [table.shard_size[r] for r in ids],
+               [table.shard_name[r] for r in ids], list(table.tags.items()),
+               [(view, np.ascontiguousarray(np.asarray(lab)[ids], np.int64)) for view, lab in labels.items()], bool(sidecar))
+        if self.workers > 1:
+            self.pending.append(_pool(self.workers).submit(_worker_write_assignments, job))
+        else:
+            _worker_write_assignments(job)
+
+    def finish(self):
+        for f in self.pending:
+            f.result()
+        self.pending = []
 
 
 # --------------------------------------------------------------------------- assignment shards

@@ -132,3 +132,29 @@ def test_columnar_sidecars_round_trip(tmp_path, golden_dir, monkeypatch):
     assert len(io.load_assignment_shards(apaths)[2]) == len(ref_a[2]) - 1
     with pytest.raises(ValueError):
         io.sidecar_mode("sometimes")
+
+
+def test_parallel_loader_equals_serial(tmp_path):
+    """shards read by worker processes straight into shared memory (shards.py _load_parallel) == the plain loop: same
+    matrices, same row metadata, same shard -> rows map; a shard with an unexpected size makes the call fall back."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import synth
+    from collections import OrderedDict
+    glob = synth.write_feature_shards(str(tmp_path), n_shards=20, rows=12, seed=3, audio_dims=[8, 16], video_dims=[24])
+    paths = sorted(io.brace_expand(glob))
+    serial = io.load_feature_shards(paths, sidecar="off")
+    sizes = {os.path.basename(p)[:-4]: 12 for p in paths}
+    dims = OrderedDict((v, m.shape[1]) for v, m in serial.views.items())
+    par = io.load_feature_shards(paths, sidecar="off", workers=3, expect_rows=sizes, expect_views=dims)
+    assert getattr(par, "_shm", None), "the parallel path was not taken"
+    assert list(par.views) == list(serial.views) and par.filename == serial.filename
+    assert par.shard_name == serial.shard_name and par.shard_size == serial.shard_size
+    assert par.shard_rows == serial.shard_rows and par.tags == serial.tags
+    for v in serial.views:
+        assert np.array_equal(par.views[v], serial.views[v])
+    sizes[os.path.basename(paths[5])[:-4]] = 11  # metadata and shard disagree: plain loop, same result
+    again = io.load_feature_shards(paths, sidecar="off", workers=3, expect_rows=sizes, expect_views=dims)
+    assert getattr(again, "_shm", None) is None and again.filename == serial.filename
+    for v in serial.views:
+        assert np.array_equal(again.views[v], serial.views[v])

@@ -1,0 +1,157 @@
+"""Throughput of the OUT-OF-CORE clustering path: synthetic feature shards in the reference's pkl
+schema go through acav100m_amd.clustering.run_clustering with a device budget that forces several row groups
+(ACAV_RESIDENT_BYTES), once from the pkl files and once from the columnar sidecars (ACAV_SHARD_SIDECAR).  Reports
+rows/s of the host load (unpickle / mmap), the upload, training and the assign sweep, and how much of the host load
+hides under the GPU work (the loader thread runs one group ahead).
+
+    python tools/bench_streamed.py [rows=1000000] [d=1024] [K=256] [budget_gb=2.0] [root=/tmp/acav_streamed]
+"""
+import os
+import pickle
+import shutil
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+
+def write_shards(root, n, d, k, rows_per_shard=1000, seed=0):
+    import json
+    feat, meta = os.path.join(root, "features"), os.path.join(root, "videos")
+    os.makedirs(feat, exist_ok=True)
+    os.makedirs(meta, exist_ok=True)
+    rs = np.random.RandomState(seed)
+    cen = [rs.randn(k, d).astype(np.float32) for _ in range(2)]
+    t0 = time.perf_counter()
+    for s in range(n // rows_per_shard):
+        comp = rs.randint(0, k, rows_per_shard)
+        a = (cen[0][comp] + 0.3 * rs.randn(rows_per_shard, d)).astype(np.float32)
+        v = (cen[1][comp] + 0.3 * rs.randn(rows_per_shard, d)).astype(np.float32)
+        name = "shard-%06d" % s
+        rows = [{"video_features": [{"model_key": "visual_model", "extractor_name": "V", "dataset": "synthetic",
+                                     "array": {"layer_0": v[i]}}],
+                 "audio_features": [{"model_key": "audio_model", "extractor_name": "A", "dataset": "synthetic",
+                                     "array": {"layer_0": a[i]}}],
+                 "filename": "vid%09d_010.mp4" % (s * rows_per_shard + i), "shard_size": rows_per_shard, "shard_name": name}
+                for i in range(rows_per_shard)]
+        with open(os.path.join(feat, name + ".pkl"), "wb") as f:
+            pickle.dump(rows, f, protocol=4)
+        with open(os.path.join(meta, name + ".json"), "w") as f:
+            json.dump([{"filename": r["filename"], "id": r["filename"][:12], "segment": [10, 20]} for r in rows], f)
+    print("wrote %d shards x %d rows (2 views x %d-d) in %.1f s" % (n // rows_per_shard, rows_per_shard, d, time.perf_counter() - t0), flush=True)
+    return os.path.join(feat, "shard-{000000..%06d}.pkl" % (n // rows_per_shard - 1))
+
+
+def run(glob, out, n, k, label, d=1024):
+    import torch
+    import acav100m_amd
+    from acav100m_amd import shards as io
+    from acav100m_amd.clustering import cli, run_clustering as rc
+    from acav100m_amd.clustering.sgd_clustering import KMeans
+    acc = {"load": 0.0, "upload": 0.0, "train": 0.0, "assign": 0.0, "write": 0.0, "groups": 0}
+    orig_load, orig_multi, orig_best, orig_dump = io.load_feature_shards, KMeans.train_epoch_multi, KMeans.calc_best, io.dump_pickle
+
+    def load(*a, **kw):
+        t0 = time.perf_counter()
+        r = orig_load(*a, **kw)
+        acc["load"] += time.perf_counter() - t0
+        acc["groups"] += 1
+        return r
+
+    def multi(kms, xs, *a, **kw):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = orig_multi(kms, xs, *a, **kw)
+        for km in kms:
+            km.synchronize()
+        acc["train"] += time.perf_counter() - t0
+        return r
+
+    def best(self, x, *a, **kw):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = orig_best(self, x, *a, **kw)
+        torch.cuda.synchronize()
+        acc["assign"] += time.perf_counter() - t0
+        return r
+
+    def dump(obj, path, *a, **kw):
+        t0 = time.perf_counter()
+        r = orig_dump(obj, path, *a, **kw)
+        acc["write"] += time.perf_counter() - t0
+        return r
+
+    orig_finish = io.AssignmentWriter.finish
+
+    def finish(self):
+        t0 = time.perf_counter()
+        orig_finish(self)
+        acc["write"] += time.perf_counter() - t0
+    io.AssignmentWriter.finish = finish
+
+    orig_from = torch.from_numpy
+
+    class _Up:  # time the H2D copies issued by _RowGroups (torch.from_numpy(...).to(dev))
+        pass
+    io.load_feature_shards, KMeans.train_epoch_multi, KMeans.calc_best, io.dump_pickle = load, staticmethod(multi), best, dump
+    rc.io.load_feature_shards = load
+    made = []
+    orig_groups = rc._RowGroups
+
+    class Groups(orig_groups):
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            made.append(self)
+    rc._RowGroups = Groups
+    try:
+        shutil.rmtree(out, ignore_errors=True)
+        acav100m_amd.manual_seed(0)
+        args = cli.get_args(feature_path=glob, out_path=out, meta_path=os.path.join(os.path.dirname(os.path.dirname(glob)), "videos"),
+                            **{"clustering.ncentroids": k, "computation.num_gpus": 1})
+        args.data.output.path.mkdir(parents=True, exist_ok=True)
+        t0 = time.perf_counter()
+        saved = rc.run_clustering(args)
+        wall = time.perf_counter() - t0
+    finally:
+        io.load_feature_shards, KMeans.train_epoch_multi, KMeans.calc_best, io.dump_pickle = orig_load, orig_multi, orig_best, orig_dump
+        rc.io.load_feature_shards = orig_load
+        rc._RowGroups = orig_groups
+        io.AssignmentWriter.finish = orig_finish
+    t_wait, t_up = sum(g.t_wait for g in made), sum(g.t_upload for g in made)
+    passes = 3  # 2 training epochs + the assign pass each read every row once
+    print("%-8s wall %.1f s for %d rows x 2 views (%d shard files written): %.0f rows/s end to end" % (label, wall, n, len(saved), n / wall))
+    print("         loader thread %.1f s over %d group loads = %.0f rows/s per pass, of which the main thread WAITED %.1f s "
+          "(%.0f %% hidden under the other stages); host->device copies %.1f s (%.2f GB/s); GPU train %.2f s (%.0f rows/s per "
+          "epoch); assign sweep %.3f s (%.0f rows/s); assignment pkl writing (main-thread wait) %.1f s; rest (batch carry, python) %.1f s"
+          % (acc["load"], acc["groups"], passes * n / acc["load"], t_wait, 100.0 * (1 - t_wait / max(acc["load"], 1e-9)), t_up,
+             passes * n * 8.0 * d / 1e9 / max(t_up, 1e-9), acc["train"], 2 * n / max(acc["train"], 1e-9), acc["assign"],
+             n / max(acc["assign"], 1e-9), acc["write"], wall - t_wait - t_up - acc["train"] - acc["assign"] - acc["write"]), flush=True)
+    return t_up
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+    d = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    k = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+    budget = float(sys.argv[4]) if len(sys.argv) > 4 else 2.0
+    root = sys.argv[5] if len(sys.argv) > 5 else "/tmp/acav_streamed"
+    shutil.rmtree(root, ignore_errors=True)
+    glob = write_shards(root, n, d, k)
+    os.environ["ACAV_RESIDENT_BYTES"] = str(int(budget * 1e9))
+    print("data %.1f GB of fp32 rows, device budget %.1f GB -> groups of %.1f GB" % (n * d * 8 / 1e9, budget, budget / 2), flush=True)
+    os.environ["ACAV_SHARD_SIDECAR"] = "off"
+    run(glob, os.path.join(root, "out_pkl"), n, k, "pkl", d)
+    os.environ["ACAV_SHARD_SIDECAR"] = "write"   # builds the columnar twins while it reads the pkl files
+    t0 = time.perf_counter()
+    from acav100m_amd import shards as io
+    for p in sorted(io.brace_expand(glob)):
+        io.load_feature_shards([p])
+    print("sidecars written in %.1f s" % (time.perf_counter() - t0), flush=True)
+    os.environ["ACAV_SHARD_SIDECAR"] = "auto"
+    run(glob, os.path.join(root, "out_sidecar"), n, k, "sidecar", d)
+    shutil.rmtree(root, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
