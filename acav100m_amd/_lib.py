@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libacav_hip.so")
+# ACAV_LIB_PATH: another build of the same library (experiment builds with -D knobs, tools/exp/) -- still the HIP path
+LIB_PATH = os.environ.get("ACAV_LIB_PATH") or os.path.join(_HERE, "libacav_hip.so")
 
 vp, i64, i32, f32, f64, u32 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double, C.c_uint32
 pp = C.POINTER(C.c_void_p)
@@ -56,6 +57,7 @@ SIGNATURES = {
     "acav_kmeans_timer_begin": [vp],
     "acav_kmeans_timer_end": [vp, C.POINTER(f32)],
     "acav_kmeans_stats": [vp, C.POINTER(i64), C.POINTER(i64)],
+    "acav_kmeans_train_stats": [vp, C.POINTER(i64), C.POINTER(i64)],
     "acav_kmeans_filter_stats": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
     "acav_kmeans_filter_time": [vp, C.POINTER(f32)],
     "acav_contrastive_create": [pp, i32, i32, i32, i32, vp, vp],

@@ -245,6 +245,12 @@ class KMeans:
         _lib.check(_lib._lib.acav_kmeans_assign(h, xp, b, _lib.ptr(labels), C.byref(mean)))
         return labels, mean.value
 
+    def train_stats(self):
+        """(bulk training calls that ran as one persistent launch, launches that gave up and were re-run per step)"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib._lib.acav_kmeans_train_stats(self._require_handle(), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def filter_stats(self):
         """(filter launches, rows of the last one, rows that needed the exact re-check)"""
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)

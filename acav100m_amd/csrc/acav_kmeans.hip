@@ -2249,6 +2249,392 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
     }
 }
 
+// ---------------------------------------------------------------- k_train_persistent_split
+// The owner-computes epoch for 1024 < d <= 2048 (cfg4's 2048-d visual view; round 3).  K = 1024 centres x 2048 columns are
+// 8 MB: no workgroup count <= 256 holds them in LDS next to whole batch rows, so the COLUMNS are split: workgroup
+// (cg, rg, ch) owns centres [16 cg, 16 cg + 16) x columns [1024 ch, 1024 ch + 1024) (64 KB) and labels rows
+// [16 rg, 16 rg + 16) of every step (one 64 KB row buffer: the rows of step t + 1 are fetched by LDS-DMA as soon as the
+// FMA phase of step t has read the buffer, under the exchange).  K = 1024, b = 32: 64 x 2 x 2 = 256 workgroups, one per CU.
+//   * canonical dot: the fold over 256-column segments is left to right, ((((s0 + s1) + s2) + s3) + s4) + ... -- the ch = 0
+//     workgroup folds its four segments into t0 and hands it to its ch = 1 partner (same cg, rg) as one tagged 8-byte
+//     granule per (centre, row) pair (256 per pair of workgroups and step); the partner adds ITS segments in order and owns
+//     the distances, the argmin over its 16 centres and the label granule of the existing exchange.  Same bits as one chain.
+//   * canonical ||c||^2 (32 interleaved chains over ALL columns, then the fixed tree): after an update the ch = 0 workgroup
+//     runs the chains over its half and hands the 32 partial sums of each touched centre to the partner, which continues
+//     them over its half.  Only ch = 1 needs the norms.
+//   * both halves sweep the label granules and apply the identical update to their columns.
+// Hand-off slots are single (no ring): ch = 0 cannot reach its next publish before it has seen the label granules of the
+// step, which its partner only writes after consuming the slot.  Tags are the step number + 1 (the rings are zeroed
+// before every launch).  Bounded spins + error flag + re-run on the per-step path, as k_train_persistent.
+constexpr int TS_NC = 16;      // centres per workgroup
+constexpr int TS_NR = 16;      // batch rows per workgroup
+constexpr int TS_COLS = 1024;  // columns per workgroup (= TP_DS: the LDS row stride of tp_dma_block / dot_blocks)
+constexpr size_t TS_SMEM = sizeof(float) * (size_t)(2 * 16 * TS_COLS + 2 * TS_NC + 4 * 4 * 64 + 32) + 8 * 32 + 64;
+
+__device__ __forceinline__ unsigned long long ts_granule(float v, unsigned tag)
+{
+    return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+}
+// spin until the slot carries `tag`; false = gave up (another workgroup is not resident / error flag raised)
+__device__ __forceinline__ bool ts_poll(const unsigned long long *slot, unsigned tag, TrainCtl *ctl, float *out)
+{
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned long long g = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(g >> 32) == tag) {
+            *out = __uint_as_float((unsigned)g);
+            return true;
+        }
+        if (spins > TP_SPIN_LIMIT || (spins & 1023) == 1023) {
+            if (spins > TP_SPIN_LIMIT || __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(&ctl->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+}
+
+// Four canonical segment sums at once: the (centre, row) pairs (kk, ii), (kk, ii + 8), (kk + 8, ii), (kk + 8, ii + 8) of one
+// 256-column block -- four independent v_fma chains per lane (a lone chain is latency-bound: 4 cycles per column) fed by two
+// centre and two row chunks per step instead of one of each per chain.  Ascending columns within each chain, as dot_blocks.
+__device__ __forceinline__ void dot_quad(const float *pc, const float *px, int scz, int sxz, float out[4])
+{
+    // chunk tt (4 columns) sits at float offset ((tt ^ s) << 2): 8 per-lane base pointers + compile-time offsets, and the
+    // loads of chunk tt + 1 in flight under the FMAs of chunk tt (as dot_blocks)
+    const float *pcu[8], *pxu[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        pcu[u] = pc + ((u << 2) ^ scz);
+        pxu[u] = px + ((u << 2) ^ sxz);
+    }
+    float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+    float4 cA[2], xA[2], cB[2], xB[2];
+#define TS_LD(Cq, Xq, tt)                                                                       \
+    Cq[0] = *reinterpret_cast<const float4 *>(pcu[(tt) & 7] + (((tt) >> 3) << 5));                \
+    Cq[1] = *reinterpret_cast<const float4 *>(pcu[(tt) & 7] + 8 * TS_COLS + (((tt) >> 3) << 5));  \
+    Xq[0] = *reinterpret_cast<const float4 *>(pxu[(tt) & 7] + (((tt) >> 3) << 5));                \
+    Xq[1] = *reinterpret_cast<const float4 *>(pxu[(tt) & 7] + 8 * TS_COLS + (((tt) >> 3) << 5));
+#define TS_FMA4(e)                                                                                   \
+    a00 = __builtin_fmaf(Cq[0].e, Xq[0].e, a00), a01 = __builtin_fmaf(Cq[0].e, Xq[1].e, a01),       \
+    a10 = __builtin_fmaf(Cq[1].e, Xq[0].e, a10), a11 = __builtin_fmaf(Cq[1].e, Xq[1].e, a11);
+#define TS_FMA(Cq_, Xq_)            \
+    {                               \
+        const float4 *Cq = Cq_, *Xq = Xq_; \
+        TS_FMA4(x) TS_FMA4(y) TS_FMA4(z) TS_FMA4(w) \
+    }
+    TS_LD(cA, xA, 0)
+#pragma unroll
+    for (int tt = 0; tt < 64; tt += 2) {
+        TS_LD(cB, xB, tt + 1)
+        TS_FMA(cA, xA)
+        if (tt + 2 < 64) { TS_LD(cA, xA, tt + 2) }
+        TS_FMA(cB, xB)
+    }
+#undef TS_LD
+#undef TS_FMA4
+#undef TS_FMA
+    out[0] = a00, out[1] = a01, out[2] = a10, out[3] = a11;  // quadrant q = 2 (centre half) + (row half)
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(256) void k_train_persistent_split(
+    const float *__restrict__ x, const float *__restrict__ xn, int b, int d, int K, float *__restrict__ centers,
+    float *__restrict__ cn, float *__restrict__ counts, const float *__restrict__ thr, double lr0, float r,
+    const int64_t *__restrict__ forced, int need, int T, TrainCtl *__restrict__ ctl, StepScalars *__restrict__ sc,
+    unsigned long long *__restrict__ t0ring, unsigned long long *__restrict__ nring)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ts_smem[];
+    float *sC = reinterpret_cast<float *>(ts_smem);   // [16][1024]
+    float *sX = sC + TS_NC * TS_COLS;                  // [16][1024]
+    float *sCn = sX + TS_NR * TS_COLS;                 // [16]
+    float *sCnt = sCn + TS_NC;                         // [16]
+    float *sPart = sCnt + TS_NC;                       // [4 quadrants][4 column blocks][64]
+    unsigned long long *sKey = reinterpret_cast<unsigned long long *>(sPart + 4 * 4 * 64);  // [4][8]
+    int *sBest = reinterpret_cast<int *>(sKey + 32);   // [32]
+    __shared__ int sDead;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kk = lane >> 3, ii = lane & 7;
+    const int cg = blockIdx.x, rg = blockIdx.y, ch = blockIdx.z;
+    const int ncg = gridDim.x;
+    const int pair = cg * gridDim.y + rg;
+    const int kbase = cg * TS_NC, rbase = rg * TS_NR, coff = ch * TS_COLS;
+    const int nck = min(TS_NC, K - kbase), nrv = min(TS_NR, b - rbase);
+    const int nblk = ch == 0 ? 4 : (d - TS_COLS) >> 8;  // 256-column blocks of this half (d % 256 == 0)
+    const bool active = wave < nblk;                    // this wave has a column block (DMA, FMA chains, update)
+    unsigned long long *my_t0 = t0ring + (size_t)pair * 256 + tid;  // slot of (quadrant = wave, lane)
+    unsigned long long *my_nr = nring + (size_t)pair * (TS_NC * 32);
+
+    if (active) {
+        tp_dma_block<false>(sC, centers + coff, kbase, min(8, nck), d, wave, lane);
+        tp_dma_block<false>(sC + 8 * TS_COLS, centers + coff, kbase + (nck > 8 ? 8 : 0), max(min(8, nck - 8), 1), d, wave, lane);
+    }
+    if (tid < TS_NC) {
+        const int k = kbase + (tid < nck ? tid : 0);
+        sCn[tid] = cn[k];
+        sCnt[tid] = counts[k];
+    }
+    if (tid == 0) sDead = 0;
+    auto dma_rows = [&](int t) {
+        const float *src = x + (size_t)t * b * d + coff;
+        tp_dma_block<false>(sX, src, rbase, min(8, nrv), d, wave, lane);
+        tp_dma_block<false>(sX + 8 * TS_COLS, src, rbase + (nrv > 8 ? 8 : 0), max(min(8, nrv - 8), 1), d, wave, lane);
+    };
+    if (need < T && active) dma_rows(need);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ||c||^2 of the centres flagged in pend16: chains over this half (continued from the partner's partial sums when
+    // ch = 1), half-wave per centre, 8 centres per pass; tag: the step the refresh runs in, + 1
+    auto refresh_norms = [&](unsigned pend16, unsigned tag) -> bool {
+        bool ok = true;
+        for (int cp = 0; cp < 2; ++cp) {
+            const unsigned p8 = (pend16 >> (cp * 8)) & 0xFFu;
+            if (!p8) continue;
+            const int c8 = 2 * wave + (lane >> 5), q = lane & 31, c = cp * 8 + c8;
+            const bool mine = (p8 >> c8) & 1u;
+            float p = 0.f;
+            if (mine && ch == 1) ok = ts_poll(my_nr + c * 32 + q, tag, ctl, &p) && ok;
+            if (mine) {
+                const float *base = sC + c * TS_COLS + ((((q >> 2) ^ (c8 & 7))) << 2) + (q & 3);
+                const int nu = nblk * 8;  // 32-column groups of this half
+#pragma unroll 8
+                for (int u = 0; u < nu; ++u) {
+                    const float v = base[u * 32];
+                    p = __builtin_fmaf(v, v, p);
+                }
+            }
+            if (ch == 0) {
+                if (mine) __hip_atomic_store(my_nr + c * 32 + q, ts_granule(p, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                p = p + __shfl_xor(p, 1);
+                p = p + __shfl_xor(p, 2);
+                p = p + __shfl_xor(p, 4);
+                p = p + __shfl_xor(p, 8);
+                p = p + __shfl_xor(p, 16);
+                if (q == 0 && mine) sCn[c] = norm2_from_sumsq(p);
+            }
+        }
+        return ok;
+    };
+
+    unsigned nsync = 0;
+    unsigned pend = 0;  // centres whose ||c||^2 is stale: refreshed under the next step's FMA phase
+#define TS_CLK() (PROF ? (long long)clock64() : 0ll)
+    long long pr[6] = {0, 0, 0, 0, 0, 0};  // ACAV_PROFILE_STEPS: cycles in row wait / FMA+norms / hand-off+keys / sweep / update / step
+    for (int t = 0; t < T; ++t) {
+        const float *xb = x + (size_t)t * b * d;
+        const long long c0 = TS_CLK();
+        long long c4 = c0;
+        if (t < need) {
+            __syncthreads();  // every wave has read the previous step's labels
+            if (tid < b) sBest[tid] = (int)forced[(size_t)t * b + tid];
+            __syncthreads();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my blocks of step t's rows landed (a wave reads only its own block)
+            const unsigned tag = (unsigned)t + 1u;
+            const long long c1 = TS_CLK();
+            // quadrant q of the 16 x 16 (centre, row) pairs: centres 8 (q >> 1) + kk, rows 8 (q & 1) + ii
+            float xn_t = 0.f, thr_t = 0.f;
+            if (ch == 1) {  // in flight under the FMA chains: wave = quadrant in the fold below
+                const int i = (wave & 1) * 8 + ii;
+                xn_t = xn[(size_t)t * b + rbase + (i < nrv ? i : 0)];
+                thr_t = thr[t];
+            }
+            if (active) {
+                float seg[4];
+                dot_quad(sC + kk * TS_COLS + wave * 256, sX + ii * TS_COLS + wave * 256, kk << 2, ii << 2, seg);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sPart[(q * 4 + wave) * 64 + lane] = seg[q];
+            }
+            bool ok = true;
+            if (pend) {  // uniform: the previous update's norm refresh, off the update's critical path
+                ok = refresh_norms(pend, tag);
+                pend = 0;
+            }
+            __syncthreads();  // partial sums in place, sX free
+            const long long c2 = TS_CLK();
+            {
+                const int q = wave;  // this wave folds quadrant q
+                const int c = (q >> 1) * 8 + kk, i = (q & 1) * 8 + ii;
+                float acc = 0.f;
+                if (ch == 0) {
+                    acc = sPart[(q * 4) * 64 + lane];
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) acc = acc + sPart[(q * 4 + w) * 64 + lane];  // canonical left fold
+                    __hip_atomic_store(my_t0, ts_granule(acc, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    ok = ts_poll(my_t0, tag, ctl, &acc) && ok;
+                    for (int w = 0; w < nblk; ++w) acc = acc + sPart[(q * 4 + w) * 64 + lane];  // ... continued over this half
+                    unsigned long long key = ~0ull;
+                    if (c < nck && i < nrv) key = pack_key(dist_epilogue(acc, xn_t, sCn[c], sCnt[c] < thr_t, r), kbase + c);
+                    unsigned long long o = __shfl_xor(key, 8);
+                    key = o < key ? o : key;
+                    o = __shfl_xor(key, 16);
+                    key = o < key ? o : key;
+                    o = __shfl_xor(key, 32);
+                    key = o < key ? o : key;
+                    if (lane < 8) sKey[q * 8 + lane] = key;  // best of this quadrant's 8 centres for row 8 (q & 1) + lane
+                }
+            }
+            if (!__all(ok) ) {
+                if (lane == 0) sDead = 1;
+            }
+            // the rows of the next step: 16 DMA instructions per wave, issued AFTER the hand-off left (they land under the sweep)
+            if (t + 1 < T && active) dma_rows(t + 1);
+            __syncthreads();
+            const long long c3 = TS_CLK();
+            if (wave == 0) {
+                const unsigned long long tag16 = (unsigned long long)((nsync % 65535u) + 1u) << 48;
+                unsigned long long(*ring)[TP_MAXB] = ctl->gran[nsync % TP_RING];
+                if (ch == 1 && lane < nrv) {
+                    const int hq = lane >> 3, i8 = lane & 7;  // row half, row in it: quadrants hq and hq + 2 cover its 16 centres
+                    const unsigned long long k0 = sKey[hq * 8 + i8], k1 = sKey[(hq + 2) * 8 + i8];
+                    const unsigned long long key = k1 < k0 ? k1 : k0;
+                    const unsigned long long local = (key == ~0ull) ? 0xFFFFull : ((key & 0xffffffffull) - (unsigned)kbase);
+                    __hip_atomic_store(&ring[cg][rbase + lane], tag16 | (local << 32) | (key >> 32), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const int srow = lane & 31, half = lane >> 5;
+                unsigned long long bestkey = ~0ull;
+                unsigned okw = 1;
+                unsigned long long g[TPW_SW];
+                unsigned needm = 0;  // bit u: granule u of this lane not yet seen with this step's tag
+#pragma unroll
+                for (int u = 0; u < TPW_SW; ++u)
+                    if (srow < b && half + 2 * u < ncg) needm |= 1u << u;
+                for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+                    for (int u = 0; u < TPW_SW; ++u)
+                        if ((needm >> u) & 1u)
+                            g[u] = __hip_atomic_load(&ring[half + 2 * u][srow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int u = 0; u < TPW_SW; ++u)
+                        if (((needm >> u) & 1u) && (g[u] >> 48) == (tag16 >> 48)) needm &= ~(1u << u);
+                    if (__all(needm == 0)) break;
+                    if (spins > TP_SPIN_LIMIT || (spins & 1023) == 1023) {
+                        if (spins > TP_SPIN_LIMIT || __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            if (lane == 0) __hip_atomic_store(&ctl->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            okw = 0;
+                            break;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < TPW_SW; ++u) {
+                    const int cgu = half + 2 * u;
+                    if (srow < b && cgu < ncg && okw) {
+                        const unsigned loc = (unsigned)(g[u] >> 32) & 0xFFFFu;
+                        const unsigned long long cand =
+                            loc == 0xFFFFu ? ~0ull : (((g[u] & 0xffffffffull) << 32) | (unsigned)(cgu * TS_NC + loc));
+                        bestkey = cand < bestkey ? cand : bestkey;
+                    }
+                }
+                const unsigned long long o = __shfl_xor(bestkey, 32);
+                bestkey = o < bestkey ? o : bestkey;
+                if (lane < b) sBest[lane] = (int)(bestkey & 0xffffffffull);
+                if (!okw && lane == 0) sDead = 1;
+            }
+            ++nsync;
+            __syncthreads();
+            c4 = TS_CLK();
+            if (PROF) pr[0] += c1 - c0, pr[1] += c2 - c1, pr[2] += c3 - c2, pr[3] += c4 - c3;
+            if (sDead) break;  // uniform
+        }
+        // ---- update: every replica of a centre group does the same arithmetic on its columns; wave w owns block w
+        const int best = (lane < b) ? sBest[lane] : -1;
+        double lr = lr0;
+        bool fell = false;
+        if ((double)b * lr0 >= 1.0) {  // lr fallback (:116-119) possible at all?  (never at the defaults 32 * 0.01)
+            int cmaxi = 0;
+#pragma unroll
+            for (int i = 0; i < TP_MAXB; ++i) {
+                const int li = __builtin_amdgcn_readlane(best, i);  // scalar; -1 for rows >= b
+                const int c = __popcll(__ballot(lane < b && best == li));
+                cmaxi = (i < b && c > cmaxi) ? c : cmaxi;
+            }
+            if ((double)(float)cmaxi * lr >= 1.0) {
+                lr = 0.5 / (double)(float)cmaxi;
+                fell = true;
+            }
+        }
+        const float lr32 = (float)lr;
+        if (fell && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) sc->fallback += 1;
+        if (__ballot(lane < b && best >= kbase && best < kbase + nck) == 0ull) {  // uniform: nothing of mine was hit
+            if (PROF) pr[5] += TS_CLK() - c0;
+            continue;
+        }
+        for (int cp = 0; cp < 2; ++cp) {
+            unsigned long long msk[8];
+            unsigned touched = 0;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                msk[c8] = (cp * 8 + c8 < nck) ? __ballot(lane < b && best == kbase + cp * 8 + c8) : 0ull;
+                touched |= (msk[c8] ? 1u : 0u) << c8;
+            }
+            if (!touched) continue;  // uniform over the workgroup
+            if (active) {
+                float4 dl[8];
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    unsigned long long m = msk[c8];
+                    bool have = false;
+                    while (m) {  // rows of the batch with this label, ascending (torch_scatter's CPU order)
+                        const int i = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const float4 x4 = *reinterpret_cast<const float4 *>(xb + (size_t)i * d + coff + wave * 256 + (lane << 2));
+                        const float4 v = make_float4(x4.x * lr32, x4.y * lr32, x4.z * lr32, x4.w * lr32);
+                        dl[c8] = have ? make_float4(dl[c8].x + v.x, dl[c8].y + v.y, dl[c8].z + v.z, dl[c8].w + v.w) : v;
+                        have = true;
+                    }
+                }
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    if (msk[c8]) {
+                        const float f = 1.0f - (float)__popcll(msk[c8]) * lr32;
+                        float4 *pc4 = reinterpret_cast<float4 *>(sC + (cp * 8 + c8) * TS_COLS + wave * 256 + ((lane ^ (c8 & 7)) << 2));
+                        const float4 c4 = *pc4;
+                        *pc4 = make_float4(c4.x * f + dl[c8].x, c4.y * f + dl[c8].y, c4.z * f + dl[c8].z, c4.w * f + dl[c8].w);
+                    }
+                }
+            }
+            if (tid < 8 && ((touched >> tid) & 1u)) {
+                int cnt = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cnt = (e == (int)tid) ? __popcll(msk[e]) : cnt;
+                sCnt[cp * 8 + tid] = sCnt[cp * 8 + tid] + (float)cnt;
+            }
+            pend |= touched << (cp * 8);
+        }
+        __syncthreads();  // the updated centres and counts are in place before the next step reads them
+        if (PROF) {
+            const long long c5 = TS_CLK();
+            pr[4] += c5 - c4, pr[5] += c5 - c0;
+        }
+    }
+#undef TS_CLK
+    if (PROF && tid == 0 && cg == 1 % ncg && rg == 0)  // one pair of workgroups reports: ch = 1 into prof[0..5], ch = 0 into prof_wg[0]
+        for (int i = 0; i < 6; ++i) (ch ? ctl->prof : ctl->prof_wg[0])[i] = (unsigned long long)pr[i];
+    if (pend && !sDead) {  // uniform
+        if (!__all(refresh_norms(pend, (unsigned)T + 1u)) && lane == 0) sDead = 1;
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a row fetch may still be in flight after an early exit
+    __syncthreads();
+    // ---- write the owned state back (one replica per centre group and column half)
+    if (rg == 0 && !sDead) {
+        if (active)
+            for (int c = 0; c < nck; ++c) {
+                const float4 v = *reinterpret_cast<const float4 *>(sC + c * TS_COLS + wave * 256 + ((lane ^ (c & 7)) << 2));
+                *reinterpret_cast<float4 *>(centers + (size_t)(kbase + c) * d + coff + wave * 256 + (lane << 2)) = v;
+            }
+        if (ch == 1 && tid < nck) {
+            cn[kbase + tid] = sCn[tid];
+            counts[kbase + tid] = sCnt[tid];
+        }
+    }
+}
+
 __global__ void k_fill_u64(unsigned long long *p, int n, unsigned long long v)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2266,7 +2652,7 @@ struct acav_kmeans {
     int64_t count = 0;  // python int self.count (deterministic on the host)
     DevBuf centers, cn, counts, scalars;
     DevBuf stage_x, stage_lab, stage_forced, keys, xn, wg_sum, minval, thr, ctl;
-    DevBuf cb16, caux, cmu, recheck_list, recheck_count, backup, grec;
+    DevBuf cb16, caux, cmu, recheck_list, recheck_count, backup, grec, split_rings;
     hipEvent_t ev_f0 = nullptr, ev_f1 = nullptr;  // around the last k_assign_bf16 launch (acav_kmeans_filter_time)
     bool cb16_valid = false;  // bf16 copy of the centres matches `centers`
     bool rg_attr_set = false; // dynamic-LDS attribute of the large-batch distance kernels set
@@ -2364,6 +2750,14 @@ ACAV_EXPORT int acav_kmeans_stats(acav_kmeans *km, int64_t *assign_launches, int
     ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");
     if (assign_launches) *assign_launches = km->n_assign_launches;
     if (step_launches) *step_launches = km->n_step_launches;
+    return ACAV_OK;
+}
+
+ACAV_EXPORT int acav_kmeans_train_stats(acav_kmeans *km, int64_t *persistent_launches, int64_t *persistent_fallbacks)
+{
+    ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");
+    if (persistent_launches) *persistent_launches = km->n_persistent_launches;
+    if (persistent_fallbacks) *persistent_fallbacks = km->n_persistent_fallbacks;
     return ACAV_OK;
 }
 
@@ -2730,7 +3124,7 @@ struct TrainCall {
     const int64_t *dw = nullptr;
     const void *x_user = nullptr, *w_user = nullptr;
     int nwg = 0;
-    bool launched = false, prof = false, active = false;
+    bool launched = false, prof = false, split_prof = false, active = false;
     std::vector<float> thr;  // staging of the per-step thresholds: alive until the launch has been waited for
 };
 
@@ -2823,8 +3217,25 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
             }
         if (best_ncp) ncp = best_ncp, persistent = true;
     }
+    // 1024 < d <= 2048 (cfg4's visual view): the columns are split over pairs of workgroups (k_train_persistent_split)
+    bool split = false;
+    int split_wg = 0;
+    const int s_ncg = (km->K + TS_NC - 1) / TS_NC, s_nrg = (int)((b + TS_NR - 1) / TS_NR);
+    // (worth it from K = 512 on: below that the per-step launches are as fast -- 14.5 us at K = 256 -- because the two
+    // dependent hand-offs of a split step cost more than the launches they replace; ACAV_SPLIT_MINK overrides)
+    const char *smk = getenv("ACAV_SPLIT_MINK");
+    const int split_mink = smk ? atoi(smk) : 512;
+    if (!persistent && steps > 0 && !(nop && nop[0] == '1') && km->d > TP_DS && km->d <= 2 * TP_DS && (km->d & 255) == 0 &&
+        b <= TP_MAXB && ((uintptr_t)fx & 15) == 0 && s_ncg <= 2 * TPW_SW && km->K >= split_mink) {
+        auto sk = prof ? k_train_persistent_split<true> : k_train_persistent_split<false>;
+        ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TS_SMEM));
+        int occ2 = 0;
+        ACAV_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2, reinterpret_cast<const void *>(sk), 256, TS_SMEM));
+        split_wg = s_ncg * s_nrg * 2;
+        if (occ2 >= 1 && split_wg <= occ2 * km->num_cus && split_wg <= (budget ? *budget : occ2 * km->num_cus)) split = persistent = true;
+    }
     if (!persistent) return ACAV_OK;
-    tc.nwg = ncp == 1 ? nwg : wide_wg;
+    tc.nwg = split ? split_wg : ncp == 1 ? nwg : wide_wg;
     if (budget) *budget -= tc.nwg;
     tc.thr.resize((size_t)steps);
     for (int64_t t = 0; t < steps; ++t)
@@ -2841,7 +3252,18 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
     ACAV_HIP_TRY(hipMemcpyAsync(bk + cbytes, km->cn.p, kbytes, hipMemcpyDeviceToDevice, st));
     ACAV_HIP_TRY(hipMemcpyAsync(bk + cbytes + kbytes, km->counts.p, kbytes, hipMemcpyDeviceToDevice, st));
     ACAV_HIP_TRY(hipMemcpyAsync(bk + cbytes + 2 * kbytes, km->scalars.p, sizeof(StepScalars), hipMemcpyDeviceToDevice, st));
-    if (ncp == 1) {
+    if (split) {
+        tc.prof = false;
+        tc.split_prof = prof;
+        const size_t t0b = sizeof(unsigned long long) * (size_t)s_ncg * s_nrg * 256, nrb = sizeof(unsigned long long) * (size_t)s_ncg * s_nrg * TS_NC * 32;
+        ACAV_TRY(km->split_rings.ensure(t0b + nrb));
+        ACAV_HIP_TRY(hipMemsetAsync(km->split_rings.p, 0, t0b + nrb, st));  // every hand-off tag = 0 (never a live tag)
+        unsigned long long *t0r = km->split_rings.as<unsigned long long>();
+        hipLaunchKernelGGL((prof ? k_train_persistent_split<true> : k_train_persistent_split<false>), dim3((unsigned)s_ncg, (unsigned)s_nrg, 2), dim3(256), TS_SMEM, st, fx,
+                           km->xn.as<float>(), (int)b, km->d, km->K, km->centers.as<float>(), km->cn.as<float>(),
+                           km->counts.as<float>(), km->thr.as<float>(), lr, (float)km->reinit_r, tc.dw, (int)need, (int)steps,
+                           km->ctl.as<TrainCtl>(), km->scalars.as<StepScalars>(), t0r, t0r + t0b / sizeof(unsigned long long));
+    } else if (ncp == 1) {
         hipLaunchKernelGGL(tkern, dim3((km->K + TP_NC - 1) / TP_NC, (unsigned)((b + TP_NR - 1) / TP_NR)),
                            dim3(256), 0, st, fx, km->xn.as<float>(), (int)b, km->d, km->K, km->centers.as<float>(),
                            km->cn.as<float>(), km->counts.as<float>(), km->thr.as<float>(), lr, (float)km->reinit_r,
@@ -2891,6 +3313,16 @@ static int train_finish(acav_kmeans *km, TrainCall &tc)
                 }
             fprintf(stderr, "[acav]   over workgroups: wait %.0f..%.0f fma %.0f..%.0f exch %.0f..%.0f upd %.0f..%.0f; sweep passes/step %.2f\n", mn[0],
                     mx[0], mn[1], mx[1], mn[2], mx[2], mn[3], mx[3], head.prof[7] / den);
+        }
+        if (tc.split_prof) {
+            struct { unsigned err, pad[3]; unsigned long long prof[8]; unsigned long long wg0[8]; } hs{};
+            ACAV_HIP_TRY(hipMemcpy(&hs, km->ctl.p, sizeof(hs), hipMemcpyDeviceToHost));
+            const double den = (double)(steps > need ? steps - need : 1);
+            for (int h2 = 1; h2 >= 0; --h2) {
+                const unsigned long long *v = h2 ? hs.prof : hs.wg0;
+                fprintf(stderr, "[acav] split epoch, column half %d: cycles/step: row wait %.0f, fma+norms %.0f, hand-off+keys %.0f, sweep %.0f, "
+                                "update %.0f, total %.0f\n", h2, v[0] / den, v[1] / den, v[2] / den, v[3] / den, v[4] / den, v[5] / den);
+            }
         }
         if (head.err == 0) {
             km->count += steps * b;

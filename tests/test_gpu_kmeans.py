@@ -401,3 +401,41 @@ def test_train_epoch_multi_equals_one_by_one(env):
                     ref.add(xb)
             assert np.array_equal(km.centers.numpy(), ref.centers), f"epoch {epoch}"
             assert np.array_equal(km.counts.numpy(), ref.counts) and km.count == ref.count
+
+
+@pytest.mark.parametrize("n,d,K,b", [(4096, 2048, 1024, 32), (2048, 2048, 256, 32), (2048, 1280, 300, 32), (1600, 1536, 40, 20),
+                                     (2048, 1792, 64, 16), (700, 2048, 24, 7)])
+def test_split_column_persistent_kernel(env, n, d, K, b):
+    """k_train_persistent_split (1024 < d <= 2048, d % 256 == 0): pairs of workgroups own the two column halves of 16
+    centres; the canonical segment fold and the canonical ||c||^2 chains run across the pair through tagged hand-offs.
+    Two epochs (warm-up inside the first launch) == the oracle bit for bit, in ONE launch per epoch (no per-step
+    launches); ragged centre groups (K = 300 / 40 / 24), a second half of 1 / 2 / 3 column blocks (d = 1280 / 1536 /
+    1792), ragged row groups (b = 20 / 7) and the lr fallback."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    os.environ["ACAV_SPLIT_MINK"] = "1"  # the product takes this kernel from K = 512 on; the small shapes exercise its edges
+    x = _mixture(d + K, n, d, K)
+    acav.manual_seed(21)
+    km = KMeans(None, d, K).to("cuda:0")
+    ref = O.KMeans(d, K, O.Rng(21))
+    xt = torch.from_numpy(x).cuda()
+    for e in range(2):
+        km.train_epoch(xt, b, lr=0.01)
+        ref.train_epoch(x, b, lr=0.01)
+        assert np.array_equal(km.centers.numpy(), ref.centers), f"epoch {e}"
+        assert np.array_equal(km.counts.numpy(), ref.counts)
+    assert km.count == ref.count
+    launches, gave_up = km.train_stats()
+    assert launches == 2 and gave_up == 0, f"persistent launches {launches}, fallbacks {gave_up}: the split kernel was not taken (or gave up)"
+    lab, _ = km.calc_best(xt)
+    assert np.array_equal(lab.cpu().numpy(), ref.calc_best(x)[0])
+    km2 = KMeans(None, d, K).to("cuda:0")
+    ref2 = O.KMeans(d, K, O.Rng(13))
+    km2.centers, km2.counts, km2.count = ref2.centers, ref2.counts, 0
+    acav.manual_seed(14)
+    ref2.rng = O.Rng(14)
+    km2.train_epoch(xt, b, lr=0.3)
+    ref2.train_epoch(x, b, lr=0.3)
+    assert km2.fallback == ref2.fallback and (km2.fallback > 0 or K > 64)  # many centres: the batch never piles up on one
+    assert np.array_equal(km2.centers.numpy(), ref2.centers)
+    os.environ.pop("ACAV_SPLIT_MINK", None)
