@@ -46,14 +46,46 @@ def feature_batches(table, batch_size):
     return np.ascontiguousarray(visual[idx]), np.ascontiguousarray(audio[idx]), np.asarray(offsets, np.int64), rows
 
 
+def copy_measure(measure, prev_measure):
+    """run_contrastive.py:63-69: ONLY the two weight matrices (and the epoch) travel into the new object -- the biases stay
+    the freshly initialised ones of `measure`"""
+    sd, prev = measure.state_dict(), prev_measure.state_dict()
+    for k in ('visual_linear.weight', 'audio_linear.weight'):
+        sd[k] = prev[k]
+    measure.load_state_dict(sd)
+    measure.epoch = prev_measure.epoch
+    return measure
+
+
+def _new_measure(args, sizes):
+    cfg = args.contrastive
+    return Contrastive(cfg.num_epochs, args.computation.device, cfg.base_lr, cfg.num_warmup_steps, sizes=sizes)
+
+
+def _train(args, paths, batches, sizes, measure=None):
+    """run_contrastive.py:72-86: a NEW Contrastive (its own nn.Linear draws from the global generator), the weights of
+    the cached model copied in when there is one, then the training loop"""
+    prev = measure
+    measure = _new_measure(args, sizes)
+    if prev is not None:
+        measure = copy_measure(measure, prev)
+    print("training contrastive loss")
+    measure.train(args, paths, batches, args.log_every, args.verbose)
+    return measure
+
+
 def _run(args, paths):
-    """run_contrastive.py:16-51: load a cached model or train, then score every clip"""
+    """run_contrastive.py:16-51,97-116 object for object: the reference builds one Contrastive in _run (first pair of
+    nn.Linear draws), trains a SECOND one in _train (second pair of draws) and scores with a THIRD one in _infer whose
+    weights are copied from the trained model while its biases are its own fresh draws (copy_measure, :63-69) -- a seeded
+    run ranks the clips with exactly those parameters.  (The shuffled DataLoader order of the reference is not
+    reproduced: batches are taken in shard order.)"""
     cfg = args.contrastive
     table = io.load_feature_shards([Path(p) for p in paths])
     visual, audio, offsets, rows = feature_batches(table, int(cfg.train_batch_size))
-    measure = Contrastive(cfg.num_epochs, args.computation.device, cfg.base_lr, cfg.num_warmup_steps,
-                          sizes=(visual.shape[1], audio.shape[1]))
-    trained = False
+    sizes = (visual.shape[1], audio.shape[1])
+    batches = (visual, audio, offsets)
+    measure = _new_measure(args, sizes)
     if cfg.cached_epoch is not None:
         cache_path = measure.get_cache_path_load(args, paths, cfg.cached_epoch)
         if cache_path is not None and Path(cache_path).is_file():
@@ -61,17 +93,22 @@ def _run(args, paths):
                 print("cache file found: {}".format(Path(cache_path).stem))
                 print("loading from cached file")
             measure.load_cache(args, paths, cfg.cached_epoch)
-            trained = not cfg.train_from_cached
-        elif args.verbose:
-            print("no cache file found")
-            print("training from scratch")
-    if not trained:
-        print("training contrastive loss")
-        measure.train(args, paths, (visual, audio, offsets), args.log_every, args.verbose)
+            if cfg.train_from_cached:
+                if args.verbose:
+                    print("training from cached file")
+                measure = _train(args, paths, batches, sizes, measure)
+        else:
+            if args.verbose:
+                print("no cache file found")
+                print("training from scratch")
+            measure = _train(args, paths, batches, sizes)
+    else:
+        measure = _train(args, paths, batches, sizes)
+    scorer = copy_measure(_new_measure(args, sizes), measure)  # _infer (:97-103)
     print("(node 0) running inference")
     tv, ta, toff, trows = feature_batches(table, int(cfg.test_batch_size))
     metas = io.load_metas([Path(p) for p in paths], args.data.meta.path)
-    scores, ids, _ = measure.infer(args, (tv, ta, toff), trows, metas, args.subset.size, args.verbose)
+    scores, ids, _ = scorer.infer(args, (tv, ta, toff), trows, metas, args.subset.size, args.verbose)
     print("(node 0) done inference")
     return measure, scores, [trows[i] for i in ids]
 

@@ -136,18 +136,25 @@ def test_contrastive_cli_end_to_end(env, tmp_path_factory, golden_dir):
     assert len(inf) == 1
     rows = list(csv.reader(open(os.path.join(root, "sel", "caches", inf[0]))))
     assert len(rows) == 600 and len(rows[0]) == 5
-    # the oracle, same seeded init, same batch stream and schedule
+    # the oracle, same seeded stream, same batch stream and schedule, the reference's object flow (run_contrastive.py:16-116):
+    # the first Contrastive of _run only consumes its draws, _train builds and trains the second, _infer builds a third and
+    # copies the trained WEIGHTS into it -- the scores come from the trained weights with the third object's fresh biases
     rng = O.Rng(0)
-    wv, bv = CR.linear_init(lambda n: rng.rand(n), 128, 2304)
-    wa, ba = CR.linear_init(lambda n: rng.rand(n), 128, 128)
-    orc = CR.Contrastive(wv, bv, wa, ba)
+
+    def draw():
+        wv, bv = CR.linear_init(lambda n: rng.rand(n), 128, 2304)
+        wa, ba = CR.linear_init(lambda n: rng.rand(n), 128, 128)
+        return wv, bv, wa, ba
+    draw()
+    orc = CR.Contrastive(*draw())
     table = io.load_feature_shards(sorted(io.brace_expand(glob)))
     visual, audio, off, meta_rows = feature_batches(table, 128)
     for epoch in range(3):
         lr = lr_func_linear(epoch + 1, 4, 1) * 2e-4
         for i in range(len(off) - 1):
             orc.train_batch(visual[off[i]:off[i + 1]], audio[off[i]:off[i + 1]], lr)
-    want = orc.infer(visual, audio)
+    _, bv3, _, ba3 = draw()
+    want = CR.Contrastive(orc.p[0], bv3, orc.p[2], ba3).infer(visual, audio)
     got = np.array([float(r[0]) for r in rows], np.float32)
     assert [r[2] for r in rows] == [m["filename"] for m in meta_rows]
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)
