@@ -52,6 +52,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_COPY_GBS = 6290.0  # same guide: 6.29 TB/s measured with a float4 copy (79 % of the spec) -- context, not the roof
+HBM_MEASURED_READ_GBS = 7100.0  # profiles/r03_stream_bench.txt: read-only coalesced nt stream on this chip (0.888 of the spec)
+FILTER_DMA_SKELETON_MS = 0.75   # same file: the filter's two LDS-DMA streams (rows nt + bf16 centres from L2) with no compute, 1M x 1024
 EPOCHS = 2                 # clustering/code/config.py: clustering.epochs
 RATIO, BATCH_B, SELECT_K = 0.2, 20, 4   # subset_selection/code/config.py: subset.ratio, batch.*
 
@@ -130,6 +132,17 @@ def cpu_baseline(n, d, k, b, views, seed):
                   f"iteration, 1 thread) scaled to {iters} iterations; oracle C port, per-clip times summed and inverted",
         "train_clips_per_s_per_epoch": 1.0 / t_train, "assign_clips_per_s": 1.0 / t_assign,
         "mi_ms_per_iteration": t_iter * 1e3,
+        # how this port relates to the TRUE reference (its Python, imported in the build container:
+        # 8 cores, torch 2.10 CPU) on the rows of BASELINE.md section 2 -- the port is 2.4-12.6x FASTER than the code it
+        # restates (no per-op dispatch, no unique()), so the GPU / reference ratio is larger than value / this value
+        "calibration_vs_true_reference": {
+            "where": "build container, 8 cores; reference = /root/reference imported (BASELINE.md section 2), port = oracle/acav_oracle.c",
+            "kmeans_train_10k_x512_K64_624_steps_s": {"reference": 1.21, "port_1_thread": 0.096},
+            "kmeans_assign_10k_x512_K64_s": {"reference": 0.04, "port_1_thread": 0.032, "port_8_threads": 0.0059},
+            "mi_greedy_V10k_C64_500_iters_s": {"reference": 1.81, "port_dense_1_thread": 0.338},
+            "mi_greedy_V100k_C64_5000_iters_s": {"reference": 14.0, "port_dense_1_thread": 5.81},
+            "cfg1_like_end_to_end_s": {"reference": 4.3, "port": 0.59},
+        },
     }
 
 
@@ -294,8 +307,14 @@ def main():
                        "train_clips_per_s": n / st["train"], "assign_clips_per_s": n / st["assign"],
                        "mi_clips_per_s": n / st["mi"]},
             "roofline": {"kernel": "k_assign_bf16_rw", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         # HBM bytes per launch from the rocprofv3 --pmc passes of this kernel on this workload's shape
+                         # (FETCH_SIZE x 2 per the MI355X guide + WRITE_SIZE; separate runs, tools/collect_profiles.sh): the
+                         # committed summary named below -- a counter pass cannot run inside the timed region
+                         "traffic": traffic_profile["bytes_per_launch"] if traffic_profile else None,
                          "frac_of_measured_copy_rate": gbs / HBM_MEASURED_COPY_GBS,
+                         "frac_of_measured_read_rate": gbs / HBM_MEASURED_READ_GBS,
+                         "dma_only_skeleton_ms_1M_x_1024": FILTER_DMA_SKELETON_MS,
                          "traffic_from_committed_profile": traffic_profile,
                          "launch_ms": f_ms, "algorithmic_bytes": bytes_per_launch,
                          "algorithmic_flops": flops_per_launch, "effective_TFLOPs": flops_per_launch / (f_ms * 1e-3) / 1e12,

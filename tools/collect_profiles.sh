@@ -4,7 +4,7 @@
 # Separate runs, as the MI355X guide prescribes: kernel trace + stats, then one --pmc pass per counter (never combined
 # with a trace domain).  Copy the results into profiles/ afterwards.
 set -u
-P=${1:-r02}
+P=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profiles
 mkdir -p "$OUT"
@@ -37,6 +37,9 @@ ACAV_FILTER_V1=1 timeout 300 python tools/run_assign_only.py 1000000 20 filter >
 python tools/summarize_counters.py "$OUT" "$P" > "$OUT/${P}_assign_pipe_counters.json"
 stats assign_exact python tools/run_assign_only.py 1000000 3 exact
 stats assign_k1024 python tools/run_assign_only.py 1000000 3 filter 1024 1024
+pmc fetch_k1024 "k_assign" FETCH_SIZE python tools/run_assign_only.py 1000000 3 filter 1024 1024
+pmc write_k1024 "k_assign" WRITE_SIZE python tools/run_assign_only.py 1000000 3 filter 1024 1024
+python tools/summarize_pmc.py "$OUT" "$P" _k1024 1000000 1024 1024
 # cfg4's per-GPU partition (10M clips over 8 GPUs): 1.25M rows, 2048-d visual / 128-d audio, K = 1024
 (python tools/run_assign_only.py 1250000 3 filter 2048 1024; python tools/run_assign_only.py 1250000 3 filter 128 1024) > "$OUT/${P}_assign_cfg4.txt" 2> /dev/null
 # 3. MI greedy: one chunk at V = 1M (3000 iterations) and V = 100k, legacy global-atomic kernels for the A/B, 8 chunks in lockstep
@@ -52,7 +55,7 @@ if [ -x tools/exp/fy_bench ]; then
 fi
 # 4. SGD step per shape (persistent / wide persistent / per-step launches)
 : > "$OUT/${P}_train_shapes.txt"
-for shape in "1024 256" "512 64" "1024 1024" "128 1024" "2048 1024" "2048 256"; do
+for shape in "1024 256" "512 64" "1024 1024" "128 1024" "2048 1024" "2048 512" "2048 256"; do
     set -- $shape
     echo "d=$1 K=$2" >> "$OUT/${P}_train_shapes.txt"
     BENCH_D=$1 BENCH_K=$2 timeout 300 python tools/bench_train_b.py 32 2> /dev/null | tail -1 >> "$OUT/${P}_train_shapes.txt"
@@ -61,6 +64,11 @@ done
 echo "d=1024 K=256, larger batches (the DDP path trains on global batches of 32 W rows; SURVEY 8(d): a large-batch point)" >> "$OUT/${P}_train_shapes.txt"
 BENCH_D=1024 BENCH_K=256 timeout 600 python tools/bench_train_b.py 64 128 256 1024 2> /dev/null | sed 's/^/   /' >> "$OUT/${P}_train_shapes.txt"
 ACAV_PROFILE_STEPS=1 BENCH_D=1024 BENCH_K=256 timeout 300 python tools/bench_train_b.py 32 > "$OUT/${P}_train_phase_cycles.txt" 2>&1
+ACAV_PROFILE_STEPS=1 BENCH_D=2048 BENCH_K=1024 timeout 300 python tools/bench_train_b.py 32 > "$OUT/${P}_train_split_phase_cycles.txt" 2>&1
+# 5. round 3: read ceilings of the filter's access pattern, sweep time vs re-check fraction, the out-of-core path
+if [ -x tools/exp/stream_bench ]; then (cd tools/exp && ./stream_bench) > "$OUT/${P}_stream_bench.txt" 2>&1; fi
+timeout 600 python tools/recheck_table.py > "$OUT/${P}_recheck_table.txt" 2>&1
+timeout 900 python tools/bench_streamed.py 1000000 1024 256 2.0 > "$OUT/${P}_streamed_now.txt" 2>&1
 for f in "$OUT"/${P}_*.txt; do sed -i '/amdgpu.ids/d' "$f"; done
 for f in "$OUT/${P}_mi_1m.txt" "$OUT/${P}_mi_1m_legacy.txt" "$OUT/${P}_mi_100k.txt" "$OUT/${P}_mi_lockstep8.txt" "$OUT/${P}_bench_under_rocprof.txt"; do grep "^{" "$f" | tail -1 > "$f.tmp" && mv "$f.tmp" "${f%.txt}.json" && rm -f "$f"; done
 ls -la "$OUT"

@@ -1,0 +1,45 @@
+"""Sweep time of KMeans.calc_best (bf16 filter + exact re-check) against the fraction of rows the filter cannot decide
+(VERDICT r2 item 2): 1M x 1024, K = 256, centres out of real training, cluster overlap turned up step by step
+(centre spread relative to the 0.3 noise).  argv: [rows]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+
+import torch
+
+import acav100m_amd
+from acav100m_amd import _lib
+from acav100m_amd.clustering import KMeans
+
+n, d, K, b = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, 1024, 256, 32
+print("| centre spread | rows re-checked | fraction | filter kernel ms | whole sweep ms | of 8 TB/s (sweep) |")
+print("|---|---|---|---|---|---|")
+for spread in (1.0, 0.25, 0.12, 0.09, 0.07, 0.06, 0.05, 0.04):
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    cen = spread * torch.randn(K, d, device="cuda", generator=gen)
+    comp = torch.randint(0, K, (n,), device="cuda", generator=gen)
+    x = torch.empty(n, d, device="cuda")
+    for s in range(0, n, 65536):
+        e = min(n, s + 65536)
+        x[s:e] = cen[comp[s:e]] + 0.3 * torch.randn(e - s, d, device="cuda", generator=gen)
+    acav100m_amd.manual_seed(3)
+    km = KMeans(None, d, K).to("cuda:0")
+    km.train_epoch(x[:262144], b, lr=0.01)
+    lib = _lib.load_library()
+    lab = torch.empty(n, dtype=torch.long, device="cuda")
+    best = (1e9, 1e9)
+    for rep in range(4):
+        _lib.check(lib.acav_kmeans_timer_begin(km._h))
+        _lib.check(lib.acav_kmeans_assign(km._h, _lib.ptr(x), n, _lib.ptr(lab), None))
+        ms, fm = C.c_float(0), C.c_float(0)
+        _lib.check(lib.acav_kmeans_timer_end(km._h, C.byref(ms)))
+        _lib.check(lib.acav_kmeans_filter_time(km._h, C.byref(fm)))
+        if rep:
+            best = min(best, (ms.value, fm.value))
+    _, rows, rechecked = km.filter_stats()
+    print("| %.2f | %d | %.4f | %.3f | %.3f | %.3f |" % (spread, rechecked, rechecked / rows, best[1], best[0],
+                                                   (n * d * 4 + n * 8) / (best[0] * 1e-3) / 8e12), flush=True)
+    del x

@@ -6,7 +6,9 @@ import re
 import sys
 
 out, prefix = sys.argv[1], sys.argv[2]
-N, D, K = 1_000_000, 1024, 256
+# optional: tag of the pass pair (files <prefix>_pmc_fetch<tag>_..., <prefix>_pmc_write<tag>_...) and the shape they ran
+tag = sys.argv[3] if len(sys.argv) > 3 else ""
+N, D, K = (int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (1_000_000, 1024, 256)
 
 
 def per_kernel(path):
@@ -23,21 +25,23 @@ def per_kernel(path):
     return {k: sum(v) / len(v) for k, v in acc.items()}  # mean per launch
 
 
-fetch = per_kernel(f"{out}/{prefix}_pmc_fetch_counter_collection.csv")
-write = per_kernel(f"{out}/{prefix}_pmc_write_counter_collection.csv")
+fetch = per_kernel(f"{out}/{prefix}_pmc_fetch{tag}_counter_collection.csv")
+write = per_kernel(f"{out}/{prefix}_pmc_write{tag}_counter_collection.csv")
 fk = fetch.get("k_assign_bf16_rw", fetch.get("k_assign_bf16", 0.0))
 wk = write.get("k_assign_bf16_rw", write.get("k_assign_bf16", 0.0))
-traffic = (2.0 * fk + wk + 2.0 * fetch.get("k_assign_f32", 0.0) + write.get("k_assign_f32", 0.0)) * 1024.0
+# K > 256: the group-split filter leaves 16-byte records per (row, group) that k_assign_merge folds
+traffic = (2.0 * fk + wk + 2.0 * fetch.get("k_assign_f32", 0.0) + write.get("k_assign_f32", 0.0) +
+           2.0 * fetch.get("k_assign_merge", 0.0) + write.get("k_assign_merge", 0.0)) * 1024.0
 alg = N * D * 4 + N * 8
 json.dump({
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-include-regex k_assign -- python tools/run_assign_only.py "
-               "1000000 5 filter (separate passes; tools/collect_profiles.sh)",
-    "kernel": "k_assign_bf16_rw + k_assign_f32 (exact re-check pass, empty list on this data)",
+               f"{N} 5 filter {D} {K} (separate passes; tools/collect_profiles.sh)",
+    "kernel": "k_assign_bf16_rw (+ k_assign_merge for K > 256) + k_assign_f32 (exact re-check pass, empty list on this data)",
     "rows": N, "d": D, "K": K,
     "FETCH_SIZE_raw_KB": fetch, "WRITE_SIZE_raw_KB": write,
     "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads "
                   "on gfx950 -> x2; units are KB; mean per launch",
     "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg,
     "traffic_over_algorithmic": traffic / alg if alg else None,
-}, open(f"{out}/{prefix}_pmc_assign.json", "w"), indent=1)
-print(open(f"{out}/{prefix}_pmc_assign.json").read())
+}, open(f"{out}/{prefix}_pmc_assign{tag}.json", "w"), indent=1)
+print(open(f"{out}/{prefix}_pmc_assign{tag}.json").read())
