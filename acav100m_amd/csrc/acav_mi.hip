@@ -764,6 +764,20 @@ constexpr int FYA_CH = ACAV_FYA_CH;  // steps per k_fy_part workgroup
 constexpr int FYA_THREADS = 1024;
 constexpr int64_t FY_TILED_MAX = 16 << 20;
 constexpr unsigned FY_EREF = 0x80000000u;
+// store flavours of the two scattered write streams of the position kernels (experiments: -DACAV_FY_BUCKET_NT, -DACAV_FY_SRC_NT,
+// -DACAV_FY_SRC_SC1; measured in tools/exp/NOTES_r03.md)
+#if defined(ACAV_FY_BUCKET_NT)
+#define FY_ST_BUCKET(p, v) __builtin_nontemporal_store((v).x, &(p)->x), __builtin_nontemporal_store((v).y, &(p)->y)
+#else
+#define FY_ST_BUCKET(p, v) (*(p) = (v))
+#endif
+#if defined(ACAV_FY_SRC_NT)
+#define FY_ST_SRC(p, v) __builtin_nontemporal_store((unsigned)(v), (p))
+#elif defined(ACAV_FY_SRC_SC1)
+#define FY_ST_SRC(p, v) __hip_atomic_store((p), (unsigned)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define FY_ST_SRC(p, v) (*(p) = (v))
+#endif
 #ifndef ACAV_FY_GROUP
 #define ACAV_FY_GROUP 16
 #endif
@@ -830,7 +844,7 @@ __device__ __forceinline__ void fy_part_body(const unsigned *__restrict__ draws,
         if (tr[u] >= 0) {
             const int tile = tr[u] >> 16, pos = lbase[tile] + (tr[u] & 0xffff);
             if (pos < capg)
-                bucket[((size_t)tile * FY_SHARDS + shard) * capg + pos] = make_int2(base + u * FYA_THREADS + tid, hh[u]);
+                FY_ST_BUCKET(&bucket[((size_t)tile * FY_SHARDS + shard) * capg + pos], make_int2(base + u * FYA_THREADS + tid, hh[u]));
             else
                 atomicOr(err, 1u);
         }
@@ -917,7 +931,7 @@ __device__ __forceinline__ void fy_tile_body(int L, const int *__restrict__ ebou
                 const int jj = ej[x];
                 if (jj < j && jj > pred) pred = jj;
             }
-            src[j] = pred >= 0 ? (FY_EREF | (unsigned)pred) : (unsigned)(q_lo + p);
+            FY_ST_SRC(&src[j], pred >= 0 ? (FY_EREF | (unsigned)pred) : (unsigned)(q_lo + p));
         }
         FY_CLK(3);
         for (int p = p0 + tid; p < p1; p += FYT_THREADS)
