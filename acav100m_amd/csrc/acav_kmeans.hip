@@ -1068,24 +1068,44 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
         __syncthreads();
         // compare-free top-2 scan of this lane's 8 x 16 distances: the 7 low mantissa bits carry the position
         float s1 = INFINITY, s2 = INFINITY;
-        const float xoff = centred ? 0.0f : xn;
+        if (centred) {
+            // no centre is under-used: every scale is 1 and ||x||^2 is left out -- v = fl(-2 dot + ||c||^2') is ONE fma (-2 dot is
+            // exact), the same value the general form below produces through its three operations; no scale table read
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
+            for (int ct = 0; ct < 8; ++ct) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int kl = ct * 32 + 4 * h + 8 * g;
-                const float4 cnv = *reinterpret_cast<const float4 *>(sCn + kl);
-                const float4 scv = *reinterpret_cast<const float4 *>(sSc + kl);
-                const float cn4[4] = {cnv.x, cnv.y, cnv.z, cnv.w};
-                const float sc4[4] = {scv.x, scv.y, scv.z, scv.w};
+                for (int g = 0; g < 4; ++g) {
+                    const float4 cnv = *reinterpret_cast<const float4 *>(sCn + ct * 32 + 4 * h + 8 * g);
+                    const float cn4[4] = {cnv.x, cnv.y, cnv.z, cnv.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = __builtin_fmaf(-2.0f, acc[ct][4 * g + j], xoff);  // == (-2 dot) + xn
-                    v = v + cn4[j];
-                    v = v * sc4[j];  // * (1/r) where the exact path divides by r
-                    v = __uint_as_float((__float_as_uint(v) & 0xFFFFFF80u) | (unsigned)(ct * 16 + g * 4 + j));
-                    s2 = fminf(s2, fmaxf(s1, v));
-                    s1 = fminf(s1, v);
+                    for (int j = 0; j < 4; ++j) {
+                        float v = __builtin_fmaf(-2.0f, acc[ct][4 * g + j], cn4[j]);
+                        v = __uint_as_float((__float_as_uint(v) & 0xFFFFFF80u) | (unsigned)(ct * 16 + g * 4 + j));
+                        s2 = fminf(s2, fmaxf(s1, v));
+                        s1 = fminf(s1, v);
+                    }
+                }
+            }
+        } else {
+            const float xoff = xn;
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int kl = ct * 32 + 4 * h + 8 * g;
+                    const float4 cnv = *reinterpret_cast<const float4 *>(sCn + kl);
+                    const float4 scv = *reinterpret_cast<const float4 *>(sSc + kl);
+                    const float cn4[4] = {cnv.x, cnv.y, cnv.z, cnv.w};
+                    const float sc4[4] = {scv.x, scv.y, scv.z, scv.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = __builtin_fmaf(-2.0f, acc[ct][4 * g + j], xoff);  // == (-2 dot) + xn
+                        v = v + cn4[j];
+                        v = v * sc4[j];  // * (1/r) where the exact path divides by r
+                        v = __uint_as_float((__float_as_uint(v) & 0xFFFFFF80u) | (unsigned)(ct * 16 + g * 4 + j));
+                        s2 = fminf(s2, fmaxf(s1, v));
+                        s1 = fminf(s1, v);
+                    }
                 }
             }
         }

@@ -309,3 +309,38 @@ def test_streamed_clustering_equals_resident(tmp_path_factory, golden_dir):
                     assert np.array_equal(c1[mk][layer]["centers"], c2[mk][layer]["centers"]), (streamed, e, mk, layer)
                     assert np.array_equal(c1[mk][layer]["counts"], c2[mk][layer]["counts"])
                     assert c1[mk][layer]["count"] == c2[mk][layer]["count"]
+
+
+def test_worker_process_loader_and_writer_equal_the_serial_run(tmp_path_factory, golden_dir):
+    """round 3: with >= 16 shards the clustering CLI reads the shards with worker processes (straight into reused, pinned
+    shared memory) and writes the assignment shards with the same pool.  Resident and streamed, the files must be the
+    serial run's, byte for byte; a shard that does not match its metadata sends its group back to the plain loop."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, golden_dir)
+    import synth
+    import acav100m_amd
+    from acav100m_amd.clustering.cli import Cli
+    root = str(tmp_path_factory.mktemp("acav_workers"))
+    glob = synth.write_feature_shards(root, n_shards=24, rows=48, seed=9, audio_dims=[64, 128], video_dims=[88, 352])
+    outs = {}
+    modes = [("serial", "0", None), ("workers", "4", None), ("workers_streamed", "4", str(1_500_000))]
+    for mode, workers, budget in modes:
+        os.environ["ACAV_LOAD_WORKERS"] = workers
+        if budget is not None:
+            os.environ["ACAV_RESIDENT_BYTES"] = budget
+        try:
+            acav100m_amd.manual_seed(0)
+            out = os.path.join(root, "clusters_" + mode)
+            saved = Cli().cluster(feature_path=glob, out_path=out, meta_path=os.path.join(root, "videos"),
+                                  **{"clustering.ncentroids": 16})
+            assert len(saved) == 24
+            outs[mode] = out
+        finally:
+            os.environ.pop("ACAV_LOAD_WORKERS", None)
+            os.environ.pop("ACAV_RESIDENT_BYTES", None)
+    for mode in ("workers", "workers_streamed"):
+        for s in range(24):
+            name = "shard-%06d.pkl" % s
+            assert open(os.path.join(outs["serial"], name), "rb").read() == open(os.path.join(outs[mode], name), "rb").read(), (mode, name)
