@@ -385,7 +385,7 @@ class KMeans:
         comm = default_comm(comm_slot) if hasattr(x_local, "is_cuda") and x_local.is_cuda else None
         if comm is None:  # gloo / host tensors (CPU tests): the same schedule through torch.distributed
             from ..parallel import train_epoch_dp
-            return train_epoch_dp(self, x_local, int(batch_size), lr, chunk_steps=chunk_steps)
+            return train_epoch_dp(self, x_local, int(batch_size), lr, chunk_steps=chunk_steps, trainer=trainer)
         self.train_epoch_comm(comm, x_local, int(batch_size), lr, chunk_steps, train_here, wait, trainer)
 
     @staticmethod
@@ -407,8 +407,8 @@ class KMeans:
         comms = [default_comm(v) for v in range(len(kms))] if on_gpu else [None] * len(kms)
         if any(c is None for c in comms):
             from ..parallel import train_epoch_dp
-            for km, x in zip(kms, xs_local):
-                train_epoch_dp(km, x, int(batch_size), lr, chunk_steps=chunk_steps)
+            for v, (km, x) in enumerate(zip(kms, xs_local)):
+                train_epoch_dp(km, x, int(batch_size), lr, chunk_steps=chunk_steps, trainer=trainers[v])
             return trainers
         import torch
         keep, ptrs, warms, needs = [], [], [], []

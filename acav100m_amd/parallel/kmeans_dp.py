@@ -39,7 +39,7 @@ def distributed_add(engine, batch, lr):
     return mean
 
 
-def train_epoch_dp(engine, x_local, b_local, lr, chunk_steps=1024, force_collective=False):
+def train_epoch_dp(engine, x_local, b_local, lr, chunk_steps=1024, force_collective=False, trainer=None):
     """One training epoch with the reference's DDP semantics (sgd_clustering.py:94-129 under is_distributed):
     step t's global batch is the rank-major concatenation of every rank's rows [t*b_local, (t+1)*b_local), and
     every rank applies the same update.
@@ -53,7 +53,10 @@ def train_epoch_dp(engine, x_local, b_local, lr, chunk_steps=1024, force_collect
     generator) travel separately: a few KB, once.
 
     `engine`: train_epoch(x, b, lr, warm_best=), warmup_steps(b, steps), draw_warmup(b), synchronize().
-    force_collective: take the gather path even with one rank (single-GPU test of the plumbing)."""
+    force_collective: take the gather path even with one rank (single-GPU test of the plumbing).
+    trainer: the ONE rank that runs the chain (the same number on every rank; the others follow with broadcast_state):
+    the rows are gathered TO it (dist.gather) instead of all-gathered -- what acav_kmeans_train_dp does under
+    ACAV_DP_ROOTED -- and a rank that only sends keeps `count` in step through engine.skip_epoch."""
     rank, w = world()
     x_local = _as_tensor(x_local)
     n_local, d = x_local.shape
@@ -72,10 +75,19 @@ def train_epoch_dp(engine, x_local, b_local, lr, chunk_steps=1024, force_collect
         dist.all_gather_into_tensor(allw, mine)
         warm = allw.view(w, need, b_local).permute(1, 0, 2).reshape(need, bg).cpu().numpy()  # [step, rank-major rows]
 
+    here = trainer is None or int(trainer) == rank
+
     def gather(c0, s):
         loc = x_local[c0 * b_local:(c0 + s) * b_local].contiguous()
-        g = torch.empty((w * s * b_local, d), dtype=loc.dtype, device=loc.device)  # rank-major concatenation
-        dist.all_gather_into_tensor(g, loc)
+        if trainer is None:
+            g = torch.empty((w * s * b_local, d), dtype=loc.dtype, device=loc.device)  # rank-major concatenation
+            dist.all_gather_into_tensor(g, loc)
+        else:  # only the trainer receives
+            parts = [torch.empty_like(loc) for _ in range(w)] if here else None
+            dist.gather(loc, parts, dst=int(trainer))
+            if not here:
+                return None
+            g = torch.cat(parts)
         # [rank, step, row] -> [step, rank, row]: the global batches, contiguous
         return g.view(w, s, b_local, d).permute(1, 0, 2, 3).reshape(s * bg, d).contiguous()
 
@@ -90,10 +102,13 @@ def train_epoch_dp(engine, x_local, b_local, lr, chunk_steps=1024, force_collect
         if need:
             wb = warm[done_warm:done_warm + nw]
             done_warm += nw
-        engine.train_epoch(cur, bg, lr, warm_best=wb if need else None)  # asynchronous on the engine's stream
+        if here:
+            engine.train_epoch(cur, bg, lr, warm_best=wb if need else None)  # asynchronous on the engine's stream
         if c0 + s < steps:  # gather the next chunk while this one trains
             nxt = gather(c0 + s, min(chunk_steps, steps - c0 - s))
     engine.synchronize()
+    if not here:
+        engine.skip_epoch(steps * bg)
 
 
 def average_state(centers, counts):

@@ -64,7 +64,8 @@ class _Engine:
         self.km.set_state(np.ascontiguousarray(centers, np.float32), np.ascontiguousarray(counts, np.float32), int(count))
 
     def skip_epoch(self, rows):
-        pass
+        c, cnt, count, fb = self.km.get_state()
+        self.km.set_state(None, None, count + int(rows))
 
 
 def _worker(rank, world, port, tmp):
@@ -109,6 +110,17 @@ def _worker(rank, world, port, tmp):
         train_epoch_dp(eng2, torch.from_numpy(xl), bl, 0.01, chunk_steps=4)
         c2, cnt2, count2, _ = eng2.km.get_state()
         np.savez(os.path.join(tmp, f"dp_rank{rank}.npz"), c=c2, cnt=cnt2, count=count2, x=xl, lab=np.stack(my_labels))
+        # the same epoch with ONE trainer (rank 1): the rows are gathered to it only, the other rank follows by broadcast
+        from acav100m_amd.parallel import broadcast_state
+        eng3 = _Engine(O, d, k, cen, np.zeros(k, np.float32), 0)
+        eng3.rng_labels = [a.copy() for a in my_labels]
+        train_epoch_dp(eng3, torch.from_numpy(xl), bl, 0.01, chunk_steps=4, trainer=1)
+        if rank == 0:  # a rank that only sends has not touched its state
+            c3, cnt3, _, _ = eng3.km.get_state()
+            assert np.array_equal(c3, cen) and not cnt3.any()
+        broadcast_state(eng3, 1)
+        c3, cnt3, count3, _ = eng3.km.get_state()
+        assert np.array_equal(c3, c2) and np.array_equal(cnt3, cnt2) and count3 == count2, f"rooted epoch, rank {rank}"
         assert list(shard_slice(7)) == list(range(rank, 7, world))
         # view-parallel epochs (the CLI's multi-GPU mode): 3 clusterings dealt out over 2 ranks, 2 epochs; every rank
         # must end with the state a single process reaches for every clustering

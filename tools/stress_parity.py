@@ -54,7 +54,7 @@ def stress(seed=0, budget=60.0, max_cases=None):
             assert np.array_equal(a.cpu().numpy(), want) and np.array_equal(b.cpu().numpy(), want), ("assign", n, d, k, s)
             counts["assign"] += 1
         elif which == 1:  # bulk training
-            d = int(rs.choice([8, 30, 64, 88, 128, 130, 256, 352, 704, 1000, 1024, 1408]))
+            d = int(rs.choice([8, 30, 64, 88, 128, 130, 256, 352, 704, 1000, 1024, 1280, 1408, 2048]))  # 1280 / 2048 with K >= 512: the column-split kernel
             k = int(rs.choice([3, 16, 40, 64, 100, 256, 300, 600, 1000, 1024, 1030, 2048]))
             b = int(rs.choice([1, 7, 16, 24, 32, 48, 64, 128, 200, 256, 512, 1024]))  # >= 128: several row groups per workgroup
             steps = int(rs.randint(3, 60)) if b <= 128 else int(rs.randint(3, 12))
