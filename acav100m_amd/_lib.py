@@ -74,6 +74,7 @@ SIGNATURES = {
                            C.POINTER(i64), vp, vp, vp, vp, i64],
     "acav_mi_run_greedy_multi": [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "acav_mi_run_exact": [vp, vp, i64, i32, i64, vp, vp, C.POINTER(i64), vp, vp, vp],
+    "acav_mi_set_measure": [vp, i32],
     "acav_mi_get_counts": [vp, vp, vp, vp, C.POINTER(i64)],
     "acav_mi_sync": [vp],
     "acav_mi_timer_begin": [vp],

@@ -85,6 +85,76 @@ __device__ __forceinline__ double mi_pair_score(const int *__restrict__ asg, int
     return (((sN - sa) - sb) + phi[nc + 1]) / (double)(nc + 1);
 }
 
+// exp(x) of the `ami` score: the SAME sequence of IEEE double operations as oracle/acav_oracle.c canon_exp (the device's
+// and libm's exp differ in the last bit); x <= ~0 (logs of probabilities)
+__device__ __forceinline__ double canon_exp(double x)
+{
+    if (x < -745.0) return 0.0;
+    const double k = rint(x * 1.4426950408889634074);
+    double r = x - k * 6.93147180369123816490e-01;
+    r = r - k * 1.90821492927058770002e-10;
+    double p = 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    return ldexp(p, (int)k);
+}
+
+// EfficientAMI._calc_score (mi.py:212-259) of cache + candidate `id` for pair p: (MI - EMI) / max(mean entropy - EMI, eps)
+// with the reference's one-term-per-cell EMI, over integer counts; every log / log-factorial is a look-up in the host-built
+// tables lnk / lf (the oracle's doubles), the cells are walked row-major: the canonical form of oracle ami_score_canon.
+__device__ double ami_pair_score(const int *__restrict__ asg, int D, int C, int p, const int *__restrict__ pairs, int id,
+                                 const int *__restrict__ Nc, const int *__restrict__ ac, const int *__restrict__ bc,
+                                 const double *__restrict__ SN, const double *__restrict__ Sa, const double *__restrict__ Sb,
+                                 const double *__restrict__ phi, const double *__restrict__ lnk, const double *__restrict__ lf,
+                                 long long nc)
+{
+    const int *row = asg + (size_t)id * D;
+    const int i = row[pairs[2 * p]], j = row[pairs[2 * p + 1]];
+    const int *Np = Nc + (size_t)p * C * C, *ap = ac + (size_t)p * C, *bp = bc + (size_t)p * C;
+    const long long n1i = nc + 1;
+    const double n1 = (double)n1i, ln_n = lnk[n1i];
+    const int cN = Np[(size_t)i * C + j], ca = ap[j], cb = bp[i];
+    const double sN = SN[p] - phi[cN] + phi[cN + 1];
+    const double sa = Sa[p] - phi[ca] + phi[ca + 1];
+    const double sb = Sb[p] - phi[cb] + phi[cb + 1];
+    const double mi = (((sN - sa) - sb) + phi[n1i]) / n1;
+    double emi = 0.0;
+    for (int r = 0; r < C; ++r) {
+        const long long b1 = bp[r] + (r == i);
+        if (b1 == 0) continue;
+        for (int c = 0; c < C; ++c) {
+            const long long N1 = Np[(size_t)r * C + c] + (r == i && c == j);
+            if (N1 == 0) continue;
+            const long long a1 = ap[c] + (c == j);
+            const double t1 = ((double)N1 / n1) * (((lnk[N1] + ln_n) - lnk[a1]) - lnk[b1]);
+            double l2 = lf[a1] + lf[b1];
+            l2 = l2 + lf[n1i - a1];
+            l2 = l2 + lf[n1i - b1];
+            l2 = l2 - lf[n1i];
+            l2 = l2 - lf[N1];
+            l2 = l2 - lf[a1 - N1];
+            l2 = l2 - lf[b1 - N1];
+            l2 = l2 - lf[n1i - a1 - b1 + N1];
+            emi = emi + t1 * canon_exp(l2);
+        }
+    }
+    const double ha = ln_n - sa / n1, hb = ln_n - sb / n1;
+    double den = (ha + hb) / 2.0 - emi;
+    if (den < 2.220446049250313e-16) den = 2.220446049250313e-16;
+    return (mi - emi) / den;
+}
+
 constexpr int SEL_MAXB = 64;
 constexpr int SEL_MAXBP = 8192;
 
@@ -400,8 +470,14 @@ __global__ __launch_bounds__(256) void k_mi_exact_iter(
     double *__restrict__ SN, double *__restrict__ Sa, double *__restrict__ Sb, const double *__restrict__ phi,
     MiScalars *__restrict__ sc, ExactBest *__restrict__ blockbest, unsigned *__restrict__ ticket,
     long long *__restrict__ S_out, double *__restrict__ G_out, const int *__restrict__ forced,
-    double *__restrict__ trace_scores, int *__restrict__ trace_argmax)
+    double *__restrict__ trace_scores, int *__restrict__ trace_argmax, int measure, const double *__restrict__ lnk,
+    const double *__restrict__ lf)
 {
+    // measure 0: calc_MI ('mi' / 'mem_mi'); 1: calc_AMI ('ami')
+    auto pair_score = [&](int p, int id, long long n) -> double {
+        return measure == 1 ? ami_pair_score(asg, D, C, p, pairs, id, Nc, ac, bc, SN, Sa, Sb, phi, lnk, lf, n)
+                            : mi_pair_score(asg, D, C, p, pairs, id, Nc, ac, bc, SN, Sa, Sb, phi, n);
+    };
     __shared__ double sS[4];
     __shared__ int sP[4];
     __shared__ int sLast;
@@ -413,7 +489,7 @@ __global__ __launch_bounds__(256) void k_mi_exact_iter(
     if (w < L && !removed[w]) {
         const int id = A[w];
         double tot = 0.0;
-        for (int p = 0; p < P; ++p) tot = tot + mi_pair_score(asg, D, C, p, pairs, id, Nc, ac, bc, SN, Sa, Sb, phi, nc);
+        for (int p = 0; p < P; ++p) tot = tot + pair_score(p, id, nc);
         s = tot / (double)P;
         pos = w;
     }
@@ -459,8 +535,7 @@ __global__ __launch_bounds__(256) void k_mi_exact_iter(
         if (forced) {
             pos = *forced;
             double tot = 0.0;
-            for (int p = 0; p < P; ++p)
-                tot = tot + mi_pair_score(asg, D, C, p, pairs, A[pos], Nc, ac, bc, SN, Sa, Sb, phi, nc);
+            for (int p = 0; p < P; ++p) tot = tot + pair_score(p, A[pos], nc);
             s = tot / (double)P;
         }
         sP[0] = pos;
@@ -1188,6 +1263,8 @@ struct acav_mi {
     DevBuf removed, blockbest, ticket, tr_am;  // exact greedy
     DevBuf chunk_desc;                         // descriptor array of a multi-chunk run (lead handle)
     DevBuf lane_states, ring, polys;           // MT19937 lanes of the single-chunk greedy (MtStream)
+    DevBuf lnk, lf;   // ln k and ln k! tables of the `ami` score (acav_mi_set_measure)
+    int measure = 0;  // exact greedy: 0 = calc_MI, 1 = calc_AMI
     DevBuf fy_table, fy_bounds, fy_bucket, fy_count, fy_src[FY_GROUP], fy_g[FY_GROUP], fy_perm[FY_NBUF], fy_tail, fy_err;  // tiled Fisher-Yates
     hipStream_t st_fy = nullptr;               // the position kernels of group g+1 run beside the gathers of group g
     hipEvent_t ev_tile[FY_NBUF] = {}, ev_gather[FY_NBUF] = {};
@@ -1914,6 +1991,27 @@ ACAV_EXPORT int acav_mi_run_greedy_multi(acav_mi **mis, int nchunks, const int64
     return ACAV_OK;
 }
 
+// which score the exact greedy (acav_mi_run_exact) maximises: 0 = calc_MI ('mi', 'mem_mi'; mi.py:85-91), 1 = calc_AMI ('ami',
+// mi.py:212-259).  The adjusted score reads two more host-built tables, ln k and ln k! for k <= V + 1.
+ACAV_EXPORT int acav_mi_set_measure(acav_mi *mi, int measure)
+{
+    ACAV_REQUIRE(mi, ACAV_EINVAL, "handle is NULL");
+    ACAV_REQUIRE(measure == 0 || measure == 1, ACAV_EINVAL, "unknown measure %d", measure);
+    if (measure == 1 && !mi->lnk.p) {
+        ACAV_HIP_TRY(hipSetDevice(mi->ctx.device));
+        std::vector<double> lnk((size_t)mi->V + 2), lf((size_t)mi->V + 2);
+        lnk[0] = 0.0, lf[0] = 0.0;
+        for (int64_t k = 1; k < mi->V + 2; ++k) lnk[(size_t)k] = log((double)k), lf[(size_t)k] = lgamma((double)k + 1.0);
+        ACAV_TRY(mi->lnk.ensure(sizeof(double) * lnk.size()));
+        ACAV_TRY(mi->lf.ensure(sizeof(double) * lf.size()));
+        ACAV_HIP_TRY(hipMemcpyAsync(mi->lnk.p, lnk.data(), sizeof(double) * lnk.size(), hipMemcpyHostToDevice, mi->ctx.stream));
+        ACAV_HIP_TRY(hipMemcpyAsync(mi->lf.p, lf.data(), sizeof(double) * lf.size(), hipMemcpyHostToDevice, mi->ctx.stream));
+        ACAV_HIP_TRY(hipStreamSynchronize(mi->ctx.stream));  // the vectors are locals
+    }
+    mi->measure = measure;
+    return ACAV_OK;
+}
+
 ACAV_EXPORT int acav_mi_run_exact(acav_mi *mi, const int64_t *candidates, int64_t L, int ns, int64_t subset,
                                   int64_t *S_out, double *GAIN_out, int64_t *n_selected, const int64_t *forced_pos,
                                   double *trace_scores, int64_t *trace_argmax)
@@ -1960,7 +2058,7 @@ ACAV_EXPORT int acav_mi_run_exact(acav_mi *mi, const int64_t *candidates, int64_
                            mi->ticket.as<unsigned>(), mi->S.as<long long>() + it, mi->G.as<double>() + it,
                            forced_pos ? mi->forced.as<int>() + it : nullptr,
                            trace_scores ? mi->tr_sc.as<double>() + (size_t)it * (size_t)L : nullptr,
-                           trace_argmax ? mi->tr_am.as<int>() + it : nullptr);
+                           trace_argmax ? mi->tr_am.as<int>() + it : nullptr, mi->measure, mi->lnk.as<double>(), mi->lf.as<double>());
     }
     ACAV_HIP_TRY(hipGetLastError());
     ACAV_HIP_TRY(hipMemcpyAsync(S_out, mi->S.p, sizeof(long long) * (size_t)iters, hipMemcpyDeviceToHost, st));

@@ -1,16 +1,17 @@
 """Measure registry: the names the reference's `get_measure` knows (subset_selection/code/measures/__init__.py:5-14).
 
 'batch_mi' is the pipeline default (config.py:45); 'mi' and 'mem_mi' are the exact-greedy measures (SURVEY.md 8(f)
-rank 2), 'contrastive' the baseline selector.  'ami' (adjusted MI, mi.py:212-260) is not built.
+rank 2) and 'ami' their adjusted-MI variant (mi.py:212-259), 'contrastive' the baseline selector.
 """
 from .batch import EfficientBatchMI
 from .contrastive import Contrastive
-from .mi import EfficientMI, EfficientMemMI
+from .mi import EfficientAMI, EfficientMI, EfficientMemMI
 
 _REGISTRY = {
     'batch_mi': EfficientBatchMI,
     'mi': EfficientMI,
     'mem_mi': EfficientMemMI,
+    'ami': EfficientAMI,
     'contrastive': Contrastive,
 }
 

@@ -77,3 +77,15 @@ class EfficientMI(EfficientBatchMI):
 
 class EfficientMemMI(EfficientMI):
     """mi.py:284-412: the memory-lean formulation of the same greedy; identical here."""
+
+
+class EfficientAMI(EfficientMI):
+    """adjusted MI (mi.py:212-259; 'ami' in measures/__init__.py:5-14): the exact greedy on
+    (MI - EMI) / max(mean entropy - EMI, eps), EMI being the reference's own one-term-per-cell expression (calc_EMI).
+    Same kernel as `mi` with the adjusted score (acav_mi_set_measure); float64 over integer counts, within 4e-7 relative of
+    the reference's fp32 scores (tests/golden/mi_ami_*.npz).  average_method: 'arithmetic' (the reference default) only."""
+
+    def init(self, clustering_combinations, candidates):
+        assert self.average_method == 'arithmetic', "ami: only the reference's default average_method is built"
+        super().init(clustering_combinations, candidates)
+        _lib.check(_lib._lib.acav_mi_set_measure(self._h, 1))

@@ -63,6 +63,9 @@ def lib():
             "orc_mi_run_greedy": (i64, [vp, vp, i64, vp, i32, i64, i32, i32, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp]),
             "orc_mi_run_exact": (i64, [vp, vp, i64, vp, i32, i64, vp, vp, vp, vp, vp]),
             "orc_mi_get_counts": (None, [vp, vp, vp, vp, vp]),
+            "orc_mi_set_measure": (None, [vp, i32]),
+            "orc_mi_scores_ami": (None, [vp, vp, i32, vp]),
+            "orc_canon_exp": (f64, [f64]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -233,6 +236,16 @@ class BatchMI:
         ids = _i64(ids)
         out = np.empty(len(ids), np.float64)
         lib().orc_mi_scores_canon(self.h, _p(ids), len(ids), _p(out))
+        return out
+
+    def set_measure(self, name):
+        """exact greedy scores: 'mi' / 'mem_mi' (calc_MI) or 'ami' (calc_AMI, mi.py:212-259)"""
+        lib().orc_mi_set_measure(self.h, 1 if name == "ami" else 0)
+
+    def scores_ami(self, ids):
+        ids = _i64(ids)
+        out = np.empty(len(ids), np.float64)
+        lib().orc_mi_scores_ami(self.h, _p(ids), len(ids), _p(out))
         return out
 
     def counts(self):

@@ -7,7 +7,7 @@ this script and the tiny stand-in modules under _stubs/ for the reference's un-v
 imports (torch_scatter, diffdist, wget, braceexpand).
 
     python tests/golden/gen_golden.py            # all three groups
-    python tests/golden/gen_golden.py kmeans|kmeans_big|mi|mi_exact|rng|cli|contrastive
+    python tests/golden/gen_golden.py kmeans|kmeans_big|mi|mi_exact|mi_ami|rng|cli|contrastive
 
 Groups:
   rng.npz     torch.manual_seed/rand/randperm and random.shuffle streams (G6)
@@ -384,6 +384,63 @@ def gen_mi_exact():
               f"GAIN diff max {np.abs(out['mi_GAIN'] - out['mem_mi_GAIN']).max():.3e}")
 
 
+# --------------------------------------------------------------------- ami (exact greedy on the adjusted score)
+def gen_mi_ami():
+    """reference `ami` (EfficientAMI, mi.py:212-259: (MI - EMI) / (mean entropy - EMI) with the reference's own one-term-
+    per-cell EMI), exact greedy: per-iteration score vectors, picks, S, GAIN"""
+    sys.path.insert(0, os.path.join(REF, "subset_selection", "code"))
+    import torch
+    import run_greedy as ref_run_greedy  # noqa: E402  (the reference)
+    from measures.mi import EfficientMI  # noqa: E402
+
+    cases = {
+        # name: (seed, V, D, C, subset)
+        "a": (0, 240, 2, 6, 50),
+        "b": (1, 200, 3, 5, 40),
+        "c": (2, 320, 2, 12, 36),
+    }
+    for name, (seed, v, dd, c, subset) in cases.items():
+        rs = np.random.RandomState(400 + seed)
+        comp = rs.randint(0, c, size=v)
+        cols = []
+        for _ in range(dd):
+            indep = rs.randint(0, c, size=v)
+            share = rs.rand(v) < 0.5
+            cols.append(np.where(share, comp, indep))
+        assignments = np.stack(cols, 1).astype(np.int64)
+        assignments[0, :] = c - 1
+        types = [("m%d" % i, "layer_0") for i in range(dd)]
+        rec = dict(scores=[], idx=[])
+        orig = EfficientMI.calc_score
+
+        def calc_score(self, *a, **k):
+            sc = self._calc_score(*a, **k).mean(dim=-1)
+            score, idx = sc.max(dim=0)
+            rec["scores"].append(sc.cpu().numpy().astype(np.float32).copy())
+            rec["idx"].append(int(idx.item()))
+            return score.item(), idx.item()
+
+        EfficientMI.calc_score = calc_score
+        args = _NS(batch=_NS(batch_size=20, selection_size=4, keep_unselected=True),
+                   computation=_NS(device="cpu"), log_every=10 ** 9, log_times=None,
+                   node_rank=None, parent_pid=None)
+        random.seed(seed)
+        torch.manual_seed(seed)
+        S, GAIN, _ = ref_run_greedy._run_greedy(args, assignments, types, subset, None, "ami", "combination", True, False)
+        EfficientMI.calc_score = orig
+        w0 = len(rec["scores"][0])
+        sc = np.full((len(rec["scores"]), w0), np.nan, np.float32)
+        for t, row in enumerate(rec["scores"]):
+            sc[t, :len(row)] = row
+        random.seed(seed)
+        cand = list(range(v))
+        random.shuffle(cand)
+        np.savez_compressed(os.path.join(HERE, f"mi_ami_{name}.npz"), assignments=assignments, seed=seed, C=c, subset=subset,
+                            S=np.array(S, np.int64), GAIN=np.array(GAIN, np.float64), scores=sc,
+                            idx=np.array(rec["idx"], np.int64), shuffled=np.array(cand, np.int64))
+        print(f"mi_ami_{name}.npz written: {len(S)} selected, score range {np.nanmin(sc):.4f} .. {np.nanmax(sc):.4f}")
+
+
 # ----------------------------------------------------------------------------- cli
 def gen_cli_clustering(root):
     """reference `cli.py cluster` on 4 synthetic shards (real 5+5 layer dims, K=32, 2 epochs)"""
@@ -511,10 +568,10 @@ if __name__ == "__main__":
     if sys.argv[1:2] == ["cli_subset"]:
         gen_cli_subset(sys.argv[2])
         sys.exit(0)
-    which = sys.argv[1:] or ["rng", "kmeans", "kmeans_big", "mi", "mi_exact", "cli", "contrastive"]
+    which = sys.argv[1:] or ["rng", "kmeans", "kmeans_big", "mi", "mi_exact", "mi_ami", "cli", "contrastive"]
     if len(which) > 1:
         for w in which:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
-        {"rng": gen_rng, "kmeans": gen_kmeans, "kmeans_big": gen_kmeans_big, "mi": gen_mi, "mi_exact": gen_mi_exact, "cli": gen_cli,
+        {"rng": gen_rng, "kmeans": gen_kmeans, "kmeans_big": gen_kmeans_big, "mi": gen_mi, "mi_exact": gen_mi_exact, "mi_ami": gen_mi_ami, "cli": gen_cli,
          "contrastive": gen_contrastive}[which[0]]()

@@ -213,6 +213,59 @@ def test_exact_greedy_golden_teacher_forced(env, golden_dir, name, measure):
     assert len(m.candidate_ids) == L - (subset - 2)
 
 
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_ami_exact_greedy_golden_and_free_running(env, golden_dir, name):
+    """'ami' (measures/mi.py:212-259) on the GPU: replaying the reference's recorded picks, S / GAIN / every score vector
+    equal the oracle's canonical float64 form bit for bit (table look-ups + the shared canon_exp), hence
+    (test_oracle_golden) the reference's fp32 scores to 4e-7 relative; free-running == the oracle, pick for pick."""
+    torch, acav, O = env
+    from acav100m_amd.subset_selection import get_measure
+    g = np.load(os.path.join(golden_dir, f"mi_ami_{name}.npz"))
+    a, c, subset, cand = g["assignments"], int(g["C"]), int(g["subset"]), g["shuffled"]
+    pairs = list(itertools.combinations(range(a.shape[1]), 2))
+    idx = g["idx"]
+    L = len(cand) - 1
+    m = get_measure("ami")(a, ncentroids=c, batch_size=20, selection_size=4, device="cuda:0", keep_unselected=True)
+    m.init(pairs, [int(i) for i in cand[1:]])
+    S, GAIN, _, _ = m.run_greedy(subset, [int(cand[0])], None, record_trace=True, forced_pos=_remaining_to_original(idx, L))
+    assert S == g["S"].tolist()
+    om = O.BatchMI(a, c, pairs)
+    om.set_measure("ami")
+    ref = om.run_exact(cand[1:], cand[:1], subset, forced_idx=idx, trace=True)
+    assert np.array_equal(np.array(GAIN), ref["GAIN"])  # float64, bit for bit
+    alive = list(range(L))
+    for t in range(subset - 2):
+        row = m.trace["scores"][t]
+        assert np.array_equal(row[alive], ref["scores"][t, :len(alive)])
+        assert m.trace["argmax"][t] == alive[int(ref["argmax"][t])]
+        alive.pop(int(idx[t]))
+    np.testing.assert_allclose(np.array(GAIN), g["GAIN"], rtol=1e-5, atol=1e-7)  # the reference's own fp32 gains
+    m2 = get_measure("ami")(a, ncentroids=c, device="cuda:0")
+    m2.init(pairs, [int(i) for i in cand[1:]])
+    S2, G2, _, _ = m2.run_greedy(subset, [int(cand[0])])
+    om2 = O.BatchMI(a, c, pairs)
+    om2.set_measure("ami")
+    free = om2.run_exact(cand[1:], cand[:1], subset)
+    assert S2[1:] == free["S"].tolist() and np.array_equal(np.array(G2), free["GAIN"])
+
+
+def test_ami_larger_tables_free_running_equals_oracle(env):
+    """ami beyond the golden sizes: D = 4 (P = 6), C = 24, 2 000 candidates, 80 picks -- GPU == oracle bit for bit"""
+    torch, acav, O = env
+    from acav100m_amd.subset_selection import get_measure
+    v, dd, c, subset = 2000, 4, 24, 80
+    a = _correlated(77, v, dd, c)
+    pairs = list(itertools.combinations(range(dd), 2))
+    cand = np.random.RandomState(5).permutation(v)
+    m = get_measure("ami")(a, ncentroids=c, device="cuda:0")
+    m.init(pairs, [int(i) for i in cand[1:]])
+    S, GAIN, _, _ = m.run_greedy(subset, [int(cand[0])])
+    om = O.BatchMI(a, c, pairs)
+    om.set_measure("ami")
+    ref = om.run_exact(cand[1:], cand[:1], subset)
+    assert S[1:] == ref["S"].tolist() and np.array_equal(np.array(GAIN), ref["GAIN"])
+
+
 @pytest.mark.parametrize("v,dd,c,subset,pairing", [(3000, 2, 16, 200, "combination"), (1500, 4, 40, 120, "combination"),
                                                     (5000, 10, 12, 60, "bipartite"), (700, 3, 300, 90, "combination")])
 def test_exact_greedy_free_running_equals_oracle(env, v, dd, c, subset, pairing):

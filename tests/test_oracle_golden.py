@@ -238,6 +238,41 @@ def test_mi_exact_greedy_golden(golden_dir, name, measure):
         assert np.array_equal(free["S"], g["mem_mi_S"][1:])
 
 
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_ami_exact_greedy_golden(golden_dir, name):
+    """'ami' (measures/mi.py:212-259, registered in measures/__init__.py): exact greedy on the adjusted score
+    (MI - EMI) / (mean entropy - EMI) with the reference's own one-term-per-cell EMI.  Teacher-forced on the reference's
+    picks: the canonical float64 scores (table look-ups + canon_exp over integer counts) equal its fp32 score vectors to
+    1e-5 relative (BASELINE's bar; observed 3.6e-7) at every iteration, every reference pick is within that band of the
+    canonical maximum (the scores tie in fp32 exactly as those of `mi`), S and GAIN follow."""
+    g = np.load(os.path.join(golden_dir, f"mi_ami_{name}.npz"))
+    a, c, subset, cand = g["assignments"], int(g["C"]), int(g["subset"]), g["shuffled"]
+    pairs = list(itertools.combinations(range(a.shape[1]), 2))
+    idx, ref_sc = g["idx"], g["scores"]
+    m = O.BatchMI(a, c, pairs)
+    m.set_measure("ami")
+    r = m.run_exact(cand[1:], cand[:1], subset, forced_idx=idx, trace=True)
+    n = subset - 2
+    assert r["iters"] == n == len(idx)
+    assert np.array_equal(r["S"], g["S"][1:]) and g["S"][0] == cand[0]
+    np.testing.assert_allclose(r["GAIN"], g["GAIN"], rtol=1e-5, atol=1e-7)
+    worst = 0.0
+    for t in range(n):
+        L = ref_sc.shape[1] - t
+        mine, ref = r["scores"][t, :L], ref_sc[t, :L].astype(np.float64)
+        assert np.isnan(r["scores"][t, L:]).all()
+        rel = np.abs(mine - ref) / np.maximum(np.abs(ref), 1e-6)
+        worst = max(worst, float(rel.max()))
+        assert rel.max() <= 1e-5
+        assert mine.max() - mine[idx[t]] <= 1e-5 * max(1e-6, abs(mine.max()))
+        assert r["argmax"][t] == int(np.argmax(mine))
+    print(f"ami_{name}: max relative score difference from the reference {worst:.2e}")
+    # the deterministic exp of the canonical score against libm
+    import math
+    for x in (0.0, -1e-9, -0.3, -3.7, -50.0, -700.0):
+        assert abs(O.lib().orc_canon_exp(x) - math.exp(x)) <= 4e-16 * math.exp(x)
+
+
 def _contrastive_data(seed, n, vis, aud):
     """the generator recipe of tests/golden/gen_golden.py:gen_contrastive (case c only stores the first columns)"""
     rs = np.random.RandomState(seed)
