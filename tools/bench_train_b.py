@@ -26,4 +26,4 @@ for b in [int(a) for a in sys.argv[1:]] or [32, 64, 128, 256]:
     km.train_epoch(x, b, lr=0.01)
     km.synchronize()
     dt = time.perf_counter() - t0
-    print(f"b={b}: {dt / (n // b) * 1e6:.2f} us/step, {n / dt / 1e6:.2f} M rows/s")
+    print(f"b={b}: {dt / (n // b) * 1e6:.2f} us/step, {n / dt / 1e6:.2f} M rows/s; persistent launches / fallbacks {km.train_stats()}")
