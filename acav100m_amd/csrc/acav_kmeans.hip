@@ -2927,7 +2927,9 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         const int ngroups = (km->K + 255) / 256;
         const char *vgs = getenv("ACAV_FILTER_GS"), *vnw = getenv("ACAV_FILTER_NW"), *vsc = getenv("ACAV_FILTER_SCHED");
         const bool gs = rw && ngroups > 1 && !(vgs && vgs[0] == '0');
-        const int nw = !rw ? 4 : (vnw && vnw[0] == '8') ? 8 : (vnw && vnw[0] == '4') ? 4 : (gs ? 8 : FILTER_NW_DEFAULT);
+        // (narrow views, d <= 256: a pair is only 4-8 stages long and its ring fill and epilogue weigh as much as its stage loop
+        // -- two 128-row workgroups per CU hide them under each other: d = 128, K = 1024: 0.59 vs 0.72 ms per 1.25M rows)
+        const int nw = !rw ? 4 : (vnw && vnw[0] == '8') ? 8 : (vnw && vnw[0] == '4') ? 4 : (gs ? (km->d <= 256 ? 4 : 8) : FILTER_NW_DEFAULT);
         const bool nt_eff = gs ? !(vnt && vnt[0] == '0') : nt;  // nt rows are still found in L2 by the tile's other groups (PMC)
         const int dcr = nw == 8 ? 3 : 2;  // centre ring depth (3 only fits the one-workgroup-per-CU tile)
         const int sched = nw == 8 ? 2 : (vsc ? (vsc[0] == '2' ? 2 : 0) : FILTER_SCHED_DEFAULT);
