@@ -868,6 +868,46 @@ constexpr int GS_EPT = 4;          // outputs per thread of the gather
 constexpr int FY_SHARDS = 8;       // sub-buckets per tile (capg entries each), filled by workgroups b with b % 8 == shard
 constexpr int FYT_THREADS = ACAV_FYT_THREADS;  // k_fy_tile: the list walks are chains of dependent LDS reads -- many waves hide them
 
+// exclusive prefix sums of cnt[0 .. n) into pre[0 .. n) (both in LDS, distinct), by all threads of the workgroup (a multiple of
+// 64, at most 1024); wsum: 16 ints of LDS; returns the total.  Ends with a barrier.
+__device__ __forceinline__ int block_excl_scan(const int *cnt, int *pre, int n, int *wsum)
+{
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6;
+    const int per = (n + nthr - 1) / nthr, lo = tid * per;
+    int s = 0;
+    for (int q = 0; q < per; ++q) s += lo + q < n ? cnt[lo + q] : 0;
+    int v = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        v += lane >= o ? t : 0;
+    }
+    if (lane == 63) wsum[tid >> 6] = v;
+    __syncthreads();
+    if (tid < 64) {
+        int w = tid < nw ? wsum[tid] : 0;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int t = __shfl_up(w, o, 64);
+            w += lane >= o ? t : 0;
+        }
+        if (tid < nw) wsum[tid] = w;
+    }
+    __syncthreads();
+    int run = ((tid >> 6) ? wsum[(tid >> 6) - 1] : 0) + v - s;
+    for (int q = 0; q < per; ++q)
+        if (lo + q < n) {
+            pre[lo + q] = run;
+            run += cnt[lo + q];
+        }
+    const int total = wsum[nw - 1];
+    __syncthreads();
+    return total;
+}
+
+// STAGED: the workgroup's appends are first sorted by tile in LDS and leave as runs of consecutive slots per tile (adjacent
+// lanes -> adjacent addresses: a few L2 requests per wave store instead of one per lane)
+template <bool STAGED>
 __device__ __forceinline__ void fy_part_body(const unsigned *__restrict__ draws, int L, const unsigned short *__restrict__ table,
                                              int ntab, int gsh, int NT, int capg, int2 *__restrict__ bucket,
                                              int *__restrict__ gcount, unsigned *__restrict__ src, unsigned *__restrict__ err,
@@ -875,7 +915,10 @@ __device__ __forceinline__ void fy_part_body(const unsigned *__restrict__ draws,
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fy_smem[];
     int *lhist = reinterpret_cast<int *>(fy_smem), *lbase = lhist + NT;
-    unsigned short *ltab = reinterpret_cast<unsigned short *>(lbase + NT);  // the tile table, a few KB: LDS lookups
+    int2 *stage = reinterpret_cast<int2 *>(lbase + NT);                    // [FYA_CH] (STAGED)
+    int *lpre = reinterpret_cast<int *>(stage + (STAGED ? FYA_CH : 0));    // [NT] (STAGED)
+    int *wsum = lpre + (STAGED ? NT : 0);                                  // [16] (STAGED)
+    unsigned short *ltab = reinterpret_cast<unsigned short *>(wsum + (STAGED ? 16 : 0));  // the tile table, a few KB: LDS lookups
     const int tid = threadIdx.x;
     constexpr int PER = FYA_CH / FYA_THREADS;
     const int base = bx * FYA_CH;
@@ -913,13 +956,34 @@ __device__ __forceinline__ void fy_part_body(const unsigned *__restrict__ draws,
         const int c = lhist[t];
         lbase[t] = c ? atomicAdd(&gcount[t * FY_SHARDS + shard], c) : 0;
     }
+    if constexpr (STAGED) {
+        const int total = block_excl_scan(lhist, lpre, NT, wsum);  // (its first barrier also publishes lbase)
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if (tr[u] >= 0) stage[lpre[tr[u] >> 16] + (tr[u] & 0xffff)] = make_int2(base + u * FYA_THREADS + tid, hh[u]);
+        __syncthreads();
+        for (int x = tid; x < total; x += FYA_THREADS) {
+            const int2 e = stage[x];
+            const int tile = ltab[(L - 1 - e.y) >> gsh], pos = lbase[tile] + (x - lpre[tile]);
+            if (pos < capg)
+                FY_ST_BUCKET(&bucket[((size_t)tile * FY_SHARDS + shard) * capg + pos], e);
+            else
+                atomicOr(err, 1u);
+        }
+        return;
+    }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < PER; ++u)
         if (tr[u] >= 0) {
             const int tile = tr[u] >> 16, pos = lbase[tile] + (tr[u] & 0xffff);
+#ifdef ACAV_FY_ABL_BKSEQ  // timing-only ablation (tools/exp/fy_bench.hip): the appends as one sequential stream
+            if (pos < capg)
+                FY_ST_BUCKET(&bucket[(size_t)base + u * FYA_THREADS + tid], make_int2(base + u * FYA_THREADS + tid, hh[u]));
+#else
             if (pos < capg)
                 FY_ST_BUCKET(&bucket[((size_t)tile * FY_SHARDS + shard) * capg + pos], make_int2(base + u * FYA_THREADS + tid, hh[u]));
+#endif
             else
                 atomicOr(err, 1u);
         }
@@ -1006,7 +1070,11 @@ __device__ __forceinline__ void fy_tile_body(int L, const int *__restrict__ ebou
                 const int jj = ej[x];
                 if (jj < j && jj > pred) pred = jj;
             }
+#ifdef ACAV_FY_ABL_SRCSEQ  // timing-only ablation: the src stores in entry order instead of step order
+            FY_ST_SRC(&src[((size_t)tile * 4096 + e) % (size_t)L], pred >= 0 ? (FY_EREF | (unsigned)pred) : (unsigned)(q_lo + p));
+#else
             FY_ST_SRC(&src[j], pred >= 0 ? (FY_EREF | (unsigned)pred) : (unsigned)(q_lo + p));
+#endif
         }
         FY_CLK(3);
         for (int p = p0 + tid; p < p1; p += FYT_THREADS)
@@ -1055,6 +1123,7 @@ __device__ __forceinline__ const unsigned *chunk_draw_ptr(const TileChunk &c, in
     return r0 < c.head ? c.ring - (c.head - r0) : c.ring + (r0 - c.head) % c.ring_words;
 }
 
+template <bool STAGED>
 __global__ __launch_bounds__(FYA_THREADS) void k_fy_part_multi(const TileChunk *__restrict__ cd, int it0, int dl)
 {
     const TileChunk &c = cd[blockIdx.y];
@@ -1062,7 +1131,7 @@ __global__ __launch_bounds__(FYA_THREADS) void k_fy_part_multi(const TileChunk *
     const int L = c.L0 - it * dl;
     if (it >= c.iters || (int)blockIdx.x * FYA_CH >= L) return;
     const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    fy_part_body(chunk_draw_ptr(c, it, dl), L, c.table, c.ntab, c.gsh, c.NT, c.capg, c.bucket + (size_t)z * c.NT * FY_SHARDS * c.capg,
+    fy_part_body<STAGED>(chunk_draw_ptr(c, it, dl), L, c.table, c.ntab, c.gsh, c.NT, c.capg, c.bucket + (size_t)z * c.NT * FY_SHARDS * c.capg,
                  c.gcount + (size_t)z * c.NT * FY_SHARDS, c.src[z], c.err, (int)blockIdx.x, (int)(lin & (FY_SHARDS - 1)));
 }
 
@@ -1088,7 +1157,11 @@ __global__ __launch_bounds__(256) void k_fy_resolve_multi(const TileChunk *__res
     if (it >= c.iters || i >= L) return;
     const unsigned s = c.src[z][i];
     int a = (int)(s & 0x7fffffffu);
+#ifdef ACAV_FY_ABL_NOWALK  // timing-only ablation: no chain reads
+    if (0) {
+#else
     if (s & FY_EREF) {  // what step a left behind: walk back to the position whose original content that was
+#endif
         const int *__restrict__ g = c.g[z];
         int ga;
         while ((ga = g[a]) >= 0) a = ga;
@@ -1481,6 +1554,11 @@ struct FyPlan {
     size_t tile_smem() const { return (size_t)wcap * 8 + (size_t)ecap_lds * 8; }
 };
 
+static size_t fy_part_smem(int NT, size_t ntab, bool staged)
+{
+    return sizeof(int) * (staged ? 3 : 2) * (size_t)NT + (staged ? sizeof(int2) * FYA_CH + sizeof(int) * 16 : 0) + sizeof(unsigned short) * ntab;
+}
+
 // tiling of a list of (at most) L candidates and the handle's buffers for it: table, tile bounds, sharded buckets and their
 // counters (one set per iteration of a group; zeroed), error flag (cleared), src / g (per iteration of a group) and perm
 // (two groups deep) buffers; uploads are stream-ordered on st (fp must stay alive
@@ -1667,7 +1745,7 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
     std::vector<MtStream> streams((size_t)nchunks);
     int64_t iters_max = 0, lmax = 0;
     int pmax = 1, dmax = 1, ntmax = 1;
-    size_t part_smem = 0, tile_smem = 0;
+    size_t part_smem = 0, part_smem_staged = 0, tile_smem = 0;
     for (int c = 0; c < nchunks; ++c) {
         acav_mi *mi = mis[c];
         ACAV_HIP_TRY(hipStreamSynchronize(mi->ctx.stream));  // whatever the handle was doing on its own stream is over
@@ -1707,8 +1785,9 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
         FyPlan &fp = plans[(size_t)c];
         ACAV_TRY(fy_setup(mi, L[c], fp, st));
         ntmax = fp.NT > ntmax ? fp.NT : ntmax;
-        const size_t ps = sizeof(int) * 2 * (size_t)fp.NT + sizeof(unsigned short) * fp.table.size();
+        const size_t ps = fy_part_smem(fp.NT, fp.table.size(), false), pss = fy_part_smem(fp.NT, fp.table.size(), true);
         part_smem = ps > part_smem ? ps : part_smem;
+        part_smem_staged = pss > part_smem_staged ? pss : part_smem_staged;
         tile_smem = fp.tile_smem() > tile_smem ? fp.tile_smem() : tile_smem;
         // hand the host MT19937 stream to the device: W lanes generate it superblock by superblock on their own stream
         // (MtStream); nothing they do depends on what gets selected (L shrinks by a fixed amount per iteration)
@@ -1744,6 +1823,13 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
     ACAV_HIP_TRY(hipStreamSynchronize(st));  // tables, counters, candidate lists, forced positions and descriptors are in place
     ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fy_tile_multi), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)tile_smem));
+    // the staged form of k_fy_part wants 64 KB of LDS beside the tile table (which grows with L: 64 KB at 16 Mi candidates)
+    const bool part_staged = part_smem_staged <= 96 * 1024 && !getenv("ACAV_FY_PART_DIRECT");
+    if (part_staged) {
+        part_smem = part_smem_staged;
+        ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fy_part_multi<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)part_smem));
+    }
     const TileChunk *dcd = lead->chunk_desc.as<TileChunk>();
     const int sel_f = sel_mode(B, pmax, k);  // one mode for every chunk of the launch: sized for the largest P and D
     const size_t sel_smem = sel_layout(B, pmax, dmax, k, sel_f).total;
@@ -1770,8 +1856,9 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
             ACAV_TRY(streams[(size_t)c].acquire(r0[(size_t)c], nd, &unused));
             r0[(size_t)c] += nd;
         }
-        hipLaunchKernelGGL(k_fy_part_multi, dim3((unsigned)((lt + FYA_CH - 1) / FYA_CH), (unsigned)nchunks, gz), dim3(FYA_THREADS),
-                           part_smem, sf, dcd, (int)g0, (int)dl);
+        hipLaunchKernelGGL(part_staged ? k_fy_part_multi<true> : k_fy_part_multi<false>,
+                           dim3((unsigned)((lt + FYA_CH - 1) / FYA_CH), (unsigned)nchunks, gz), dim3(FYA_THREADS), part_smem, sf, dcd,
+                           (int)g0, (int)dl);
         for (int c = 0; c < nchunks; ++c)
             if (g0 < iters[(size_t)c]) ACAV_TRY(streams[(size_t)c].release(r0[(size_t)c]));  // k_fy_part is the only reader of the draws
         hipLaunchKernelGGL(k_fy_tile_multi, dim3((unsigned)ntmax, (unsigned)nchunks, gz), dim3(FYT_THREADS), tile_smem, sf, dcd, (int)g0,

@@ -48,9 +48,8 @@ def prepare(**kwargs):
 def run(args):
     """cli.py:90-100"""
     if args.measure_name == 'contrastive':
-        assert args.chunk_size is None, "the chunked contrastive mode (chunk_contrastive.py) is not built: run it on all shards"
-        from .run_contrastive import run_single_contrastive
-        return run_single_contrastive(args)
+        from .run_contrastive import run_chunks_contrastive, run_single_contrastive
+        return run_single_contrastive(args) if args.chunk_size is None else run_chunks_contrastive(args)
     return run_single(args) if args.chunk_size is None else run_chunks(args)
 
 

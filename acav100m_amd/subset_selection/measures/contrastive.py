@@ -202,7 +202,9 @@ class Contrastive:
     def save_inference(self, args, logits, metas, json_metas):
         cache_dir = Path(args.data.output.path).parent / 'caches'
         cache_dir.mkdir(parents=True, exist_ok=True)
-        name = "{}_contrastive_inferred_cache_{}_{}.csv".format(Path(args.data.output.path).stem, args.parent_pid, 0)
+        # one file per process (contrastive.py:243-246: local rank); the chunks of a rank append to it
+        name = "{}_contrastive_inferred_cache_{}_{}.csv".format(Path(args.data.output.path).stem, args.parent_pid,
+                                                                int(args.node_rank or 0))
         print("saving cache to {}".format(cache_dir / name))
         with open(cache_dir / name, 'a+', newline='') as f:
             writer = csv.writer(f)

@@ -127,6 +127,44 @@ def run_single_contrastive(args):
     return out
 
 
+def run_chunks_contrastive(args):
+    """chunk_contrastive.py:17-49,115-131 for THIS process's rank (one process per GPU): the shards are cut into chunks of
+    `chunk_size`, every rank takes a contiguous block of them (utils.split_chunks) and runs the whole contrastive flow --
+    train a model on the chunk, score the chunk's clips -- chunk after chunk; every chunk appends its scores to the rank's
+    inference cache, `merge_contrastive` ranks all of them afterwards.
+    Deviation, on purpose: the reference cannot finish this mode -- its run_chunk unpacks the `None` that run_contrastive._run
+    returns (chunk_contrastive.py:146-148 vs run_contrastive.py:45-51: the `return` sits inside a string literal) and raises
+    after the first chunk of every rank.  Here every chunk is processed; the files written per chunk are the reference's."""
+    import copy
+    import math
+    from ..parallel import world
+    args.parent_pid = str(args.parent_pid or os.environ.get('ACAV_PARENT_PID') or os.getpid())
+    paths = [p for p in sorted(io.brace_expand(args.data.path)) if Path(p).is_file()]
+    chunks = list(enumerate(io.chunked(paths, int(args.chunk_size))))
+    num_chunks = len(chunks)
+    rank, w = world()
+    gpus = max(1, min(w, num_chunks))
+    if w > num_chunks:
+        print("num_gpus ({}) exceeds num_chunks ({})".format(w, num_chunks))
+        print("thresholding num_gpus to be equal to num_chunks")
+    chunk_args = copy.deepcopy(args)
+    if isinstance(chunk_args.subset.size, int):
+        chunk_args.subset.size = math.ceil(chunk_args.subset.size / num_chunks)
+    print("running {} chunks in {} gpus".format(num_chunks, gpus))
+    per = math.ceil(num_chunks / gpus)
+    mine = chunks[rank * per:(rank + 1) * per] if rank < gpus else []
+    chunk_args.node_rank = rank
+    done = []
+    for i, (num, chunk) in enumerate(mine):
+        print("running chunk {}".format(num))
+        one = copy.deepcopy(chunk_args)
+        one.chunk_num = i
+        _run(one, chunk)
+        done.append(num)
+    print("done")
+    return done
+
+
 def merge_contrastive(args):
     """merge_contrastive.py:107-131 without the shell: concatenate the inference caches of the run with the most files,
     sort by score descending (then by the rest of the line, duplicates of the sort key dropped: `sort -t , -u -k 1,1gr

@@ -163,3 +163,44 @@ def test_contrastive_cli_end_to_end(env, tmp_path_factory, golden_dir):
     assert len(final) == 600 and len({r[1] for r in final}) == 600 and len(final[0]) == 4
     order = np.argsort(-got, kind="stable")
     assert [r[1] for r in final[:50]] == [rows[i][2] for i in order[:50]]
+
+
+def test_contrastive_chunked_cli(env, tmp_path_factory, golden_dir):
+    """`cli.py run --measure_name=contrastive --chunk_size=2`: every chunk of shards trains its own model and scores its own
+    clips (chunk_contrastive.py:17-49,115-131); the rank's inference cache collects all chunks, merge_contrastive ranks them.
+    The first chunk's scores equal a plain run on those two shards with the same seed."""
+    torch, acav = env
+    sys.path.insert(0, golden_dir)
+    import synth
+    from acav100m_amd.subset_selection.cli import Cli
+    root = str(tmp_path_factory.mktemp("acav_ctr_chunks"))
+    glob = synth.write_feature_shards(root, n_shards=4, rows=150, seed=9)
+    out_csv = os.path.join(root, "sel", "output.csv")
+    kw = dict(shards_path=glob, meta_path=os.path.join(root, "videos"), out_path=out_csv, measure_name="contrastive")
+    acav.manual_seed(3)
+    done = Cli().run(chunk_size=2, **kw)
+    assert done == [0, 1]
+    caches = sorted(os.listdir(os.path.join(root, "sel", "caches")))
+    models = [c for c in caches if c.startswith("contrastive_model_cache_epoch_") and c.endswith(".pkl")]
+    assert len(models) == 6 and {c[:-4].rsplit("_", 1)[1] for c in models} == {"0", "1"}  # 3 epochs x 2 chunks, chunk_num last
+    inf = [c for c in caches if "contrastive_inferred_cache" in c]
+    assert len(inf) == 1
+    rows = list(csv.reader(open(os.path.join(root, "sel", "caches", inf[0]))))
+    assert len(rows) == 600 and len({r[2] for r in rows}) == 600
+    Cli().merge_contrastive(**kw)
+    final = list(csv.reader(open(out_csv)))
+    assert len(final) == 600 and len({r[1] for r in final}) == 600
+    got = np.array([float(r[0]) for r in rows], np.float32)
+    order = np.argsort(-got, kind="stable")
+    assert [r[1] for r in final[:50]] == [rows[i][2] for i in order[:50]]
+    # chunk 0 alone, same seed: the same 300 scores
+    assert "{000000..000003}" in glob
+    root2 = str(tmp_path_factory.mktemp("acav_ctr_chunk0"))
+    out2 = os.path.join(root2, "sel", "output.csv")
+    acav.manual_seed(3)
+    Cli().run(shards_path=glob.replace("{000000..000003}", "{000000..000001}"), meta_path=os.path.join(root, "videos"), out_path=out2,
+              measure_name="contrastive")
+    c2 = os.path.join(root2, "sel", "caches")
+    rows2 = list(csv.reader(open(os.path.join(c2, [c for c in os.listdir(c2) if "contrastive_inferred_cache" in c][0]))))
+    assert [r[2] for r in rows2] == [r[2] for r in rows[:300]]
+    np.testing.assert_array_equal(np.array([float(r[0]) for r in rows2]), got[:300].astype(np.float64))

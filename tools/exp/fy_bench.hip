@@ -48,9 +48,12 @@ int main(int argc, char **argv)
     c.D = D; c.C = C; c.P = P;
     TileChunk *dcd; CK(hipMalloc(&dcd, sizeof(c))); CK(hipMemcpy(dcd, &c, sizeof(c), hipMemcpyHostToDevice));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fy_tile_multi), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.tile_smem()));
-    const size_t part_smem = sizeof(int) * 2 * (size_t)fp.NT + sizeof(unsigned short) * fp.table.size();
+    const bool staged = getenv("FYB_PART_DIRECT") == nullptr;
+    const size_t part_smem = fy_part_smem(fp.NT, fp.table.size(), staged);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fy_part_multi<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fy_part_smem(fp.NT, fp.table.size(), true)));
+    printf("part: %s, %zu B of LDS\n", staged ? "staged" : "direct", part_smem);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto part = [&]() { hipLaunchKernelGGL(k_fy_part_multi, dim3((L + FYA_CH - 1) / FYA_CH, 1, G), dim3(FYA_THREADS), part_smem, 0, dcd, 0, dl); };
+    auto part = [&]() { if (staged) hipLaunchKernelGGL(k_fy_part_multi<true>, dim3((L + FYA_CH - 1) / FYA_CH, 1, G), dim3(FYA_THREADS), part_smem, 0, dcd, 0, dl); else hipLaunchKernelGGL(k_fy_part_multi<false>, dim3((L + FYA_CH - 1) / FYA_CH, 1, G), dim3(FYA_THREADS), part_smem, 0, dcd, 0, dl); };
     auto tile = [&]() { hipLaunchKernelGGL(k_fy_tile_multi, dim3(fp.NT, 1, G), dim3(FYT_THREADS), fp.tile_smem(), 0, dcd, 0, dl); };
     auto resolve = [&]() { hipLaunchKernelGGL(k_fy_resolve_multi, dim3((L + 255) / 256, 1, G), dim3(256), 0, 0, dcd, 0, dl, B - k); };
     auto timeit = [&](const char *name, auto fn, double base_us) {
@@ -66,6 +69,7 @@ int main(int argc, char **argv)
     };
     const double t_ms = timeit("memset counters", [&]() { CK(hipMemsetAsync(c.gcount, 0, 4 * nc, 0)); }, 0);
     const double t_p = timeit("memset + part", [&]() { CK(hipMemsetAsync(c.gcount, 0, 4 * nc, 0)); part(); }, t_ms);
+    if (getenv("FYB_ONLY_PART")) return 0;  // -DACAV_FY_ABL_BKSEQ leaves buckets the tile kernel must not read
     const double t_pt = timeit("memset + part + tile", [&]() { CK(hipMemsetAsync(c.gcount, 0, 4 * nc, 0)); part(); tile(); }, t_p);
     timeit("part + tile + resolve", [&]() { part(); tile(); resolve(); }, t_pt - t_ms);
     (void)t_ms;
@@ -115,7 +119,8 @@ int main(int argc, char **argv)
         }
         CK(hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, pri ? hi : 0));
         auto side = [&](hipStream_t st) {
-            hipLaunchKernelGGL(k_fy_part_multi, dim3((L + FYA_CH - 1) / FYA_CH, 1, G), dim3(FYA_THREADS), part_smem, st, dcd, 8, dl);
+            if (staged) hipLaunchKernelGGL(k_fy_part_multi<true>, dim3((L + FYA_CH - 1) / FYA_CH, 1, G), dim3(FYA_THREADS), part_smem, st, dcd, 8, dl);
+            else hipLaunchKernelGGL(k_fy_part_multi<false>, dim3((L + FYA_CH - 1) / FYA_CH, 1, G), dim3(FYA_THREADS), part_smem, st, dcd, 8, dl);
             hipLaunchKernelGGL(k_fy_tile_multi, dim3(fp.NT, 1, G), dim3(FYT_THREADS), fp.tile_smem(), st, dcd, 8, dl);
             hipLaunchKernelGGL(k_fy_resolve_multi, dim3((L + 255) / 256, 1, G), dim3(256), 0, st, dcd, 8, dl, B - k);
         };
