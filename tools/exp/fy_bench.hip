@@ -124,9 +124,10 @@ int main(int argc, char **argv)
             hipLaunchKernelGGL(k_fy_tile_multi, dim3(fp.NT, 1, G), dim3(FYT_THREADS), fp.tile_smem(), st, dcd, 8, dl);
             hipLaunchKernelGGL(k_fy_resolve_multi, dim3((L + 255) / 256, 1, G), dim3(256), 0, st, dcd, 8, dl, B - k);
         };
+        const bool nosel = getenv("FYB_NOSEL") != nullptr;  // every gather as launch 0: no selection beside it
         auto gath = [&](hipStream_t st) {
             for (int i = 0; i < G; ++i)
-                hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 256 * GS_EPT - 1) / (256 * GS_EPT) + 1, 1), dim3(256), sel_smem, st, dcd, i, dl, B, k, sel_m, 1);
+                hipLaunchKernelGGL(k_fy_gather_select_multi, dim3((L + 256 * GS_EPT - 1) / (256 * GS_EPT) + 1, 1), dim3(256), sel_smem, st, dcd, nosel ? 0 : i, dl, B, k, sel_m, 1);
         };
         auto wall = [&](const char *name, auto fn) {
             fn(); CK(hipDeviceSynchronize());
