@@ -66,6 +66,11 @@ SIGNATURES = {
     "acav_contrastive_set_params": [vp, vp],
     "acav_contrastive_train": [vp, vp, vp, vp, i64, f64, vp, vp],
     "acav_contrastive_infer": [vp, vp, vp, i64, vp],
+    "acav_contrastive_set_comm": [vp, vp],
+    "acav_contrastive_backward": [vp, vp, vp, i64, vp, vp],
+    "acav_contrastive_get_grads": [vp, vp],
+    "acav_contrastive_set_grads": [vp, vp],
+    "acav_contrastive_step": [vp, f64],
     "acav_mi_create": [pp, i32, vp, i64, i32, i32, vp, i32, vp],
     "acav_mi_destroy": [vp],
     "acav_mi_add_samples": [vp, vp, i64],

@@ -117,6 +117,7 @@ SUBSET_DEFAULTS = {
         'num_gpus': None,
         'dist_backend': 'nccl',
         'dist_init_method': 'tcp://localhost:9967',
+        'use_distributed': True,  # contrastive: one worker per GPU, gradients averaged (run_contrastive.py:56-60,118-168)
         'load_async': False,
         'concurrent_chunks': 1,  # ours: > 1 selects from that many chunks in lockstep on one GPU (own RNG stream each)
     },

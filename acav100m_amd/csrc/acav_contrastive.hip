@@ -211,6 +211,12 @@ __global__ __launch_bounds__(256) void k_ct_adamw(float *__restrict__ p, const f
     p[i] = pi - step_size * (mi / denom);
 }
 
+__global__ __launch_bounds__(256) void k_ct_scale(float *__restrict__ g, long n, float f)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) g[i] = g[i] * f;
+}
+
 __global__ __launch_bounds__(256) void k_ct_pair_dot(const float *__restrict__ o1, const float *__restrict__ o2, float *__restrict__ out_logits,
                                                      int rows, int out)
 {
@@ -231,6 +237,8 @@ struct acav_contrastive {
     size_t nparam = 0;                      // vis*out + out + aud*out + out, in state_dict order
     DevBuf params, grads, m, v, vmax;       // flat [Wv | bv | Wa | ba]
     DevBuf stage_v, stage_a, z1, z2, o1, o2, den1, den2, L, mx, se, nll, hit, G, do1, do2, dz1, dz2, loss, acc, logits;
+    acav_comm *comm = nullptr;              // set: the gradients are averaged over its ranks before every optimizer step
+    int world = 1;
     float *Wv() { return params.as<float>(); }
     float *bv() { return Wv() + (size_t)vis * out; }
     float *Wa() { return bv() + out; }
@@ -327,8 +335,73 @@ static int ct_forward(acav_contrastive *c, const float *dv, const float *da, int
     return ACAV_OK;
 }
 
+static int ct_ensure_train_buffers(acav_contrastive *c, int64_t nbatches)
+{
+    ACAV_TRY(c->loss.ensure(sizeof(float) * (size_t)(nbatches + 1)));
+    ACAV_TRY(c->acc.ensure(sizeof(float) * (size_t)(nbatches + 1)));
+    const size_t bb = sizeof(float) * CT_MAXB * CT_MAXB, bo = sizeof(float) * CT_MAXB * (size_t)c->out;
+    ACAV_TRY(c->L.ensure(bb));
+    ACAV_TRY(c->G.ensure(bb));
+    for (DevBuf *b : {&c->mx, &c->se, &c->nll}) ACAV_TRY(b->ensure(sizeof(float) * 2 * CT_MAXB));
+    ACAV_TRY(c->hit.ensure(sizeof(int) * 2 * CT_MAXB));
+    for (DevBuf *b : {&c->do1, &c->do2, &c->dz1, &c->dz2}) ACAV_TRY(b->ensure(bo));
+    return ACAV_OK;
+}
+
+// forward + backward of one batch of B clips (device rows): the gradients ACCUMULATE into .grad, loss / acc land in slot i
+static int ct_backward(acav_contrastive *c, const float *xv, const float *xa, int B, int64_t i)
+{
+    hipStream_t st = c->ctx.stream;
+    const float inv_t = 1.0f / CT_TEMPERATURE;
+    ACAV_TRY(ct_forward(c, xv, xa, B));
+    float *o1 = c->o1.as<float>(), *o2 = c->o2.as<float>(), *L = c->L.as<float>(), *G = c->G.as<float>();
+    ct_gemm(st, o1, c->out, 1, o2, c->out, 1, L, B, B, B, c->out, inv_t, nullptr, 0);  // logits_ab = o1 o2^T / T
+    hipLaunchKernelGGL(k_ct_stats, dim3((unsigned)(2 * B)), dim3(256), 0, st, L, B, c->mx.as<float>(), c->se.as<float>(),
+                       c->nll.as<float>(), c->hit.as<int>());
+    hipLaunchKernelGGL(k_ct_grad_logits, dim3((unsigned)((B * B + 255) / 256)), dim3(256), 0, st, L, B, c->mx.as<float>(),
+                       c->se.as<float>(), c->nll.as<float>(), c->hit.as<int>(), G, c->loss.as<float>() + i, c->acc.as<float>() + i);
+    // d o1 = G o2 / T (NN), d o2 = G^T o1 / T (TN)
+    ct_gemm(st, G, B, 1, o2, 1, c->out, c->do1.as<float>(), c->out, B, c->out, B, inv_t, nullptr, 0);
+    ct_gemm(st, G, 1, B, o1, 1, c->out, c->do2.as<float>(), c->out, B, c->out, B, inv_t, nullptr, 0);
+    hipLaunchKernelGGL(k_ct_normalize_bwd, dim3((unsigned)((B + 3) / 4), 2), dim3(256), 0, st, o1, o2, c->do1.as<float>(),
+                       c->do2.as<float>(), c->den1.as<float>(), c->den2.as<float>(), c->dz1.as<float>(), c->dz2.as<float>(), B,
+                       c->out);
+    // weight gradients (TN, accumulated into .grad): dW [out, in] += dz^T x
+    ct_gemm(st, c->dz1.as<float>(), 1, c->out, xv, 1, c->vis, c->g(c->Wv()), c->vis, c->out, c->vis, B, 1.0f, nullptr, 1);
+    ct_gemm(st, c->dz2.as<float>(), 1, c->out, xa, 1, c->aud, c->g(c->Wa()), c->aud, c->out, c->aud, B, 1.0f, nullptr, 1);
+    hipLaunchKernelGGL(k_ct_bias_grad, dim3((unsigned)((c->out + 255) / 256), 2), dim3(256), 0, st, c->dz1.as<float>(),
+                       c->dz2.as<float>(), c->g(c->bv()), c->g(c->ba()), B, c->out);
+    ACAV_HIP_TRY(hipGetLastError());
+    return ACAV_OK;
+}
+
+// ContrastiveModule.average_gradient (module.py:96-101): all-reduce SUM of every .grad, then / world -- on the flat buffer
+static int ct_average_grads(acav_contrastive *c)
+{
+    if (!c->comm || c->world <= 1) return ACAV_OK;
+    ACAV_HIP_TRY(hipStreamSynchronize(c->ctx.stream));  // the communicator has its own stream
+    ACAV_TRY(acav_comm_allreduce_f32(c->comm, c->grads.as<float>(), (int64_t)c->nparam));
+    ACAV_TRY(acav_comm_sync(c->comm));
+    hipLaunchKernelGGL(k_ct_scale, dim3((unsigned)((c->nparam + 255) / 256)), dim3(256), 0, c->ctx.stream, c->grads.as<float>(),
+                       (long)c->nparam, 1.0f / (float)c->world);
+    ACAV_HIP_TRY(hipGetLastError());
+    return ACAV_OK;
+}
+
+static int ct_step(acav_contrastive *c, double lr)
+{
+    c->step += 1;
+    const double b1 = 0.9, b2 = 0.999, bc1 = 1.0 - pow(b1, (double)c->step), bc2 = 1.0 - pow(b2, (double)c->step);
+    hipLaunchKernelGGL(k_ct_adamw, dim3((unsigned)((c->nparam + 255) / 256)), dim3(256), 0, c->ctx.stream, c->params.as<float>(),
+                       c->grads.as<float>(), c->m.as<float>(), c->v.as<float>(), c->vmax.as<float>(), (long)c->nparam,
+                       (float)(1.0 - lr * 0.01), (float)b1, (float)b2, (float)sqrt(bc2), 1e-6f, (float)(lr / bc1));
+    ACAV_HIP_TRY(hipGetLastError());
+    return ACAV_OK;
+}
+
 // Contrastive.train's inner loop over `nbatches` batches (contrastive.py:92-101,117-132): batch i = rows
-// [offsets[i], offsets[i+1]) of visual / audio; forward, backward (gradients accumulate), AdamW step with this epoch's lr.
+// [offsets[i], offsets[i+1]) of visual / audio; forward, backward (gradients accumulate), [with a communicator: average of
+// the gradients over the ranks,] AdamW step with this epoch's lr.
 // losses / accs [nbatches] = the reference's loss.item() / acc.item().  Host or device inputs.
 ACAV_EXPORT int acav_contrastive_train(acav_contrastive *c, const float *visual, const float *audio, const int64_t *offsets,
                                        int64_t nbatches, double lr, float *losses, float *accs)
@@ -343,49 +416,76 @@ ACAV_EXPORT int acav_contrastive_train(acav_contrastive *c, const float *visual,
     const void *dv = nullptr, *da = nullptr;
     ACAV_TRY(to_device(visual, sizeof(float) * (size_t)n * c->vis, c->stage_v, st, &dv));
     ACAV_TRY(to_device(audio, sizeof(float) * (size_t)n * c->aud, c->stage_a, st, &da));
-    ACAV_TRY(c->loss.ensure(sizeof(float) * (size_t)(nbatches + 1)));
-    ACAV_TRY(c->acc.ensure(sizeof(float) * (size_t)(nbatches + 1)));
-    const size_t bb = sizeof(float) * CT_MAXB * CT_MAXB, bo = sizeof(float) * CT_MAXB * (size_t)c->out;
-    ACAV_TRY(c->L.ensure(bb));
-    ACAV_TRY(c->G.ensure(bb));
-    for (DevBuf *b : {&c->mx, &c->se, &c->nll}) ACAV_TRY(b->ensure(sizeof(float) * 2 * CT_MAXB));
-    ACAV_TRY(c->hit.ensure(sizeof(int) * 2 * CT_MAXB));
-    for (DevBuf *b : {&c->do1, &c->do2, &c->dz1, &c->dz2}) ACAV_TRY(b->ensure(bo));
-    const float inv_t = 1.0f / CT_TEMPERATURE;
+    ACAV_TRY(ct_ensure_train_buffers(c, nbatches));
     for (int64_t i = 0; i < nbatches; ++i) {
         const int B = (int)(offsets[i + 1] - offsets[i]);
-        const float *xv = static_cast<const float *>(dv) + (size_t)offsets[i] * c->vis;
-        const float *xa = static_cast<const float *>(da) + (size_t)offsets[i] * c->aud;
-        ACAV_TRY(ct_forward(c, xv, xa, B));
-        float *o1 = c->o1.as<float>(), *o2 = c->o2.as<float>(), *L = c->L.as<float>(), *G = c->G.as<float>();
-        ct_gemm(st, o1, c->out, 1, o2, c->out, 1, L, B, B, B, c->out, inv_t, nullptr, 0);  // logits_ab = o1 o2^T / T
-        hipLaunchKernelGGL(k_ct_stats, dim3((unsigned)(2 * B)), dim3(256), 0, st, L, B, c->mx.as<float>(), c->se.as<float>(),
-                           c->nll.as<float>(), c->hit.as<int>());
-        hipLaunchKernelGGL(k_ct_grad_logits, dim3((unsigned)((B * B + 255) / 256)), dim3(256), 0, st, L, B, c->mx.as<float>(),
-                           c->se.as<float>(), c->nll.as<float>(), c->hit.as<int>(), G, c->loss.as<float>() + i, c->acc.as<float>() + i);
-        // d o1 = G o2 / T (NN), d o2 = G^T o1 / T (TN)
-        ct_gemm(st, G, B, 1, o2, 1, c->out, c->do1.as<float>(), c->out, B, c->out, B, inv_t, nullptr, 0);
-        ct_gemm(st, G, 1, B, o1, 1, c->out, c->do2.as<float>(), c->out, B, c->out, B, inv_t, nullptr, 0);
-        hipLaunchKernelGGL(k_ct_normalize_bwd, dim3((unsigned)((B + 3) / 4), 2), dim3(256), 0, st, o1, o2, c->do1.as<float>(),
-                           c->do2.as<float>(), c->den1.as<float>(), c->den2.as<float>(), c->dz1.as<float>(), c->dz2.as<float>(), B,
-                           c->out);
-        // weight gradients (TN, accumulated into .grad): dW [out, in] += dz^T x
-        ct_gemm(st, c->dz1.as<float>(), 1, c->out, xv, 1, c->vis, c->g(c->Wv()), c->vis, c->out, c->vis, B, 1.0f, nullptr, 1);
-        ct_gemm(st, c->dz2.as<float>(), 1, c->out, xa, 1, c->aud, c->g(c->Wa()), c->aud, c->out, c->aud, B, 1.0f, nullptr, 1);
-        hipLaunchKernelGGL(k_ct_bias_grad, dim3((unsigned)((c->out + 255) / 256), 2), dim3(256), 0, st, c->dz1.as<float>(),
-                           c->dz2.as<float>(), c->g(c->bv()), c->g(c->ba()), B, c->out);
-        c->step += 1;
-        const double b1 = 0.9, b2 = 0.999, bc1 = 1.0 - pow(b1, (double)c->step), bc2 = 1.0 - pow(b2, (double)c->step);
-        hipLaunchKernelGGL(k_ct_adamw, dim3((unsigned)((c->nparam + 255) / 256)), dim3(256), 0, st, c->params.as<float>(),
-                           c->grads.as<float>(), c->m.as<float>(), c->v.as<float>(), c->vmax.as<float>(), (long)c->nparam,
-                           (float)(1.0 - lr * 0.01), (float)b1, (float)b2, (float)sqrt(bc2), 1e-6f, (float)(lr / bc1));
-        ACAV_HIP_TRY(hipGetLastError());
+        ACAV_TRY(ct_backward(c, static_cast<const float *>(dv) + (size_t)offsets[i] * c->vis,
+                             static_cast<const float *>(da) + (size_t)offsets[i] * c->aud, B, i));
+        ACAV_TRY(ct_average_grads(c));
+        ACAV_TRY(ct_step(c, lr));
     }
     if (nbatches) {
         if (losses) ACAV_HIP_TRY(hipMemcpyAsync(losses, c->loss.p, sizeof(float) * (size_t)nbatches, hipMemcpyDeviceToHost, st));
         if (accs) ACAV_HIP_TRY(hipMemcpyAsync(accs, c->acc.p, sizeof(float) * (size_t)nbatches, hipMemcpyDeviceToHost, st));
     }
     ACAV_HIP_TRY(hipStreamSynchronize(st));
+    return ACAV_OK;
+}
+
+// The distributed form of the loop (run_contrastive.py:118-168, contrastive.py:92-101 with distributed=True), in pieces.
+// acav_contrastive_set_comm: with an RCCL communicator of more than one rank, acav_contrastive_train averages the gradients
+// itself.  Without RCCL (the ranks share a GPU, or a host-side process group is all there is) the caller runs
+// backward -> get_grads -> its own all-reduce / world -> set_grads -> step per batch.
+ACAV_EXPORT int acav_contrastive_set_comm(acav_contrastive *c, acav_comm *comm)
+{
+    ACAV_REQUIRE(c, ACAV_EINVAL, "handle is NULL");
+    c->comm = comm;
+    c->world = 1;
+    if (comm) {
+        int rank = 0;
+        ACAV_TRY(acav_comm_info(comm, &rank, &c->world));
+    }
+    return ACAV_OK;
+}
+ACAV_EXPORT int acav_contrastive_backward(acav_contrastive *c, const float *visual, const float *audio, int64_t n, float *loss,
+                                          float *acc)
+{
+    ACAV_REQUIRE(c && visual && audio && n >= 1 && n <= CT_MAXB, ACAV_EINVAL, "bad argument (1..%d rows)", CT_MAXB);
+    ACAV_HIP_TRY(hipSetDevice(c->ctx.device));
+    hipStream_t st = c->ctx.stream;
+    const void *dv = nullptr, *da = nullptr;
+    ACAV_TRY(to_device(visual, sizeof(float) * (size_t)n * c->vis, c->stage_v, st, &dv));
+    ACAV_TRY(to_device(audio, sizeof(float) * (size_t)n * c->aud, c->stage_a, st, &da));
+    ACAV_TRY(ct_ensure_train_buffers(c, 1));
+    ACAV_TRY(ct_backward(c, static_cast<const float *>(dv), static_cast<const float *>(da), (int)n, 0));
+    if (loss) ACAV_HIP_TRY(hipMemcpyAsync(loss, c->loss.p, sizeof(float), hipMemcpyDeviceToHost, st));
+    if (acc) ACAV_HIP_TRY(hipMemcpyAsync(acc, c->acc.p, sizeof(float), hipMemcpyDeviceToHost, st));
+    ACAV_HIP_TRY(hipStreamSynchronize(st));
+    return ACAV_OK;
+}
+ACAV_EXPORT int acav_contrastive_get_grads(acav_contrastive *c, float *grads_host)
+{
+    ACAV_REQUIRE(c && grads_host, ACAV_EINVAL, "NULL argument");
+    ACAV_HIP_TRY(hipSetDevice(c->ctx.device));
+    ACAV_HIP_TRY(hipMemcpyAsync(grads_host, c->grads.p, sizeof(float) * c->nparam, hipMemcpyDeviceToHost, c->ctx.stream));
+    ACAV_HIP_TRY(hipStreamSynchronize(c->ctx.stream));
+    return ACAV_OK;
+}
+ACAV_EXPORT int acav_contrastive_set_grads(acav_contrastive *c, const float *grads_host)
+{
+    ACAV_REQUIRE(c && grads_host, ACAV_EINVAL, "NULL argument");
+    ACAV_HIP_TRY(hipSetDevice(c->ctx.device));
+    ACAV_HIP_TRY(hipMemcpyAsync(c->grads.p, grads_host, sizeof(float) * c->nparam, hipMemcpyHostToDevice, c->ctx.stream));
+    ACAV_HIP_TRY(hipStreamSynchronize(c->ctx.stream));
+    return ACAV_OK;
+}
+ACAV_EXPORT int acav_contrastive_step(acav_contrastive *c, double lr)
+{
+    ACAV_REQUIRE(c, ACAV_EINVAL, "handle is NULL");
+    ACAV_HIP_TRY(hipSetDevice(c->ctx.device));
+    ACAV_TRY(ct_average_grads(c));
+    ACAV_TRY(ct_step(c, lr));
+    ACAV_HIP_TRY(hipStreamSynchronize(c->ctx.stream));
     return ACAV_OK;
 }
 

@@ -106,11 +106,30 @@ def main(argv=None):
             if want > 1:
                 launch.spawn_per_gpu('acav100m_amd.subset_selection.cli', argv, want, {'ACAV_NO_GROUP': '1'})
                 return None
+        elif command == 'run' and _contrastive_ddp(kwargs):
+            # run_contrastive.py:118-152: the unchunked contrastive run trains and scores with one worker per GPU
+            import torch
+            want = kwargs.get('computation.num_gpus')
+            have = torch.cuda.device_count()
+            if os.environ.get('ACAV_OVERSUBSCRIBE') == '1':
+                have = max(have, int(want or have))
+            want = have if want is None else min(int(want), have)
+            if want > 1:
+                launch.spawn_per_gpu('acav100m_amd.subset_selection.cli', argv, want)
+                return None
+    elif command == 'run' and kwargs.get('chunk_size') is None and _contrastive_ddp(kwargs):
+        launch.init_process_group(kwargs.get('computation.dist_backend', 'nccl'))
     else:
         os.environ.setdefault('ACAV_NO_GROUP', '1')
         launch.bind_device()
     _seed_from_env()
     return getattr(Cli(), command)(**kwargs)
+
+
+def _contrastive_ddp(kwargs):
+    use = kwargs.get('computation.use_distributed')
+    use = SUBSET_DEFAULTS['computation']['use_distributed'] if use is None else use
+    return kwargs.get('measure_name') == 'contrastive' and kwargs.get('chunk_size') is None and str(use).lower() not in ('false', '0')
 
 
 def _seed_from_env():

@@ -126,6 +126,73 @@ class Contrastive:
                                                     _lib.ptr(losses), _lib.ptr(accs)))
         return losses, accs
 
+    # ------------------------------------------------------------------ distributed training (contrastive.py:92-124)
+    def set_comm(self, comm):
+        """an RCCL communicator (parallel.rccl_comm.Comm) of more than one rank: train_batches / step average the
+        gradients over its ranks before every optimizer step (ContrastiveModule.average_gradient, module.py:96-101)"""
+        _lib.check(_lib._lib.acav_contrastive_set_comm(self._h, comm._h if comm is not None else None))
+        self._comm = comm
+
+    @staticmethod
+    def rank_rows(offsets, rank, world):
+        """get_features under distributed=True (contrastive.py:117-124): rows rank::world of every batch.
+        -> (row indices, offsets of the rank's batches)"""
+        idx, off = [], [0]
+        for i in range(len(offsets) - 1):
+            r = np.arange(int(offsets[i]) + rank, int(offsets[i + 1]), world, dtype=np.int64)
+            assert len(r) > 0, ("batch {} has {} rows for {} ranks: the reference's cross_entropy over an empty slice is "
+                                "NaN on that rank and poisons the averaged gradients".format(i, offsets[i + 1] - offsets[i], world))
+            idx.append(r)
+            off.append(off[-1] + len(r))
+        return (np.concatenate(idx) if idx else np.zeros(0, np.int64)), np.asarray(off, np.int64)
+
+    def backward(self, visual, audio):
+        """forward + backward of ONE batch, no optimizer step -> (loss, acc); the gradients accumulate"""
+        visual, audio = np.ascontiguousarray(visual, np.float32), np.ascontiguousarray(audio, np.float32)
+        loss, acc = np.empty(1, np.float32), np.empty(1, np.float32)
+        _lib.check(_lib._lib.acav_contrastive_backward(self._h, _lib.ptr(visual), _lib.ptr(audio), visual.shape[0],
+                                                       _lib.ptr(loss), _lib.ptr(acc)))
+        return float(loss[0]), float(acc[0])
+
+    def _nparam(self):
+        vis, aud, out = self.sizes
+        return out * vis + out + out * aud + out
+
+    def get_grads(self):
+        g = np.empty(self._nparam(), np.float32)
+        _lib.check(_lib._lib.acav_contrastive_get_grads(self._h, _lib.ptr(g)))
+        return g
+
+    def set_grads(self, g):
+        g = np.ascontiguousarray(g, np.float32)
+        assert g.size == self._nparam()
+        _lib.check(_lib._lib.acav_contrastive_set_grads(self._h, _lib.ptr(g)))
+
+    def step(self, lr):
+        _lib.check(_lib._lib.acav_contrastive_step(self._h, float(lr)))
+
+    def train_batches_distributed(self, visual, audio, offsets, lr, rank, world):
+        """train_batch with distributed=True for every batch of the stream: this rank's rows of the batch, backward, the
+        gradients averaged over the ranks, AdamW step.  With an RCCL communicator set the whole loop is one library call;
+        otherwise (the ranks share a GPU, gloo) the flat gradient buffer takes the torch.distributed route per batch."""
+        idx, off = self.rank_rows(offsets, rank, world)
+        v, a = np.ascontiguousarray(np.asarray(visual)[idx], np.float32), np.ascontiguousarray(np.asarray(audio)[idx], np.float32)
+        if getattr(self, '_comm', None) is not None:
+            return self.train_batches(v, a, off, lr)
+        import torch
+        import torch.distributed as dist
+        nb = len(off) - 1
+        losses, accs = np.empty(nb, np.float32), np.empty(nb, np.float32)
+        on_gpu = dist.get_backend() == "nccl"
+        for i in range(nb):
+            losses[i], accs[i] = self.backward(v[off[i]:off[i + 1]], a[off[i]:off[i + 1]])
+            g = torch.from_numpy(self.get_grads())
+            g = g.cuda() if on_gpu else g
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            self.set_grads((g / float(world)).cpu().numpy())
+            self.step(lr)
+        return losses, accs
+
     def infer_scores(self, visual, audio):
         visual = np.ascontiguousarray(visual, np.float32) if not hasattr(visual, 'data_ptr') else visual
         audio = np.ascontiguousarray(audio, np.float32) if not hasattr(audio, 'data_ptr') else audio
@@ -140,18 +207,26 @@ class Contrastive:
         stream of run_contrastive.feature_batches (what the reference's dataloader + get_features yield)."""
         visual, audio, offsets = batches
         nb = len(offsets) - 1
+        rank, world = 0, 1
+        if self.distributed:
+            from ...parallel import world as _world
+            rank, world = _world()
         for epoch in range(self.epoch, self.num_epochs):
             lr = lr_func_linear(epoch + 1, self.num_epochs + 1, self.num_warmup_steps) * self.base_lr  # update_lr (:48-51)
-            losses, accs = self.train_batches(visual, audio, offsets, lr)
+            if world > 1:
+                losses, accs = self.train_batches_distributed(visual, audio, offsets, lr, rank, world)
+            else:
+                losses, accs = self.train_batches(visual, audio, offsets, lr)
             if verbose:
                 for count in range(0, nb, max(1, log_every)):
                     print("(node {}) training epoch ({}/{}) iter ({}/{}) (lr: {:04f}, loss: {:04f}, acc: {:04f})".format(
-                        0, epoch, self.num_epochs, count, nb, lr, losses[count], accs[count]))
+                        rank, epoch, self.num_epochs, count, nb, lr, losses[count], accs[count]))
                 print("(node {}) epoch ({}/{}) done (lr: {:04f}, loss: {:04f}, acc: {:04f})".format(
-                    0, epoch, self.num_epochs, lr, float(np.mean(losses)) if nb else float('nan'),
+                    rank, epoch, self.num_epochs, lr, float(np.mean(losses)) if nb else float('nan'),
                     float(np.mean(accs)) if nb else float('nan')))
             self.epoch = epoch
-            self.save_cache(args, path, epoch, verbose)
+            if rank == 0:  # the replicas are identical; the reference's ranks all write the same file name
+                self.save_cache(args, path, epoch, verbose)
 
     def get_cache_path_run(self, args, epoch):
         cache_dir = Path(args.data.output.path).parent / 'caches'
@@ -192,7 +267,14 @@ class Contrastive:
     def infer(self, args, batches, metas_rows, json_metas, subset_size, verbose=True):
         """contrastive.py:204-256: scores of every clip, appended to the per-process inference cache csv
         (score, shard_name, filename, id, segment); returns (scores desc, ids, rows) like the reference's topk."""
-        visual, audio, _ = batches
+        visual, audio, offsets = batches
+        if self.distributed:  # every rank scores its rows of every batch and writes its own cache file (contrastive.py:117-124,243)
+            from ...parallel import world as _world
+            rank, world = _world()
+            if world > 1:
+                idx, _ = self.rank_rows(offsets, rank, world)
+                visual, audio = np.asarray(visual)[idx], np.asarray(audio)[idx]
+                metas_rows = [metas_rows[i] for i in idx]
         logits = self.infer_scores(visual, audio)
         self.save_inference(args, logits, metas_rows, json_metas)
         k = len(logits) if subset_size is None or subset_size > len(logits) else int(subset_size)

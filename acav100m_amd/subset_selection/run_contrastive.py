@@ -57,9 +57,26 @@ def copy_measure(measure, prev_measure):
     return measure
 
 
+def _distributed(args):
+    """run_contrastive.py:56-60,88-93: `computation.use_distributed` (the reference's default) sends training and inference
+    through one worker per GPU.  Here the workers ARE the processes of the run (one per GPU, cli.main / torchrun): with a
+    single process the flag changes nothing but which process draws the biases the reference's spawned child draws from its
+    own, unseeded generator -- not reproducible there either."""
+    import torch.distributed as dist
+    return (bool(getattr(args.computation, 'use_distributed', False)) and dist.is_available() and dist.is_initialized()
+            and dist.get_world_size() > 1)
+
+
 def _new_measure(args, sizes):
     cfg = args.contrastive
-    return Contrastive(cfg.num_epochs, args.computation.device, cfg.base_lr, cfg.num_warmup_steps, sizes=sizes)
+    m = Contrastive(cfg.num_epochs, args.computation.device, cfg.base_lr, cfg.num_warmup_steps, distributed=_distributed(args),
+                    sizes=sizes)
+    if m.distributed:
+        from ..parallel.rccl_comm import default_comm
+        comm = default_comm()  # None under gloo: the gradients take the torch.distributed route
+        if comm is not None:
+            m.set_comm(comm)
+    return m
 
 
 def _train(args, paths, batches, sizes, measure=None):
@@ -69,8 +86,16 @@ def _train(args, paths, batches, sizes, measure=None):
     measure = _new_measure(args, sizes)
     if prev is not None:
         measure = copy_measure(measure, prev)
-    print("training contrastive loss")
+    print("training contrastive loss" + (" with distributed" if measure.distributed else ""))
     measure.train(args, paths, batches, args.log_every, args.verbose)
+    if measure.distributed:  # _train_distributed (:156-168): the master leaves the trained model for the parent to load
+        from ..parallel import world
+        if world()[0] == 0:
+            import torch
+            cache_dir = Path(args.data.output.path).parent / 'caches'
+            cache_dir.mkdir(parents=True, exist_ok=True)
+            torch.save({'base_lr': measure.base_lr, 'model': {k: torch.from_numpy(v) for k, v in measure.state_dict().items()}},
+                       cache_dir / "contrastive_trained_model_cache_{}.pkl".format(args.parent_pid))
     return measure
 
 
@@ -105,18 +130,22 @@ def _run(args, paths):
     else:
         measure = _train(args, paths, batches, sizes)
     scorer = copy_measure(_new_measure(args, sizes), measure)  # _infer (:97-103)
-    print("(node 0) running inference")
+    if scorer.distributed:
+        from ..parallel import world
+        args.node_rank = world()[0]  # the inference cache of this process (contrastive.py:243-246: du.get_rank())
+        print("inferring with distributed")
+    print("(node {}) running inference".format(args.node_rank or 0))
     tv, ta, toff, trows = feature_batches(table, int(cfg.test_batch_size))
     metas = io.load_metas([Path(p) for p in paths], args.data.meta.path)
     scores, ids, _ = scorer.infer(args, (tv, ta, toff), trows, metas, args.subset.size, args.verbose)
-    print("(node 0) done inference")
+    print("(node {}) done inference".format(args.node_rank or 0))
     return measure, scores, [trows[i] for i in ids]
 
 
 def run_single_contrastive(args):
     """run_contrastive.py:236-247: the whole dataset is scored (subset.size = None, ratio = 1); the selection is made
     afterwards by `merge_contrastive` from the inference caches"""
-    args.parent_pid = str(args.parent_pid or os.getpid())
+    args.parent_pid = str(args.parent_pid or os.environ.get('ACAV_PARENT_PID') or os.getpid())  # one name for all workers
     args.node_rank = 0 if args.node_rank is None else args.node_rank
     args.chunk_num = 0 if args.chunk_num is None else args.chunk_num
     paths = [p for p in sorted(io.brace_expand(args.data.path)) if Path(p).is_file()]
@@ -159,6 +188,7 @@ def run_chunks_contrastive(args):
         print("running chunk {}".format(num))
         one = copy.deepcopy(chunk_args)
         one.chunk_num = i
+        one.computation.use_distributed = False  # a chunk is one process's job from training to scoring
         _run(one, chunk)
         done.append(num)
     print("done")

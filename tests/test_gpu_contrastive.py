@@ -204,3 +204,107 @@ def test_contrastive_chunked_cli(env, tmp_path_factory, golden_dir):
     rows2 = list(csv.reader(open(os.path.join(c2, [c for c in os.listdir(c2) if "contrastive_inferred_cache" in c][0]))))
     assert [r[2] for r in rows2] == [r[2] for r in rows[:300]]
     np.testing.assert_array_equal(np.array([float(r[0]) for r in rows2]), got[:300].astype(np.float64))
+
+
+def test_contrastive_distributed_two_workers(env, tmp_path_factory, golden_dir):
+    """`cli.py run --measure_name=contrastive` with computation.use_distributed (the reference's default) on TWO workers
+    (both on cuda:0, gloo carries the gradient average): every worker trains on rows rank::2 of every batch, the averaged
+    gradients drive identical AdamW steps (run_contrastive.py:118-168, contrastive.py:92-124, module.py:96-101); each
+    worker scores its rows and writes its own inference cache.  Against the oracle's replica simulation."""
+    import subprocess
+    torch, acav = env
+    sys.path.insert(0, golden_dir)
+    import synth
+    from acav100m_amd.subset_selection.cli import Cli
+    from acav100m_amd.subset_selection.measures.contrastive import PARAM_NAMES, lr_func_linear
+    from acav100m_amd.subset_selection.run_contrastive import feature_batches
+    from acav100m_amd import shards as io
+    from oracle import contrastive_ref as CR
+    from oracle import oracle as O
+    root = str(tmp_path_factory.mktemp("acav_ctr_ddp"))
+    glob = synth.write_feature_shards(root, n_shards=3, rows=200, seed=5)
+    out_csv = os.path.join(root, "sel", "output.csv")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    envp = dict(os.environ, ACAV_OVERSUBSCRIBE="1", ACAV_DIST_BACKEND="gloo", ACAV_SEED="0", PYTHONPATH=repo)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        envp.pop(k, None)
+    cmd = [sys.executable, "-m", "acav100m_amd.subset_selection.cli", "run", "--shards_path=" + glob,
+           "--meta_path=" + os.path.join(root, "videos"), "--out_path=" + out_csv, "--measure_name=contrastive",
+           "--computation.num_gpus=2"]
+    res = subprocess.run(cmd, env=envp, cwd=repo, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert "training contrastive loss with distributed" in res.stdout and "(node 1) running inference" in res.stdout
+    cdir = os.path.join(root, "sel", "caches")
+    caches = sorted(os.listdir(cdir))
+    trained = [c for c in caches if c.startswith("contrastive_trained_model_cache_")]
+    assert len(trained) == 1
+    ck = torch.load(os.path.join(cdir, trained[0]), weights_only=False)
+    assert sorted(ck.keys()) == ["base_lr", "model"] and sorted(ck["model"].keys()) == sorted(PARAM_NAMES)
+    inf = sorted(c for c in caches if "contrastive_inferred_cache" in c)
+    assert len(inf) == 2 and inf[0].endswith("_0.csv") and inf[1].endswith("_1.csv")
+    rows = [list(csv.reader(open(os.path.join(cdir, f)))) for f in inf]
+    # the oracle: same seeded stream and object flow as the single-process run, two replicas per batch
+    rng = O.Rng(0)
+
+    def draw():
+        wv, bv = CR.linear_init(lambda n: rng.rand(n), 128, 2304)
+        wa, ba = CR.linear_init(lambda n: rng.rand(n), 128, 128)
+        return wv, bv, wa, ba
+    draw()
+    orc = CR.Contrastive(*draw())
+    table = io.load_feature_shards(sorted(io.brace_expand(glob)))
+    visual, audio, off, meta_rows = feature_batches(table, 128)
+    for epoch in range(3):
+        lr = lr_func_linear(epoch + 1, 4, 1) * 2e-4
+        for i in range(len(off) - 1):
+            orc.train_batch_ddp(visual[off[i]:off[i + 1]], audio[off[i]:off[i + 1]], lr, 2)
+    for k, op in zip(PARAM_NAMES, orc.p):
+        np.testing.assert_allclose(ck["model"][k].numpy(), op, rtol=3e-4, atol=3e-6)
+    _, bv3, _, ba3 = draw()
+    want = CR.Contrastive(orc.p[0], bv3, orc.p[2], ba3).infer(visual, audio)
+    for rank in (0, 1):
+        idx = np.concatenate([np.arange(off[i] + rank, off[i + 1], 2) for i in range(len(off) - 1)])
+        assert [r[2] for r in rows[rank]] == [meta_rows[i]["filename"] for i in idx]
+        np.testing.assert_allclose(np.array([float(r[0]) for r in rows[rank]], np.float32), want[idx], rtol=3e-4, atol=3e-5)
+    kw = dict(shards_path=glob, meta_path=os.path.join(root, "videos"), out_path=out_csv, measure_name="contrastive")
+    Cli().merge_contrastive(**kw)
+    final = list(csv.reader(open(out_csv)))
+    assert len(final) == 600 and len({r[1] for r in final}) == 600
+
+
+def test_contrastive_pieces_and_world1_comm(env):
+    """backward / get_grads / set_grads / step are the pieces of train_batches (bit for bit), and a world-1 RCCL communicator
+    set on the handle (the gradient average runs through acav_comm) changes nothing"""
+    torch, acav = env
+    from acav100m_amd.subset_selection.measures.contrastive import Contrastive
+    from acav100m_amd.parallel.rccl_comm import Comm
+    rs = np.random.RandomState(7)
+    n, vis, aud = 96, 80, 48
+    visual, audio = rs.randn(n, vis).astype(np.float32), rs.randn(n, aud).astype(np.float32)
+    off = np.array([0, 32, 64, 96], np.int64)
+    models = []
+    for mode in range(3):
+        acav.manual_seed(4)
+        m = Contrastive(2, "cuda", 1e-3, 1, sizes=(vis, aud), out_size=24)
+        if mode == 0:
+            lo, ac = m.train_batches(visual, audio, off, 1e-3)
+        elif mode == 1:
+            lo, ac = [], []
+            for i in range(3):
+                l, a = m.backward(visual[off[i]:off[i + 1]], audio[off[i]:off[i + 1]])
+                g = m.get_grads()
+                m.set_grads(g)  # the host round trip of the torch.distributed route
+                m.step(1e-3)
+                lo.append(l), ac.append(a)
+        else:
+            comm = Comm(0, 1, Comm.unique_id(), 0)
+            m.set_comm(comm)
+            lo, ac = m.train_batches(visual, audio, off, 1e-3)
+            m.set_comm(None)
+        models.append((np.asarray(lo, np.float32), np.asarray(ac, np.float32), m.state_dict(), m.get_grads()))
+    for lo, ac, sd, g in models[1:]:
+        assert np.array_equal(lo, models[0][0]) and np.array_equal(ac, models[0][1]) and np.array_equal(g, models[0][3])
+        for k in sd:
+            assert np.array_equal(sd[k], models[0][2][k])
+    idx, o2 = Contrastive.rank_rows(off, 1, 3)
+    assert idx.tolist() == [i for b in range(3) for i in range(32 * b + 1, 32 * (b + 1), 3)] and o2.tolist() == [0, 11, 22, 33]
