@@ -1200,6 +1200,50 @@ __device__ __forceinline__ float key_value(unsigned long long key)
     return __uint_as_float(u);
 }
 
+// The single-chain form (one 256-column segment) with the order of LDS reads and FMAs pinned: left to itself the compiler
+// clumps the ds_read_b128s and drains them with lgkmcnt(1) before most groups of FMAs (3 800 cycles for a 1 024-cycle chain,
+// measured in k_train_persistent).  A ring of four 8-column groups keeps three groups (12 reads) in flight ahead of the group
+// being multiplied; __builtin_amdgcn_sched_group_barrier pins "4 DS reads, then 8 VALU" per group, the waits stay the
+// compiler's own (LDS returns in order: lgkmcnt(12)).  Same chain, same order: bit-identical.
+// (The same schedule written as inline-asm reads + counted waits was 25 % faster still and WRONG under register pressure: the
+// compiler may copy an asm output to another register before the asm wait that makes it valid -- k_train_persistent_wide.)
+__device__ __forceinline__ float dot_block_sched(const float *pc, const float *px, int scz, int sxz)
+{
+    const float *pcu[8], *pxu[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        pcu[u] = pc + ((u << 2) ^ scz);
+        pxu[u] = px + ((u << 2) ^ sxz);
+    }
+    float4 C[4][2], X[4][2];
+    float acc = 0.f;
+#define ACAV_LDG(slot, g)                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                \
+        C[slot][u] = *reinterpret_cast<const float4 *>(pcu[((g) * 2 + u) & 7] + ((((g) * 2 + u) >> 3) << 5));     \
+        X[slot][u] = *reinterpret_cast<const float4 *>(pxu[((g) * 2 + u) & 7] + ((((g) * 2 + u) >> 3) << 5));     \
+    }
+    ACAV_LDG(0, 0)
+    ACAV_LDG(1, 1)
+    ACAV_LDG(2, 2)
+    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {
+        if (g + 3 < 32) { ACAV_LDG((g + 3) & 3, g + 3) }
+        const int s = g & 3;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            acc = __builtin_fmaf(C[s][u].x, X[s][u].x, acc);
+            acc = __builtin_fmaf(C[s][u].y, X[s][u].y, acc);
+            acc = __builtin_fmaf(C[s][u].z, X[s][u].z, acc);
+            acc = __builtin_fmaf(C[s][u].w, X[s][u].w, acc);
+        }
+        if (g + 3 < 32) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the 4 DS reads of group g + 3 ...
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                  // ... then the 8 FMAs of group g
+    }
+#undef ACAV_LDG
+    return acc;
+}
+
 // Canonical dot over NB resident 256-column blocks (one segment each) of two swizzled LDS rows: NB
 // independent FMA chains per lane, interleaved so the VALU is issue-bound instead of latency-bound;
 // ds_read_b128 pairs software-pipelined two chunks ahead.  Returns fold(tot_in, seg_0, .., seg_NB-1).
@@ -1208,6 +1252,12 @@ __device__ __forceinline__ float dot_blocks(const float *pc, const float *px, in
 {
     // chunk tt (4 columns) of a row sits at float offset ((tt ^ s) << 2), s = row & 7: the XOR only touches
     // the low 3 bits of tt, so 8 per-lane base pointers + compile-time offsets address every chunk
+#ifndef ACAV_DOT_COMPILER_SCHEDULE
+    if constexpr (NB == 1) {
+        const float seg = dot_block_sched(pc, px, scz, sxz);
+        return first ? seg : tot + seg;
+    }
+#endif
     const float *pcu[8], *pxu[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1230,13 +1280,15 @@ __device__ __forceinline__ float dot_blocks(const float *pc, const float *px, in
         _Pragma("unroll") for (int q = 0; q < NB; ++q) acc[q] = __builtin_fmaf(Cq[q][u].z, Xq[q][u].z, acc[q]); \
         _Pragma("unroll") for (int q = 0; q < NB; ++q) acc[q] = __builtin_fmaf(Cq[q][u].w, Xq[q][u].w, acc[q]); \
     }
-    ACAV_LD_GROUP(cA, xA, 0)
+    {
+        ACAV_LD_GROUP(cA, xA, 0)
 #pragma unroll
-    for (int g = 0; g < 32; g += 2) {
-        ACAV_LD_GROUP(cB, xB, g + 1)
-        ACAV_FMA_GROUP(cA, xA)
-        if (g + 2 < 32) { ACAV_LD_GROUP(cA, xA, g + 2) }
-        ACAV_FMA_GROUP(cB, xB)
+        for (int g = 0; g < 32; g += 2) {
+            ACAV_LD_GROUP(cB, xB, g + 1)
+            ACAV_FMA_GROUP(cA, xA)
+            if (g + 2 < 32) { ACAV_LD_GROUP(cA, xA, g + 2) }
+            ACAV_FMA_GROUP(cB, xB)
+        }
     }
 #undef ACAV_LD_GROUP
 #undef ACAV_FMA_GROUP
@@ -1611,6 +1663,10 @@ constexpr int TP_NR = 8;
 constexpr int TP_DS = 1024;
 constexpr int TP_MAXB = 32;
 constexpr unsigned TP_SPIN_LIMIT = 1u << 24;
+#ifndef ACAV_TP_FIRST_SLEEP
+#define ACAV_TP_FIRST_SLEEP 32
+#endif
+constexpr int TP_FIRST_SWEEP_PAUSE = ACAV_TP_FIRST_SLEEP;  // x 64 clocks between a workgroup's publish and its first sweep
 
 constexpr int TP_RING = 4;
 struct TrainCtl {
@@ -1819,6 +1875,7 @@ __global__ __launch_bounds__(256) void k_train_persistent(
             if (active)
                 part = dot_blocks<1>(sC + kk * TP_DS + wave * 256, sX[t & 1] + ii * TP_DS + wave * 256, kk << 2, ii << 2,
                                      0.f, true);
+            if (PROF) pr[5] += TP_CLK() - c1;  // the chain alone
             sPart[wave][lane] = part;
             if (pend) {  // uniform: the previous update's norm refresh, off the update's critical path
                 tp_refresh_norms(pend, sC, sCn, wave, lane, d);
@@ -1858,6 +1915,12 @@ __global__ __launch_bounds__(256) void k_train_persistent(
 #pragma unroll
                 for (int u = 0; u < TP_SW; ++u)
                     if (srow < b && half + 2 * u < ncg) need |= 1u << u;
+                // the first sweep leaves ~0.9 us after the publish: sent at once it nearly always comes back incomplete (the
+                // other workgroups' stores are still on their way) and every pass costs a full round trip of ~1.7 us --
+                // 2.5 passes per step without the pause, 1.7 with it (7.20 -> 7.00 us per step at K = 256, d = 1024; 24 / 28 /
+                // 32 / 36 / 40 / 48 x 64 clocks: 7.08 / 7.01 / 7.00 / 7.02 / 7.08 / 7.24).  With few centre groups the first
+                // pass is more often complete and the pause costs more than it saves (K = 64: 7.34 -> 7.43)
+                if (ncg >= 16) __builtin_amdgcn_s_sleep(TP_FIRST_SWEEP_PAUSE);
                 for (unsigned spins = 0;; ++spins) {
                     // only the granules still missing are re-read: later passes are short and load the fabric less
 #pragma unroll
@@ -3323,7 +3386,7 @@ static int train_finish(acav_kmeans *km, TrainCall &tc)
         if (prof) {
             const double den = (double)(steps > need ? steps - need : 1);
             fprintf(stderr, "[acav] persistent epoch: %lld steps; cycles/step: wait+dma-issue %.0f, fma %.0f, exchange %.0f, "
-                            "update %.0f (hist %.0f, rows+apply %.0f), total %.0f\n", (long long)steps, head.prof[0] / den,
+                            "update %.0f (fma chain alone %.0f, rows+apply %.0f), total %.0f\n", (long long)steps, head.prof[0] / den,
                     head.prof[1] / den, head.prof[2] / den, head.prof[3] / den, head.prof[5] / den, head.prof[6] / den,
                     head.prof[4] / den);
             double mx[4] = {0, 0, 0, 0}, mn[4] = {1e30, 1e30, 1e30, 1e30};
