@@ -30,12 +30,17 @@ __global__ __launch_bounds__(256) void k_ct_gemm(const float *__restrict__ A, lo
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     float acc[4][4] = {};
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    // split-K (gridDim.z > 1): slice z of the k range, raw sums into the z-th M x N plane of C (= the partial buffer); the
+    // caller folds the planes in ascending z (k_ct_splitk_reduce): deterministic, unlike atomic adds
+    const int kslice = gridDim.z > 1 ? ((K + (int)gridDim.z - 1) / (int)gridDim.z + 15) & ~15 : K;
+    const int kbeg = (int)blockIdx.z * kslice, kend = min(K, kbeg + kslice);
+    if (gridDim.z > 1) C += (size_t)blockIdx.z * (size_t)M * (size_t)ldc;
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
         for (int e = tid; e < 64 * 16; e += 256) {
             const int r = e >> 4, kk = e & 15;  // consecutive threads walk k: contiguous for the NT operands
             const int m = m0 + r, n = n0 + r, k = k0 + kk;
-            sA[kk][r] = (m < M && k < K) ? A[m * sam + k * sak] : 0.f;
-            sB[kk][r] = (n < N && k < K) ? B[n * sbn + k * sbk] : 0.f;
+            sA[kk][r] = (m < M && k < kend) ? A[m * sam + k * sak] : 0.f;
+            sB[kk][r] = (n < N && k < kend) ? B[n * sbn + k * sbk] : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -61,6 +66,20 @@ __global__ __launch_bounds__(256) void k_ct_gemm(const float *__restrict__ A, lo
                 C[m * ldc + n] = accumulate ? C[m * ldc + n] + v : v;
             }
         }
+}
+
+// C[m][n] (+)= alpha * (P_0 + P_1 + ... + P_{S-1})[m][n] (+ bias[n]): the planes of a split-K product, folded in order
+__global__ __launch_bounds__(256) void k_ct_splitk_reduce(const float *__restrict__ P, int S, float *__restrict__ C, long ldc, int M, int N,
+                                                          float alpha, const float *__restrict__ bias, int accumulate)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)M * N) return;
+    const int m = (int)(i / N), n = (int)(i % N);
+    float v = P[i];
+    for (int z = 1; z < S; ++z) v = v + P[(size_t)z * M * N + i];
+    v = v * alpha;
+    if (bias) v = v + bias[n];
+    C[m * ldc + n] = accumulate ? C[m * ldc + n] + v : v;
 }
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -236,7 +255,7 @@ struct acav_contrastive {
     int64_t step = 0;
     size_t nparam = 0;                      // vis*out + out + aud*out + out, in state_dict order
     DevBuf params, grads, m, v, vmax;       // flat [Wv | bv | Wa | ba]
-    DevBuf stage_v, stage_a, z1, z2, o1, o2, den1, den2, L, mx, se, nll, hit, G, do1, do2, dz1, dz2, loss, acc, logits;
+    DevBuf stage_v, stage_a, z1, z2, o1, o2, den1, den2, L, mx, se, nll, hit, G, do1, do2, dz1, dz2, loss, acc, logits, splitk;
     acav_comm *comm = nullptr;              // set: the gradients are averaged over its ranks before every optimizer step
     int world = 1;
     float *Wv() { return params.as<float>(); }
@@ -247,8 +266,24 @@ struct acav_contrastive {
 };
 
 static void ct_gemm(hipStream_t st, const float *A, long sam, long sak, const float *B, long sbn, long sbk, float *C, long ldc, int M,
-                    int N, int K, float alpha, const float *bias, int accumulate)
+                    int N, int K, float alpha, const float *bias, int accumulate, float *splitk = nullptr, size_t splitk_floats = 0)
 {
+    // a product of a few 64 x 64 tiles with a long k (the 128 x 128 x 2304 visual projection of a training batch: four
+    // workgroups walking 144 stages each on a 256-CU chip) is cut along k into >= 128 workgroups and folded afterwards
+    const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
+    int S = 1;
+    if (splitk && tiles < 64 && K >= 256) {
+        S = (128 + tiles - 1) / tiles;
+        if (S > K / 64) S = K / 64;
+        while (S > 1 && (size_t)S * M * N > splitk_floats) --S;
+    }
+    if (S > 1) {
+        hipLaunchKernelGGL(k_ct_gemm, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)S), dim3(256), 0, st, A, sam,
+                           sak, B, sbn, sbk, splitk, (long)N, M, N, K, 1.0f, nullptr, 0);
+        hipLaunchKernelGGL(k_ct_splitk_reduce, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, st, splitk, S, C, ldc, M, N,
+                           alpha, bias, accumulate);
+        return;
+    }
     hipLaunchKernelGGL(k_ct_gemm, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0, st, A, sam, sak, B, sbn,
                        sbk, C, ldc, M, N, K, alpha, bias, accumulate);
 }
@@ -327,8 +362,11 @@ static int ct_forward(acav_contrastive *c, const float *dv, const float *da, int
     for (DevBuf *b : {&c->z1, &c->z2, &c->o1, &c->o2}) ACAV_TRY(b->ensure(zo));
     ACAV_TRY(c->den1.ensure(sizeof(float) * rows));
     ACAV_TRY(c->den2.ensure(sizeof(float) * rows));
-    ct_gemm(st, dv, c->vis, 1, c->Wv(), c->vis, 1, c->z1.as<float>(), c->out, rows, c->out, c->vis, 1.0f, c->bv(), 0);
-    ct_gemm(st, da, c->aud, 1, c->Wa(), c->aud, 1, c->z2.as<float>(), c->out, rows, c->out, c->aud, 1.0f, c->ba(), 0);
+    const size_t skf = (size_t)64 * CT_MAXB * c->out;  // up to 64 planes of a training batch's projection
+    if (rows <= CT_MAXB) ACAV_TRY(c->splitk.ensure(sizeof(float) * skf));
+    float *sk = rows <= CT_MAXB ? c->splitk.as<float>() : nullptr;
+    ct_gemm(st, dv, c->vis, 1, c->Wv(), c->vis, 1, c->z1.as<float>(), c->out, rows, c->out, c->vis, 1.0f, c->bv(), 0, sk, skf);
+    ct_gemm(st, da, c->aud, 1, c->Wa(), c->aud, 1, c->z2.as<float>(), c->out, rows, c->out, c->aud, 1.0f, c->ba(), 0, sk, skf);
     hipLaunchKernelGGL(k_ct_normalize, dim3((unsigned)((rows + 3) / 4), 2), dim3(256), 0, st, c->z1.as<float>(), c->z2.as<float>(),
                        c->o1.as<float>(), c->o2.as<float>(), c->den1.as<float>(), c->den2.as<float>(), rows, c->out);
     ACAV_HIP_TRY(hipGetLastError());
