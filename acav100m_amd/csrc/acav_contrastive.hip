@@ -207,7 +207,14 @@ __global__ __launch_bounds__(256) void k_ct_bias_grad(const float *__restrict__ 
     if (j >= out) return;
     const float *dz = blockIdx.y ? dz2 : dz1;
     float s = 0.f;
-    for (int b = 0; b < rows; ++b) s = s + dz[(size_t)b * out + j];
+    for (int b0 = 0; b0 < rows; b0 += 16) {  // sixteen loads in flight, summed in row order (a load per add was 28 us per batch)
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = b0 + q < rows ? dz[(size_t)(b0 + q) * out + j] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (b0 + q < rows) s = s + v[q];
+    }
     float *g = blockIdx.y ? g2 : g1;
     g[j] = g[j] + s;
 }
