@@ -101,11 +101,14 @@ def test_free_running_equals_oracle(env, v, dd, c, keep, subset):
     assert idx_o == idx_p and np.array_equal(mt_o, mt_p)
 
 
-@pytest.mark.parametrize("switch", [("ACAV_FY_LEGACY", "1"), ("ACAV_FY_ECAP", "64"), ("ACAV_FY_CAP", "256")])
+@pytest.mark.parametrize("switch", [("ACAV_FY_LEGACY", "1"), ("ACAV_FY_ECAP", "64"), ("ACAV_FY_CAP", "256"),
+                                    ("ACAV_FY_PART_DIRECT", "1")])
 def test_permutation_variants_equal_oracle(env, switch, monkeypatch):
     """The other evaluations of the same swap sequence give the same selection: the global-atomic Fisher-Yates kernels
     (ACAV_FY_LEGACY=1, also the path of lists beyond the tile table), the tiled kernels with the tile's LDS capacity cut
-    so that every loaded tile takes the sub-ranged overload path (ACAV_FY_ECAP), and smaller tiles (ACAV_FY_CAP)."""
+    so that every loaded tile takes the sub-ranged overload path (ACAV_FY_ECAP), smaller tiles (ACAV_FY_CAP), and the bucket
+    appends written one by one instead of as LDS-sorted runs (ACAV_FY_PART_DIRECT: the form lists of millions of candidates
+    fall back to when the tile table leaves no room for the staging area)."""
     torch, acav, O = env
     monkeypatch.setenv(*switch)
     v, dd, c, subset = 20000, 2, 32, 1200
