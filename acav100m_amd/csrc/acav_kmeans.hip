@@ -15,55 +15,9 @@
 //         k-ordered), segment sums folded left to right;
 //   sumsq = 32 interleaved FMA chains (class = j mod 32) + fixed butterfly tree;
 //   every other op is a single correctly-rounded fp32 op, compiled with -ffp-contract=off.
-#include <cmath>
-#include <cstdlib>
-
-#include "acav_common.h"
-
-using namespace acav;
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "acav_kmeans_shared.h"
 
 namespace {
-
-// ------------------------------------------------------------------------------- helpers
-__device__ __forceinline__ float4 ld4_guard(const float *row, int j, int d, bool row_ok, bool vec_ok)
-{
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!row_ok) return v;
-    if (vec_ok && j + 3 < d) return *reinterpret_cast<const float4 *>(row + j);
-    if (j < d) v.x = row[j];
-    if (j + 1 < d) v.y = row[j + 1];
-    if (j + 2 < d) v.z = row[j + 2];
-    if (j + 3 < d) v.w = row[j + 3];
-    return v;
-}
-
-// lexicographic (value, index) minimum: smaller value wins, ties -> smaller index (torch.min first index)
-__device__ __forceinline__ void lexmin(float &bv, int &bi, float v, int i)
-{
-    if (v < bv || (v == bv && i < bi)) {
-        bv = v;
-        bi = i;
-    }
-}
-
-__device__ __forceinline__ float norm2_from_sumsq(float ss)
-{
-    const float s = __builtin_sqrtf(ss);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
-    return s * s;
-}
-
-// one distance of the reference's calc_best (:72-77)
-__device__ __forceinline__ float dist_epilogue(float dot, float xn, float cn, bool discount, float r)
-{
-    float t = -2.0f * dot;  // exact
-    t = t + xn;
-    t = t + cn;
-    if (discount) t = t / r;
-    return t;
-}
 
 // --------------------------------------------------------------------------- k_row_norm2
 // one half-wave (32 lanes = the 32 canonical chains) per row
@@ -83,1101 +37,6 @@ __global__ __launch_bounds__(256) void k_row_norm2(const float *__restrict__ v, 
     p = p + __shfl_xor(p, 8);
     p = p + __shfl_xor(p, 16);
     if (row < rows && lane32 == 0) out[row] = norm2_from_sumsq(p);
-}
-
-// --------------------------------------------------------------------------- k_assign_f32
-constexpr int AS_ROWS = 64;   // rows per workgroup: 2 MFMA row tiles
-constexpr int AS_CG = 256;    // centres per group: 8 MFMA tiles, 2 per wave
-constexpr int AS_BK = 32;     // feature columns per LDS stage (= the 32 canonical sumsq classes)
-constexpr int AS_LD = 36;     // padded LDS row (floats): 144 B = 9 x 16 B -> conflict-free ds_read_b128
-
-// LDS image of one staged row: within each group of 8 columns the even columns come first
-// (pos = g8*8 + (e&1)*4 + (e>>1)), so that lane (i, h = lane>>5) reads with ONE ds_read_b128 the
-// four values j = 8*g8 + 2m + h, m = 0..3, it must feed to four consecutive 32x32x2 MFMAs --
-// keeping the FMA chain in ascending j.
-__device__ __forceinline__ void stage_row4(float *srow, int q, float4 v)
-{
-    const int base = (q >> 1) * 8 + (q & 1) * 2;
-    *reinterpret_cast<float2 *>(srow + base) = make_float2(v.x, v.z);      // even columns (h = 0)
-    *reinterpret_cast<float2 *>(srow + base + 4) = make_float2(v.y, v.w);  // odd columns  (h = 1)
-}
-
-// GUARD = false: d % 32 == 0 and 16-byte aligned rows -> unconditional float4 loads with CLAMPED row /
-// centre indices (rows >= n and centres >= K compute on a duplicate and are discarded), so the
-// compiler keeps all 10 prefetch loads in flight under the MFMAs.  GUARD = true: element-guarded loads
-// for ragged d (hipcc serialises those behind vmcnt(0) -- correctness path only).
-template <bool GUARD>
-__global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__ x, int64_t n, int d,
-                                                       const float *__restrict__ centers,
-                                                       const float *__restrict__ cn,
-                                                       const float *__restrict__ counts, int K, float thr,
-                                                       float r, int64_t *__restrict__ labels,
-                                                       float *__restrict__ minval_out,
-                                                       double *__restrict__ wg_sum,
-                                                       const int *__restrict__ row_idx,
-                                                       const unsigned *__restrict__ row_cnt)
-{
-    // row_idx != NULL: exact re-check pass of the bf16 filter -- the rows to label are x[row_idx[0 .. *row_cnt)].
-    // The list length is only known on the device: that pass is launched with a small fixed grid whose workgroups
-    // stride over the row tiles (an empty list costs one tiny launch, not a worst-case grid of early exits).
-    if (row_idx) n = (int64_t)*row_cnt;
-    const int64_t ntiles = (n + AS_ROWS - 1) / AS_ROWS;
-    __shared__ __attribute__((aligned(16))) float sC[AS_CG * AS_LD];
-    __shared__ __attribute__((aligned(16))) float sX[AS_ROWS * AS_LD];
-    __shared__ float sXn[AS_ROWS];
-    __shared__ float sCn[AS_CG];    // ||c||^2 of the current centre group
-    __shared__ int sDisc[AS_CG];    // 1 = under-used centre (distance / r), -1 = centre index >= K
-    __shared__ float sMinV[4][AS_ROWS];
-    __shared__ int sMinI[4][AS_ROWS];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31;
-    const int h = lane >> 5;
-    const bool vec_ok = (d & 3) == 0;
-
-    // staging roles: 8 threads per row (q = float4 index inside the 32-column stage)
-    const int srow = tid >> 3;  // 0..31
-    const int sq = tid & 7;
-    const int nchunks = (d + AS_BK - 1) / AS_BK;
-    const int ngroups = (K + AS_CG - 1) / AS_CG;
-
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // one trip except in the re-check pass
-    const int64_t row0 = tile * AS_ROWS;
-    float ssq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    float gbv = INFINITY;  // running best of row (tid) across centre groups, threads 0..63
-    int gbi = 0x7fffffff;
-
-    for (int cg = 0; cg < ngroups; ++cg) {
-        const int kbase = cg * AS_CG;
-        f32x16 acc[2][2], tot[2][2];  // acc: the running 256-column segment chain; tot: folded segments
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    acc[a][b][e] = 0.f;
-                    tot[a][b][e] = 0.f;
-                }
-
-        {   // epilogue operands of this centre group: one element per thread, read back from LDS later
-            const int k = kbase + tid;
-            sCn[tid] = k < K ? cn[k] : 0.f;
-            sDisc[tid] = k < K ? (counts[k] < thr ? 1 : 0) : -1;
-        }
-        float4 xr[2], cr[8];
-        auto issue_loads = [&](int c) {
-            const int j = c * AS_BK + sq * 4;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int64_t gr = row0 + srow + 32 * m;
-                if (GUARD) {
-                    xr[m] = ld4_guard(x + (size_t)gr * d, j, d, gr < n, vec_ok);
-                } else {
-                    int64_t src = gr < n ? gr : n - 1;
-                    if (row_idx) src = row_idx[src];
-                    xr[m] = *reinterpret_cast<const float4 *>(x + (size_t)src * d + j);
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int k = kbase + srow + 32 * m;
-                if (GUARD)
-                    cr[m] = ld4_guard(centers + (size_t)k * d, j, d, k < K, vec_ok);
-                else
-                    cr[m] = *reinterpret_cast<const float4 *>(centers + (size_t)(k < K ? k : K - 1) * d + j);
-            }
-        };
-        issue_loads(0);
-
-        for (int c = 0; c < nchunks; ++c) {
-            __syncthreads();  // everyone finished reading the previous stage
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                stage_row4(sX + (srow + 32 * m) * AS_LD, sq, xr[m]);
-                if (cg == 0) {
-                    ssq[m][0] = __builtin_fmaf(xr[m].x, xr[m].x, ssq[m][0]);
-                    ssq[m][1] = __builtin_fmaf(xr[m].y, xr[m].y, ssq[m][1]);
-                    ssq[m][2] = __builtin_fmaf(xr[m].z, xr[m].z, ssq[m][2]);
-                    ssq[m][3] = __builtin_fmaf(xr[m].w, xr[m].w, ssq[m][3]);
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < 8; ++m) stage_row4(sC + (srow + 32 * m) * AS_LD, sq, cr[m]);
-            __syncthreads();
-            if (c + 1 < nchunks) issue_loads(c + 1);  // in flight under the MFMAs below
-
-            const float *pa0 = sC + ((2 * wave) * 32 + l31) * AS_LD + h * 4;
-            const float *pa1 = pa0 + 32 * AS_LD;
-            const float *pb0 = sX + l31 * AS_LD + h * 4;
-            const float *pb1 = pb0 + 32 * AS_LD;
-#pragma unroll
-            for (int g8 = 0; g8 < 4; ++g8) {
-                const float4 a0 = *reinterpret_cast<const float4 *>(pa0 + g8 * 8);
-                const float4 a1 = *reinterpret_cast<const float4 *>(pa1 + g8 * 8);
-                const float4 b0 = *reinterpret_cast<const float4 *>(pb0 + g8 * 8);
-                const float4 b1 = *reinterpret_cast<const float4 *>(pb1 + g8 * 8);
-                const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-                const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv0[m], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv1[m], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv0[m], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv1[m], acc[1][1], 0, 0, 0);
-                }
-            }
-            if ((c & 7) == 7 || c + 1 == nchunks) {  // end of a 256-column segment: tot = (first) ? acc : tot + acc
-                const bool first = c < 8;
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            tot[a][b][e] = first ? acc[a][b][e] : tot[a][b][e] + acc[a][b][e];
-                            acc[a][b][e] = 0.f;
-                        }
-            }
-        }
-
-        if (cg == 0) {
-            // finish ||x||^2: (p0+p1)+(p2+p3) in the thread, then the 8 threads of the row
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                float t = (ssq[m][0] + ssq[m][1]) + (ssq[m][2] + ssq[m][3]);
-                t = t + __shfl_xor(t, 1);
-                t = t + __shfl_xor(t, 2);
-                t = t + __shfl_xor(t, 4);
-                if (sq == 0) sXn[srow + 32 * m] = norm2_from_sumsq(t);
-            }
-        }
-        __syncthreads();
-
-        // epilogue: distances -> per-lane argmin over this wave's 64 centres, both row tiles
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const float xn = sXn[rt * 32 + l31];
-            float bv = INFINITY;
-            int bi = 0x7fffffff;
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int kl = (2 * wave + ct) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const int disc = sDisc[kl];
-                    if (disc >= 0) {
-                        const float t = dist_epilogue(tot[ct][rt][e], xn, sCn[kl], disc != 0, r);
-                        lexmin(bv, bi, t, kbase + kl);
-                    }
-                }
-            }
-            const float ov = __shfl_xor(bv, 32);
-            const int oi = __shfl_xor(bi, 32);
-            lexmin(bv, bi, ov, oi);
-            if (h == 0) {
-                sMinV[wave][rt * 32 + l31] = bv;
-                sMinI[wave][rt * 32 + l31] = bi;
-            }
-        }
-        __syncthreads();
-        if (tid < AS_ROWS) {
-#pragma unroll
-            for (int w = 0; w < 4; ++w) lexmin(gbv, gbi, sMinV[w][tid], sMinI[w][tid]);
-        }
-        // the next group's first __syncthreads orders these reads before sMin* is rewritten
-    }
-
-    if (tid < AS_ROWS) {  // wave 0
-        const bool ok = row0 + tid < n;
-        if (ok) {
-            const int64_t dst = row_idx ? (int64_t)row_idx[row0 + tid] : row0 + tid;
-            labels[dst] = (int64_t)gbi;
-            if (minval_out) minval_out[dst] = gbv;
-        }
-        double s = ok ? (double)gbv : 0.0;
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        s += __shfl_xor(s, 8);
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (tid == 0) wg_sum[tile] = s;
-    }
-    __syncthreads();  // the next tile rewrites the epilogue scratch
-  }
-}
-
-// --------------------------------------------------------------------------- k_assign_bf16
-// HBM-bound calc_best: a bf16-MFMA FILTER followed by an exact fp32 re-check of the ambiguous rows.
-//   1. distances with centres and rows rounded to bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate), the
-//      same fused epilogue; per row the best (d1, k1) and the runner-up value d2 are tracked
-//   2. |D~ - D| <= E_i for every centre (E_i: rigorous bound, see below), so d2 - d1 > 2 E_i proves that k1
-//      is the argmin of the canonical fp32 distances -- first-index ties included, because the inequality
-//      is strict; such rows are final
-//   3. every other row is appended to a list and re-labelled by the exact kernel (k_assign_f32)
-// The result is therefore bit-identical to the exact kernel for ANY input; only the speed depends on how
-// well separated the clusters are.
-// Error bound (per row i, any centre k):  dot~ uses c~ = c(1+a), x~ = x(1+b), |a|,|b| <= 2^-9 (RNE to 8
-// significant bits), products exact in fp32, accumulation error <= d 2^-24 sum|c~x~|; the canonical dot has
-// error <= d 2^-24 sum|cx|; sum|cx| <= ||c|| ||x||.  Hence |dot~ - dot| <= ||c|| ||x|| (2^-8 (1+2^-10) + 2.02 d 2^-24)
-// and, through -2 dot + ||x||^2 + ||c||^2 (three fp32 roundings of magnitude <= (||x||+||c||)^2):
-//   E_i = 2.02 (2^-8 1.002 + 2.02 d 2^-24) cmax ||x_i|| + 2^-17 (||x_i|| + cmax)^2,   cmax = max_k ||c_k||
-// CENTRED CENTRES.  With c = c' + mu for ANY common vector mu, -2 x.c = -2 x.c' - 2 x.mu and the last term is the
-// same for every centre of a row: it moves d1 and d2 alike.  The filter therefore multiplies by c' = fl(c - mu)
-// (mu = the mean centre) and its bf16 error scales with cmax' = max_k ||c'_k|| -- the SPREAD of the centres -- instead
-// of their norm; embeddings with a large common component (post-ReLU features) would otherwise send almost every
-// row to the exact re-check.  Only the accumulation error of the canonical dot keeps the raw norm:
-//   E_i = 2.02 [ (2^-8 1.002 + 1.01 d 2^-24) cmax' + (1.01 d 2^-24 + 2^-24) cmax ] ||x_i|| + 2^-17 (||x_i|| + cmax)^2
-// (2^-24 ||x|| cmax' covers the rounding of c - mu; mu = 0 gives back the formula above).  A row constant does not
-// survive the under-use division by r, so the centres are only centred when no centre is under-used.
-// The second term also covers what the filter's epilogue does differently from the exact one: it multiplies by
-// fl(1/r) where the exact path divides by r (< 2 ulp), and it overwrites the 5 low mantissa bits of a distance
-// with the centre's position in the lane (< 2^-18 relative) -- together < 2^-17 (||x_i|| + cmax)^2 with room to
-// spare.  (The under-use scaling by 1/r < 1 only shrinks both sides.)
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int FB_ROWS = 128;  // rows per workgroup (4 MFMA row tiles)
-constexpr int FILTER_NW_DEFAULT = 4, FILTER_SCHED_DEFAULT = 0;  // K <= 256 defaults of k_assign_bf16_rw (see acav_kmeans_assign)
-
-struct CentersAux {
-    unsigned cmax_bits;   // bits of max_k ||c_k||^2 (non-negative floats order like unsigned)
-    unsigned cmaxc_bits;  // bits of (an upper bound of) max_k ||c'_k||^2 of the copy the filter multiplies by
-    unsigned any_disc;    // some centre is under-used (distance / r): no centring
-    unsigned pad;
-};
-
-// mu[j] = mean over the centres of column j (any vector would do, see the bound): 32 columns x 8 centre lanes per block
-// Block 0 also scans the per-centre scalars: max ||c_k||^2 and whether any centre is under-used.
-__global__ __launch_bounds__(256) void k_centers_mu(const float *__restrict__ c, const float *__restrict__ cn,
-                                                    const float *__restrict__ counts, int K, int d, float thr,
-                                                    float *__restrict__ mu, CentersAux *__restrict__ aux)
-{
-    __shared__ float sp[8][32];
-    if (blockIdx.x == 0)
-        for (int k = threadIdx.x; k < K; k += blockDim.x) {
-            atomicMax(&aux->cmax_bits, __float_as_uint(cn[k]));
-            if (counts[k] < thr) atomicOr(&aux->any_disc, 1u);
-        }
-    const int cj = threadIdx.x & 31, ky = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + cj;
-    float s = 0.f;
-    if (j < d)
-        for (int k = ky; k < K; k += 8) s = s + c[(size_t)k * d + j];
-    sp[ky][cj] = s;
-    __syncthreads();
-    if (ky == 0 && j < d) {
-        float t = sp[0][cj];
-#pragma unroll
-        for (int q = 1; q < 8; ++q) t = t + sp[q][cj];
-        mu[j] = t / (float)K;
-    }
-}
-
-// one block per centre: the bf16 copy of c_k (or of c_k - mu) and the largest squared norm of what was rounded
-__global__ __launch_bounds__(256) void k_centers_bf16(const float *__restrict__ c, const float *__restrict__ mu, int d,
-                                                      __bf16 *__restrict__ out, CentersAux *__restrict__ aux)
-{
-    __shared__ float sred[4];
-    const bool centred = aux->any_disc == 0u;
-    const size_t base = (size_t)blockIdx.x * d;
-    float ss = 0.f;
-    for (int j = threadIdx.x; j < d; j += blockDim.x) {
-        const float v = centred ? c[base + j] - mu[j] : c[base + j];
-        out[base + j] = (__bf16)v;
-        ss = __builtin_fmaf(v, v, ss);
-    }
-#pragma unroll
-    for (int dlt = 1; dlt < 64; dlt <<= 1) ss = ss + __shfl_xor(ss, dlt);
-    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = ss;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float tot = ((sred[0] + sred[1]) + (sred[2] + sred[3])) * (1.0f + 2.0f * (float)d * 5.9604645e-8f);  // >= exact
-        atomicMax(&aux->cmaxc_bits, __float_as_uint(tot));
-    }
-}
-
-struct Top2 {
-    float d1;
-    int k1;
-    float d2;
-};
-__device__ __forceinline__ Top2 top2_merge(Top2 a, Top2 b)
-{
-    const bool b_wins = b.d1 < a.d1 || (b.d1 == a.d1 && b.k1 < a.k1);
-    Top2 m;
-    m.d1 = b_wins ? b.d1 : a.d1;
-    m.k1 = b_wins ? b.k1 : a.k1;
-    m.d2 = fminf(b_wins ? b.d2 : a.d2, b_wins ? a.d1 : b.d1);
-    return m;
-}
-
-// The filter kernel.  Built so the HBM stream never drains: the raw fp32 rows and the bf16 centres both arrive by
-// LDS-DMA (global_load_lds_dwordx4) into rings -- no staging VGPRs -- and the fp32 -> bf16 rounding happens when a
-// wave reads its B fragment.
-//   * 4 "fat" waves (256 threads, 256 VGPRs), 128 rows x 256 centres per workgroup, TWO workgroups per CU (80 KB of
-//     LDS each): one workgroup's epilogue / ring fill hides under the other's main loop.  Wave w owns centres
-//     64 w .. 64 w + 63 against all 128 rows (2 x 4 accumulator tiles of 32x32).
-//   * 32 columns per stage (2 MFMA k-steps); rows ring of 3 stages, centres ring of 2.  Every wave issues a quarter
-//     of both: per stage 4 centre DMAs (stage c+1) THEN 4 row DMAs (stage c+2), so that the in-order
-//     `s_waitcnt vmcnt(4)` at the top of a stage retires rows c and centres c and leaves rows c+1 in flight.
-//   * one raw s_barrier per stage: after it every wave may read stage c, and the slots of stage c-1 are free for
-//     the next DMA (a __syncthreads() would drain the DMA queue: vmcnt(0)).
-//   * the DMAs are issued from inline asm: hipcc cannot prove that a ds_read does not alias an in-flight builtin
-//     LDS-DMA and would put `s_waitcnt vmcnt(0)` in front of the first fragment read of every stage (measured:
-//     the ring then never holds more than one stage).
-//   * rows: 128-B row chunks, 16-B slots XOR-swizzled by ((row >> 1) & 7); centres: 64-B row chunks, slots
-//     XOR-swizzled by ((row >> 2) & 3) -- both applied to the DMA source address, the LDS image stays
-//     lane-linear; with ds_read_b128's 16-lane groups {0-3,12-15,20-27}/{4-11,16-19,28-31} both fragment reads
-//     are conflict-free.
-//   * canonical ||x||^2: wave w accumulates the 16 classes per lane of row tile w (both k-steps).
-//   * the epilogue scratch aliases the row ring; it multiplies by 1/r where the exact path divides by r (inside
-//     the e2 term of the acceptance bound).
-constexpr int FD_BK = 32;
-constexpr int FD_DX = 3;  // row ring depth (2 stages = 32 KB in flight per workgroup, two workgroups per CU)
-constexpr int FD_DC = 2;  // centre ring depth (1 stage in flight: an L2 round trip is shorter than a stage)
-constexpr int FD_SLOT = 16384;  // bytes per ring slot: 128 rows x 32 fp32 == 256 centres x 32 bf16
-constexpr int FD_SMEM = (FD_DX + FD_DC) * FD_SLOT;  // 80 KB: two workgroups fill the CU's 160 KB
-
-// LDS byte address of a __shared__ pointer (wave-uniform) and a 16-byte-per-lane LDS-DMA issued from inline asm:
-// lane l's 16 bytes at gbase + voff(l) land at lds + 16 l.  The compiler does not see the pending LDS write, so the
-// caller owns the ordering: counted `s_waitcnt vmcnt(N)` + barrier before any read of the destination.
-__device__ __forceinline__ unsigned lds_addr(const void *p)
-{
-    return __builtin_amdgcn_readfirstlane(
-        (unsigned)(__SIZE_TYPE__)(const __attribute__((address_space(3))) void *)(p));
-}
-__device__ __forceinline__ void dma16_asm(const void *gbase_uniform, unsigned voff, unsigned lds)
-{
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gbase_uniform), "s"(lds)
-                 : "memory", "m0");
-}
-// the same with the non-temporal policy: for data that is read exactly once (the feature rows)
-__device__ __forceinline__ void dma16_asm_nt(const void *gbase_uniform, unsigned voff, unsigned lds)
-{
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(gbase_uniform), "s"(lds)
-                 : "memory", "m0");
-}
-
-__device__ __forceinline__ bf16x8 cvt_bf16x8(float4 lo, float4 hi)
-{
-    bf16x8 r = {(__bf16)lo.x, (__bf16)lo.y, (__bf16)lo.z, (__bf16)lo.w, (__bf16)hi.x, (__bf16)hi.y, (__bf16)hi.z, (__bf16)hi.w};
-    return r;
-}
-
-#ifdef ACAV_RW_PROF  // tools/exp/assign_bench.hip only: per-stage phase cycles of k_assign_bf16_rw (s_memtime)
-__device__ unsigned long long g_rw_prof[16];
-#define RW_T(v) const long long v = clock64()
-#else
-#define RW_T(v)
-#endif
-#ifdef ACAV_FD_PROF
-__device__ unsigned long long g_fd_prof[20];
-#define FD_T(v) const long long v = clock64()
-#else
-#define FD_T(v)
-#endif
-
-template <bool NT>
-__global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict__ x, int64_t n, int d,
-                                                            const __bf16 *__restrict__ cb, const float *__restrict__ cn,
-                                                            const float *__restrict__ counts, int K, float thr, float r,
-                                                            const CentersAux *__restrict__ aux, float e1c, float e1r, float e2coef,
-                                                            int64_t *__restrict__ labels, int *__restrict__ recheck_list,
-                                                            unsigned *__restrict__ recheck_count)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
-    float *sXr = reinterpret_cast<float *>(fd_smem);                        // [FD_DX][128][32] fp32
-    __bf16 *sCb = reinterpret_cast<__bf16 *>(fd_smem + FD_DX * FD_SLOT);    // [FD_DC][256][32] bf16
-    // epilogue scratch ALIASES the row ring (the rings are idle between the last stage and the next group's first DMA)
-    float *sXn = reinterpret_cast<float *>(fd_smem);  // [128]
-    float *sCn = sXn + 128;                           // [256]
-    float *sSc = sCn + 256;                           // [256] 1, or 1/r for a discounted centre
-    float *sD1 = sSc + 256;                           // [4][128]
-    int *sK1 = reinterpret_cast<int *>(sD1 + 512);    // [4][128]
-    float *sD2 = reinterpret_cast<float *>(sK1 + 512);  // [4][128]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = centre quarter (64 centres)
-    const int l31 = lane & 31, h = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * 128;
-    const int nchunks = d / FD_BK;
-    const int ngroups = (K + 255) / 256;
-    const float inv_r = 1.0f / r;
-
-    // DMA share of this wave: instructions 4 wq .. 4 wq + 3 of the 16 per slot, for rows and for centres.
-    // Source = uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset; destination = slot + (4 wq + q) KB.
-    unsigned voffx[4], voffc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int rr = (wq * 4 + q) * 8 + (lane >> 3);
-        const int rc = row0 + rr < n ? rr : (int)(n - 1 - row0);  // ragged tail: re-read the last row
-        voffx[q] = (unsigned)rc * (unsigned)d * 4u + (((lane & 7) ^ ((rr >> 1) & 7)) << 4);
-    }
-    const unsigned xring = lds_addr(sXr) + wq * 4096, cring = lds_addr(sCb) + wq * 4096;
-
-    float ssq[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) ssq[e] = 0.f;
-    Top2 run = {INFINITY, 0x7fffffff, INFINITY};
-    float my_xn = 0.f;                         // ||x||^2 of row tid (tid < 128), kept across centre groups
-    float xn_rt[4] = {0.f, 0.f, 0.f, 0.f};     // ... and of this lane's four fragment rows
-#ifdef ACAV_FD_PROF
-    long long fdp0 = 0, fdp1 = 0, fdp2 = 0, fdp3 = 0, fdp4 = 0, fdp5 = 0, fdp6 = 0;
-    const long long fd_tstart = clock64(), fd_wstart = wall_clock64();
-#endif
-
-    for (int cg = 0; cg < ngroups; ++cg) {
-        const int kbase = cg * 256;
-#ifdef ACAV_FD_PROF
-        const long long fd_tgrp = clock64();
-#endif
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int rr = (wq * 4 + q) * 16 + (lane >> 2);
-            const int rc = kbase + rr < K ? rr : K - 1 - kbase;
-            voffc[q] = (unsigned)rc * (unsigned)d * 2u + (((lane & 3) ^ ((rr >> 2) & 3)) << 4);
-        }
-        const char *gx = reinterpret_cast<const char *>(x + (size_t)row0 * d);
-        const char *gc = reinterpret_cast<const char *>(cb + (size_t)kbase * d);
-        int wx = 0, wc = 0;  // ring slots the next issue fills
-        auto issue_x = [&]() {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (NT) dma16_asm_nt(gx, voffx[q], xring + wx * FD_SLOT + q * 1024);
-                else dma16_asm(gx, voffx[q], xring + wx * FD_SLOT + q * 1024);
-            }
-            gx += FD_BK * 4;
-            wx = wx + 1 == FD_DX ? 0 : wx + 1;
-        };
-        auto issue_c = [&]() {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dma16_asm(gc, voffc[q], cring + wc * FD_SLOT + q * 1024);
-            gc += FD_BK * 2;
-            wc = wc + 1 == FD_DC ? 0 : wc + 1;
-        };
-
-        f32x16 acc[2][4];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave is done with the previous centre group's epilogue scratch
-        issue_x();                     // rows 0, centres 0, rows 1: the steady-state order (centres c+1, rows c+2)
-        issue_c();
-        if (nchunks > 1) issue_x();
-        int rx = 0, rcs = 0;  // ring slots stage c is read from
-#ifdef ACAV_FD_PROF
-        const long long fd_tloop0 = clock64();
-#endif
-        for (int c = 0; c < nchunks; ++c) {
-            FD_T(t0);
-            // retire rows c and centres c; rows c+1 (the 4 newest loads) may stay in flight
-            if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            FD_T(t1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            FD_T(t2);
-            const float *px = sXr + rx * (128 * 32);
-            const __bf16 *pc = sCb + rcs * (256 * 32);
-            rx = rx + 1 == FD_DX ? 0 : rx + 1;
-            rcs = rcs + 1 == FD_DC ? 0 : rcs + 1;
-            const int swz = (l31 >> 1) & 7;  // ((rowX >> 1) & 7) for every row tile (32 rows = 2 swizzle periods)
-            const float *pxl = px + l31 * 32;
-            const __bf16 *pcl = pc + (wq * 64 + l31) * 32;
-            const int swa = (l31 >> 2) & 3;  // ((rowA >> 2) & 3), likewise
-#define FD_LOAD_A(ks, A)                                                                          \
-    A[0] = *reinterpret_cast<const bf16x8 *>(pcl + (((2 * (ks) + h) ^ swa) << 3));                \
-    A[1] = *reinterpret_cast<const bf16x8 *>(pcl + 32 * 32 + (((2 * (ks) + h) ^ swa) << 3));
-            // accumulator slot j of this wave holds row tile (j + wq) & 3: slot 0 is always the wave's OWN tile, the
-            // one whose canonical ||x||^2 it accumulates -- from the fragments it reads anyway, no branch, no re-read
-            const float *pxj[4] = {pxl + ((0 + wq) & 3) * 1024, pxl + ((1 + wq) & 3) * 1024, pxl + ((2 + wq) & 3) * 1024,
-                                   pxl + ((3 + wq) & 3) * 1024};
-#define FD_LOAD_X(ks, j, F0, F1)                                                                               \
-    const float4 F0 = *reinterpret_cast<const float4 *>(pxj[j] + (((4 * (ks) + 2 * h) ^ swz) << 2));          \
-    const float4 F1 = *reinterpret_cast<const float4 *>(pxj[j] + (((4 * (ks) + 2 * h + 1) ^ swz) << 2));
-#define FD_SSQ(ks, F0, F1)                                           \
-    ssq[8 * (ks) + 0] = __builtin_fmaf(F0.x, F0.x, ssq[8 * (ks) + 0]); \
-    ssq[8 * (ks) + 1] = __builtin_fmaf(F0.y, F0.y, ssq[8 * (ks) + 1]); \
-    ssq[8 * (ks) + 2] = __builtin_fmaf(F0.z, F0.z, ssq[8 * (ks) + 2]); \
-    ssq[8 * (ks) + 3] = __builtin_fmaf(F0.w, F0.w, ssq[8 * (ks) + 3]); \
-    ssq[8 * (ks) + 4] = __builtin_fmaf(F1.x, F1.x, ssq[8 * (ks) + 4]); \
-    ssq[8 * (ks) + 5] = __builtin_fmaf(F1.y, F1.y, ssq[8 * (ks) + 5]); \
-    ssq[8 * (ks) + 6] = __builtin_fmaf(F1.z, F1.z, ssq[8 * (ks) + 6]); \
-    ssq[8 * (ks) + 7] = __builtin_fmaf(F1.w, F1.w, ssq[8 * (ks) + 7]);
-#define FD_MMA(A, rt, B)                                                                            \
-    acc[0][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B, acc[0][rt], 0, 0, 0);              \
-    acc[1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B, acc[1][rt], 0, 0, 0);
-            // k-step 0 operands of the first two row tiles are read BEFORE the DMA issue: the issue stalls while the
-            // memory pipe accepts 8 KB, which hides this LDS latency
-            bf16x8 a0[2], a1[2];
-            FD_LOAD_A(0, a0)
-            FD_LOAD_X(0, 0, p00, p01)
-            FD_LOAD_X(0, 1, p10, p11)
-            if (c + 1 < nchunks) issue_c();  // into the slots stage c-1 just vacated
-            if (c + 2 < nchunks) issue_x();
-            FD_T(t3);
-            {
-                const bf16x8 b0 = cvt_bf16x8(p00, p01), b1 = cvt_bf16x8(p10, p11);
-                FD_LOAD_X(0, 2, p20, p21)
-                FD_LOAD_X(0, 3, p30, p31)
-                FD_MMA(a0, 0, b0)
-                FD_MMA(a0, 1, b1)
-                const bf16x8 b2 = cvt_bf16x8(p20, p21), b3 = cvt_bf16x8(p30, p31);
-                FD_LOAD_A(1, a1)
-                FD_LOAD_X(1, 0, q00, q01)
-                FD_LOAD_X(1, 1, q10, q11)
-                FD_MMA(a0, 2, b2)
-                FD_MMA(a0, 3, b3)
-                const bf16x8 d0 = cvt_bf16x8(q00, q01), d1 = cvt_bf16x8(q10, q11);
-                FD_LOAD_X(1, 2, q20, q21)
-                FD_LOAD_X(1, 3, q30, q31)
-                FD_MMA(a1, 0, d0)
-                FD_MMA(a1, 1, d1)
-                const bf16x8 d2 = cvt_bf16x8(q20, q21), d3 = cvt_bf16x8(q30, q31);
-                FD_MMA(a1, 2, d2)
-                FD_MMA(a1, 3, d3)
-                if (cg == 0) {  // uniform: this wave's share of the canonical ||x||^2 (row tile wq, classes 16 ks + 8 h + e)
-                    FD_SSQ(0, p00, p01)
-                    FD_SSQ(1, q00, q01)
-                }
-            }
-#undef FD_LOAD_A
-#undef FD_LOAD_X
-#undef FD_SSQ
-#undef FD_MMA
-#ifdef ACAV_FD_PROF
-            {
-                const long long t4 = clock64();
-                fdp0 += t1 - t0, fdp1 += t2 - t1, fdp2 += t3 - t2, fdp3 += t4 - t3, fdp4 += 1;
-            }
-#endif
-        }
-#ifdef ACAV_FD_PROF
-        const long long fd_tloop1 = clock64();
-        fdp5 += fd_tloop0 - fd_tgrp;
-        fdp6 += fd_tloop1 - fd_tloop0;
-#endif
-        // beyond K: a huge FINITE norm -- such a centre never wins and never becomes the runner-up.  (+inf would turn
-        // into a NaN under the position tag, and fmaxf(s1, NaN) = s1 makes the runner-up collapse onto the minimum: every
-        // lane that mixes real and padding centres would send its row to the re-check.)
-        float my_cn = 3.0e38f, my_sc = 1.0f;
-        if (kbase + tid < K) {
-            my_cn = cn[kbase + tid];
-            my_sc = counts[kbase + tid] < thr ? inv_r : 1.0f;
-        }
-        __syncthreads();  // every wave has read its last fragments: the row ring becomes epilogue scratch
-        sCn[tid] = my_cn;
-        sSc[tid] = my_sc;
-        if (cg == 0) {
-            // lane (i, h) of wave w holds classes 16 ks + 8 h + e of row 32 w + i.  Canonical tree: (p0+p1)+(p2+p3)
-            // per group of 4 classes, then ((g0+g1)+(g2+g3)) + ((g4+g5)+(g6+g7)): g0,g1 = (ks 0, h 0), g2,g3 =
-            // (ks 0, h 1), g4,g5 = (ks 1, h 0), g6,g7 = (ks 1, h 1).
-            float ta = ((ssq[0] + ssq[1]) + (ssq[2] + ssq[3])) + ((ssq[4] + ssq[5]) + (ssq[6] + ssq[7]));
-            float tb = ((ssq[8] + ssq[9]) + (ssq[10] + ssq[11])) + ((ssq[12] + ssq[13]) + (ssq[14] + ssq[15]));
-            ta = ta + __shfl_xor(ta, 32);
-            tb = tb + __shfl_xor(tb, 32);
-            if (h == 0) sXn[wq * 32 + l31] = norm2_from_sumsq(ta + tb);
-        }
-        __syncthreads();
-        if (cg == 0) {
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt) xn_rt[rt] = sXn[((rt + wq) & 3) * 32 + l31];  // slot rt = row tile (rt + wq) & 3
-            if (tid < 128) my_xn = sXn[tid];
-        }
-        // Scan of this lane's 4 x 32 distances without a single compare: the low 5 mantissa bits of every distance
-        // are replaced by its position (ct, g, j) in the lane, so min() carries the argmin along and
-        // d2 = min(d2, max(d1, v)) tracks the runner-up.  The perturbation (< 2^-18 relative) is part of the e2
-        // term of the acceptance bound; exact ties, NaNs and infinities end in a zero / NaN margin -> re-check.
-        float s1[4], s2[4];
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) s1[rt] = INFINITY, s2[rt] = INFINITY;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int kl = wq * 64 + ct * 32 + 4 * h + 8 * g;
-                const float4 cnv = *reinterpret_cast<const float4 *>(sCn + kl);
-                const float4 scv = *reinterpret_cast<const float4 *>(sSc + kl);
-                const float cn4[4] = {cnv.x, cnv.y, cnv.z, cnv.w};
-                const float sc4[4] = {scv.x, scv.y, scv.z, scv.w};
-#pragma unroll
-                for (int rt = 0; rt < 4; ++rt) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = __builtin_fmaf(-2.0f, acc[ct][rt][4 * g + j], xn_rt[rt]);  // == (-2 dot) + xn
-                        v = v + cn4[j];
-                        v = v * sc4[j];  // * (1/r) where the exact path divides by r
-                        v = __uint_as_float((__float_as_uint(v) & 0xFFFFFFE0u) | (unsigned)(ct * 16 + g * 4 + j));
-                        s2[rt] = fminf(s2[rt], fmaxf(s1[rt], v));
-                        s1[rt] = fminf(s1[rt], v);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-            const int row = ((rt + wq) & 3) * 32 + l31;
-            const unsigned c5 = __float_as_uint(s1[rt]) & 31u;  // (ct, g, j) of the lane's minimum
-            Top2 t = {s1[rt], kbase + wq * 64 + 4 * h + (int)((c5 >> 4) * 32 + ((c5 >> 2) & 3) * 8 + (c5 & 3)), s2[rt]}, o;
-            o.d1 = __shfl_xor(t.d1, 32);
-            o.k1 = __shfl_xor(t.k1, 32);
-            o.d2 = __shfl_xor(t.d2, 32);
-            t = top2_merge(t, o);
-            if (h == 0) {
-                sD1[wq * 128 + row] = t.d1;
-                sK1[wq * 128 + row] = t.k1;
-                sD2[wq * 128 + row] = t.d2;
-            }
-        }
-        __syncthreads();
-        if (tid < 128) {
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                Top2 o = {sD1[w * 128 + tid], sK1[w * 128 + tid], sD2[w * 128 + tid]};
-                run = top2_merge(run, o);
-            }
-        }
-    }
-#ifdef ACAV_FD_PROF
-    if (lane == 0 && (blockIdx.x & 31) == 0 && (wq == 0 || wq == 3)) {
-        const int o = wq == 0 ? 0 : 8;
-        atomicAdd(&g_fd_prof[o + 0], (unsigned long long)fdp0);
-        atomicAdd(&g_fd_prof[o + 1], (unsigned long long)fdp1);
-        atomicAdd(&g_fd_prof[o + 2], (unsigned long long)fdp2);
-        atomicAdd(&g_fd_prof[o + 3], (unsigned long long)fdp3);
-        atomicAdd(&g_fd_prof[o + 4], (unsigned long long)fdp4);
-        atomicAdd(&g_fd_prof[o + 5], (unsigned long long)(clock64() - fd_tstart));
-        atomicAdd(&g_fd_prof[o + 6], (unsigned long long)(wall_clock64() - fd_wstart));
-        atomicAdd(&g_fd_prof[o + 7], 1ull);
-        atomicAdd(&g_fd_prof[16 + o / 8 * 2], (unsigned long long)fdp5);
-        atomicAdd(&g_fd_prof[17 + o / 8 * 2], (unsigned long long)fdp6);
-    }
-#endif
-    if (tid < 128 && row0 + tid < n) {
-        const float xnorm = __builtin_sqrtf(my_xn);
-        const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
-        const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
-        const float s = xnorm + cmax;
-        const float E = (e1c * cmaxc + e1r * cmax) * xnorm + e2coef * s * s;
-        labels[row0 + tid] = (int64_t)run.k1;
-        if (!((run.d2 - run.d1) > 2.0f * E)) {  // also catches NaN / inf
-            const unsigned slot = atomicAdd(recheck_count, 1u);
-            recheck_list[slot] = (int)(row0 + tid);
-        }
-    }
-}
-
-// k_assign_bf16_rw -- the same filter with the waves cut the other way ("row waves"): wave w owns ROWS 32 w .. 32 w + 31
-// of the workgroup's 128 against ALL 256 centres of the group (8 accumulator tiles of 32x32).
-//   * a wave reads and converts only its own rows' fp32 fragments: 8 v_cvt_pk_bf16_f32 per 32-column stage instead of
-//     32 (in the centre-quarter layout every wave re-read and re-converted all 128 rows); the bf16 centre fragments,
-//     which need no conversion, are the ones every wave reads
-//   * a lane ends up with all 128 centres of its half for ITS row: the top-2 scan completes in the lane, the two
-//     halves meet with one shfl_xor 32, and the running top-2 over centre groups stays in registers -- no cross-wave
-//     merge through LDS, no per-group scratch for it
-//   * the position tag needs 7 bits (128 distances per lane): 128 ulp = 2^-16 of the tagged distance.  That is charged
-//     to the two distances the acceptance test compares (|d1| + |d2|) instead of to (||x|| + cmax)^2; what is left in the
-//     e2 term are the 3 + 3 fp32 roundings of the two epilogues (< 6 x 2^-24 (||x|| + cmax)^2): e2 = 2^-20 here
-// Rings, swizzles, DMA shares, counted waits and the one raw barrier per stage are those of k_assign_bf16.
-// Ablations of this kernel on one MI355X (1M x 1024, K = 256; wrong labels, timing only): full 0.93 ms; without the
-// centre DMA 0.71 ms; DMA only (no fragment reads, no MFMA) 0.78 ms -- the bf16 centre stage (16 KB from L2 per 16 KB of
-// rows from HBM) is the largest single cost.  A persistent 256-row workgroup (eight row waves sharing one centre stage,
-// DMA cursors running across tile boundaries, one workgroup per CU) halves that traffic and was SLOWER (0.94 vs 0.90 ms):
-// eight waves in lockstep on one barrier lose more than the centre traffic costs; two independent 128-row workgroups
-// per CU interleave their phases.  (round 2, measured and rejected)
-// Same-box ablations of the compute side (full 0.87-0.93 ms): half of the centre fragment reads 0.82, one centre tile's
-// fragments only 0.81, half of the MFMAs 0.80, both halved 0.80 -- neither the LDS reads nor the matrix pipe is the floor:
-// the two DMA streams are (rows from HBM + as many bytes of centres from L2: 8.2 GB through the LDS-DMA path per launch,
-// DMA only 0.78 ms), against a chip that copies at 6.3 TB/s (0.65 ms for the rows alone, MI355X_MICROARCH.md).
-// Halving the centre stream the other way -- a wave owning 64 rows (two accumulator sets = 256 registers, 512 with the
-// fragments, 7 spills), 256 rows per workgroup against one centre stage, 128 KB of LDS, one wave per SIMD -- was correct
-// and SLOWER too (0.97-0.98 vs 0.91-0.94 ms same box): with one wave per SIMD every barrier and LDS wait idles the SIMD.
-//
-// Template parameters (round 3):
-//   NW   waves per workgroup = 32-row tiles per workgroup: 4 (128 rows, 80 KB of LDS, two workgroups per CU) or 8 (256 rows
-//        against ONE centre stage, 128 KB, one workgroup per CU: half the centre bytes per row)
-//   GS   "group split" for K > 256: one workgroup = one (row tile, group of 256 centres) PAIR instead of a loop over the
-//        groups that re-streams the tile's rows from HBM once per group.  The pairs of a tile are consecutive in dispatch
-//        order on ONE XCD (block b runs on XCD b % 8): the tile's rows come from HBM once and from that XCD's L2 for the
-//        other groups.  Each pair leaves a (d1, k1, d2, ||x||^2) record per row; k_assign_merge folds the groups in
-//        ascending order (the order of the loop) and applies the acceptance test.
-//   DCR  centre ring depth.  2: a centre stage is issued one stage ahead (rows two).  With the rows L2-resident (GS) the
-//        stage time is no longer set by HBM but by how long a DMA piece takes to land under load (~1 us, L2 hit or not)
-//        over the stages of look-ahead: 3 gives the centre stream two stages like the rows (order per stage: centres
-//        c+2 THEN rows c+2, counted wait leaves one stage of both in flight).
-struct Top2Rec {
-    float d1;
-    int k1;
-    float d2;
-    float xn;
-};
-template <bool NT, int NW, bool GS, int DCR = FD_DC, int SCHED = 0>
-__global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__restrict__ x, int64_t n, int d,
-                                                            const __bf16 *__restrict__ cb, const float *__restrict__ cn,
-                                                            const float *__restrict__ counts, int K, float thr, float r,
-                                                            const CentersAux *__restrict__ aux, float e1c, float e1r, float e2coef,
-                                                            int64_t *__restrict__ labels, int *__restrict__ recheck_list,
-                                                            unsigned *__restrict__ recheck_count, Top2Rec *__restrict__ grec)
-{
-    constexpr int XSLOT = NW * 4096;  // bytes per row-ring slot: NW x 32 rows x 32 fp32
-    constexpr int CQ = 16 / NW;       // centre-stage DMA pieces (1 KB = 16 centres x 64 B) per wave
-    extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
-    float *sXr = reinterpret_cast<float *>(fd_smem);                        // [FD_DX][NW * 32][32] fp32
-    __bf16 *sCb = reinterpret_cast<__bf16 *>(fd_smem + FD_DX * XSLOT);      // [FD_DC][256][32] bf16
-    float *sCn = reinterpret_cast<float *>(fd_smem);  // [256] epilogue scratch, aliases the (idle) row ring
-    float *sSc = sCn + 256;                           // [256] 1, or 1/r for a discounted centre
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = row tile (32 rows)
-    const int l31 = lane & 31, h = lane >> 5;
-    const int nchunks = d / FD_BK;
-    const int ngroups = (K + 255) / 256;
-    int64_t tile = blockIdx.x;
-    int cg0 = 0, cg1 = ngroups;
-    if (GS) {
-        const int j = blockIdx.x >> 3;  // sequence number on XCD (blockIdx.x & 7)
-        tile = (int64_t)(j / ngroups) * 8 + (blockIdx.x & 7);
-        cg0 = j % ngroups;
-        cg1 = cg0 + 1;
-        if (tile * (NW * 32) >= n) return;  // the grid is rounded up to whole rounds of 8 tiles
-    }
-    const int64_t row0 = tile * (NW * 32);
-    const float inv_r = 1.0f / r;
-    // Centred mode (no centre is under-used: the filter multiplies by c - mu): every distance of a row carries the same
-    // constant ||x||^2 + M - 2 x.mu, M = any number.  It is left out of the compared values -- ||x||^2 is not added and
-    // M = ||c_0||^2 is subtracted from every ||c_k||^2 (exact by Sterbenz when the norms are within a factor 2, else one
-    // more rounding inside e2) -- so the position tag perturbs numbers of the size of the distance SPREAD, not of the
-    // squared norms.  With an under-used centre the division by r does not commute with a row constant: full values.
-    const bool centred = aux->any_disc == 0u;
-    const float cn_shift = centred ? cn[0] : 0.0f;
-
-    unsigned voffx[4], voffc[CQ];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int rr = (wq * 4 + q) * 8 + (lane >> 3);
-        const int rc = row0 + rr < n ? rr : (int)(n - 1 - row0);  // ragged tail: re-read the last row
-        voffx[q] = (unsigned)rc * (unsigned)d * 4u + (((lane & 7) ^ ((rr >> 1) & 7)) << 4);
-    }
-    const unsigned xring = lds_addr(sXr) + wq * 4096, cring = lds_addr(sCb) + wq * (CQ * 1024);
-
-    float ssq[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) ssq[e] = 0.f;
-    Top2 run = {INFINITY, 0x7fffffff, INFINITY};
-    float xn = 0.f;  // ||x||^2 of this lane's row
-#ifdef ACAV_RW_PROF
-    long long rwp[6] = {0, 0, 0, 0, 0, 0};
-    const long long rw_tstart = clock64(), rw_wstart = wall_clock64();
-#endif
-
-    for (int cg = cg0; cg < cg1; ++cg) {
-        const int kbase = cg * 256;
-#pragma unroll
-        for (int q = 0; q < CQ; ++q) {
-            const int rr = (wq * CQ + q) * 16 + (lane >> 2);
-            const int rc = kbase + rr < K ? rr : K - 1 - kbase;
-            voffc[q] = (unsigned)rc * (unsigned)d * 2u + (((lane & 3) ^ ((rr >> 2) & 3)) << 4);
-        }
-        const char *gx = reinterpret_cast<const char *>(x + (size_t)row0 * d);
-        const char *gc = reinterpret_cast<const char *>(cb + (size_t)kbase * d);
-        int wx = 0, wc = 0;
-        auto issue_x = [&]() {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (NT) dma16_asm_nt(gx, voffx[q], xring + wx * XSLOT + q * 1024);
-                else dma16_asm(gx, voffx[q], xring + wx * XSLOT + q * 1024);
-            }
-            gx += FD_BK * 4;
-            wx = wx + 1 == FD_DX ? 0 : wx + 1;
-        };
-        auto issue_c = [&]() {
-#pragma unroll
-            for (int q = 0; q < CQ; ++q) dma16_asm(gc, voffc[q], cring + wc * FD_SLOT + q * 1024);
-            gc += FD_BK * 2;
-            wc = wc + 1 == DCR ? 0 : wc + 1;
-        };
-
-        f32x16 acc[8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
-
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave is done with the previous centre group's epilogue scratch
-        if (DCR == 2) {
-            issue_x();
-            issue_c();
-            if (nchunks > 1) issue_x();
-        } else {
-            issue_c();
-            issue_x();
-            if (nchunks > 1) {
-                issue_c();
-                issue_x();
-            }
-        }
-        int rx = 0, rcs = 0;
-        const int swz = (l31 >> 1) & 7, swa = (l31 >> 2) & 3;
-        for (int c = 0; c < nchunks; ++c) {
-            RW_T(t0);
-#if defined(ACAV_ABL_NOXDMA)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-            // what stays in flight behind stage c: DCR 2 -- the 4 row pieces of stage c+1 (issued last, after the
-            // centres of stage c); DCR 3 -- the CQ centre + 4 row pieces of stage c+1
-            if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DCR == 2 ? 4 : CQ + 4) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            RW_T(t1);
-            __builtin_amdgcn_s_barrier();
-            RW_T(t2);
-            const float *pxl = sXr + rx * (XSLOT / 4) + wq * 1024 + l31 * 32;  // this lane's row of the wave's own tile
-            const __bf16 *pcl = sCb + rcs * (256 * 32) + l31 * 32;            // row l31 of centre tile 0 (+ 1024 per tile)
-            rx = rx + 1 == FD_DX ? 0 : rx + 1;
-            rcs = rcs + 1 == DCR ? 0 : rcs + 1;
-#define RW_LDB(ks, F0, F1)                                                                         \
-    const float4 F0 = *reinterpret_cast<const float4 *>(pxl + (((4 * (ks) + 2 * h) ^ swz) << 2));  \
-    const float4 F1 = *reinterpret_cast<const float4 *>(pxl + (((4 * (ks) + 2 * h + 1) ^ swz) << 2));
-#define RW_LDA(ks, ct) (*reinterpret_cast<const bf16x8 *>(pcl + (ct) * 1024 + (((2 * (ks) + h) ^ swa) << 3)))
-            // ACAV_ABL_*: timing-only ablations for tools/exp/assign_bench.hip (never defined in the product build)
-#ifdef ACAV_ABL_NOAFRAG
-#define RW_CT(ct) 0
-#else
-#define RW_CT(ct) (ct)
-#endif
-#ifdef ACAV_ABL_NOMFMA
-#define RW_MFMA(a, b, cc) cc[0] += (float)(a)[0] + (float)(b)[0]
-#else
-#define RW_MFMA(a, b, cc) cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, cc, 0, 0, 0)
-#endif
-            // SCHED: when a wave issues its CQ + 4 DMA pieces of the stage (an issue costs the wave 60-120 cycles while the
-            // path is busy: tools/exp/assign_bench.hip -DACAV_RW_PROF).  0: all of them in one burst before the MFMAs.
-            // 1 (512-thread workgroups): the second half of the waves shares its SIMDs with the first half and issues its
-            // burst AFTER its MFMAs.  2: one piece after every second MFMA -- the DMA path sees a steady stream instead of
-            // a burst per barrier, and while one wave of a SIMD sits in an issue the other one feeds the matrix pipe.
-            const bool dma_first = SCHED == 0 || (SCHED == 1 && (NW == 4 || wq < 4));
-            const bool dma_last = SCHED == 1 && !dma_first;
-            constexpr int NP = CQ + 4, NP1 = NP / 2;
-            auto piece = [&](int i) {
-                if (i < CQ) {
-#ifndef ACAV_ABL_NOCDMA
-                    if (c + DCR - 1 < nchunks) dma16_asm(gc, voffc[i], cring + wc * FD_SLOT + i * 1024);
-#endif
-                    if (i == CQ - 1) {
-                        gc += FD_BK * 2;
-                        wc = wc + 1 == DCR ? 0 : wc + 1;
-                    }
-                } else {
-                    const int q = i - CQ;
-#ifndef ACAV_ABL_NOXDMA
-                    if (c + 2 < nchunks) {
-                        if (NT) dma16_asm_nt(gx, voffx[q], xring + wx * XSLOT + q * 1024);
-                        else dma16_asm(gx, voffx[q], xring + wx * XSLOT + q * 1024);
-                    }
-#endif
-                    if (q == 3) {
-                        gx += FD_BK * 4;
-                        wx = wx + 1 == FD_DX ? 0 : wx + 1;
-                    }
-                }
-            };
-            RW_LDB(0, p0, p1)
-            bf16x8 a0[8], a1[8];
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct) a0[ct] = RW_LDA(0, RW_CT(ct));
-            RW_T(t3);
-            if (dma_first) {  // into the slots stage c-1 just vacated
-#pragma unroll
-                for (int i = 0; i < NP; ++i) piece(i);
-            }
-            RW_T(t4);
-            RW_LDB(1, q0, q1)
-            const bf16x8 b0 = cvt_bf16x8(p0, p1);
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct) {
-                RW_MFMA(a0[ct], b0, acc[ct]);
-                a1[ct] = RW_LDA(1, RW_CT(ct));
-                if (SCHED == 2 && (ct & 1) == 0 && ct / 2 < NP1) piece(ct / 2);
-            }
-            const bf16x8 b1 = cvt_bf16x8(q0, q1);
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct) {
-                RW_MFMA(a1[ct], b1, acc[ct]);
-                if (SCHED == 2 && (ct & 1) == 0 && NP1 + ct / 2 < NP) piece(NP1 + ct / 2);
-            }
-            if (dma_last) {
-#pragma unroll
-                for (int i = 0; i < NP; ++i) piece(i);
-            }
-#undef RW_MFMA
-#undef RW_CT
-#ifdef ACAV_RW_PROF
-            {
-                RW_T(t5);
-                rwp[0] += t1 - t0, rwp[1] += t2 - t1, rwp[2] += t3 - t2, rwp[3] += t4 - t3, rwp[4] += t5 - t4, rwp[5] += 1;
-            }
-#endif
-            if (cg == cg0) {  // uniform: canonical ||x||^2 of the lane's row, classes 16 ks + 8 h + e
-                ssq[0] = __builtin_fmaf(p0.x, p0.x, ssq[0]), ssq[1] = __builtin_fmaf(p0.y, p0.y, ssq[1]);
-                ssq[2] = __builtin_fmaf(p0.z, p0.z, ssq[2]), ssq[3] = __builtin_fmaf(p0.w, p0.w, ssq[3]);
-                ssq[4] = __builtin_fmaf(p1.x, p1.x, ssq[4]), ssq[5] = __builtin_fmaf(p1.y, p1.y, ssq[5]);
-                ssq[6] = __builtin_fmaf(p1.z, p1.z, ssq[6]), ssq[7] = __builtin_fmaf(p1.w, p1.w, ssq[7]);
-                ssq[8] = __builtin_fmaf(q0.x, q0.x, ssq[8]), ssq[9] = __builtin_fmaf(q0.y, q0.y, ssq[9]);
-                ssq[10] = __builtin_fmaf(q0.z, q0.z, ssq[10]), ssq[11] = __builtin_fmaf(q0.w, q0.w, ssq[11]);
-                ssq[12] = __builtin_fmaf(q1.x, q1.x, ssq[12]), ssq[13] = __builtin_fmaf(q1.y, q1.y, ssq[13]);
-                ssq[14] = __builtin_fmaf(q1.z, q1.z, ssq[14]), ssq[15] = __builtin_fmaf(q1.w, q1.w, ssq[15]);
-            }
-#undef RW_LDB
-#undef RW_LDA
-        }
-        // beyond K: a huge FINITE norm -- such a centre never wins and never becomes the runner-up.  (+inf would turn
-        // into a NaN under the position tag, and fmaxf(s1, NaN) = s1 makes the runner-up collapse onto the minimum: every
-        // lane that mixes real and padding centres would send its row to the re-check.)
-        float my_cn = 3.0e38f, my_sc = 1.0f;
-        if (kbase + tid < K && tid < 256) {
-            my_cn = cn[kbase + tid] - cn_shift;
-            my_sc = counts[kbase + tid] < thr ? inv_r : 1.0f;
-        }
-        __syncthreads();  // every wave has read its last fragments: the row ring becomes epilogue scratch
-        if (NW == 4 || tid < 256) {
-            sCn[tid] = my_cn;
-            sSc[tid] = my_sc;
-        }
-        if (cg == cg0) {
-            // canonical tree: (p0+p1)+(p2+p3) per group of 4 classes, then ((g0+g1)+(g2+g3)) + ((g4+g5)+(g6+g7)):
-            // g0,g1 = (ks 0, h 0), g2,g3 = (ks 0, h 1), g4,g5 = (ks 1, h 0), g6,g7 = (ks 1, h 1); fp32 + commutes bitwise
-            float ta = ((ssq[0] + ssq[1]) + (ssq[2] + ssq[3])) + ((ssq[4] + ssq[5]) + (ssq[6] + ssq[7]));
-            float tb = ((ssq[8] + ssq[9]) + (ssq[10] + ssq[11])) + ((ssq[12] + ssq[13]) + (ssq[14] + ssq[15]));
-            const float oa = __shfl_xor(ta, 32), ob = __shfl_xor(tb, 32);
-            ta = h ? oa + ta : ta + oa;  // (h 0) + (h 1) in both halves
-            tb = h ? ob + tb : tb + ob;
-            xn = norm2_from_sumsq(ta + tb);
-        }
-        __syncthreads();
-        // compare-free top-2 scan of this lane's 8 x 16 distances: the 7 low mantissa bits carry the position
-        float s1 = INFINITY, s2 = INFINITY;
-        if (centred) {
-            // no centre is under-used: every scale is 1 and ||x||^2 is left out -- v = fl(-2 dot + ||c||^2') is ONE fma (-2 dot is
-            // exact), the same value the general form below produces through its three operations; no scale table read
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 cnv = *reinterpret_cast<const float4 *>(sCn + ct * 32 + 4 * h + 8 * g);
-                    const float cn4[4] = {cnv.x, cnv.y, cnv.z, cnv.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = __builtin_fmaf(-2.0f, acc[ct][4 * g + j], cn4[j]);
-                        v = __uint_as_float((__float_as_uint(v) & 0xFFFFFF80u) | (unsigned)(ct * 16 + g * 4 + j));
-                        s2 = fminf(s2, fmaxf(s1, v));
-                        s1 = fminf(s1, v);
-                    }
-                }
-            }
-        } else {
-            const float xoff = xn;
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int kl = ct * 32 + 4 * h + 8 * g;
-                    const float4 cnv = *reinterpret_cast<const float4 *>(sCn + kl);
-                    const float4 scv = *reinterpret_cast<const float4 *>(sSc + kl);
-                    const float cn4[4] = {cnv.x, cnv.y, cnv.z, cnv.w};
-                    const float sc4[4] = {scv.x, scv.y, scv.z, scv.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = __builtin_fmaf(-2.0f, acc[ct][4 * g + j], xoff);  // == (-2 dot) + xn
-                        v = v + cn4[j];
-                        v = v * sc4[j];  // * (1/r) where the exact path divides by r
-                        v = __uint_as_float((__float_as_uint(v) & 0xFFFFFF80u) | (unsigned)(ct * 16 + g * 4 + j));
-                        s2 = fminf(s2, fmaxf(s1, v));
-                        s1 = fminf(s1, v);
-                    }
-                }
-            }
-        }
-        const unsigned c7 = __float_as_uint(s1) & 127u;  // (ct, g, j) of the lane's minimum
-        Top2 t = {s1, kbase + 4 * h + (int)((c7 >> 4) * 32 + ((c7 >> 2) & 3) * 8 + (c7 & 3)), s2}, o;
-        o.d1 = __shfl_xor(t.d1, 32);
-        o.k1 = __shfl_xor(t.k1, 32);
-        o.d2 = __shfl_xor(t.d2, 32);
-        run = top2_merge(run, top2_merge(t, o));
-    }
-#ifdef ACAV_RW_PROF
-    if (lane == 0 && (blockIdx.x & 15) == 3 && (wq == 0 || wq == NW - 1)) {
-        const int o = wq == 0 ? 0 : 8;
-        for (int i = 0; i < 6; ++i) atomicAdd(&g_rw_prof[o + i], (unsigned long long)rwp[i]);
-        atomicAdd(&g_rw_prof[o + 6], (unsigned long long)(clock64() - rw_tstart));
-        atomicAdd(&g_rw_prof[o + 7], (unsigned long long)(wall_clock64() - rw_wstart));
-    }
-#endif
-    const int64_t row = row0 + wq * 32 + l31;
-    if (GS) {
-        if (h == 0 && row < n) {
-            const Top2Rec rec = {run.d1, run.k1, run.d2, xn};
-            grec[(size_t)cg0 * (size_t)n + (size_t)row] = rec;
-        }
-        return;
-    }
-    if (h == 0 && row < n) {
-        const float xnorm = __builtin_sqrtf(xn);
-        const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
-        const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
-        const float s = xnorm + cmax;
-        const float E = (e1c * cmaxc + e1r * cmax) * xnorm + e2coef * s * s;
-        labels[row] = (int64_t)run.k1;
-        // the position tag perturbs a distance by < 2^-16 of ITS OWN magnitude (and fl(1/r) by 2 ulp more): charged to the
-        // two distances that are compared instead of to (||x|| + cmax)^2 -- with a large common component the distances
-        // are orders of magnitude smaller than the norms
-        const float tagged = 1.6e-5f * (fabsf(run.d1) + fabsf(run.d2));  // > (2^-16 + 2^-22) x 1.01
-        if (!((run.d2 - run.d1) > 2.0f * E + tagged)) {  // also catches NaN / inf
-            const unsigned slot = atomicAdd(recheck_count, 1u);
-            recheck_list[slot] = (int)row;
-        }
-    }
-}
-
-// Folds the per-group records of the group-split filter (ascending group order = the order of the single-workgroup loop;
-// top2_merge breaks distance ties towards the lower centre index, so the fold is order-independent anyway) and applies
-// k_assign_bf16_rw's acceptance test.  One thread per row; 16-byte records, coalesced.
-__global__ __launch_bounds__(256) void k_assign_merge(const Top2Rec *__restrict__ grec, int ngroups, int64_t n,
-                                                      const CentersAux *__restrict__ aux, float e1c, float e1r, float e2coef,
-                                                      int64_t *__restrict__ labels, int *__restrict__ recheck_list,
-                                                      unsigned *__restrict__ recheck_count)
-{
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (row >= n) return;
-    Top2Rec r0 = grec[row];
-    Top2 run = {r0.d1, r0.k1, r0.d2};
-    for (int g = 1; g < ngroups; ++g) {
-        const Top2Rec rg = grec[(size_t)g * (size_t)n + (size_t)row];
-        const Top2 o = {rg.d1, rg.k1, rg.d2};
-        run = top2_merge(run, o);
-    }
-    const float xnorm = __builtin_sqrtf(r0.xn);
-    const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
-    const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
-    const float s = xnorm + cmax;
-    const float E = (e1c * cmaxc + e1r * cmax) * xnorm + e2coef * s * s;
-    labels[row] = (int64_t)run.k1;
-    const float tagged = 1.6e-5f * (fabsf(run.d1) + fabsf(run.d2));
-    if (!((run.d2 - run.d1) > 2.0f * E + tagged)) {
-        const unsigned slot = atomicAdd(recheck_count, 1u);
-        recheck_list[slot] = (int)row;
-    }
 }
 
 // ------------------------------------------------------------------------- SGD step kernels
@@ -2726,36 +1585,13 @@ __global__ void k_fill_u64(unsigned long long *p, int n, unsigned long long v)
 
 }  // namespace
 
-// =============================================================================== handle
-struct acav_kmeans {
-    StreamCtx ctx;
-    int K = 0, d = 0;
-    int initial_rounds = 10;
-    double reinit_p = 0.7, reinit_r = 5.0;
-    int64_t count = 0;  // python int self.count (deterministic on the host)
-    DevBuf centers, cn, counts, scalars;
-    DevBuf stage_x, stage_lab, stage_forced, keys, xn, wg_sum, minval, thr, ctl;
-    DevBuf cb16, caux, cmu, recheck_list, recheck_count, backup, grec, split_rings;
-    hipEvent_t ev_f0 = nullptr, ev_f1 = nullptr;  // around the last k_assign_bf16 launch (acav_kmeans_filter_time)
-    bool cb16_valid = false;  // bf16 copy of the centres matches `centers`
-    bool rg_attr_set = false; // dynamic-LDS attribute of the large-batch distance kernels set
-    int64_t n_filter_launches = 0;
-    uint64_t last_recheck = 0, last_rows = 0;
-    int64_t n_persistent_launches = 0, n_persistent_fallbacks = 0;
-    int num_cus = 0;  // multiProcessorCount of the handle's device (queried on first use)
-    int key_phase = 0;  // which half of `keys` the next step's distance kernel folds into
-    int64_t n_assign_launches = 0, n_step_launches = 0;
-
-    float threshold() const { return (float)pow((double)count / (double)K, reinit_p); }
-    bool warm() const { return count < (int64_t)initial_rounds * K; }
-    int refresh_cn()
-    {
-        hipLaunchKernelGGL(k_row_norm2, dim3((K + 7) / 8), dim3(256), 0, ctx.stream, centers.as<float>(), K, d,
-                           cn.as<float>());
-        ACAV_HIP_TRY(hipGetLastError());
-        return ACAV_OK;
-    }
-};
+int acav_kmeans::refresh_cn()
+{
+    hipLaunchKernelGGL(k_row_norm2, dim3((K + 7) / 8), dim3(256), 0, ctx.stream, centers.as<float>(), K, d,
+                       cn.as<float>());
+    ACAV_HIP_TRY(hipGetLastError());
+    return ACAV_OK;
+}
 
 ACAV_EXPORT int acav_kmeans_create(acav_kmeans **out, int device, int k, int d, const float *centers0,
                                    void *stream)
@@ -2844,30 +1680,6 @@ ACAV_EXPORT int acav_kmeans_train_stats(acav_kmeans *km, int64_t *persistent_lau
     return ACAV_OK;
 }
 
-ACAV_EXPORT int acav_kmeans_filter_stats(acav_kmeans *km, int64_t *filter_launches, int64_t *rows, int64_t *rechecked)
-{
-    ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");
-    unsigned cnt = 0;
-    if (km->recheck_count.p && km->n_filter_launches) {
-        ACAV_HIP_TRY(hipSetDevice(km->ctx.device));
-        ACAV_HIP_TRY(hipMemcpyAsync(&cnt, km->recheck_count.p, sizeof(cnt), hipMemcpyDeviceToHost, km->ctx.stream));
-        ACAV_HIP_TRY(hipStreamSynchronize(km->ctx.stream));
-    }
-    if (filter_launches) *filter_launches = km->n_filter_launches;
-    if (rows) *rows = (int64_t)km->last_rows;
-    if (rechecked) *rechecked = (int64_t)cnt;
-    return ACAV_OK;
-}
-
-ACAV_EXPORT int acav_kmeans_filter_time(acav_kmeans *km, float *ms)
-{
-    ACAV_REQUIRE(km && ms, ACAV_EINVAL, "NULL argument");
-    ACAV_REQUIRE(km->ev_f0 && km->n_filter_launches > 0, ACAV_ESTATE, "no filter launch yet");
-    ACAV_HIP_TRY(hipSetDevice(km->ctx.device));
-    ACAV_HIP_TRY(hipEventSynchronize(km->ev_f1));
-    ACAV_HIP_TRY(hipEventElapsedTime(ms, km->ev_f0, km->ev_f1));
-    return ACAV_OK;
-}
 
 ACAV_EXPORT int acav_kmeans_set_hyper(acav_kmeans *km, int initial_rounds, double reinit_p, double reinit_r)
 {
@@ -2927,171 +1739,6 @@ ACAV_EXPORT int acav_kmeans_set_state(acav_kmeans *km, const float *centers, con
     return ACAV_OK;
 }
 
-ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, int64_t *labels, float *mean_dist)
-{
-    ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");
-    ACAV_REQUIRE(n >= 0, ACAV_EINVAL, "n must be >= 0");
-    ACAV_REQUIRE(n == 0 || (x && labels), ACAV_EINVAL, "NULL argument");  // an empty tensor has no storage
-    ACAV_REQUIRE(!km->warm(), ACAV_ESTATE,
-                 "count=%lld < initial_rounds*k=%lld: labels come from the warm-up rng (acav_rng_warmup_best)",
-                 (long long)km->count, (long long)km->initial_rounds * km->K);
-    if (n == 0) {
-        if (mean_dist) *mean_dist = NAN;  // torch: mean of an empty tensor
-        return ACAV_OK;
-    }
-    ACAV_HIP_TRY(hipSetDevice(km->ctx.device));
-    hipStream_t st = km->ctx.stream;
-    const void *dx = nullptr;
-    ACAV_TRY(to_device(x, sizeof(float) * (size_t)n * km->d, km->stage_x, st, &dx));
-    const bool lab_dev = is_device_ptr(labels);
-    int64_t *dlab = labels;
-    if (!lab_dev) {
-        ACAV_TRY(km->stage_lab.ensure(sizeof(int64_t) * (size_t)n));
-        dlab = km->stage_lab.as<int64_t>();
-    }
-    const int64_t grid = (n + AS_ROWS - 1) / AS_ROWS;
-    ACAV_REQUIRE(grid <= 0x7fffffff, ACAV_EINVAL, "n too large for one launch");
-    ACAV_TRY(km->wg_sum.ensure(sizeof(double) * (size_t)grid));
-    const bool fast = (km->d % AS_BK) == 0 && ((uintptr_t)dx & 15) == 0;
-    // bf16 filter + exact re-check (bit-identical labels, HBM-bound when the clusters are separated): taken when
-    // the caller does not need the mean distance (the filter's distances are approximate)
-    const char *noflt = getenv("ACAV_ASSIGN_EXACT_ONLY");
-    const bool filter = !mean_dist && fast && (km->d % FD_BK) == 0 && km->K >= 2 && n >= FB_ROWS &&
-                        !(noflt && noflt[0] == '1') && n < 0x7fffffff;
-    if (filter) {
-        if (!km->cb16_valid) {
-            ACAV_TRY(km->cb16.ensure(sizeof(unsigned short) * (size_t)km->K * km->d));
-            ACAV_TRY(km->caux.ensure(sizeof(CentersAux)));
-            ACAV_HIP_TRY(hipMemsetAsync(km->caux.p, 0, sizeof(CentersAux), st));
-            ACAV_TRY(km->cmu.ensure(sizeof(float) * (size_t)km->d));
-            hipLaunchKernelGGL(k_centers_mu, dim3((unsigned)((km->d + 31) / 32)), dim3(256), 0, st, km->centers.as<float>(),
-                               km->cn.as<float>(), km->counts.as<float>(), km->K, km->d, km->threshold(), km->cmu.as<float>(),
-                               km->caux.as<CentersAux>());
-            hipLaunchKernelGGL(k_centers_bf16, dim3((unsigned)km->K), dim3(256), 0, st, km->centers.as<float>(),
-                               km->cmu.as<float>(), km->d, km->cb16.as<__bf16>(), km->caux.as<CentersAux>());
-            ACAV_HIP_TRY(hipGetLastError());
-            km->cb16_valid = true;
-        }
-        ACAV_TRY(km->recheck_list.ensure(sizeof(int) * (size_t)n));
-        ACAV_TRY(km->recheck_count.ensure(sizeof(unsigned)));
-        ACAV_HIP_TRY(hipMemsetAsync(km->recheck_count.p, 0, sizeof(unsigned), st));
-        const double acc = 1.01 * (double)km->d * ldexp(1.0, -24);  // accumulation error of one fp32 dot, relative
-        const float e1c = (float)(2.02 * (ldexp(1.0, -8) * 1.002 + acc) * 1.001);   // x ||c'|| ||x||: bf16 roundings + filter dot
-        const float e1r = (float)(2.02 * (acc + ldexp(1.0, -24)) * 1.001);           // x ||c|| ||x||: canonical dot, c - mu
-        // rows are read exactly once: non-temporal DMA policy (ACAV_FILTER_NT=0 restores the default policy);
-        // ACAV_FILTER_V1=1 selects the round-1 wave layout (wave = centre quarter) for A/B measurements
-        const char *vnt = getenv("ACAV_FILTER_NT"), *v1 = getenv("ACAV_FILTER_V1");
-        const bool nt = !(vnt && vnt[0] == '0'), rw = !(v1 && v1[0] == '1');
-        const float e2 = (float)ldexp(1.0, rw ? -20 : -17);  // row waves: epilogue roundings only, the tag is charged separately
-        // Tile shape and DMA schedule of k_assign_bf16_rw (template parameters there).  K > 256: one workgroup per (row tile,
-        // centre group) pair, the pairs of a tile side by side on one XCD, 256-row tiles (8 waves), centre ring of 3, DMA
-        // pieces spread between the MFMAs -- rows from HBM once.  Knobs for A/B runs: ACAV_FILTER_GS=0 (loop over the groups
-        // inside one workgroup), ACAV_FILTER_NW=4|8, ACAV_FILTER_SCHED=0|2.
-        const int ngroups = (km->K + 255) / 256;
-        const char *vgs = getenv("ACAV_FILTER_GS"), *vnw = getenv("ACAV_FILTER_NW"), *vsc = getenv("ACAV_FILTER_SCHED");
-        const bool gs = rw && ngroups > 1 && !(vgs && vgs[0] == '0');
-        // (narrow views, d <= 256: a pair is only 4-8 stages long and its ring fill and epilogue weigh as much as its stage loop
-        // -- two 128-row workgroups per CU hide them under each other: d = 128, K = 1024: 0.59 vs 0.72 ms per 1.25M rows)
-        const int nw = !rw ? 4 : (vnw && vnw[0] == '8') ? 8 : (vnw && vnw[0] == '4') ? 4 : (gs ? (km->d <= 256 ? 4 : 8) : FILTER_NW_DEFAULT);
-        const bool nt_eff = gs ? !(vnt && vnt[0] == '0') : nt;  // nt rows are still found in L2 by the tile's other groups (PMC)
-        const int dcr = nw == 8 ? 3 : 2;  // centre ring depth (3 only fits the one-workgroup-per-CU tile)
-        const int sched = nw == 8 ? 2 : (vsc ? (vsc[0] == '2' ? 2 : 0) : FILTER_SCHED_DEFAULT);
-        typedef void (*FilterKern)(const float *, int64_t, int, const __bf16 *, const float *, const float *, int, float, float,
-                                   const CentersAux *, float, float, float, int64_t *, int *, unsigned *, Top2Rec *);
-        FilterKern rwk = nullptr;
-        if (rw) {
-            if (nw == 8) rwk = gs ? (nt_eff ? k_assign_bf16_rw<true, 8, true, 3, 2> : k_assign_bf16_rw<false, 8, true, 3, 2>)
-                                  : (nt_eff ? k_assign_bf16_rw<true, 8, false, 3, 2> : k_assign_bf16_rw<false, 8, false, 3, 2>);
-            else if (gs) rwk = nt_eff ? k_assign_bf16_rw<true, 4, true, 2, 0> : k_assign_bf16_rw<false, 4, true, 2, 0>;
-            else if (sched == 2) rwk = nt_eff ? k_assign_bf16_rw<true, 4, false, 2, 2> : k_assign_bf16_rw<false, 4, false, 2, 2>;
-            else rwk = nt_eff ? k_assign_bf16_rw<true, 4, false, 2, 0> : k_assign_bf16_rw<false, 4, false, 2, 0>;
-        }
-        const int fsmem = FD_DX * nw * 4096 + dcr * FD_SLOT;
-        const int64_t tile_rows = (int64_t)nw * 32, ntiles = (n + tile_rows - 1) / tile_rows;
-        const int64_t fgrid = gs ? (ntiles + 7) / 8 * 8 * ngroups : ntiles;
-        ACAV_REQUIRE(fgrid <= 0x7fffffff, ACAV_EINVAL, "n too large for one launch");
-        if (gs) ACAV_TRY(km->grec.ensure(sizeof(Top2Rec) * (size_t)ngroups * (size_t)n));
-        if (!km->ev_f0) {
-            ACAV_HIP_TRY(hipEventCreate(&km->ev_f0));
-            ACAV_HIP_TRY(hipEventCreate(&km->ev_f1));
-        }
-        if (rw) {
-            ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rwk), hipFuncAttributeMaxDynamicSharedMemorySize, fsmem));
-            ACAV_HIP_TRY(hipEventRecord(km->ev_f0, st));
-            hipLaunchKernelGGL(rwk, dim3((unsigned)fgrid), dim3(nw * 64), fsmem, st, static_cast<const float *>(dx), n, km->d,
-                               km->cb16.as<__bf16>(), km->cn.as<float>(), km->counts.as<float>(), km->K, km->threshold(),
-                               (float)km->reinit_r, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, km->recheck_list.as<int>(),
-                               km->recheck_count.as<unsigned>(), gs ? km->grec.as<Top2Rec>() : (Top2Rec *)nullptr);
-            if (gs)
-                hipLaunchKernelGGL(k_assign_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, km->grec.as<Top2Rec>(),
-                                   ngroups, n, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, km->recheck_list.as<int>(),
-                                   km->recheck_count.as<unsigned>());
-        } else {
-            auto kern = nt ? k_assign_bf16<true> : k_assign_bf16<false>;
-            ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FD_SMEM));
-            ACAV_HIP_TRY(hipEventRecord(km->ev_f0, st));
-            hipLaunchKernelGGL(kern, dim3((unsigned)((n + FB_ROWS - 1) / FB_ROWS)), dim3(256), FD_SMEM, st,
-                               static_cast<const float *>(dx), n, km->d, km->cb16.as<__bf16>(), km->cn.as<float>(),
-                               km->counts.as<float>(), km->K, km->threshold(), (float)km->reinit_r, km->caux.as<CentersAux>(), e1c,
-                               e1r, e2, dlab, km->recheck_list.as<int>(), km->recheck_count.as<unsigned>());
-        }
-        ACAV_HIP_TRY(hipGetLastError());
-        ACAV_HIP_TRY(hipEventRecord(km->ev_f1, st));
-#ifdef ACAV_FD_PROF
-        {
-            unsigned long long hp[20];
-            hipStreamSynchronize(st);
-            hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_fd_prof), sizeof(hp));
-            for (int o = 0; o < 16; o += 8)
-                fprintf(stderr, "fd_prof wave%d: stages %llu  vmwait %.0f  barrier %.0f  issue %.0f  compute %.0f cycles/stage\n",
-                        o ? 3 : 0, hp[o + 4], (double)hp[o] / hp[o + 4], (double)hp[o + 1] / hp[o + 4],
-                        (double)hp[o + 2] / hp[o + 4], (double)hp[o + 3] / hp[o + 4]),
-                fprintf(stderr, "   prologue %.0f loop %.0f cycles per WG\n", (double)hp[16 + o / 8 * 2] / hp[o + 7], (double)hp[17 + o / 8 * 2] / hp[o + 7]),
-                fprintf(stderr, "   per WG: %.0f cycles, %.2f us (100 MHz wall clock) -> %.2f GHz\n", (double)hp[o + 5] / hp[o + 7],
-                        (double)hp[o + 6] / hp[o + 7] / 100.0, (double)hp[o + 5] / hp[o + 6] * 0.1);
-            memset(hp, 0, sizeof(hp));
-            hipMemcpyToSymbol(HIP_SYMBOL(g_fd_prof), hp, sizeof(hp));
-        }
-#endif
-        // exact pass over the listed rows (no host round trip): a fixed grid of 2 workgroups per CU strides over
-        // however many row tiles the list turns out to hold
-        if (km->num_cus == 0) {
-            hipDeviceProp_t prop;
-            ACAV_HIP_TRY(hipGetDeviceProperties(&prop, km->ctx.device));
-            km->num_cus = prop.multiProcessorCount;
-        }
-        const int64_t rgrid = grid < 2 * (int64_t)km->num_cus ? grid : 2 * (int64_t)km->num_cus;
-        hipLaunchKernelGGL(k_assign_f32<false>, dim3((unsigned)rgrid), dim3(256), 0, st, static_cast<const float *>(dx), n,
-                           km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
-                           km->threshold(), (float)km->reinit_r, dlab, (float *)nullptr, km->wg_sum.as<double>(),
-                           km->recheck_list.as<int>(), km->recheck_count.as<unsigned>());
-        km->n_filter_launches += 1;
-        km->last_rows = (uint64_t)n;
-    } else if (fast)
-        hipLaunchKernelGGL(k_assign_f32<false>, dim3((unsigned)grid), dim3(256), 0, st, static_cast<const float *>(dx), n,
-                           km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
-                           km->threshold(), (float)km->reinit_r, dlab, (float *)nullptr, km->wg_sum.as<double>(),
-                           (const int *)nullptr, (const unsigned *)nullptr);
-    else
-        hipLaunchKernelGGL(k_assign_f32<true>, dim3((unsigned)grid), dim3(256), 0, st, static_cast<const float *>(dx), n,
-                           km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
-                           km->threshold(), (float)km->reinit_r, dlab, (float *)nullptr, km->wg_sum.as<double>(),
-                           (const int *)nullptr, (const unsigned *)nullptr);
-    ACAV_HIP_TRY(hipGetLastError());
-    km->n_assign_launches += 1;
-    if (!lab_dev) ACAV_HIP_TRY(hipMemcpyAsync(labels, dlab, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, st));
-    if (mean_dist) {
-        std::vector<double> part((size_t)grid);
-        ACAV_HIP_TRY(hipMemcpyAsync(part.data(), km->wg_sum.p, sizeof(double) * (size_t)grid, hipMemcpyDeviceToHost, st));
-        ACAV_HIP_TRY(hipStreamSynchronize(st));
-        double s = 0.0;
-        for (double v : part) s += v;
-        *mean_dist = (float)(s / (double)n);
-    } else if (!lab_dev || dx != x) {
-        ACAV_HIP_TRY(hipStreamSynchronize(st));
-    }
-    return ACAV_OK;
-}
 
 // one add() on device-resident x [b,d]; forced (device) optional; xn_dev: ||x||^2 of the b rows
 // when the caller already has them (bulk training), else computed here.

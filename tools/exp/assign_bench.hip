@@ -1,7 +1,7 @@
 // Experiment harness (not product): the assign filter k_assign_bf16_rw<NT, NW, GS> of acav_kmeans.hip launched alone on
 // synthetic rows, for timing-only ablations (-DACAV_ABL_NOMFMA / NOAFRAG / NOCDMA / NOXDMA) and tile-shape comparisons.
 // Labels are garbage under an ablation.  Build: tools/exp/build_assign.sh <name> [-D...]; run: ./<name> rows d K
-#include "../../acav100m_amd/csrc/acav_kmeans.hip"
+#include "../../acav100m_amd/csrc/acav_kmeans_assign.hip"
 #include <algorithm>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
