@@ -59,6 +59,7 @@ SIGNATURES = {
     "acav_kmeans_stats": [vp, C.POINTER(i64), C.POINTER(i64)],
     "acav_kmeans_train_stats": [vp, C.POINTER(i64), C.POINTER(i64)],
     "acav_kmeans_filter_stats": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
+    "acav_kmeans_recheck_stats": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
     "acav_kmeans_filter_time": [vp, C.POINTER(f32)],
     "acav_contrastive_create": [pp, i32, i32, i32, i32, vp, vp],
     "acav_contrastive_destroy": [vp],

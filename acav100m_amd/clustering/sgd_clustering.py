@@ -257,6 +257,13 @@ class KMeans:
         _lib.check(_lib._lib.acav_kmeans_filter_stats(self._require_handle(), C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def recheck_stats(self):
+        """(rows settled by their candidate centres, (row, centre) pairs evaluated for them, rows that took the full exact sweep)
+        of the last filter sweep"""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib._lib.acav_kmeans_recheck_stats(self._require_handle(), C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     @property
     def is_distributed(self):
         """sgd_clustering.py:81-86"""

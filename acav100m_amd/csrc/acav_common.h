@@ -13,6 +13,15 @@
 
 #define ACAV_EXPORT extern "C" __attribute__((visibility("default")))
 
+// The timing-only ablation switches of the experiment harnesses (tools/exp) compile kernels that produce WRONG results on
+// purpose (no MFMA, no DMA, sequential stand-ins for scattered stores).  They must never reach a product library through a
+// stray -D (ACAV_EXTRA_HIPCC_FLAGS in __graft_entry__.build()): a build that defines one of them has to say so.
+#if (defined(ACAV_ABL_NOAFRAG) || defined(ACAV_ABL_NOCDMA) || defined(ACAV_ABL_NOMFMA) || defined(ACAV_ABL_NOXDMA) || \
+     defined(ACAV_FY_ABL_BKSEQ) || defined(ACAV_FY_ABL_NOWALK) || defined(ACAV_FY_ABL_SRCSEQ)) &&                     \
+    !defined(ACAV_EXPERIMENT_BUILD)
+#error "ACAV_ABL_* / ACAV_FY_ABL_* select timing-only kernels with wrong results: experiment harnesses only (-DACAV_EXPERIMENT_BUILD)"
+#endif
+
 namespace acav {
 
 void set_error(const char *fmt, ...);

@@ -1736,7 +1736,7 @@ ACAV_EXPORT int acav_kmeans_set_state(acav_kmeans *km, const float *centers, con
     // the filter's centre copy depends on all three: centred or not is decided by whether any usage count is below the
     // threshold (count / K)^p -- a stale "centred" copy under a discount would drop a row constant that no longer cancels
     km->cb16_valid = false;
-    return ACAV_OK;
+    return km->prepare_filter();  // no-op while the state is still in its warm-up phase or the shape does not take the filter
 }
 
 
@@ -2088,7 +2088,8 @@ ACAV_EXPORT int acav_kmeans_train(acav_kmeans *km, const float *x, int64_t n, in
 {
     TrainCall tc;
     ACAV_TRY(train_launch(km, tc, x, n, b, lr, warm_best, n_warm, nullptr));
-    return train_finish(km, tc);
+    ACAV_TRY(train_finish(km, tc));
+    return km->prepare_filter();  // the sweep that follows an epoch finds the filter's centre copy ready (stream-ordered, ~25 us)
 }
 
 // The same call for SEVERAL clusterings at once (independent handles on one device, e.g. the audio and visual views of
@@ -2122,12 +2123,16 @@ ACAV_EXPORT int acav_kmeans_train_multi(acav_kmeans *const *kms, int count, cons
             }
         }
         const bool retry = last < count && calls[(size_t)last].active && !calls[(size_t)last].launched;
-        for (int i = first; i < last; ++i) ACAV_TRY(train_finish(kms[i], calls[(size_t)i]));
+        for (int i = first; i < last; ++i) {
+            ACAV_TRY(train_finish(kms[i], calls[(size_t)i]));
+            ACAV_TRY(kms[i]->prepare_filter());
+        }
         if (retry) {
             int whole = prop.multiProcessorCount;
             ACAV_TRY(train_launch(kms[last], calls[(size_t)last], xs[last], ns[last], b, lr,
                                   warm_best ? warm_best[last] : nullptr, n_warm[last], &whole));
             ACAV_TRY(train_finish(kms[last], calls[(size_t)last]));
+            ACAV_TRY(kms[last]->prepare_filter());
             ++last;
         }
         first = last;

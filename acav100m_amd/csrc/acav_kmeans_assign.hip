@@ -1,6 +1,9 @@
 // acav_kmeans_assign.hip -- the assign sweep of the SGD k-means (reference: clustering/code/sgd_clustering.py:63-79,
 // KMeans.calc_best over a row partition) on gfx950: the bf16-MFMA filter, the exact fp32 sweep / re-check, the
 // centre preparation, and their C-ABI entry points.  Training lives in acav_kmeans.hip.
+#include <algorithm>
+#include <cstddef>
+
 #include "acav_kmeans_shared.h"
 
 namespace {
@@ -25,6 +28,10 @@ __device__ __forceinline__ void stage_row4(float *srow, int q, float4 v)
 // centre indices (rows >= n and centres >= K compute on a duplicate and are discarded), so the
 // compiler keeps all 10 prefetch loads in flight under the MFMAs.  GUARD = true: element-guarded loads
 // for ragged d (hipcc serialises those behind vmcnt(0) -- correctness path only).
+struct AssignCtl;
+__device__ __forceinline__ void assign_ctl_finish(AssignCtl *ctl, unsigned nblocks);
+__device__ __forceinline__ AssignCtl *ctl_of_f32_count(const unsigned *f32_count);
+
 template <bool GUARD>
 __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__ x, int64_t n, int d,
                                                        const float *__restrict__ centers,
@@ -227,6 +234,10 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
     }
     __syncthreads();  // the next tile rewrites the epilogue scratch
   }
+  // re-check pass = the last kernel of a filter sweep: the last workgroup to finish hands the sweep's counters to the
+  // statistics copy and zeroes the control block for the next sweep (every workgroup has read the list length by then)
+  // (row_cnt of a re-check pass is always the f32_count member of the sweep's AssignCtl)
+  if (row_idx != nullptr && tid == 0) assign_ctl_finish(ctl_of_f32_count(row_cnt), gridDim.x);
 }
 
 // --------------------------------------------------------------------------- k_assign_bf16
@@ -332,6 +343,18 @@ __device__ __forceinline__ Top2 top2_merge(Top2 a, Top2 b)
     m.d2 = fminf(b_wins ? b.d2 : a.d2, b_wins ? a.d1 : b.d1);
     return m;
 }
+
+// One step of the compare-free top-2 scan: (s1, s2) <- the two smallest of {s1, s2, v}, s1 <= s2 on entry and exit.
+// new s2 = median(s1, s2, v), new s1 = min(s1, v): v_med3_f32 + v_min_f32.  Written as asm because fminf / fmaxf on a
+// value that comes out of integer ops (the position tag) make the compiler put a NaN-canonicalising `v_max x, x, x` in
+// front of every use -- the round-3 scan spent 5.5 VALU per distance where 3.5 suffice.  A NaN distance: v_min keeps s1,
+// v_med3 returns min3 = s1 -> s2 collapses onto s1 and the row goes to the exact re-check, as before.
+__device__ __forceinline__ void top2_push(float &s1, float &s2, float v)
+{
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(s2) : "v"(s1), "v"(s2), "v"(v));
+    asm("v_min_f32 %0, %1, %2" : "=v"(s1) : "v"(s1), "v"(v));
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // The filter kernel.  Built so the HBM stream never drains: the raw fp32 rows and the bf16 centres both arrive by
 // LDS-DMA (global_load_lds_dwordx4) into rings -- no staging VGPRs -- and the fp32 -> bf16 rounding happens when a
@@ -733,6 +756,56 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict_
 //        stage time is no longer set by HBM but by how long a DMA piece takes to land under load (~1 us, L2 hit or not)
 //        over the stages of look-ahead: 3 gives the centre stream two stages like the rows (order per stage: centres
 //        c+2 THEN rows c+2, counted wait leaves one stage of both in flight).
+// ---- candidate-restricted exact re-check (round 4) ------------------------------------------------------------------
+// A row the filter cannot decide does NOT need all K exact distances.  With E_i the row's error bound and c the tag slack
+// (both as in the acceptance test), any centre k whose filter value v_k satisfies  v_k - d1 > 2 E_i + c (|d1| + |v_k|)  is
+// strictly beaten by k1 in canonical fp32 arithmetic (the acceptance argument applied to the pair (k1, k)), so the canonical
+// argmin -- and every centre that ties with it -- lies in  CAND_i = { k : that inequality FAILS }  (k1 is a member).  The
+// filter's epilogue emits CAND_i for every undecided row (its 128 distances per lane are still in the accumulators) and
+// k_assign_cand evaluates the canonical chain for those (row, centre) pairs only; lexmin over exact distances of a superset
+// of the minimisers is the exact first-index argmin.  Rows with more than CAND_MAX candidates, or that do not fit the pair
+// pool, go to the full exact sweep (k_assign_f32) as before -- never a wrong label, only a slower row.
+// The emission test uses T_i >= every v that could fail the inequality (derivation at the use): a superset is always safe.
+struct AssignCtl {                  // device-side control block of one assign sweep; all zero between sweeps
+    unsigned long long alloc;       // low 32 bits: candidate row slots handed out, high 32 bits: candidate pairs handed out
+    unsigned f32_count;             // rows on the full exact re-check list
+    unsigned ticket;                // workgroups of the sweep's last kernel that have finished (the last one resets the block)
+    unsigned pool_over;             // rows that hold a slot but whose pairs did not fit the pool (they are on the f32 list too)
+    unsigned pad0;
+    unsigned long long last_alloc;  // copies for acav_kmeans_filter_stats, written by the sweep's last kernel
+    unsigned last_f32, last_pool_over;
+};
+struct CandRow {        // one undecided row: its pairs are cpair[pair_base .. pair_base + cnt)
+    int row;
+    unsigned pair_base;
+    unsigned cnt;
+    float xn;           // canonical ||x||^2 of the row (the filter has it)
+};
+struct CandPair {
+    unsigned slot;      // index into the CandRow array (slots and pair ranges are handed out by ONE 64-bit atomic, so both
+    int k;              // are ordered alike: consecutive slots own consecutive pair ranges)
+};
+constexpr unsigned CAND_MAX = 16;  // candidates per row beyond which the row takes the full exact sweep
+__device__ __forceinline__ AssignCtl *ctl_of_f32_count(const unsigned *f32_count)
+{
+    return reinterpret_cast<AssignCtl *>(reinterpret_cast<char *>(const_cast<unsigned *>(f32_count)) - offsetof(AssignCtl, f32_count));
+}
+__device__ __forceinline__ void assign_ctl_finish(AssignCtl *ctl, unsigned nblocks)
+{
+    // no fence: every workgroup read the list length long before its ticket, nobody reads the block after the reset inside
+    // this kernel, and the kernel boundary publishes the stores (__threadfence() = buffer_wbl2 + buffer_inv: an L2 write-back
+    // and an L1 invalidate under the other workgroups of the CU)
+    if (atomicAdd(&ctl->ticket, 1u) == nblocks - 1u) {
+        ctl->last_alloc = atomicAdd(&ctl->alloc, 0ull);  // read at the coherence point
+        ctl->last_f32 = atomicAdd(&ctl->f32_count, 0u);
+        ctl->last_pool_over = atomicAdd(&ctl->pool_over, 0u);
+        ctl->alloc = 0ull;
+        ctl->f32_count = 0u;
+        ctl->pool_over = 0u;
+        ctl->ticket = 0u;
+    }
+}
+
 struct Top2Rec {
     float d1;
     int k1;
@@ -745,7 +818,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
                                                             const float *__restrict__ counts, int K, float thr, float r,
                                                             const CentersAux *__restrict__ aux, float e1c, float e1r, float e2coef,
                                                             int64_t *__restrict__ labels, int *__restrict__ recheck_list,
-                                                            unsigned *__restrict__ recheck_count, Top2Rec *__restrict__ grec)
+                                                            unsigned *__restrict__ recheck_count, Top2Rec *__restrict__ grec,
+                                                            unsigned long long *__restrict__ cand_alloc, CandRow *__restrict__ crow,
+                                                            CandPair *__restrict__ cpair, unsigned pair_cap,
+                                                            unsigned *__restrict__ pool_over)
 {
     constexpr int XSLOT = NW * 4096;  // bytes per row-ring slot: NW x 32 rows x 32 fp32
     constexpr int CQ = 16 / NW;       // centre-stage DMA pieces (1 KB = 16 centres x 64 B) per wave
@@ -997,11 +1073,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
                     const float4 cnv = *reinterpret_cast<const float4 *>(sCn + ct * 32 + 4 * h + 8 * g);
                     const float cn4[4] = {cnv.x, cnv.y, cnv.z, cnv.w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = __builtin_fmaf(-2.0f, acc[ct][4 * g + j], cn4[j]);
-                        v = __uint_as_float((__float_as_uint(v) & 0xFFFFFF80u) | (unsigned)(ct * 16 + g * 4 + j));
-                        s2 = fminf(s2, fmaxf(s1, v));
-                        s1 = fminf(s1, v);
+                    for (int j = 0; j < 4; j += 2) {  // two distances per v_pk_fma_f32 (each half is one IEEE fma)
+                        const f32x2 a2 = {acc[ct][4 * g + j], acc[ct][4 * g + j + 1]}, c2 = {cn4[j], cn4[j + 1]}, m2 = {-2.0f, -2.0f};
+                        const f32x2 v2 = __builtin_elementwise_fma(m2, a2, c2);
+                        top2_push(s1, s2, __uint_as_float((__float_as_uint(v2.x) & 0xFFFFFF80u) | (unsigned)(ct * 16 + g * 4 + j)));
+                        top2_push(s1, s2, __uint_as_float((__float_as_uint(v2.y) & 0xFFFFFF80u) | (unsigned)(ct * 16 + g * 4 + j + 1)));
                     }
                 }
             }
@@ -1017,13 +1093,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
                     const float cn4[4] = {cnv.x, cnv.y, cnv.z, cnv.w};
                     const float sc4[4] = {scv.x, scv.y, scv.z, scv.w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = __builtin_fmaf(-2.0f, acc[ct][4 * g + j], xoff);  // == (-2 dot) + xn
-                        v = v + cn4[j];
-                        v = v * sc4[j];  // * (1/r) where the exact path divides by r
-                        v = __uint_as_float((__float_as_uint(v) & 0xFFFFFF80u) | (unsigned)(ct * 16 + g * 4 + j));
-                        s2 = fminf(s2, fmaxf(s1, v));
-                        s1 = fminf(s1, v);
+                    for (int j = 0; j < 4; j += 2) {  // packed: each half is the same three IEEE operations as the scalar form
+                        const f32x2 a2 = {acc[ct][4 * g + j], acc[ct][4 * g + j + 1]}, m2 = {-2.0f, -2.0f}, x2 = {xoff, xoff};
+                        const f32x2 c2 = {cn4[j], cn4[j + 1]}, sc2 = {sc4[j], sc4[j + 1]};
+                        f32x2 v2 = __builtin_elementwise_fma(m2, a2, x2);  // == (-2 dot) + xn
+                        v2 = v2 + c2;
+                        v2 = v2 * sc2;  // * (1/r) where the exact path divides by r
+                        top2_push(s1, s2, __uint_as_float((__float_as_uint(v2.x) & 0xFFFFFF80u) | (unsigned)(ct * 16 + g * 4 + j)));
+                        top2_push(s1, s2, __uint_as_float((__float_as_uint(v2.y) & 0xFFFFFF80u) | (unsigned)(ct * 16 + g * 4 + j + 1)));
                     }
                 }
             }
@@ -1034,6 +1111,121 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
         o.k1 = __shfl_xor(t.k1, 32);
         o.d2 = __shfl_xor(t.d2, 32);
         run = top2_merge(run, top2_merge(t, o));
+
+        if (!GS && crow != nullptr && ngroups == 1) {
+            // ---- acceptance test in BOTH half-lanes of a row, and for undecided rows the candidate emission (header above)
+            const int64_t row = row0 + wq * 32 + l31;
+            const float xnorm = __builtin_sqrtf(xn);
+            const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
+            const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
+            const float sn = xnorm + cmax;
+            const float E = (e1c * cmaxc + e1r * cmax) * xnorm + e2coef * sn * sn;
+            const float tagged = 1.6e-5f * (fabsf(run.d1) + fabsf(run.d2));  // > (2^-16 + 2^-22) x 1.01
+            const bool undecided = row < n && !((run.d2 - run.d1) > 2.0f * E + tagged);  // also catches NaN / inf
+            if (h == 0 && row < n) labels[row] = (int64_t)run.k1;
+            if (__builtin_amdgcn_ballot_w64(undecided) != 0ull) {
+                // T: every v > T satisfies v - d1 > W + c |v|, W = 2 E + c |d1|, c = 1.6e-5 (untagged v: its own tag is not
+                // charged, the slack stays).  With u = d1 + W:  v >= 0: v (1 - c) > u  <=  v > u / (1 - c) < u (1 + 2 c);
+                // v < 0 (then u < 0): v (1 + c) > u  <=  v > u (1 - 2 c).  Both are u + 2 c |u|; the last term covers the
+                // roundings of this evaluation itself (a few 2^-24 of |d1| + W) sixfold.  NaN / inf bounds -> T = +inf via the
+                // comparison form below (everything is a candidate -> overflow -> full exact sweep).
+                const float W = 2.0f * E + 1.6e-5f * fabsf(run.d1);
+                const float u = run.d1 + W;
+                float T = u + 3.2e-5f * fabsf(u) + 1.6e-6f * (fabsf(run.d1) + W);
+                if (!undecided) T = -INFINITY;
+                // bit (ct * 16 + g * 4 + j) of m: distance (ct, g, j) of this lane is not > T.  Branch-free: compare, 0 / 1, shift-or.
+                unsigned m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
+#define ACAV_CAND_MARK(v, idx)                                                   \
+    {                                                                            \
+        const unsigned hit_ = (v) > T ? 0u : 1u;                                 \
+        if ((idx) < 32) m0 |= hit_ << ((idx) & 31);                              \
+        else if ((idx) < 64) m1 |= hit_ << ((idx) & 31);                         \
+        else if ((idx) < 96) m2 |= hit_ << ((idx) & 31);                         \
+        else m3 |= hit_ << ((idx) & 31);                                         \
+    }
+                if (centred) {
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 cnv = *reinterpret_cast<const float4 *>(sCn + ct * 32 + 4 * h + 8 * g);
+                            const float cn4[4] = {cnv.x, cnv.y, cnv.z, cnv.w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float v = __builtin_fmaf(-2.0f, acc[ct][4 * g + j], cn4[j]);
+                                ACAV_CAND_MARK(v, ct * 16 + g * 4 + j)
+                            }
+                        }
+                    }
+                } else {
+                    const float xoff = xn;
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int kl = ct * 32 + 4 * h + 8 * g;
+                            const float4 cnv = *reinterpret_cast<const float4 *>(sCn + kl);
+                            const float4 scv = *reinterpret_cast<const float4 *>(sSc + kl);
+                            const float cn4[4] = {cnv.x, cnv.y, cnv.z, cnv.w};
+                            const float sc4[4] = {scv.x, scv.y, scv.z, scv.w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float v = __builtin_fmaf(-2.0f, acc[ct][4 * g + j], xoff);
+                                v = v + cn4[j];
+                                v = v * sc4[j];
+                                ACAV_CAND_MARK(v, ct * 16 + g * 4 + j)
+                            }
+                        }
+                    }
+                }
+#undef ACAV_CAND_MARK
+                const unsigned m[4] = {m0, m1, m2, m3};
+                const unsigned mine = __builtin_popcount(m[0]) + __builtin_popcount(m[1]) + __builtin_popcount(m[2]) + __builtin_popcount(m[3]);
+                const unsigned other = __shfl_xor(mine, 32);
+                const unsigned total = mine + other;
+                unsigned long long got = 0ull;
+                bool full = false;  // the row takes the full exact sweep instead
+                if (undecided && h == 0) {
+                    if (total > CAND_MAX) full = true;
+                    else {
+                        got = atomicAdd(cand_alloc, ((unsigned long long)total << 32) | 1ull);
+                        if ((got >> 32) + total > (unsigned long long)pair_cap) {  // pool exhausted (the slot stays, empty)
+                            full = true;
+                            atomicAdd(pool_over, 1u);
+                        }
+                    }
+                    if (full) {
+                        const unsigned fslot = atomicAdd(recheck_count, 1u);
+                        recheck_list[fslot] = (int)row;
+                    }
+                    if (total <= CAND_MAX) {
+                        // (a row whose range runs past the pool's end -- pair_base + cnt > pair_cap -- is "lost": on the f32 list)
+                        const CandRow cr = {(int)row, (unsigned)(got >> 32), total, xn};
+                        crow[(unsigned)got] = cr;
+                    }
+                }
+                const unsigned slot_lo = __shfl(( unsigned)got, l31), base_lo = __shfl((unsigned)(got >> 32), l31);
+                const bool full_row = __shfl((int)full, l31) != 0;
+                // (a row that lost its range to the pool's end still writes the pairs that fit: every entry below the cap is a
+                // valid (slot, centre) -- k_assign_cand walks the pool as one array; that row's label comes from the full sweep)
+                (void)full_row;
+                if (undecided && total <= CAND_MAX) {
+                    unsigned wpos = base_lo + (h ? other : 0u);  // the h = 0 lane's candidates first
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        unsigned bits = w == 0 ? m0 : w == 1 ? m1 : w == 2 ? m2 : m3;
+                        while (bits) {
+                            const int bpos = __builtin_ctz(bits);
+                            bits &= bits - 1;
+                            const unsigned idx = (unsigned)(w * 32 + bpos);  // (ct, g, j) -> centre, as for the minimum
+                            const CandPair cp = {slot_lo, kbase + 4 * h + (int)((idx >> 4) * 32 + ((idx >> 2) & 3) * 8 + (idx & 3))};
+                            if (wpos < pair_cap) cpair[wpos] = cp;
+                            ++wpos;
+                        }
+                    }
+                }
+            }
+        }
     }
 #ifdef ACAV_RW_PROF
     if (lane == 0 && (blockIdx.x & 15) == 3 && (wq == 0 || wq == NW - 1)) {
@@ -1051,6 +1243,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
         }
         return;
     }
+    if (crow != nullptr && ngroups == 1) return;  // decided / emitted inside the group loop (the accumulators live there)
     if (h == 0 && row < n) {
         const float xnorm = __builtin_sqrtf(xn);
         const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
@@ -1099,6 +1292,171 @@ __global__ __launch_bounds__(256) void k_assign_merge(const Top2Rec *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------- k_assign_cand
+// Exact canonical distances of the (undecided row, candidate centre) pairs the filter emitted; the row's label = their
+// first-index lexmin.  Waves are independent.  Work item = S consecutive row slots = one contiguous pair range (slots and
+// pair ranges come from one atomic: CandPair); S adapts to the load (few rows: small items over many waves; many rows: 128
+// slots per item), item i goes to wave i mod W.  A wave walks its item in passes of up to 64 consecutive pairs that END AT A
+// ROW BOUNDARY and span at most 32 rows: every row is settled inside one pass -- no atomics, no fences.
+// (A first version cut the pool into fixed 64-pair ranges and folded the rows cut by a range boundary through global
+// atomics + __threadfence(): the fence is buffer_wbl2 + buffer_inv -- an L2 write-back and an L1 invalidate per cut row, 33 k
+// of them per launch at 62 % undecided rows: 2.4 ms instead of 1.05, TA busy 100 cycles per load instead of 22.)
+//   * lane = pair: the canonical dot is a sequential fp32 FMA chain per 256-column segment, folded left to right, so a
+//     pair's d columns are one dependent chain in one lane -- 32 FMAs per 32-column stage, 64 pairs side by side.
+//   * per stage the wave brings its 64 centre chunks and its <= 32 row chunks (128 bytes each) in as coalesced 16-byte pieces
+//     (8 lanes per chunk: every fetched line is used whole), one stage ahead in registers, and transposes them through its
+//     own 12 KB of LDS -- 16-byte slots XOR-swizzled by ((chunk >> 1) & 7): lane = chunk reads are conflict-free.  No
+//     workgroup barrier: LDS operations of one wave execute in order.
+//     (Per-lane streaming of the lane's own two lines, no LDS, measured 2.6x slower: 12 waves x 82 lines thrash the 32 KB L1
+//     between the eight 16-byte reads of a line.)
+//   * epilogue = dist_epilogue() of the exact sweep; segmented lexmin over the adjacent lanes of a row (<= CAND_MAX = 16).
+constexpr int CAND_XROWS = 32;    // distinct rows per pass
+
+__device__ __forceinline__ unsigned long long cand_key(float v, int k)
+{
+    unsigned u = __float_as_uint(v);
+    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;  // total order of the floats as unsigned
+    return ((unsigned long long)u << 32) | (unsigned)k;
+}
+
+__global__ __launch_bounds__(256, 3) void k_assign_cand(const float *__restrict__ x, int d, const float *__restrict__ centers,
+                                                         const float *__restrict__ cn, const float *__restrict__ counts, float thr,
+                                                         float r, const AssignCtl *__restrict__ ctl, const CandRow *__restrict__ crow,
+                                                         const CandPair *__restrict__ cpair, unsigned pair_cap,
+                                                         int64_t *__restrict__ labels)
+{
+    __shared__ __attribute__((aligned(16))) float sC[4][64 * 32];          // [wave][pair chunk of 32 columns], swizzled
+    __shared__ __attribute__((aligned(16))) float sX[4][CAND_XROWS * 32];  // [wave][row chunk]
+    const unsigned long long alloc = ctl->alloc;
+    const unsigned nslots = (unsigned)alloc;
+    unsigned npairs = (unsigned)(alloc >> 32);
+    if (npairs > pair_cap) npairs = pair_cap;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned gw = blockIdx.x * 4u + (unsigned)wave, nw = gridDim.x * 4u;
+    unsigned S = (nslots + nw - 1u) / nw;  // slots per item: about one item per wave, within [8, 128]
+    S = S < 8u ? 8u : (S > 128u ? 128u : S);
+    const unsigned nitems = (nslots + S - 1u) / S;
+    const int nchunks = d / 32;
+    float *wc = sC[wave], *wx = sX[wave];
+    int *wrow = reinterpret_cast<int *>(wx);
+    const int sub = lane >> 3, piece = lane & 7;  // staging role: 16-byte piece `piece` of chunk 8 q + sub
+
+    for (unsigned item = gw; item < nitems; item += nw) {
+        const unsigned s0 = item * S, s1 = s0 + S < nslots ? s0 + S : nslots;
+        unsigned p0 = crow[s0].pair_base;
+        unsigned pe = s1 < nslots ? crow[s1].pair_base : npairs;
+        if (pe > npairs) pe = npairs;  // the pool's end: pairs past it were never written (their rows are "lost": f32 list)
+        while (p0 < pe) {  // wave-uniform
+            const unsigned p = p0 + (unsigned)lane;
+            const CandPair cp = cpair[p < pe ? p : pe - 1u];  // lanes past the item shadow its last pair
+            const CandRow cr = crow[cp.slot];
+            const unsigned xs = cp.slot - (unsigned)__shfl((int)cp.slot, 0);  // row chunk of this lane's row; ascends with the lane
+            const unsigned wend = p0 + 64u < pe ? p0 + 64u : pe;
+            const unsigned row_end = cr.pair_base + cr.cnt;                   // one past the row's last pair
+            const bool lost = row_end > pair_cap;                              // only the pool's last rows
+            // taken = a prefix of the lanes: rows that end inside the window (the first row always does: <= 16 pairs), at most 32
+            const bool taken = p < pe && xs < (unsigned)CAND_XROWS && (row_end <= wend || lost);
+            const unsigned ntaken = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(taken));
+            const bool live = taken && !lost;
+            const unsigned xsc = xs < (unsigned)CAND_XROWS ? xs : (unsigned)CAND_XROWS - 1u;
+            const unsigned nrows_w = (unsigned)__shfl((int)xsc, 63) + 1u;
+            // the row of every row chunk travels through LDS (lanes of one row write the same value)
+            __builtin_amdgcn_wave_barrier();
+            if (xs < (unsigned)CAND_XROWS) wrow[xs] = cr.row;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // staging sources: centre chunk 8 q + sub = the centre of pair lane 8 q + sub; row chunk 8 q + sub (q < 4)
+            const float *cb0, *cb1, *cb2, *cb3, *cb4, *cb5, *cb6, *cb7, *xb0, *xb1, *xb2, *xb3;
+#define ACAV_CAND_CB(q) cb##q = centers + (size_t)__shfl(cp.k, 8 * q + sub) * d + piece * 4;
+#define ACAV_CAND_XB(q)                                                                      \
+    {                                                                                        \
+        const unsigned want = (unsigned)(8 * q + sub);                                       \
+        xb##q = x + (size_t)wrow[want < nrows_w ? want : 0u] * d + piece * 4;                \
+    }
+            ACAV_CAND_CB(0) ACAV_CAND_CB(1) ACAV_CAND_CB(2) ACAV_CAND_CB(3) ACAV_CAND_CB(4) ACAV_CAND_CB(5) ACAV_CAND_CB(6) ACAV_CAND_CB(7)
+            ACAV_CAND_XB(0) ACAV_CAND_XB(1) ACAV_CAND_XB(2) ACAV_CAND_XB(3)
+#undef ACAV_CAND_CB
+#undef ACAV_CAND_XB
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // wrow is dead: the first stage overwrites it
+            const bool x1 = nrows_w > 8u, x2 = nrows_w > 16u, x3 = nrows_w > 24u;  // wave-uniform: row-chunk instructions needed
+
+            f32x4 rc0, rc1, rc2, rc3, rc4, rc5, rc6, rc7, rx0, rx1, rx2, rx3;
+            rx1 = rx2 = rx3 = f32x4{0.f, 0.f, 0.f, 0.f};
+#define ACAV_CAND_LD4(p) (*reinterpret_cast<const f32x4 *>(p))
+#define ACAV_CAND_LOAD(c)                          \
+    rc0 = ACAV_CAND_LD4(cb0 + (c) * 32);           \
+    rc1 = ACAV_CAND_LD4(cb1 + (c) * 32);           \
+    rc2 = ACAV_CAND_LD4(cb2 + (c) * 32);           \
+    rc3 = ACAV_CAND_LD4(cb3 + (c) * 32);           \
+    rc4 = ACAV_CAND_LD4(cb4 + (c) * 32);           \
+    rc5 = ACAV_CAND_LD4(cb5 + (c) * 32);           \
+    rc6 = ACAV_CAND_LD4(cb6 + (c) * 32);           \
+    rc7 = ACAV_CAND_LD4(cb7 + (c) * 32);           \
+    rx0 = ACAV_CAND_LD4(xb0 + (c) * 32);           \
+    if (x1) rx1 = ACAV_CAND_LD4(xb1 + (c) * 32);   \
+    if (x2) rx2 = ACAV_CAND_LD4(xb2 + (c) * 32);   \
+    if (x3) rx3 = ACAV_CAND_LD4(xb3 + (c) * 32);
+#define ACAV_CAND_SLOT(q) ((8 * q + sub) * 32 + ((piece ^ (((8 * q + sub) >> 1) & 7)) << 2))
+            ACAV_CAND_LOAD(0)
+            float acc = 0.f, tot = 0.f;
+            const int swl = (lane >> 1) & 7, swx = ((int)xsc >> 1) & 7;
+            const float *pc = wc + lane * 32, *px = wx + xsc * 32;
+            for (int c = 0; c < nchunks; ++c) {
+                __builtin_amdgcn_wave_barrier();  // the wave's reads of the previous stage are behind (LDS ops of a wave are in order)
+                *reinterpret_cast<f32x4 *>(wc + ACAV_CAND_SLOT(0)) = rc0;
+                *reinterpret_cast<f32x4 *>(wc + ACAV_CAND_SLOT(1)) = rc1;
+                *reinterpret_cast<f32x4 *>(wc + ACAV_CAND_SLOT(2)) = rc2;
+                *reinterpret_cast<f32x4 *>(wc + ACAV_CAND_SLOT(3)) = rc3;
+                *reinterpret_cast<f32x4 *>(wc + ACAV_CAND_SLOT(4)) = rc4;
+                *reinterpret_cast<f32x4 *>(wc + ACAV_CAND_SLOT(5)) = rc5;
+                *reinterpret_cast<f32x4 *>(wc + ACAV_CAND_SLOT(6)) = rc6;
+                *reinterpret_cast<f32x4 *>(wc + ACAV_CAND_SLOT(7)) = rc7;
+                *reinterpret_cast<f32x4 *>(wx + ACAV_CAND_SLOT(0)) = rx0;
+                if (x1) *reinterpret_cast<f32x4 *>(wx + ACAV_CAND_SLOT(1)) = rx1;
+                if (x2) *reinterpret_cast<f32x4 *>(wx + ACAV_CAND_SLOT(2)) = rx2;
+                if (x3) *reinterpret_cast<f32x4 *>(wx + ACAV_CAND_SLOT(3)) = rx3;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int cn_ = c + 1 < nchunks ? c + 1 : c;  // the last stage re-loads itself (discarded): no branch around the loads
+                ACAV_CAND_LOAD(cn_)                           // in flight under the chains below
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 a = *reinterpret_cast<const float4 *>(pc + ((j ^ swl) << 2));
+                    const float4 b = *reinterpret_cast<const float4 *>(px + ((j ^ swx) << 2));
+                    acc = __builtin_fmaf(a.x, b.x, acc);
+                    acc = __builtin_fmaf(a.y, b.y, acc);
+                    acc = __builtin_fmaf(a.z, b.z, acc);
+                    acc = __builtin_fmaf(a.w, b.w, acc);
+                }
+                if ((c & 7) == 7 || c + 1 == nchunks) {  // end of a 256-column segment: tot = (first) ? acc : tot + acc
+                    tot = c < 8 ? acc : tot + acc;
+                    acc = 0.f;
+                }
+            }
+#undef ACAV_CAND_LOAD
+#undef ACAV_CAND_LD4
+#undef ACAV_CAND_SLOT
+            const bool disc = counts[cp.k] < thr;
+            const float dist = dist_epilogue(tot, cr.xn, cn[cp.k], disc, r);
+            unsigned long long key = cand_key(dist, cp.k);
+            // segmented lexmin over the run of lanes with this lane's slot (inclusive scan towards higher lanes)
+            const unsigned slot = live ? cp.slot : 0xFFFFFFFFu - (unsigned)lane;  // other lanes: unique slots, no merging
+#pragma unroll
+            for (int off = 1; off < (int)CAND_MAX; off <<= 1) {
+                const unsigned long long ko = __shfl_up(key, off);
+                const unsigned so = __shfl_up(slot, off);
+                if (lane >= off && so == slot) key = ko < key ? ko : key;
+            }
+            const unsigned snext = __shfl_down(slot, 1);
+            if (live && (lane == 63 || snext != slot))  // last lane of the row's run: the row sat in this pass whole
+                labels[cr.row] = (int64_t)(unsigned)(key & 0xFFFFFFFFull);
+            p0 += ntaken;
+        }
+    }
+}
+
 }  // namespace
 
 // The filter's copy of the centres: bf16 of c (or of c - mu when no centre is under-used), the mean centre, and the
@@ -1123,18 +1481,37 @@ int acav_kmeans::prepare_filter()
     return ACAV_OK;
 }
 
+static int read_ctl(acav_kmeans *km, AssignCtl *out)
+{
+    memset(out, 0, sizeof(*out));
+    if (km->cand_ctl.p && km->n_filter_launches) {
+        ACAV_HIP_TRY(hipSetDevice(km->ctx.device));
+        ACAV_HIP_TRY(hipMemcpyAsync(out, km->cand_ctl.p, sizeof(*out), hipMemcpyDeviceToHost, km->ctx.stream));
+        ACAV_HIP_TRY(hipStreamSynchronize(km->ctx.stream));
+    }
+    return ACAV_OK;
+}
+
 ACAV_EXPORT int acav_kmeans_filter_stats(acav_kmeans *km, int64_t *filter_launches, int64_t *rows, int64_t *rechecked)
 {
     ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");
-    unsigned cnt = 0;
-    if (km->recheck_count.p && km->n_filter_launches) {
-        ACAV_HIP_TRY(hipSetDevice(km->ctx.device));
-        ACAV_HIP_TRY(hipMemcpyAsync(&cnt, km->recheck_count.p, sizeof(cnt), hipMemcpyDeviceToHost, km->ctx.stream));
-        ACAV_HIP_TRY(hipStreamSynchronize(km->ctx.stream));
-    }
+    AssignCtl c;
+    ACAV_TRY(read_ctl(km, &c));
     if (filter_launches) *filter_launches = km->n_filter_launches;
     if (rows) *rows = (int64_t)km->last_rows;
-    if (rechecked) *rechecked = (int64_t)cnt;
+    // rows the filter could not decide = candidate rows + rows sent straight to the full exact sweep
+    if (rechecked) *rechecked = (int64_t)(unsigned)c.last_alloc + (int64_t)c.last_f32 - (int64_t)c.last_pool_over;
+    return ACAV_OK;
+}
+
+ACAV_EXPORT int acav_kmeans_recheck_stats(acav_kmeans *km, int64_t *cand_rows, int64_t *cand_pairs, int64_t *full_rows)
+{
+    ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");
+    AssignCtl c;
+    ACAV_TRY(read_ctl(km, &c));
+    if (cand_rows) *cand_rows = (int64_t)(unsigned)c.last_alloc - (int64_t)c.last_pool_over;
+    if (cand_pairs) *cand_pairs = (int64_t)(c.last_alloc >> 32);
+    if (full_rows) *full_rows = (int64_t)c.last_f32;
     return ACAV_OK;
 }
 
@@ -1182,8 +1559,29 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
     if (filter) {
         ACAV_TRY(km->prepare_filter());
         ACAV_TRY(km->recheck_list.ensure(sizeof(int) * (size_t)n));
-        ACAV_TRY(km->recheck_count.ensure(sizeof(unsigned)));
-        ACAV_HIP_TRY(hipMemsetAsync(km->recheck_count.p, 0, sizeof(unsigned), st));
+        // control block of the sweep: zero when a sweep starts -- zeroed here once, and by the last kernel of every sweep
+        if (!km->cand_ctl.p) {
+            ACAV_TRY(km->cand_ctl.ensure(sizeof(AssignCtl)));
+            ACAV_HIP_TRY(hipMemsetAsync(km->cand_ctl.p, 0, sizeof(AssignCtl), st));
+        }
+        AssignCtl *ctl = km->cand_ctl.as<AssignCtl>();
+        unsigned *f32_count = &ctl->f32_count;
+        // candidate-restricted exact re-check (K <= 256: the filter's epilogue emits the candidates); ACAV_ASSIGN_CAND=0
+        // sends every undecided row to the full exact sweep as in round 3
+        const char *vcand = getenv("ACAV_ASSIGN_CAND");
+        const bool cand = km->K <= 256 && !(vcand && vcand[0] == '0');
+        const uint64_t pair_cap64 = std::min<uint64_t>(std::max<uint64_t>(4ull * (uint64_t)n, 65536ull), 0x7fffffffull);
+        unsigned pair_cap = (unsigned)pair_cap64;
+        if (const char *vcap = getenv("ACAV_CAND_PAIR_CAP")) {  // tests: force the pool-overflow path
+            const long v = atol(vcap);
+            if (v > 0 && (uint64_t)v < pair_cap64) pair_cap = (unsigned)v;
+        }
+        if (cand) {
+            ACAV_TRY(km->cand_rows.ensure(sizeof(CandRow) * (size_t)n));
+            ACAV_TRY(km->cand_pairs.ensure(sizeof(CandPair) * (size_t)pair_cap));
+        }
+        CandRow *crow = cand ? km->cand_rows.as<CandRow>() : (CandRow *)nullptr;
+        CandPair *cpair = cand ? km->cand_pairs.as<CandPair>() : (CandPair *)nullptr;
         const double acc = 1.01 * (double)km->d * ldexp(1.0, -24);  // accumulation error of one fp32 dot, relative
         const float e1c = (float)(2.02 * (ldexp(1.0, -8) * 1.002 + acc) * 1.001);   // x ||c'|| ||x||: bf16 roundings + filter dot
         const float e1r = (float)(2.02 * (acc + ldexp(1.0, -24)) * 1.001);           // x ||c|| ||x||: canonical dot, c - mu
@@ -1206,7 +1604,8 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         const int dcr = nw == 8 ? 3 : 2;  // centre ring depth (3 only fits the one-workgroup-per-CU tile)
         const int sched = nw == 8 ? 2 : (vsc ? (vsc[0] == '2' ? 2 : 0) : FILTER_SCHED_DEFAULT);
         typedef void (*FilterKern)(const float *, int64_t, int, const __bf16 *, const float *, const float *, int, float, float,
-                                   const CentersAux *, float, float, float, int64_t *, int *, unsigned *, Top2Rec *);
+                                   const CentersAux *, float, float, float, int64_t *, int *, unsigned *, Top2Rec *,
+                                   unsigned long long *, CandRow *, CandPair *, unsigned, unsigned *);
         FilterKern rwk = nullptr;
         if (rw) {
             if (nw == 8) rwk = gs ? (nt_eff ? k_assign_bf16_rw<true, 8, true, 3, 2> : k_assign_bf16_rw<false, 8, true, 3, 2>)
@@ -1230,11 +1629,12 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
             hipLaunchKernelGGL(rwk, dim3((unsigned)fgrid), dim3(nw * 64), fsmem, st, static_cast<const float *>(dx), n, km->d,
                                km->cb16.as<__bf16>(), km->cn.as<float>(), km->counts.as<float>(), km->K, km->threshold(),
                                (float)km->reinit_r, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, km->recheck_list.as<int>(),
-                               km->recheck_count.as<unsigned>(), gs ? km->grec.as<Top2Rec>() : (Top2Rec *)nullptr);
+                               f32_count, gs ? km->grec.as<Top2Rec>() : (Top2Rec *)nullptr, &ctl->alloc, crow, cpair, pair_cap,
+                               &ctl->pool_over);
             if (gs)
                 hipLaunchKernelGGL(k_assign_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, km->grec.as<Top2Rec>(),
                                    ngroups, n, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, km->recheck_list.as<int>(),
-                                   km->recheck_count.as<unsigned>());
+                                   f32_count);
         } else {
             auto kern = nt ? k_assign_bf16<true> : k_assign_bf16<false>;
             ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FD_SMEM));
@@ -1242,7 +1642,7 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
             hipLaunchKernelGGL(kern, dim3((unsigned)((n + FB_ROWS - 1) / FB_ROWS)), dim3(256), FD_SMEM, st,
                                static_cast<const float *>(dx), n, km->d, km->cb16.as<__bf16>(), km->cn.as<float>(),
                                km->counts.as<float>(), km->K, km->threshold(), (float)km->reinit_r, km->caux.as<CentersAux>(), e1c,
-                               e1r, e2, dlab, km->recheck_list.as<int>(), km->recheck_count.as<unsigned>());
+                               e1r, e2, dlab, km->recheck_list.as<int>(), f32_count);
         }
         ACAV_HIP_TRY(hipGetLastError());
         ACAV_HIP_TRY(hipEventRecord(km->ev_f1, st));
@@ -1270,10 +1670,17 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
             km->num_cus = prop.multiProcessorCount;
         }
         const int64_t rgrid = grid < 2 * (int64_t)km->num_cus ? grid : 2 * (int64_t)km->num_cus;
+        if (cand && rw && ngroups == 1)  // exact canonical chains of the emitted (row, candidate centre) pairs; labels of those rows
+            // (3 workgroups of 4 waves per CU: the kernel is bound by the L2 -> L1 path -- 1, 2, 3, 4, 6 per CU all measure the same)
+            hipLaunchKernelGGL(k_assign_cand, dim3((unsigned)(3 * km->num_cus)), dim3(256), 0, st, static_cast<const float *>(dx),
+                               km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->threshold(),
+                               (float)km->reinit_r, ctl, crow, cpair, pair_cap, dlab);
+        // full exact sweep of the rows on the f32 list (more than CAND_MAX candidates, pool overflow, K > 256); also the
+        // sweep's last kernel: its last workgroup resets the control block
         hipLaunchKernelGGL(k_assign_f32<false>, dim3((unsigned)rgrid), dim3(256), 0, st, static_cast<const float *>(dx), n,
                            km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
                            km->threshold(), (float)km->reinit_r, dlab, (float *)nullptr, km->wg_sum.as<double>(),
-                           km->recheck_list.as<int>(), km->recheck_count.as<unsigned>());
+                           km->recheck_list.as<int>(), f32_count);
         km->n_filter_launches += 1;
         km->last_rows = (uint64_t)n;
     } else if (fast)

@@ -224,6 +224,60 @@ def test_bf16_filter_path_is_bit_identical(env, case):
         assert rechecked < n // 20  # centred centres: the common component costs nothing
 
 
+@pytest.mark.parametrize("mode", ["plain", "pool_overflow", "cand_off", "discounted", "many_ties"])
+def test_candidate_restricted_recheck(env, mode, monkeypatch):
+    """Round 4: a row the bf16 filter cannot decide is settled by the exact canonical distances of its CANDIDATE centres only
+    (those the acceptance inequality cannot rule out against the filter's minimum; k_assign_cand), not by a sweep over all
+    K.  Heavily overlapping clusters (most rows undecided, a handful of candidates each): labels == the exact sweep on every
+    row and == the oracle; the statistics show the candidate path did the work.  `pool_overflow`: a pair pool of 1 000
+    entries -- the rows that do not fit take the full exact sweep, same labels.  `cand_off`: ACAV_ASSIGN_CAND=0 restores the
+    round-3 behaviour.  `discounted`: under-used centres (distance / r, raw filter).  `many_ties`: 40 identical centres --
+    more than 16 candidates per row -> full sweep, first index wins."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    if mode == "pool_overflow":
+        monkeypatch.setenv("ACAV_CAND_PAIR_CAP", "1000")
+    if mode == "cand_off":
+        monkeypatch.setenv("ACAV_ASSIGN_CAND", "0")
+    n, d, K = 40_000, 1024, 256
+    rs = np.random.RandomState(21)
+    cen = (0.02 * rs.randn(K, d)).astype(np.float32)
+    x = (cen[rs.randint(0, K, n)] + 0.3 * rs.randn(n, d)).astype(np.float32)
+    centers = (cen + 0.004 * rs.randn(K, d)).astype(np.float32)  # centre spread << noise radius: most rows undecided
+    if mode == "many_ties":
+        centers[100:140] = centers[7]
+    counts = np.full(K, 1000, np.float32)
+    if mode == "discounted":
+        counts[rs.randint(0, K, 40)] = 3.0
+    count = 10 * K + 200_000
+    km = KMeans(None, d, K)
+    km.centers, km.counts, km.count = centers, counts, count
+    km.to("cuda:0")
+    xt = torch.from_numpy(x).cuda()
+    for rep in range(2):  # twice: the sweep's control block must come back zeroed
+        lab, _ = km.calc_best(xt, need_mean=False)
+        _, rows, rechecked = km.filter_stats()
+        cand_rows, cand_pairs, full_rows = km.recheck_stats()
+        exact, _ = km.calc_best(xt)
+        assert torch.equal(lab, exact), f"{mode}: {(lab != exact).sum().item()} labels differ from the exact sweep"
+        assert rows == n and rechecked == cand_rows + full_rows
+        print(f"{mode}: undecided {rechecked}/{n}: {cand_rows} rows by {cand_pairs} candidate pairs, {full_rows} by the full sweep")
+        if mode == "plain":
+            assert cand_rows > n // 4 and full_rows < cand_rows // 10 and cand_pairs >= cand_rows
+        if mode == "discounted":  # the raw (uncentred) filter's bound is wide: many rows exceed 16 candidates
+            assert cand_rows > 0 and cand_rows + full_rows > n // 4
+        if mode == "pool_overflow":
+            assert 0 < cand_rows < 1000 and full_rows > n // 4
+        if mode == "cand_off":
+            assert cand_rows == 0 and full_rows > n // 4
+    ref = O.KMeans(d, K, O.Rng(0), centers=centers)
+    ref.set_state(None, counts, count)
+    idx = np.sort(rs.choice(n, 4096, replace=False))
+    assert np.array_equal(lab.cpu().numpy()[idx], ref.calc_best(x[idx])[0])
+    if mode == "many_ties":
+        assert not np.isin(lab.cpu().numpy(), np.arange(100, 140)).any()  # the duplicates lose to index 7
+
+
 @pytest.mark.parametrize("switch", [("ACAV_FILTER_V1", "1"), ("ACAV_FILTER_NT", "0"), ("ACAV_ASSIGN_EXACT_ONLY", "1"),
                                     ("ACAV_NO_PERSISTENT", "1")])
 def test_diagnostic_switches_keep_the_results(env, switch, monkeypatch):

@@ -1,6 +1,6 @@
 """Sweep time of KMeans.calc_best (bf16 filter + exact re-check) against the fraction of rows the filter cannot decide
 (VERDICT r2 item 2): 1M x 1024, K = 256, centres out of real training, cluster overlap turned up step by step
-(centre spread relative to the 0.3 noise).  argv: [rows]"""
+(centre spread relative to the 0.3 noise).  argv: [rows [d [spread,spread,...]]]"""
 import os
 import sys
 import time
@@ -14,10 +14,11 @@ import acav100m_amd
 from acav100m_amd import _lib
 from acav100m_amd.clustering import KMeans
 
-n, d, K, b = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, 1024, 256, 32
-print("| centre spread | rows re-checked | fraction | filter kernel ms | whole sweep ms | of 8 TB/s (sweep) |")
-print("|---|---|---|---|---|---|")
-for spread in (1.0, 0.25, 0.12, 0.09, 0.07, 0.06, 0.05, 0.04):
+n, d, K, b = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, int(sys.argv[2]) if len(sys.argv) > 2 else 1024, 256, 32
+spreads = [float(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else (1.0, 0.25, 0.12, 0.09, 0.07, 0.06, 0.05, 0.04)
+print("| centre spread | rows undecided | fraction | filter kernel ms | whole sweep ms | of 8 TB/s (sweep) | settled by candidates: rows / pairs | by the full sweep |")
+print("|---|---|---|---|---|---|---|---|")
+for spread in spreads:
     gen = torch.Generator(device="cuda").manual_seed(7)
     cen = spread * torch.randn(K, d, device="cuda", generator=gen)
     comp = torch.randint(0, K, (n,), device="cuda", generator=gen)
@@ -40,6 +41,7 @@ for spread in (1.0, 0.25, 0.12, 0.09, 0.07, 0.06, 0.05, 0.04):
         if rep:
             best = min(best, (ms.value, fm.value))
     _, rows, rechecked = km.filter_stats()
-    print("| %.2f | %d | %.4f | %.3f | %.3f | %.3f |" % (spread, rechecked, rechecked / rows, best[1], best[0],
-                                                   (n * d * 4 + n * 8) / (best[0] * 1e-3) / 8e12), flush=True)
+    cr, cp, fr = km.recheck_stats()
+    print("| %.2f | %d | %.4f | %.3f | %.3f | %.3f | %d / %d | %d |" % (spread, rechecked, rechecked / rows, best[1], best[0],
+                                                   (n * d * 4 + n * 8) / (best[0] * 1e-3) / 8e12, cr, cp, fr), flush=True)
     del x
