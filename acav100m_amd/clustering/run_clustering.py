@@ -224,7 +224,10 @@ class _RowGroups:
             table, on_dev = self._resident
             if shards is not None and set(shards) < set(table.shard_rows):
                 idx = np.array(sorted(i for s in shards for i in (table.shard_rows.get(s) or ())), np.int64)
-                rows = OrderedDict((v, up(v, m[idx])) for v, m in table.views.items())
+                # a view that training left on the device is indexed there (no second copy of the matrix through the host)
+                idx_dev = torch.from_numpy(idx).to(dev) if on_dev else None
+                rows = OrderedDict((v, on_dev[v][idx_dev] if v in on_dev and (views is None or v in views) else up(v, m[idx]))
+                                   for v, m in table.views.items())
                 rows['_rows'] = idx
                 yield 0, table, rows
                 return
@@ -279,6 +282,8 @@ def train_clusters(args, probe, groups):
     epochs = int(args.clustering.epochs)
     b = int(args.data.batch_size)
     print("training sgd kmeans for views: {}".format([v[1:] for v in cl]))
+    if w > 1 and multi_gpu_mode(args) == 'rows':
+        return _train_clusters_rows(args, cl, groups, pre, epochs, b)
     for epoch in range(pre, pre + epochs):
         lr = 0.1 ** (2 + epoch // 5)
         for km in cl.values():
@@ -326,6 +331,54 @@ def train_clusters(args, probe, groups):
     return cl
 
 
+def multi_gpu_mode(args):
+    """clustering.multi_gpu: 'views' (default) or 'rows' -- see config.py"""
+    mode = str(args.clustering.multi_gpu or 'views')
+    if mode not in ('views', 'rows'):
+        raise ValueError("clustering.multi_gpu must be 'views' or 'rows', not {!r}".format(mode))
+    return mode
+
+
+def _train_clusters_rows(args, cl, groups, pre, epochs, b):
+    """The reference's multi-GPU training (sgd_clustering.py:94-129 under is_distributed, run_clustering.py:146): `groups`
+    holds THIS rank's shards (rank::world, mps/distributed.py:439) -- the node's aggregate HBM holds the rows, nothing
+    streams through one GPU -- step t's global batch is the rank-major concatenation of every rank's rows
+    [t b, (t + 1) b), and the epochs are divided by the number of GPUs (ceil), because a step consumes world batches.
+    What bench.py --gpus N measures: KMeans.train_epoch_distributed_multi (rows of 1 024 steps at a time to the rank that
+    runs a view's chain, no collective on the step path), then the trainers hand out their states."""
+    import math
+    import torch
+    import torch.distributed as dist
+    from ..parallel.kmeans_dp import _collective_device
+    rank, w = world()
+    if groups.streamed:
+        raise RuntimeError("clustering.multi_gpu=rows keeps every rank's rows resident: {} groups do not fit the device budget "
+                           "(raise data.resident_bytes, use more GPUs, or clustering.multi_gpu=views)".format(len(groups.groups)))
+    epochs = math.ceil(epochs / w)  # run_clustering.py:146
+    (_gi, _table, rows), = list(groups.iterate())
+    n_local = next(iter(rows.values())).shape[0] if rows else 0
+    steps = torch.tensor([n_local // b], dtype=torch.int64, device=_collective_device())
+    dist.all_reduce(steps, op=dist.ReduceOp.MIN)  # every rank feeds every step: the shortest rank decides (drop_last)
+    steps = int(steps.item())
+    print("rank {}: {} local rows, {} steps of {} x {} rows per epoch, {} epochs".format(rank, n_local, steps, w, b, epochs))
+    kms = list(cl.values())
+    for epoch in range(pre, pre + epochs):
+        lr = 0.1 ** (2 + epoch // 5)
+        for km in kms:
+            km.lr = lr
+        gen = kms[0]._generator  # the DataLoader iterator's seed draw, as in the one-GPU loop
+        gen.u32()
+        gen.u32()
+        if steps > 0:
+            xs = [rows[v][:steps * b] for v in cl]
+            trainers = KMeans.train_epoch_distributed_multi(kms, xs, b, lr=lr)
+            for i, km in enumerate(kms):
+                km.broadcast_state_from(trainers[i], comm_slot=i)
+        if rank == 0:
+            save_clusterings(args, epoch, cl)
+    return cl
+
+
 def assign_clusters(args, groups, cl, shard_names):
     """run_clustering.py:180-272: label every row of this rank's shards, write {out}/{shard}.pkl."""
     out_dir = Path(args.data.output.path)
@@ -337,8 +390,9 @@ def assign_clusters(args, groups, cl, shard_names):
     mine = [s for s in shard_names if not (out_dir / (s + '.pkl')).is_file()]
     saved = []
     writer = io.AssignmentWriter(groups.workers if len(mine) >= 16 else 0)
+    mine_set = set(mine)
     for gi, table, rows in groups.iterate(shards=mine):
-        todo = [s for s in table.shard_rows if s in set(mine)]
+        todo = [s for s in table.shard_rows if s in mine_set]
         if not todo:
             continue
         sel = rows.pop('_rows', None)  # resident table, several ranks: the rows of this rank's shards, gathered
@@ -390,7 +444,9 @@ def run_clustering(args):
         return []
     row_bytes = 4 * sum(m.shape[1] for m in probe.views.values())
     view_dims = OrderedDict((v, m.shape[1]) for v, m in probe.views.items())
-    groups = _RowGroups(args, paths, sizes, row_bytes, _device_budget(args), view_dims)
+    rows_mode = w > 1 and multi_gpu_mode(args) == 'rows'
+    # rows mode: a rank reads, holds and labels its own shards only (rank::world) -- training included
+    groups = _RowGroups(args, paths[rank::w] if rows_mode else paths, sizes, row_bytes, _device_budget(args), view_dims)
     cl = train_clusters(args, probe, groups)
     mine = [p.stem for p in paths][rank::w]  # assign: shards strided over ranks (mps/distributed.py:439)
     return assign_clusters(args, groups, cl, mine)

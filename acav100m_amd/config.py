@@ -103,6 +103,11 @@ CLUSTERING_DEFAULTS = {
         'cached_epoch': None,
         'resume_training': False,
         'load_cache_from_shard_subset': True,
+        # ours: what several GPUs do in training.  'views': the clusterings are dealt out over the GPUs, every GPU trains
+        # its share over ALL rows with the one-GPU arithmetic and epoch count (files identical to a one-GPU run).
+        # 'rows': the reference's DDP (sgd_clustering.py:94-129, run_clustering.py:146): every GPU holds the rows of its own
+        # shards (rank::world), a step's global batch is batch_size rows from every GPU, epochs = ceil(epochs / num_gpus)
+        'multi_gpu': 'views',
     },
     'debug': False,
 }

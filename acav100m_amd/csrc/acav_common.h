@@ -52,6 +52,13 @@ void set_error(const char *fmt, ...);
 // true when p is a device (or managed) pointer usable from kernels
 bool is_device_ptr(const void *p);
 
+// Blocks of up to 256 MB that a DevBuf gives back are parked (up to 2 GB per process) instead of hipFree'd, and handed
+// out again to the next request of a similar size on the same device: hipMalloc / hipFree are synchronous and cost
+// 50-200 us each -- a KMeans handle created per pass (bench.py, one CLI run per group) paid ~150 us of allocations inside
+// its first assign sweep.  The owner of a DevBuf synchronises its stream before the buffer goes (all *_destroy do).
+int devbuf_alloc(void **p, size_t *bytes, size_t want);
+void devbuf_free(void *p, size_t bytes);
+
 // A device allocation that frees itself.
 struct DevBuf {
     void *p = nullptr;
@@ -59,7 +66,7 @@ struct DevBuf {
     ~DevBuf() { release(); }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) devbuf_free(p, bytes);
         p = nullptr;
         bytes = 0;
     }
@@ -67,14 +74,7 @@ struct DevBuf {
     {
         if (n <= bytes) return ACAV_OK;
         release();
-        hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess) {
-            p = nullptr;
-            set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
-            return ACAV_ENOMEM;
-        }
-        bytes = n;
-        return ACAV_OK;
+        return devbuf_alloc(&p, &bytes, n);
     }
     template <class T> T *as() const { return static_cast<T *>(p); }
 };

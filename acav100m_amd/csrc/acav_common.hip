@@ -1,5 +1,7 @@
 // acav_common.hip -- error model, device/pointer helpers, library-level entry points, and the
 // host MT19937 stream (torch's CPU generator) of libacav_hip.so.
+#include <mutex>
+
 #include "acav_common.h"
 
 namespace acav {
@@ -25,6 +27,78 @@ bool is_device_ptr(const void *p)
     }
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged ||
            attr.type == hipMemoryTypeUnified;
+}
+
+// ---- parked device blocks (see acav_common.h)
+namespace {
+struct Parked {
+    void *p;
+    size_t bytes;
+    int device;
+};
+std::mutex g_park_mutex;
+std::vector<Parked> g_parked;
+size_t g_parked_bytes = 0;
+constexpr size_t PARK_MAX_BLOCK = 256ull << 20, PARK_MAX_TOTAL = 2048ull << 20;
+}  // namespace
+
+int devbuf_alloc(void **p, size_t *bytes, size_t want)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (want <= PARK_MAX_BLOCK) {
+        std::lock_guard<std::mutex> lock(g_park_mutex);
+        size_t best = g_parked.size();
+        for (size_t i = 0; i < g_parked.size(); ++i)  // smallest parked block of this device that fits without wasting > 2x
+            if (g_parked[i].device == dev && g_parked[i].bytes >= want && g_parked[i].bytes <= 2 * want + 4096 &&
+                (best == g_parked.size() || g_parked[i].bytes < g_parked[best].bytes))
+                best = i;
+        if (best != g_parked.size()) {
+            *p = g_parked[best].p;
+            *bytes = g_parked[best].bytes;
+            g_parked_bytes -= g_parked[best].bytes;
+            g_parked.erase(g_parked.begin() + (long)best);
+            return ACAV_OK;
+        }
+    }
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) {  // out of memory: give the parked blocks back and try once more
+        (void)hipGetLastError();
+        std::vector<Parked> drop;
+        {
+            std::lock_guard<std::mutex> lock(g_park_mutex);
+            drop.swap(g_parked);
+            g_parked_bytes = 0;
+        }
+        for (const Parked &b : drop) (void)hipFree(b.p);
+        e = hipMalloc(p, want);
+    }
+    if (e != hipSuccess) {
+        *p = nullptr;
+        *bytes = 0;
+        set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return ACAV_ENOMEM;
+    }
+    *bytes = want;
+    return ACAV_OK;
+}
+
+void devbuf_free(void *p, size_t bytes)
+{
+    if (!p) return;
+    if (bytes <= PARK_MAX_BLOCK) {
+        hipPointerAttribute_t attr;
+        int dev = -1;
+        if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device;
+        else (void)hipGetLastError();
+        std::lock_guard<std::mutex> lock(g_park_mutex);
+        if (dev >= 0 && g_parked_bytes + bytes <= PARK_MAX_TOTAL && g_parked.size() < 256) {
+            g_parked.push_back({p, bytes, dev});
+            g_parked_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
 }
 
 int to_device(const void *src, size_t bytes, DevBuf &stage, hipStream_t stream, const void **out)

@@ -20,6 +20,14 @@ value = N * n_gpus * steps / time with the features resident in HBM when the tim
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
            --master-port P bench.py --gpus N --steps K --warmup W
 
+Other workloads (`--workload`, never the default: the driver's line stays on configs[2]) run the PER-GPU SLICE of the two
+8-GPU configurations of BASELINE.json on however many GPUs are given (1 here; the driver may launch the same flag with
+--gpus 8: every rank then holds its own slice):
+  cfg4   configs[3]: 10M clips / 8 = 1.25M clips per GPU, visual 2048-d + audio 128-d, K = 1024
+  cfg5   configs[4]: 100M clips / 8 = 12.5M clips per GPU, two 1024-d views (102 GB resident), K = 1024, selection in
+         chunks of 100 shards = 100k clips, 10 chunks in lockstep (computation.concurrent_chunks)
+Their `roofline` is quoted on the K = 1024 filter against the bf16 MFMA roof that binds there (intensity K/2 = 512 flop/B).
+
 N > 1 (weak scaling): every rank holds its own 1M-clip partition.  k-means training is one global clustering per view with
 the reference's DDP semantics (global batch = 32 N rows per step, rows all-gathered in bulk ahead of the SGD chain, no
 collective on the step path; the replicated chain of a view runs on one rank, which broadcasts its state); assign is local; the MI selection runs per rank on its own partition -- the reference's
@@ -58,13 +66,25 @@ EPOCHS = 2                 # clustering/code/config.py: clustering.epochs
 RATIO, BATCH_B, SELECT_K = 0.2, 20, 4   # subset_selection/code/config.py: subset.ratio, batch.*
 
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+# per-GPU slices of BASELINE.json's configs (rows per GPU, view widths, K, selection chunk size in clips / lockstep width)
+WORKLOADS = {
+    "cfg3": dict(name="BASELINE configs[2]", n=1_000_000, dims=(1024, 1024), k=256, chunk=None, width=1),
+    "cfg4": dict(name="BASELINE configs[3], per-GPU slice (10M clips / 8)", n=1_250_000, dims=(2048, 128), k=1024, chunk=None, width=1),
+    "cfg5": dict(name="BASELINE configs[4], per-GPU slice (100M clips / 8)", n=12_500_000, dims=(1024, 1024), k=1024,
+                 chunk=100_000, width=10),
+}
+
+
 def synth_views(torch, n, d, k, seed, device, views=2, rho=0.5):
     """SURVEY 8(d) generator: K Gaussian components per view, component centres ~ N(0,1)^d, row = centre + 0.3 N(0,1);
     the views share the component id with probability rho, else draw their own (gives the MI selection a signal)."""
     gen = torch.Generator(device=device).manual_seed(seed)
     shared = torch.randint(0, k, (n,), device=device, generator=gen)
+    dims = [d] * views if isinstance(d, int) else list(d)
     out = []
-    for v in range(views):
+    for d in dims:
         cen = torch.randn(k, d, device=device, generator=gen)
         own = torch.randint(0, k, (n,), device=device, generator=gen)
         comp = torch.where(torch.rand(n, device=device, generator=gen) < rho, shared, own)
@@ -87,50 +107,59 @@ def select_args(seed=0):
                node_rank=None, parent_pid=None)
 
 
-def cpu_baseline(n, d, k, b, views, seed):
+def cpu_baseline(n, dims, k, b, seed, chunk=None):
     """Oracle on the host cores, bounded sample of the same pipeline: SGD steps (after the warm-up) + an assign slice
-    per view, and greedy iterations at V = n with the reference's dense scoring.  add() is row-parallel over only
-    b=32 rows: min(cores, 16) threads; assign uses every core; the greedy loop is serial.  Best of 3 for k-means."""
+    per view width, and greedy iterations at V = n (or the chunk size) with the reference's dense scoring.  add() is
+    row-parallel over only b=32 rows: min(cores, 16) threads; assign uses every core; the greedy loop is serial.
+    Best of 3 for k-means."""
     from oracle import oracle as O
     rs = np.random.RandomState(seed)
-    cen = rs.randn(k, d).astype(np.float32)
-    n_steps, n_assign_rows, mi_iters = 256, 65536, 1500  # ~15 s of CPU work on this sample
-    xs = (cen[rs.randint(0, k, n_steps * b + n_assign_rows)] +
-          0.3 * rs.randn(n_steps * b + n_assign_rows, d)).astype(np.float32)
+    views = len(dims)
+    n_steps, n_assign_rows = 256, 65536
+    mi_iters = 1500 if k <= 256 else 300  # dense [B,P,C,C] scoring is 16x the work at C = 1024; ~15 s of CPU work in all
     cores = os.cpu_count() or 1
     train_threads = min(cores, 16)
-    t_train, t_assign = float("inf"), float("inf")
-    for rep in range(3):
-        km = O.KMeans(d, k, O.Rng(seed), centers=(cen + 0.1 * rs.randn(k, d)).astype(np.float32))
-        km.set_state(None, np.full(k, 50.0, np.float32), 10 * k + 12800)
-        O.set_threads(train_threads)
-        t0 = time.perf_counter()
-        for t in range(n_steps):
-            km.add(xs[t * b:(t + 1) * b])
-        t_train = min(t_train, (time.perf_counter() - t0) / (n_steps * b))   # s per clip and epoch
-        O.set_threads(cores)
-        t0 = time.perf_counter()
-        km.calc_best(xs[n_steps * b:])
-        t_assign = min(t_assign, (time.perf_counter() - t0) / n_assign_rows)  # s per clip
-    comp = rs.randint(0, k, n)
-    a = np.stack([np.where(rs.rand(n) < 0.5, comp, rs.randint(0, k, n)) for _ in range(views)], 1).astype(np.int64)
+    per_d = {}
+    for d in sorted(set(dims)):
+        cen = rs.randn(k, d).astype(np.float32)
+        xs = (cen[rs.randint(0, k, n_steps * b + n_assign_rows)] +
+              0.3 * rs.randn(n_steps * b + n_assign_rows, d)).astype(np.float32)
+        t_train, t_assign = float("inf"), float("inf")
+        for rep in range(3):
+            km = O.KMeans(d, k, O.Rng(seed), centers=(cen + 0.1 * rs.randn(k, d)).astype(np.float32))
+            km.set_state(None, np.full(k, 50.0, np.float32), 10 * k + 12800)
+            O.set_threads(train_threads)
+            t0 = time.perf_counter()
+            for t in range(n_steps):
+                km.add(xs[t * b:(t + 1) * b])
+            t_train = min(t_train, (time.perf_counter() - t0) / (n_steps * b))   # s per clip and epoch
+            O.set_threads(cores)
+            t0 = time.perf_counter()
+            km.calc_best(xs[n_steps * b:])
+            t_assign = min(t_assign, (time.perf_counter() - t0) / n_assign_rows)  # s per clip
+        per_d[d] = (t_train, t_assign)
+    v = min(n, chunk) if chunk else n   # clips of one selection
+    comp = rs.randint(0, k, v)
+    a = np.stack([np.where(rs.rand(v) < 0.5, comp, rs.randint(0, k, v)) for _ in range(views)], 1).astype(np.int64)
     a[0] = k - 1
     pairs = list(itertools.combinations(range(views), 2))
-    cand = [int(i) for i in rs.permutation(n)]
+    cand = [int(i) for i in rs.permutation(v)]
     O.set_threads(1)
     t0 = time.perf_counter()
-    O.BatchMI(a, k, pairs).run_greedy(cand[1:], cand[:1], round(RATIO * n), BATCH_B, SELECT_K, O.Rng(seed), dense=True,
+    O.BatchMI(a, k, pairs).run_greedy(cand[1:], cand[:1], round(RATIO * v), BATCH_B, SELECT_K, O.Rng(seed), dense=True,
                                       max_iters=mi_iters)
     t_iter = (time.perf_counter() - t0) / mi_iters
-    iters = -(-round(RATIO * n) // SELECT_K)
-    t_clip = views * (EPOCHS * t_train + t_assign) + iters * t_iter / n
+    iters = -(-round(RATIO * v) // SELECT_K) * (n // v)   # iterations of all selections over the n clips
+    t_clip = sum(EPOCHS * per_d[d][0] + per_d[d][1] for d in dims) + iters * t_iter / n
     return {
         "value": 1.0 / t_clip, "unit": "clips/s", "cores": cores, "kind": "port",
-        "sample": f"k-means, best of 3: {n_steps} add() steps of b={b} on {train_threads} threads + calc_best over "
-                  f"{n_assign_rows} rows on {cores} threads (d={d}, K={k}), scaled to {views} views x ({EPOCHS} epochs + 1 "
-                  f"sweep); MI: {mi_iters} greedy iterations at V={n} (dense [B,P,C,C] scoring + full randperm per "
-                  f"iteration, 1 thread) scaled to {iters} iterations; oracle C port, per-clip times summed and inverted",
-        "train_clips_per_s_per_epoch": 1.0 / t_train, "assign_clips_per_s": 1.0 / t_assign,
+        "sample": f"k-means, best of 3 per view width {sorted(set(dims))}: {n_steps} add() steps of b={b} on {train_threads} "
+                  f"threads + calc_best over {n_assign_rows} rows on {cores} threads (K={k}), scaled to {views} views x "
+                  f"({EPOCHS} epochs + 1 sweep); MI: {mi_iters} greedy iterations at V={v} (dense [B,P,C,C] scoring + full "
+                  f"randperm per iteration, 1 thread) scaled to {iters} iterations; oracle C port, per-clip times summed "
+                  f"and inverted",
+        "train_clips_per_s_per_epoch": {str(d): 1.0 / per_d[d][0] for d in per_d},
+        "assign_clips_per_s": {str(d): 1.0 / per_d[d][1] for d in per_d},
         "mi_ms_per_iteration": t_iter * 1e3,
         # BASELINE.md section 3: how this port relates to the TRUE reference (its Python, imported in the build container:
         # 8 cores, torch 2.10 CPU) on the rows of BASELINE.md section 2 -- the port is 2.4-12.6x FASTER than the code it
@@ -146,14 +175,37 @@ def cpu_baseline(n, d, k, b, views, seed):
     }
 
 
+def select_chunked(a, types, chunk, width, seed0=1):
+    """The reference's chunked selection (chunk.py:21-53): every chunk of `chunk` clips selects 20 % of its own clips,
+    `width` chunks in lockstep on this GPU (computation.concurrent_chunks).  -> list of per-chunk (S, GAIN) in chunk order,
+    S in chunk-local ids."""
+    from acav100m_amd.rng import Generator
+    from acav100m_amd.subset_selection.measures.batch import EfficientBatchMI
+    from acav100m_amd.subset_selection.run_greedy import _prepare
+    sargs = select_args()
+    n = a.shape[0]
+    out = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for g0 in range(0, n, chunk * width):
+            prepared = []
+            for i, c0 in enumerate(range(g0, min(n, g0 + chunk * width), chunk)):
+                prepared.append(_prepare(sargs, a[c0:c0 + chunk], types, None, RATIO, "batch_mi", "combination", True, False,
+                                         generator=Generator(seed0 + g0 // chunk + i)))
+            res = EfficientBatchMI.run_greedy_multi([p[0] for p in prepared], [p[2] for p in prepared],
+                                                    [p[1] for p in prepared])
+            out.extend((r[0], r[1]) for r in res)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", "--rows", dest="n", type=int, default=1_000_000)  # --rows: torchrun's own parser trips over "--n"
-    ap.add_argument("--d", type=int, default=1024)
-    ap.add_argument("--k", type=int, default=256)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg3")  # cfg3 = the metric's configuration (the driver's line)
+    ap.add_argument("--n", "--rows", dest="n", type=int, default=None)  # --rows: torchrun's own parser trips over "--n"
+    ap.add_argument("--d", type=int, default=None)   # overrides (tests): one width for both views
+    ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
@@ -189,15 +241,21 @@ def main():
     from acav100m_amd.subset_selection.run_greedy import _run_greedy
     lib = acav100m_amd.load_library()
 
-    n, d, k, b, nviews = args.n, args.d, args.k, args.batch, 2
-    xs = synth_views(torch, n, d, k, 1234 + rank, dev, nviews)
+    wl = WORKLOADS[args.workload]
+    n = args.n if args.n is not None else wl["n"]
+    dims = (args.d, args.d) if args.d is not None else tuple(wl["dims"])
+    k = args.k if args.k is not None else wl["k"]
+    chunk = wl["chunk"] if wl["chunk"] and wl["chunk"] < n else None
+    b, nviews = args.batch, len(dims)
+    d = max(dims)  # the view the roofline is quoted on
+    xs = synth_views(torch, n, dims, k, 1234 + rank, dev)
     torch.cuda.synchronize()
 
     cargs = _NS(computation=_NS(device="cuda", num_gpus=world))
     sargs = select_args()
     types = [("audio_model", "layer_0"), ("visual_model", "layer_0")]
-    subset = round(RATIO * n)
-    iters = -(-subset // SELECT_K)
+    subset = round(RATIO * n) if chunk is None else sum(round(RATIO * min(chunk, n - c0)) for c0 in range(0, n, chunk))
+    iters = -(-subset // SELECT_K) if chunk is None else sum(-(-round(RATIO * min(chunk, n - c0)) // SELECT_K) for c0 in range(0, n, chunk))
 
     def barrier():
         torch.cuda.synchronize()
@@ -213,7 +271,7 @@ def main():
     def one_pass(timed):
         acav100m_amd.manual_seed(0)
         random.seed(0)
-        kms = [KMeans(cargs, d, k).to(dev) for _ in range(nviews)]
+        kms = [KMeans(cargs, dv, k).to(dev) for dv in dims]
         for km in kms:
             km.initialize()
         t0 = time.perf_counter()
@@ -233,7 +291,8 @@ def main():
         for km in kms:
             km.synchronize()
         t1 = time.perf_counter()
-        for km, x, lab in zip(kms, xs, labels):  # assign sweep, timed with HIP events on the library's own stream
+        last["train_stats"] = [list(km.train_stats()) for km in kms]
+        for vi, (km, x, lab) in enumerate(zip(kms, xs, labels)):  # assign sweep, timed with HIP events on the library's own stream
             _lib.check(lib.acav_kmeans_timer_begin(km._h))
             _lib.check(lib.acav_kmeans_assign(km._h, _lib.ptr(x), n, _lib.ptr(lab), None))
             ms = C.c_float(0)
@@ -241,16 +300,22 @@ def main():
             fm = C.c_float(0)
             _lib.check(lib.acav_kmeans_filter_time(km._h, C.byref(fm)))
             if timed:
-                sweep_ms.append(ms.value)
-                filt_ms.append(fm.value)
+                sweep_ms.append((vi, ms.value))
+                filt_ms.append((vi, fm.value))
                 filt_stats.append(km.filter_stats())
         t2 = time.perf_counter()
         a = torch.stack(labels, 1).cpu().numpy()  # the k-means -> MI hand-off (assignment shards in the CLI flow)
         t3 = time.perf_counter()
-        with contextlib.redirect_stdout(io.StringIO()):
-            S, GAIN, _ = _run_greedy(sargs, a, types, None, RATIO, "batch_mi", "combination", True, False)
-        t4 = time.perf_counter()
-        assert len(S) == subset and len(set(S)) == subset
+        if chunk is None:
+            with contextlib.redirect_stdout(io.StringIO()):
+                S, GAIN, _ = _run_greedy(sargs, a, types, None, RATIO, "batch_mi", "combination", True, False)
+            t4 = time.perf_counter()
+            assert len(S) == subset and len(set(S)) == subset
+        else:  # the reference's chunked mode: every chunk selects 20 % of its own clips, `width` chunks in lockstep
+            res = select_chunked(a, types, chunk, wl["width"])
+            t4 = time.perf_counter()
+            S = [c0 * chunk + i for c0, (Sc, _) in enumerate(res) for i in Sc]
+            assert len(S) == subset and len(set(S)) == subset
         last["S"], last["a"] = S, a
         if timed:
             stage["train"].append(t1 - t0)
@@ -276,66 +341,91 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         value = n * world * args.steps / elapsed
         st = {key: float(np.mean(v)) for key, v in stage.items()}
-        f_ms, s_ms = float(np.mean(filt_ms)), float(np.mean(sweep_ms))
+        vq = int(np.argmax(dims))  # the view the roofline is quoted on: the widest (cfg4: the 2048-d visual view)
+        f_ms = float(np.mean([t for vi, t in filt_ms if vi == vq]))
+        s_ms = float(np.mean([t for vi, t in sweep_ms if vi == vq]))
+        per_view = [{"d": dv, "filter_ms": float(np.mean([t for vi, t in filt_ms if vi == i])),
+                     "sweep_ms": float(np.mean([t for vi, t in sweep_ms if vi == i]))} for i, dv in enumerate(dims)]
         bytes_per_launch = n * d * 4 + n * 8
         flops_per_launch = 2.0 * n * k * d
         gbs = bytes_per_launch / (f_ms * 1e-3) / 1e9
+        tflops = flops_per_launch / (f_ms * 1e-3) / 1e12
+        mfma_bound = k > 256  # intensity K/2 flop/B against the bf16 ridge of ~314 flop/B
         traffic_profile = None
         pdir = os.path.join(ROOT, "profiles")
         for name in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
-            if name.endswith("_pmc_assign.json"):  # summary of the separate rocprofv3 --pmc passes (tools/collect_profiles.sh)
+            if name.endswith("_pmc_assign.json") or name.endswith("_pmc_assign_k1024.json"):  # summaries of the separate rocprofv3 --pmc passes
                 pm = json.load(open(os.path.join(pdir, name)))
-                if (pm.get("rows"), pm.get("d"), pm.get("K")) == (n, d, k) and pm.get("kernel", "").startswith("k_assign_bf16"):
-                    traffic_profile = {"file": "profiles/" + name, "bytes_per_launch": pm["traffic_bytes_per_launch"]}
+                if (pm.get("d"), pm.get("K")) == (d, k) and pm.get("kernel", "").startswith("k_assign_bf16"):
+                    scale = n / pm["rows"]  # per-row traffic of the same kernel shape, scaled to this launch's rows
+                    traffic_profile = {"file": "profiles/" + name, "rows_in_profile": pm["rows"],
+                                       "bytes_per_launch": pm["traffic_bytes_per_launch"] * scale}
                     break
         train_steps = EPOCHS * nviews * (n // b)
-        perm_bytes = sum(16 * (n - 1 - (BATCH_B - (BATCH_B - SELECT_K)) * t) for t in range(iters))
+        if chunk is None:
+            perm_bytes = sum(16 * (n - 1 - SELECT_K * t) for t in range(iters))
+        else:
+            perm_bytes = sum(sum(16 * (min(chunk, n - c0) - 1 - SELECT_K * t)
+                                 for t in range(-(-round(RATIO * min(chunk, n - c0)) // SELECT_K))) for c0 in range(0, n, chunk))
+        views_txt = " + ".join(f"{dv}-d" for dv in dims)
+        sel_txt = (f"ONE-chunk greedy batch-MI selection of {subset} clips (B={BATCH_B}, k={SELECT_K}, {iters} iterations; the "
+                   f"reference's default chunk_size=None)" if chunk is None else
+                   f"chunked greedy batch-MI selection (chunk_size = {chunk} clips = {chunk // 1000} shards, {-(-n // chunk)} chunks, "
+                   f"{wl['width']} in lockstep; every chunk selects 20 % of its clips: {subset} clips, {iters} iterations in all, "
+                   f"B={BATCH_B}, k={SELECT_K})")
+        roof = {"kernel": "k_assign_bf16_rw" + (" + k_assign_merge (K > 256: one workgroup per (row tile, centre group) pair)" if k > 256 else ""),
+                "view": f"{d}-d"}
+        if mfma_bound:
+            roof.update({"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / MFMA_BF16_PEAK_TFLOPS, "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS})
+        else:
+            roof.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "frac_of_measured_copy_rate": gbs / HBM_MEASURED_COPY_GBS,
+                         "frac_of_measured_read_rate": gbs / HBM_MEASURED_READ_GBS,
+                         "dma_only_skeleton_ms_1M_x_1024": FILTER_DMA_SKELETON_MS})
+        roof.update({
+            # HBM bytes per launch from the rocprofv3 --pmc passes of this kernel on this shape (FETCH_SIZE x 2 per the MI355X
+            # guide + WRITE_SIZE; separate runs, tools/collect_profiles.sh): the committed summary named below -- a counter
+            # pass cannot run inside the timed region
+            "traffic": traffic_profile["bytes_per_launch"] if traffic_profile else None,
+            "traffic_from_committed_profile": traffic_profile,
+            "launch_ms": f_ms, "algorithmic_bytes": bytes_per_launch, "algorithmic_flops": flops_per_launch,
+            "effective_TFLOPs": tflops, "sweep_ms": s_ms, "sweep_GBs": bytes_per_launch / (s_ms * 1e-3) / 1e9,
+            "sweep_frac": bytes_per_launch / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "sweep_over_launch": s_ms / f_ms,
+            "rows_rechecked_exact": [int(f[2]) for f in filt_stats[-nviews:]], "rows": n, "per_view": per_view})
         out = {
             "metric": "clips/sec curated (k-means train + assign, 2 views) + MI greedy selection of 20 %",
             "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: {n} clips x 2 views of {d}-d, K={k}: per view {EPOCHS} training "
-                                   f"epochs at b={b} ({n // b} SGD steps each) + 1 assign sweep, then ONE-chunk greedy "
-                                   f"batch-MI selection of {subset} clips (B={BATCH_B}, k={SELECT_K}, {iters} iterations; "
-                                   f"the reference's default chunk_size=None), end to end on 1 GPU per partition",
-                       "global_batch": b * world, "rows_per_gpu": n, "views": nviews, "epochs": EPOCHS,
-                       "select": subset, "mi_chunks": 1},
+            "config": {"workload": f"{wl['name']}: {n} clips x {nviews} views ({views_txt}), K={k}: per view {EPOCHS} training "
+                                   f"epochs at b={b} ({n // b} SGD steps each) + 1 assign sweep, then {sel_txt}, end to end "
+                                   f"on 1 GPU per partition",
+                       "global_batch": b * world, "rows_per_gpu": n, "views": nviews, "view_dims": list(dims), "epochs": EPOCHS,
+                       "select": subset, "mi_chunks": 1 if chunk is None else -(-n // chunk)},
             "stages": {"train_s": st["train"], "assign_s": st["assign"], "handoff_s": st["handoff"], "mi_s": st["mi"],
                        "train_us_per_sgd_step": st["train"] * 1e6 / train_steps,
                        "assign_sweep_ms": s_ms, "mi_us_per_iteration": st["mi"] * 1e6 / iters,
                        "train_clips_per_s": n / st["train"], "assign_clips_per_s": n / st["assign"],
                        "mi_clips_per_s": n / st["mi"]},
-            "roofline": {"kernel": "k_assign_bf16_rw", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         # HBM bytes per launch from the rocprofv3 --pmc passes of this kernel on this workload's shape
-                         # (FETCH_SIZE x 2 per the MI355X guide + WRITE_SIZE; separate runs, tools/collect_profiles.sh): the
-                         # committed summary named below -- a counter pass cannot run inside the timed region
-                         "traffic": traffic_profile["bytes_per_launch"] if traffic_profile else None,
-                         "frac_of_measured_copy_rate": gbs / HBM_MEASURED_COPY_GBS,
-                         "frac_of_measured_read_rate": gbs / HBM_MEASURED_READ_GBS,
-                         "dma_only_skeleton_ms_1M_x_1024": FILTER_DMA_SKELETON_MS,
-                         "traffic_from_committed_profile": traffic_profile,
-                         "launch_ms": f_ms, "algorithmic_bytes": bytes_per_launch,
-                         "algorithmic_flops": flops_per_launch, "effective_TFLOPs": flops_per_launch / (f_ms * 1e-3) / 1e12,
-                         "sweep_ms": s_ms, "sweep_GBs": bytes_per_launch / (s_ms * 1e-3) / 1e9,
-                         "sweep_frac": bytes_per_launch / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "rows_rechecked_exact": [int(f[2]) for f in filt_stats[-nviews:]], "rows": n},
+            "roofline": roof,
             "roofline_mi": {"kernel": "k_mt_generate_lanes + k_fy_part + k_fy_tile + k_fy_resolve + k_fy_gather_select (one greedy iteration)",
                             "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                             "algorithmic_bytes": perm_bytes, "achieved": perm_bytes / st["mi"] / 1e9,
                             "frac": perm_bytes / st["mi"] / 1e9 / HBM_PEAK_GBS,
                             "note": "16 L bytes per iteration (int64 candidate permutation read + write, SURVEY 8(d)) over "
                                     "the whole selection incl. its host part (python shuffle, table set-up)"},
-            "train_kernel": {"kernel": "k_train_persistent (both views' launches side by side: acav_kmeans_train_multi)" if world == 1 else
+            "train_kernel": {"kernel": "persistent epoch kernels (the views' launches side by side: acav_kmeans_train_multi)" if world == 1 else
                              "k_step_dist_dma + k_step_update (global batch %d)" % (b * world),
                              "bound": "latency (dependent chain of %d steps per epoch and view)" % (n // b),
-                             "us_per_step": st["train"] * 1e6 / train_steps},
+                             "us_per_step": st["train"] * 1e6 / train_steps,
+                             "persistent_launches_and_fallbacks": last.get("train_stats")},
         }
-        if not args.no_variants and world == 1:
+        if not args.no_variants and world == 1 and chunk is None and n >= 200_000:
             out["variants"] = {"chunked_lockstep": chunked_variant(last["a"], types, n, st)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n, d, k, b, nviews, 1234)
+            out["cpu_baseline"] = cpu_baseline(n, dims, k, b, 1234, chunk)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
@@ -348,23 +438,10 @@ def chunked_variant(a, types, n, st, chunk=100_000, width=10):
     (computation.concurrent_chunks).  Measured once, outside the driver's timed region; combined with the timed
     k-means stages of this run."""
     try:
-        from acav100m_amd.rng import Generator
-        from acav100m_amd.subset_selection.measures.batch import EfficientBatchMI
-        from acav100m_amd.subset_selection.run_greedy import _prepare
         import random
         random.seed(0)
-        sargs = select_args()
         t0 = time.perf_counter()
-        total = 0
-        with contextlib.redirect_stdout(io.StringIO()):
-            for g0 in range(0, n, chunk * width):
-                prepared = []
-                for i, c0 in enumerate(range(g0, min(n, g0 + chunk * width), chunk)):
-                    prepared.append(_prepare(sargs, a[c0:c0 + chunk], types, None, RATIO, "batch_mi", "combination", True, False,
-                                             generator=Generator(1 + g0 // chunk + i)))
-                res = EfficientBatchMI.run_greedy_multi([p[0] for p in prepared], [p[2] for p in prepared],
-                                                        [p[1] for p in prepared])
-                total += sum(len(r[0]) for r in res)
+        total = sum(len(r[0]) for r in select_chunked(a, types, chunk, width))
         t_mi = time.perf_counter() - t0
         t_all = st["train"] + st["assign"] + st["handoff"] + t_mi
         return {"workload": f"{n // chunk} chunks of {chunk} clips, {width} in lockstep, each selects 20 %",

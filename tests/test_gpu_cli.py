@@ -239,6 +239,62 @@ def test_cluster_cli_spawns_one_process_per_gpu(workdir):
     assert len(logs) == 2  # one manifest per process, each listing its own shards (save.py:9-17)
 
 
+def test_cluster_cli_rows_mode_two_workers(workdir):
+    """`cli.py cluster --clustering.multi_gpu=rows --computation.num_gpus=2`: the reference's DDP training through the CLI
+    (sgd_clustering.py:94-129, run_clustering.py:146) -- every worker holds the rows of its own shards (rank::2), a step's
+    global batch is 32 rows of worker 0 followed by 32 rows of worker 1, ceil(2 / 2) = 1 epoch -- the same call bench.py
+    --gpus N times.  Two workers on the one GPU of this box (gloo).  Checked against the ORACLE fed that batch stream:
+    the saved centres of all ten clusterings bit for bit, and every written label."""
+    import torch
+    from oracle import oracle as O
+    from acav100m_amd import shards as io
+    root, glob = workdir
+    out = os.path.join(root, "cl_rows")
+    log = _run_cli("acav100m_amd.clustering.cli",
+                   ["cluster", "--feature_path=" + glob, "--meta_path=" + os.path.join(root, "videos"), "--out_path=" + out,
+                    "--computation.num_gpus=2", "--clustering.multi_gpu=rows"], {"ACAV_SEED": "0", "ACAV_DIST_BACKEND": "gloo"})
+    assert log.count("done") == 2 and "16 steps of 2 x 32 rows per epoch, 1 epochs" in log
+    caches = sorted(f for f in os.listdir(out) if f.startswith("cache_epoch_"))
+    assert len(caches) == 1  # ceil(epochs / num_gpus) = 1 epoch, written by worker 0
+    saved = torch.load(os.path.join(out, caches[0]), weights_only=False)
+    # the oracle on the same stream: worker r's rows = its shards in order
+    paths = sorted(io.brace_expand(glob))
+    models, audio = ['layer_vggish', 'layer_slow_fast'], ('vggish', 'layer_vggish')
+    tabs = [io.load_feature_shards([__import__("pathlib").Path(q) for q in paths[r::2]], model_order=models, audio_models=audio)
+            for r in range(2)]
+    views = list(tabs[0].views)
+    K, b, lr = 32, 32, 0.1 ** 2  # run_clustering.py:168: lr = 0.1 ** (2 + epoch // 5)
+    rng = O.Rng(0)
+    refs = [O.KMeans(tabs[0].views[v].shape[1], K, rng) for v in views]  # ten inits in view order (run_clustering.py:32-44)
+    rng.u32(), rng.u32()                                                   # the DataLoader iterator's seed draw
+    steps = min(len(t) for t in tabs) // b
+    for ref, v in zip(refs, views):  # warm-up labels: drawn clustering by clustering; both workers draw the same stream
+        need = min(steps, -(-(10 * K) // (2 * b)))
+        warm = [np.argmin(rng.rand(K, b), axis=0) for _ in range(need)]
+        for t in range(steps):
+            xg = np.concatenate([tabs[r].views[v][t * b:(t + 1) * b] for r in range(2)])
+            if t < need:
+                ref.apply_update(xg, np.concatenate([warm[t], warm[t]]), lr)
+            else:
+                ref.lr = lr
+                ref.add(xg)
+    for ref, (kind, mk, layer) in zip(refs, views):
+        got = saved[mk][layer]
+        assert np.array_equal(np.asarray(got["centers"]), ref.centers), (mk, layer)
+        assert got["count"] == ref.count == steps * 2 * b
+    for s in range(4):
+        rows = pickle.load(open(os.path.join(out, "shard-%06d.pkl" % s), "rb"))
+        tab = tabs[s % 2]
+        ids = tab.shard_rows["shard-%06d" % s]
+        assert len(rows) == len(ids) == 256
+        for ref, view in zip(refs, views):
+            kind, mk, layer = view
+            want = ref.calc_best(tab.views[view][ids])[0]
+            key = "audio_assignments" if kind == "audio" else "video_assignments"
+            got = np.array([int(r[key][0]["array"][layer]) for r in rows])
+            assert np.array_equal(got, want), (s, mk, layer)
+
+
 def test_subset_cli_chunks_spawn_per_gpu(workdir):
     """`cli.py run --chunk_size=2 --computation.num_gpus=2`: one process per GPU (chunk.py:28,53), no process group,
     every process selects from its own block of chunks into caches/cache_{parent pid}_{rank}_{i}_output.csv;
