@@ -3,6 +3,9 @@
 // centre preparation, and their C-ABI entry points.  Training lives in acav_kmeans.hip.
 #include <algorithm>
 #include <cstddef>
+#include <mutex>
+#include <set>
+#include <tuple>
 
 #include "acav_kmeans_shared.h"
 
@@ -403,6 +406,16 @@ __device__ __forceinline__ void dma16_asm_nt(const void *gbase_uniform, unsigned
                  : "memory", "m0");
 }
 
+// the same with a full 64-bit address per lane (rows picked through a list: no common base within 4 GB)
+__device__ __forceinline__ void dma16_asm_v64(const char *addr, unsigned lds)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(addr), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ void dma16_asm_v64_nt(const char *addr, unsigned lds)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(addr), "s"(lds) : "memory", "m0");
+}
+
 __device__ __forceinline__ bf16x8 cvt_bf16x8(float4 lo, float4 hi)
 {
     bf16x8 r = {(__bf16)lo.x, (__bf16)lo.y, (__bf16)lo.z, (__bf16)lo.w, (__bf16)hi.x, (__bf16)hi.y, (__bf16)hi.z, (__bf16)hi.w};
@@ -766,15 +779,6 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict_
 // of the minimisers is the exact first-index argmin.  Rows with more than CAND_MAX candidates, or that do not fit the pair
 // pool, go to the full exact sweep (k_assign_f32) as before -- never a wrong label, only a slower row.
 // The emission test uses T_i >= every v that could fail the inequality (derivation at the use): a superset is always safe.
-struct AssignCtl {                  // device-side control block of one assign sweep; all zero between sweeps
-    unsigned long long alloc;       // low 32 bits: candidate row slots handed out, high 32 bits: candidate pairs handed out
-    unsigned f32_count;             // rows on the full exact re-check list
-    unsigned ticket;                // workgroups of the sweep's last kernel that have finished (the last one resets the block)
-    unsigned pool_over;             // rows that hold a slot but whose pairs did not fit the pool (they are on the f32 list too)
-    unsigned pad0;
-    unsigned long long last_alloc;  // copies for acav_kmeans_filter_stats, written by the sweep's last kernel
-    unsigned last_f32, last_pool_over;
-};
 struct CandRow {        // one undecided row: its pairs are cpair[pair_base .. pair_base + cnt)
     int row;
     unsigned pair_base;
@@ -784,6 +788,22 @@ struct CandRow {        // one undecided row: its pairs are cpair[pair_base .. p
 struct CandPair {
     unsigned slot;      // index into the CandRow array (slots and pair ranges are handed out by ONE 64-bit atomic, so both
     int k;              // are ordered alike: consecutive slots own consecutive pair ranges)
+};
+struct AssignCtl {                  // device-side control block of one assign sweep; the counters are zero between sweeps
+    unsigned long long alloc;       // low 32 bits: candidate row slots handed out, high 32 bits: candidate pairs handed out
+    unsigned f32_count;             // rows on the full exact re-check list
+    unsigned ticket;                // workgroups of the sweep's last kernel that have finished (the last one resets the block)
+    unsigned pool_over;             // rows that hold a slot but whose pairs did not fit the pool (they are on the f32 list too)
+    unsigned und_count;             // rows the filter could not decide (the list the emission pass walks)
+    unsigned last_und;
+    unsigned long long last_alloc;  // copies for acav_kmeans_filter_stats, written by the sweep's last kernel
+    unsigned last_f32, last_pool_over;
+};
+struct CandOut {  // where the emission pass writes: candidate rows / pairs, and the list of the full exact sweep
+    CandRow *crow;
+    CandPair *cpair;
+    int *f32_list;
+    unsigned pair_cap;
 };
 constexpr unsigned CAND_MAX = 16;  // candidates per row beyond which the row takes the full exact sweep
 __device__ __forceinline__ AssignCtl *ctl_of_f32_count(const unsigned *f32_count)
@@ -799,6 +819,8 @@ __device__ __forceinline__ void assign_ctl_finish(AssignCtl *ctl, unsigned nbloc
         ctl->last_alloc = atomicAdd(&ctl->alloc, 0ull);  // read at the coherence point
         ctl->last_f32 = atomicAdd(&ctl->f32_count, 0u);
         ctl->last_pool_over = atomicAdd(&ctl->pool_over, 0u);
+        ctl->last_und = atomicAdd(&ctl->und_count, 0u);
+        ctl->und_count = 0u;
         ctl->alloc = 0ull;
         ctl->f32_count = 0u;
         ctl->pool_over = 0u;
@@ -812,17 +834,20 @@ struct Top2Rec {
     float d2;
     float xn;
 };
-template <bool NT, int NW, bool GS, int DCR = FD_DC, int SCHED = 0>
+template <bool NT, int NW, bool GS, int DCR = FD_DC, int SCHED = 0, bool EMIT = false>
 __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__restrict__ x, int64_t n, int d,
                                                             const __bf16 *__restrict__ cb, const float *__restrict__ cn,
                                                             const float *__restrict__ counts, int K, float thr, float r,
                                                             const CentersAux *__restrict__ aux, float e1c, float e1r, float e2coef,
                                                             int64_t *__restrict__ labels, int *__restrict__ recheck_list,
-                                                            unsigned *__restrict__ recheck_count, Top2Rec *__restrict__ grec,
-                                                            unsigned long long *__restrict__ cand_alloc, CandRow *__restrict__ crow,
-                                                            CandPair *__restrict__ cpair, unsigned pair_cap,
-                                                            unsigned *__restrict__ pool_over)
+                                                            unsigned *__restrict__ recheck_count, AssignCtl *__restrict__ ctl,
+                                                            Top2Rec *__restrict__ grec, CandOut out)
 {
+    // EMIT = the EMISSION PASS over the rows the (lean) filter could not decide: the rows are x[recheck_list[0 .. *recheck_count)]
+    // (a fixed grid strides over their tiles), the main loop is the filter's, and the epilogue emits every row's candidate
+    // centres (header above) instead of listing the row.  It is a separate instantiation because the emission code costs the
+    // filter 9-18 % when it merely sits in the same kernel (0.865 vs 0.94-1.035 ms per 1M x 1024 with not one row undecided).
+    if (EMIT) n = (int64_t)*recheck_count;
     constexpr int XSLOT = NW * 4096;  // bytes per row-ring slot: NW x 32 rows x 32 fp32
     constexpr int CQ = 16 / NW;       // centre-stage DMA pieces (1 KB = 16 centres x 64 B) per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
@@ -837,7 +862,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
     const int l31 = lane & 31, h = lane >> 5;
     const int nchunks = d / FD_BK;
     const int ngroups = (K + 255) / 256;
-    int64_t tile = blockIdx.x;
+  for (int64_t tile_it = blockIdx.x;; tile_it += gridDim.x) {  // one trip, except in the emission pass
+    if (EMIT && tile_it * (NW * 32) >= n) break;
+    int64_t tile = tile_it;
     int cg0 = 0, cg1 = ngroups;
     if (GS) {
         const int j = blockIdx.x >> 3;  // sequence number on XCD (blockIdx.x & 7)
@@ -857,11 +884,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
     const float cn_shift = centred ? cn[0] : 0.0f;
 
     unsigned voffx[4], voffc[CQ];
+    const char *ax[4];  // EMIT: the 64-bit source address of this lane's piece of row (wq * 4 + q) * 8 + (lane >> 3)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int rr = (wq * 4 + q) * 8 + (lane >> 3);
         const int rc = row0 + rr < n ? rr : (int)(n - 1 - row0);  // ragged tail: re-read the last row
         voffx[q] = (unsigned)rc * (unsigned)d * 4u + (((lane & 7) ^ ((rr >> 1) & 7)) << 4);
+        ax[q] = nullptr;
+        if (EMIT)
+            ax[q] = reinterpret_cast<const char *>(x + (size_t)recheck_list[row0 + rc] * d) + (((lane & 7) ^ ((rr >> 1) & 7)) << 4);
     }
     const unsigned xring = lds_addr(sXr) + wq * 4096, cring = lds_addr(sCb) + wq * (CQ * 1024);
 
@@ -889,7 +920,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
         auto issue_x = [&]() {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (NT) dma16_asm_nt(gx, voffx[q], xring + wx * XSLOT + q * 1024);
+                if (EMIT) {
+                    if (NT) dma16_asm_v64_nt(ax[q], xring + wx * XSLOT + q * 1024);
+                    else dma16_asm_v64(ax[q], xring + wx * XSLOT + q * 1024);
+                    ax[q] += FD_BK * 4;
+                } else if (NT) dma16_asm_nt(gx, voffx[q], xring + wx * XSLOT + q * 1024);
                 else dma16_asm(gx, voffx[q], xring + wx * XSLOT + q * 1024);
             }
             gx += FD_BK * 4;
@@ -978,7 +1013,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
                     const int q = i - CQ;
 #ifndef ACAV_ABL_NOXDMA
                     if (c + 2 < nchunks) {
-                        if (NT) dma16_asm_nt(gx, voffx[q], xring + wx * XSLOT + q * 1024);
+                        if (EMIT) {
+                            if (NT) dma16_asm_v64_nt(ax[q], xring + wx * XSLOT + q * 1024);
+                            else dma16_asm_v64(ax[q], xring + wx * XSLOT + q * 1024);
+                            ax[q] += FD_BK * 4;
+                        } else if (NT) dma16_asm_nt(gx, voffx[q], xring + wx * XSLOT + q * 1024);
                         else dma16_asm(gx, voffx[q], xring + wx * XSLOT + q * 1024);
                     }
 #endif
@@ -1112,17 +1151,18 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
         o.d2 = __shfl_xor(t.d2, 32);
         run = top2_merge(run, top2_merge(t, o));
 
-        if (!GS && crow != nullptr && ngroups == 1) {
+        if (EMIT && !GS && ngroups == 1) {
             // ---- acceptance test in BOTH half-lanes of a row, and for undecided rows the candidate emission (header above)
-            const int64_t row = row0 + wq * 32 + l31;
+            const int64_t li = row0 + wq * 32 + l31;  // position in the list of undecided rows
+            const int64_t row = li < n ? (int64_t)recheck_list[li] : -1;
             const float xnorm = __builtin_sqrtf(xn);
             const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
             const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
             const float sn = xnorm + cmax;
             const float E = (e1c * cmaxc + e1r * cmax) * xnorm + e2coef * sn * sn;
             const float tagged = 1.6e-5f * (fabsf(run.d1) + fabsf(run.d2));  // > (2^-16 + 2^-22) x 1.01
-            const bool undecided = row < n && !((run.d2 - run.d1) > 2.0f * E + tagged);  // also catches NaN / inf
-            if (h == 0 && row < n) labels[row] = (int64_t)run.k1;
+            // (every listed row fails the test again: same arithmetic as the filter's; the label is already the filter's k1)
+            const bool undecided = row >= 0 && !((run.d2 - run.d1) > 2.0f * E + tagged);
             if (__builtin_amdgcn_ballot_w64(undecided) != 0ull) {
                 // T: every v > T satisfies v - d1 > W + c |v|, W = 2 E + c |d1|, c = 1.6e-5 (untagged v: its own tag is not
                 // charged, the slack stays).  With u = d1 + W:  v >= 0: v (1 - c) > u  <=  v > u / (1 - c) < u (1 + 2 c);
@@ -1183,20 +1223,23 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
                 const unsigned mine = __builtin_popcount(m[0]) + __builtin_popcount(m[1]) + __builtin_popcount(m[2]) + __builtin_popcount(m[3]);
                 const unsigned other = __shfl_xor(mine, 32);
                 const unsigned total = mine + other;
+                CandRow *const crow = out.crow;
+                CandPair *const cpair = out.cpair;
+                const unsigned pair_cap = out.pair_cap;
                 unsigned long long got = 0ull;
                 bool full = false;  // the row takes the full exact sweep instead
                 if (undecided && h == 0) {
                     if (total > CAND_MAX) full = true;
                     else {
-                        got = atomicAdd(cand_alloc, ((unsigned long long)total << 32) | 1ull);
+                        got = atomicAdd(&ctl->alloc, ((unsigned long long)total << 32) | 1ull);
                         if ((got >> 32) + total > (unsigned long long)pair_cap) {  // pool exhausted (the slot stays, empty)
                             full = true;
-                            atomicAdd(pool_over, 1u);
+                            atomicAdd(&ctl->pool_over, 1u);
                         }
                     }
                     if (full) {
-                        const unsigned fslot = atomicAdd(recheck_count, 1u);
-                        recheck_list[fslot] = (int)row;
+                        const unsigned fslot = atomicAdd(&ctl->f32_count, 1u);
+                        out.f32_list[fslot] = (int)row;
                     }
                     if (total <= CAND_MAX) {
                         // (a row whose range runs past the pool's end -- pair_base + cnt > pair_cap -- is "lost": on the f32 list)
@@ -1243,7 +1286,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
         }
         return;
     }
-    if (crow != nullptr && ngroups == 1) return;  // decided / emitted inside the group loop (the accumulators live there)
+    if (EMIT) continue;  // emitted inside the group loop (the accumulators live there); next tile of the list
     if (h == 0 && row < n) {
         const float xnorm = __builtin_sqrtf(xn);
         const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
@@ -1260,6 +1303,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
             recheck_list[slot] = (int)row;
         }
     }
+    break;  // not the emission pass: one tile per workgroup
+  }
 }
 
 // Folds the per-group records of the group-split filter (ascending group order = the order of the single-workgroup loop;
@@ -1478,6 +1523,27 @@ int acav_kmeans::prepare_filter()
                        cb16.as<__bf16>(), caux.as<CentersAux>());
     ACAV_HIP_TRY(hipGetLastError());
     cb16_valid = true;
+    // the sweep's one-time objects, so that the first sweep of a handle does not create them inside its own timing
+    if (!ev_f0) {
+        ACAV_HIP_TRY(hipEventCreate(&ev_f0));
+        ACAV_HIP_TRY(hipEventCreate(&ev_f1));
+    }
+    if (!cand_ctl.p) {
+        ACAV_TRY(cand_ctl.ensure(sizeof(AssignCtl)));
+        ACAV_HIP_TRY(hipMemsetAsync(cand_ctl.p, 0, sizeof(AssignCtl), st));
+    }
+    return ACAV_OK;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size) instead of once per sweep
+static int dyn_lds_once(const void *fn, int device, int bytes)
+{
+    static std::mutex mu;
+    static std::set<std::tuple<const void *, int, int>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({fn, device, bytes})) return ACAV_OK;
+    ACAV_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({fn, device, bytes});
     return ACAV_OK;
 }
 
@@ -1500,7 +1566,8 @@ ACAV_EXPORT int acav_kmeans_filter_stats(acav_kmeans *km, int64_t *filter_launch
     if (filter_launches) *filter_launches = km->n_filter_launches;
     if (rows) *rows = (int64_t)km->last_rows;
     // rows the filter could not decide = candidate rows + rows sent straight to the full exact sweep
-    if (rechecked) *rechecked = (int64_t)(unsigned)c.last_alloc + (int64_t)c.last_f32 - (int64_t)c.last_pool_over;
+    // (with the candidate path: the filter's own list; else everything undecided went straight to the full-sweep list)
+    if (rechecked) *rechecked = c.last_und ? (int64_t)c.last_und : (int64_t)c.last_f32;
     return ACAV_OK;
 }
 
@@ -1558,7 +1625,7 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
                         !(noflt && noflt[0] == '1') && n < 0x7fffffff;
     if (filter) {
         ACAV_TRY(km->prepare_filter());
-        ACAV_TRY(km->recheck_list.ensure(sizeof(int) * (size_t)n));
+        ACAV_TRY(km->recheck_list.ensure(sizeof(int) * (size_t)n * 2));  // [undecided rows | rows for the full exact sweep]
         // control block of the sweep: zero when a sweep starts -- zeroed here once, and by the last kernel of every sweep
         if (!km->cand_ctl.p) {
             ACAV_TRY(km->cand_ctl.ensure(sizeof(AssignCtl)));
@@ -1570,6 +1637,9 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         // sends every undecided row to the full exact sweep as in round 3
         const char *vcand = getenv("ACAV_ASSIGN_CAND");
         const bool cand = km->K <= 256 && !(vcand && vcand[0] == '0');
+        // ACAV_ASSIGN_EMIT=0: experiment -- the lean filter kernel (no emission code) even with the candidate path on
+        const char *vemit = getenv("ACAV_ASSIGN_EMIT");
+        const bool emit_allowed = !(vemit && vemit[0] == '0');
         const uint64_t pair_cap64 = std::min<uint64_t>(std::max<uint64_t>(4ull * (uint64_t)n, 65536ull), 0x7fffffffull);
         unsigned pair_cap = (unsigned)pair_cap64;
         if (const char *vcap = getenv("ACAV_CAND_PAIR_CAP")) {  // tests: force the pool-overflow path
@@ -1582,6 +1652,8 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         }
         CandRow *crow = cand ? km->cand_rows.as<CandRow>() : (CandRow *)nullptr;
         CandPair *cpair = cand ? km->cand_pairs.as<CandPair>() : (CandPair *)nullptr;
+        int *und_list = km->recheck_list.as<int>(), *f32_list = und_list + n;
+        const CandOut cout = {crow, cpair, f32_list, pair_cap};
         const double acc = 1.01 * (double)km->d * ldexp(1.0, -24);  // accumulation error of one fp32 dot, relative
         const float e1c = (float)(2.02 * (ldexp(1.0, -8) * 1.002 + acc) * 1.001);   // x ||c'|| ||x||: bf16 roundings + filter dot
         const float e1r = (float)(2.02 * (acc + ldexp(1.0, -24)) * 1.001);           // x ||c|| ||x||: canonical dot, c - mu
@@ -1604,9 +1676,10 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         const int dcr = nw == 8 ? 3 : 2;  // centre ring depth (3 only fits the one-workgroup-per-CU tile)
         const int sched = nw == 8 ? 2 : (vsc ? (vsc[0] == '2' ? 2 : 0) : FILTER_SCHED_DEFAULT);
         typedef void (*FilterKern)(const float *, int64_t, int, const __bf16 *, const float *, const float *, int, float, float,
-                                   const CentersAux *, float, float, float, int64_t *, int *, unsigned *, Top2Rec *,
-                                   unsigned long long *, CandRow *, CandPair *, unsigned, unsigned *);
+                                   const CentersAux *, float, float, float, int64_t *, int *, unsigned *, AssignCtl *, Top2Rec *,
+                                   CandOut);
         FilterKern rwk = nullptr;
+        const bool emit = cand && emit_allowed && rw && !gs && ngroups == 1 && nw == 4 && sched == 0;
         if (rw) {
             if (nw == 8) rwk = gs ? (nt_eff ? k_assign_bf16_rw<true, 8, true, 3, 2> : k_assign_bf16_rw<false, 8, true, 3, 2>)
                                   : (nt_eff ? k_assign_bf16_rw<true, 8, false, 3, 2> : k_assign_bf16_rw<false, 8, false, 3, 2>);
@@ -1624,25 +1697,23 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
             ACAV_HIP_TRY(hipEventCreate(&km->ev_f1));
         }
         if (rw) {
-            ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rwk), hipFuncAttributeMaxDynamicSharedMemorySize, fsmem));
+            ACAV_TRY(dyn_lds_once(reinterpret_cast<const void *>(rwk), km->ctx.device, fsmem));
             ACAV_HIP_TRY(hipEventRecord(km->ev_f0, st));
             hipLaunchKernelGGL(rwk, dim3((unsigned)fgrid), dim3(nw * 64), fsmem, st, static_cast<const float *>(dx), n, km->d,
                                km->cb16.as<__bf16>(), km->cn.as<float>(), km->counts.as<float>(), km->K, km->threshold(),
-                               (float)km->reinit_r, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, km->recheck_list.as<int>(),
-                               f32_count, gs ? km->grec.as<Top2Rec>() : (Top2Rec *)nullptr, &ctl->alloc, crow, cpair, pair_cap,
-                               &ctl->pool_over);
+                               (float)km->reinit_r, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, emit ? und_list : f32_list,
+                               emit ? &ctl->und_count : f32_count, ctl, gs ? km->grec.as<Top2Rec>() : (Top2Rec *)nullptr, cout);
             if (gs)
                 hipLaunchKernelGGL(k_assign_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, km->grec.as<Top2Rec>(),
-                                   ngroups, n, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, km->recheck_list.as<int>(),
-                                   f32_count);
+                                   ngroups, n, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, f32_list, f32_count);
         } else {
             auto kern = nt ? k_assign_bf16<true> : k_assign_bf16<false>;
-            ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FD_SMEM));
+            ACAV_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), km->ctx.device, FD_SMEM));
             ACAV_HIP_TRY(hipEventRecord(km->ev_f0, st));
             hipLaunchKernelGGL(kern, dim3((unsigned)((n + FB_ROWS - 1) / FB_ROWS)), dim3(256), FD_SMEM, st,
                                static_cast<const float *>(dx), n, km->d, km->cb16.as<__bf16>(), km->cn.as<float>(),
                                km->counts.as<float>(), km->K, km->threshold(), (float)km->reinit_r, km->caux.as<CentersAux>(), e1c,
-                               e1r, e2, dlab, km->recheck_list.as<int>(), f32_count);
+                               e1r, e2, dlab, f32_list, f32_count);
         }
         ACAV_HIP_TRY(hipGetLastError());
         ACAV_HIP_TRY(hipEventRecord(km->ev_f1, st));
@@ -1670,17 +1741,28 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
             km->num_cus = prop.multiProcessorCount;
         }
         const int64_t rgrid = grid < 2 * (int64_t)km->num_cus ? grid : 2 * (int64_t)km->num_cus;
-        if (cand && rw && ngroups == 1)  // exact canonical chains of the emitted (row, candidate centre) pairs; labels of those rows
+        if (emit) {
+            // emission pass: the filter's main loop once more over the undecided rows only (a fixed grid strides over the tiles
+            // of the list), the epilogue emits each row's candidate centres; then the exact canonical chains of those (row,
+            // centre) pairs and the labels of those rows
+            auto ek = nt ? k_assign_bf16_rw<true, 4, false, 2, 0, true> : k_assign_bf16_rw<false, 4, false, 2, 0, true>;
+            ACAV_TRY(dyn_lds_once(reinterpret_cast<const void *>(ek), km->ctx.device, fsmem));
+            const int64_t egrid = std::min<int64_t>(ntiles, 2 * (int64_t)km->num_cus);
+            hipLaunchKernelGGL(ek, dim3((unsigned)egrid), dim3(256), fsmem, st, static_cast<const float *>(dx), n, km->d,
+                               km->cb16.as<__bf16>(), km->cn.as<float>(), km->counts.as<float>(), km->K, km->threshold(),
+                               (float)km->reinit_r, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, und_list, &ctl->und_count, ctl,
+                               (Top2Rec *)nullptr, cout);
             // (3 workgroups of 4 waves per CU: the kernel is bound by the L2 -> L1 path -- 1, 2, 3, 4, 6 per CU all measure the same)
             hipLaunchKernelGGL(k_assign_cand, dim3((unsigned)(3 * km->num_cus)), dim3(256), 0, st, static_cast<const float *>(dx),
                                km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->threshold(),
                                (float)km->reinit_r, ctl, crow, cpair, pair_cap, dlab);
+        }
         // full exact sweep of the rows on the f32 list (more than CAND_MAX candidates, pool overflow, K > 256); also the
         // sweep's last kernel: its last workgroup resets the control block
         hipLaunchKernelGGL(k_assign_f32<false>, dim3((unsigned)rgrid), dim3(256), 0, st, static_cast<const float *>(dx), n,
                            km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
                            km->threshold(), (float)km->reinit_r, dlab, (float *)nullptr, km->wg_sum.as<double>(),
-                           km->recheck_list.as<int>(), f32_count);
+                           f32_list, f32_count);
         km->n_filter_launches += 1;
         km->last_rows = (uint64_t)n;
     } else if (fast)

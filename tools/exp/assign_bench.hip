@@ -39,7 +39,7 @@ static void bench(const char *name, const float *x, int64_t n, int d, int K, con
         CK(hipMemset(rc, 0, 4));
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), fsmem, 0, x, n, d, cb, cn, counts, K, 1.0f, 5.0f, aux, 1e-2f,
-                           1e-4f, 1e-6f, lab, rl, rc, grec, (unsigned long long *)nullptr, (CandRow *)nullptr, (CandPair *)nullptr, 0u, (unsigned *)nullptr);
+                           1e-4f, 1e-6f, lab, rl, rc, (AssignCtl *)nullptr, grec, CandOut{});
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float t;
