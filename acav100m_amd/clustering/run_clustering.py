@@ -191,7 +191,11 @@ class _RowGroups:
         return len(self.groups) > 1
 
     def _load(self, group):
-        return io.load_feature_shards(group, model_order=self.model_order, audio_models=self.audio_models,
+        # streamed: every shard is read once per epoch and once more for the assign sweep -- the first pass leaves the columnar
+        # twins behind (2.0 M rows/s instead of 0.5 M from pkl, profiles/r03_streamed.txt) unless ACAV_SHARD_SIDECAR says otherwise
+        import os
+        sidecar = 'write' if self.streamed and 'ACAV_SHARD_SIDECAR' not in os.environ else None
+        return io.load_feature_shards(group, model_order=self.model_order, audio_models=self.audio_models, sidecar=sidecar,
                                       workers=self.workers, expect_rows=self.sizes, expect_views=self.view_dims)
 
     def __iter__(self):

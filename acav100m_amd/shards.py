@@ -216,20 +216,26 @@ def read_feature_sidecar(path):
 # the shards and write their rows straight into ONE shared-memory matrix per view -- the table the parent hands to the GPU
 # upload -- and send back only the per-row metadata; nothing is pickled, piped or concatenated in the parent.
 _POOL = None
+_POOL_LOCK = __import__('threading').Lock()
 
 
 def _pool(workers):
+    """The process-wide worker pool, created ONCE (the prefetch thread and the main thread both come here: resizing it
+    under a running map() is a race): sized for the larger of this request and the reference's `num_workers` default
+    of 40, capped by the cores this rank may use (cores / world: every rank of a node has its own pool)."""
     global _POOL
-    if _POOL is None or _POOL[0] < workers:
-        import atexit
-        import multiprocessing as mp
-        from concurrent.futures import ProcessPoolExecutor
-        if _POOL is not None:
-            _POOL[1].shutdown(wait=False)
-        ex = ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context('spawn'))  # never fork a process that holds a GPU
-        atexit.register(ex.shutdown, wait=False)
-        _POOL = (workers, ex)
-    return _POOL[1]
+    with _POOL_LOCK:
+        if _POOL is None:
+            import atexit
+            import multiprocessing as mp
+            from concurrent.futures import ProcessPoolExecutor
+            world = max(1, int(os.environ.get('WORLD_SIZE', '1') or 1))
+            cap = max(2, (os.cpu_count() or 2) // world)
+            size = max(2, min(max(int(workers), 40), cap))
+            ex = ProcessPoolExecutor(max_workers=size, mp_context=mp.get_context('spawn'))  # never fork a process that holds a GPU
+            atexit.register(ex.shutdown, wait=False)
+            _POOL = (size, ex)
+        return _POOL[1]
 
 
 def _worker_load(job):
@@ -242,7 +248,7 @@ def _worker_load(job):
         try:
             rows = load_pickle(path)
         except Exception as exc:
-            return 'unreadable: {}'.format(exc)
+            return {'skip': '{}'.format(exc)}  # the parent reports and skips it, as the plain loop does
         columns = _shard_columns_from_rows(rows, path.stem)
         if mode == 'write':
             try:
@@ -250,7 +256,9 @@ def _worker_load(job):
             except OSError:
                 pass
     n = len(columns['filename'])
-    if n != n_expect or {v for v, _, _, _ in views} != {tuple(v) for v in columns['views']}:
+    # an incomplete shard (fewer rows than its metadata says: normal, shard_ok_ratio exists for it) still goes in -- the
+    # parent closes the gap; MORE rows than reserved, or another set of views, cannot be placed
+    if n > n_expect or {v for v, _, _, _ in views} != {tuple(v) for v in columns['views']}:
         return 'layout'
     for view, d, name, total in views:
         mat = columns['views'][tuple(view)]
@@ -262,7 +270,7 @@ def _worker_load(job):
         finally:
             shm.close()
     return {'filename': list(columns['filename']), 'shard_name': list(columns['shard_name']),
-            'shard_size': list(columns['shard_size']), 'tags': list(columns['tags'].items())}
+            'shard_size': list(columns['shard_size']), 'tags': list(columns['tags'].items()), 'rows': n}
 
 
 class _ShmCache:
@@ -314,7 +322,13 @@ class _ShmCache:
             if addr is not None:
                 import sys
                 sys.modules['torch'].cuda.cudart().cudaHostUnregister(addr)
+        except Exception:
+            pass
+        try:
             b.close()
+        except Exception:  # BufferError: a view of the block is still alive somewhere -- the name must go all the same
+            pass
+        try:
             b.unlink()
         except Exception:
             pass
@@ -359,17 +373,28 @@ def _load_parallel(paths, mode, expect_rows, expect_views, workers):
         _SHM.release(shms)
         return None
     table = FeatureTable()
-    base = 0
+    mats = [np.ndarray((total, int(d)), np.float32, buffer=shm.buf) for (view, d), shm in zip(expect_views.items(), shms)]
+    src = dst = 0
     for p, n, r in zip(paths, counts, results):
+        if 'skip' in r:  # unreadable: reported and skipped (clustering data/clustering.py:167-182), its slice is closed up
+            print(r['skip'])
+            print('Exception in shard loading: {}'.format(p.stem))
+            src += n
+            continue
+        have = int(r['rows'])
+        if dst != src:  # a shorter / skipped shard before this one: move this shard's rows down (dst < src: no overlap hazard)
+            for m in mats:
+                m[dst:dst + have] = m[src:src + have]
         table.filename.extend(r['filename'])
         table.shard_name.extend(r['shard_name'])
         table.shard_size.extend(r['shard_size'])
         for key, tag in r['tags']:
             table.tags.setdefault(tuple(key), tuple(tag))
-        table.shard_rows[p.stem] = list(range(base, base + n))
-        base += n
-    for (view, d), shm in zip(expect_views.items(), shms):
-        table.views[view] = np.ndarray((total, int(d)), np.float32, buffer=shm.buf)
+        table.shard_rows[p.stem] = list(range(dst, dst + have))
+        dst += have
+        src += n
+    for (view, d), m in zip(expect_views.items(), mats):
+        table.views[view] = m[:dst]
 
     table._shm = shms
     weakref.finalize(table, _SHM.release, shms)  # back to the cache when the table goes away

@@ -134,14 +134,21 @@ class Contrastive:
         self._comm = comm
 
     @staticmethod
-    def rank_rows(offsets, rank, world):
+    def rank_rows(offsets, rank, world, training=True):
         """get_features under distributed=True (contrastive.py:117-124): rows rank::world of every batch.
-        -> (row indices, offsets of the rank's batches)"""
+        -> (row indices, offsets of the rank's batches)
+
+        A batch with fewer rows than ranks (the short tail batch of drop_last=False, or one that in-batch de-duplication
+        shrank) would leave the high ranks with an empty slice: in the reference cross_entropy over it is NaN on those ranks
+        and poisons the averaged gradients.  training=True drops such a batch ON EVERY RANK -- decided from the offsets
+        alone, so all ranks agree and nobody is left waiting in the gradient all-reduce; training=False (inference: no
+        collective) keeps it and simply scores an empty slice on the ranks past its end, as the reference does."""
         idx, off = [], [0]
         for i in range(len(offsets) - 1):
-            r = np.arange(int(offsets[i]) + rank, int(offsets[i + 1]), world, dtype=np.int64)
-            assert len(r) > 0, ("batch {} has {} rows for {} ranks: the reference's cross_entropy over an empty slice is "
-                                "NaN on that rank and poisons the averaged gradients".format(i, offsets[i + 1] - offsets[i], world))
+            lo, hi = int(offsets[i]), int(offsets[i + 1])
+            if training and hi - lo < world:
+                continue
+            r = np.arange(lo + rank, hi, world, dtype=np.int64)
             idx.append(r)
             off.append(off[-1] + len(r))
         return (np.concatenate(idx) if idx else np.zeros(0, np.int64)), np.asarray(off, np.int64)
@@ -272,7 +279,7 @@ class Contrastive:
             from ...parallel import world as _world
             rank, world = _world()
             if world > 1:
-                idx, _ = self.rank_rows(offsets, rank, world)
+                idx, _ = self.rank_rows(offsets, rank, world, training=False)
                 visual, audio = np.asarray(visual)[idx], np.asarray(audio)[idx]
                 metas_rows = [metas_rows[i] for i in idx]
         logits = self.infer_scores(visual, audio)

@@ -137,9 +137,10 @@ def _run(args, paths):
     print("(node {}) running inference".format(args.node_rank or 0))
     tv, ta, toff, trows = feature_batches(table, int(cfg.test_batch_size))
     metas = io.load_metas([Path(p) for p in paths], args.data.meta.path)
-    scores, ids, _ = scorer.infer(args, (tv, ta, toff), trows, metas, args.subset.size, args.verbose)
+    # (distributed: `ids` index the rows THIS worker scored -- the third value -- not the full list)
+    scores, ids, scored_rows = scorer.infer(args, (tv, ta, toff), trows, metas, args.subset.size, args.verbose)
     print("(node {}) done inference".format(args.node_rank or 0))
-    return measure, scores, [trows[i] for i in ids]
+    return measure, scores, [scored_rows[i] for i in ids]
 
 
 def run_single_contrastive(args):

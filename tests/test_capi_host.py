@@ -200,3 +200,18 @@ def test_python_shuffle_in_library_equals_random_shuffle(acav):
         got = python_shuffled_range(n)
         assert got.tolist() == want, (seed, n)
         assert [random.random(), random.getrandbits(40)] == after, "generator state after the shuffle"
+
+
+def test_contrastive_rank_rows_short_batches(acav):
+    """a batch with fewer rows than ranks (the tail batch of drop_last=False) must not raise on a SUBSET of the
+    ranks in front of a collective.  Training drops it on every rank alike (decided from the offsets), inference scores an
+    empty slice on the ranks past its end."""
+    from acav100m_amd.subset_selection.measures.contrastive import Contrastive
+    off = [0, 128, 129]  # a 128-row batch and a 1-row tail, 2 ranks
+    per_rank = [Contrastive.rank_rows(off, r, 2) for r in range(2)]
+    assert [o.tolist() for _, o in per_rank] == [[0, 64], [0, 64]]          # same number of batches on both ranks
+    assert per_rank[0][0].tolist() == list(range(0, 128, 2)) and per_rank[1][0].tolist() == list(range(1, 128, 2))
+    inf = [Contrastive.rank_rows(off, r, 2, training=False) for r in range(2)]
+    assert inf[0][0].tolist() == list(range(0, 128, 2)) + [128] and inf[0][1].tolist() == [0, 64, 65]
+    assert inf[1][0].tolist() == list(range(1, 128, 2)) and inf[1][1].tolist() == [0, 64, 64]
+    assert sorted(inf[0][0].tolist() + inf[1][0].tolist()) == list(range(129))  # every row scored exactly once

@@ -1,7 +1,8 @@
-"""GPU test of the multi-GPU code path with a 1-rank RCCL process group: the driver runs bench.py with
---gpus N on an 8-GPU node that this session cannot reach, so at least the collective plumbing (nccl init,
-all_gather of rows + labels on device tensors, apply_update on the gathered batch, initialize()) is
-executed on a real GPU here.  With world = 1 the result must equal the plain add()."""
+"""GPU tests of the multi-GPU code path on ONE GPU: a 1-rank RCCL process group (nccl init, the bulk row exchange to the
+trainer rank + warm-up labels through the library's communicator, the state hand-out, initialize()) -- with world = 1 the
+result must equal the plain epoch -- and two ranks sharing the GPU under gloo, including bench.py --gpus 2 launched through
+torch.distributed.run as the driver launches it.  (The per-step all-gather of rows and labels of round 2 survives only in
+distributed_add(), the KMeans.add() form.)"""
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

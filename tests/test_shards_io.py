@@ -158,3 +158,29 @@ def test_parallel_loader_equals_serial(tmp_path):
     assert getattr(again, "_shm", None) is None and again.filename == serial.filename
     for v in serial.views:
         assert np.array_equal(again.views[v], serial.views[v])
+
+
+def test_parallel_loader_keeps_going_over_short_and_broken_shards(tmp_path):
+    """an incomplete shard (fewer rows than its metadata says) or an unreadable one must not send the whole
+    group back to the serial loop: the workers report what they found, the parent closes the gaps.  Result == the serial
+    loop over the same files (which reports and skips the broken shard, clustering data/clustering.py:167-182)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import synth
+    from collections import OrderedDict
+    glob = synth.write_feature_shards(str(tmp_path), n_shards=20, rows=12, seed=5, audio_dims=[8], video_dims=[24, 16])
+    paths = sorted(io.brace_expand(glob))
+    sizes = {os.path.basename(p)[:-4]: 12 for p in paths}
+    io.dump_pickle(io.load_pickle(paths[3])[:7], paths[3])      # a short shard in the middle
+    io.dump_pickle(io.load_pickle(paths[19])[:11], paths[19])   # ... and at the end
+    with open(paths[8], "wb") as f:                              # an unreadable one
+        f.write(b"not a pickle")
+    serial = io.load_feature_shards(paths, sidecar="off")
+    dims = OrderedDict((v, m.shape[1]) for v, m in serial.views.items())
+    par = io.load_feature_shards(paths, sidecar="off", workers=3, expect_rows=sizes, expect_views=dims)
+    assert getattr(par, "_shm", None), "the parallel path was abandoned"
+    assert len(par) == len(serial) == 12 * 17 + 7 + 11
+    assert par.filename == serial.filename and par.shard_name == serial.shard_name and par.shard_rows == serial.shard_rows
+    assert os.path.basename(paths[8])[:-4] not in par.shard_rows
+    for v in serial.views:
+        assert par.views[v].shape == serial.views[v].shape and np.array_equal(par.views[v], serial.views[v])
