@@ -4,7 +4,7 @@
 # Separate runs, as the MI355X guide prescribes: kernel trace + stats, then one --pmc pass per counter (never combined
 # with a trace domain).  Copy the results into profiles/ afterwards.
 set -u
-P=${1:-r03}
+P=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profiles
 mkdir -p "$OUT"
@@ -69,6 +69,27 @@ ACAV_PROFILE_STEPS=1 BENCH_D=2048 BENCH_K=1024 timeout 300 python tools/bench_tr
 if [ -x tools/exp/stream_bench ]; then (cd tools/exp && ./stream_bench) > "$OUT/${P}_stream_bench.txt" 2>&1; fi
 timeout 600 python tools/recheck_table.py > "$OUT/${P}_recheck_table.txt" 2>&1
 timeout 900 python tools/bench_streamed.py 1000000 1024 256 2.0 > "$OUT/${P}_streamed_now.txt" 2>&1
+# 6. round 4: the 8-GPU configurations' per-GPU slices (bench lines with the K = 1024 roofline against the MFMA roof), the
+#    candidate-restricted re-check (kernel statistics + counters at 62 % undecided rows)
+timeout 900 python bench.py --workload cfg4 --steps 2 --warmup 1 > "$OUT/${P}_cfg4_slice.json" 2> /dev/null
+timeout 1800 python bench.py --workload cfg5 --steps 1 --warmup 1 > "$OUT/${P}_cfg5_slice.json" 2> /dev/null
+stats recheck_hard python tools/recheck_table.py 1000000 1024 0.06,0.05
+: > "$OUT/${P}_cand_pmc.txt"
+for C in "TCC_REQ_sum TCC_HIT_sum" "TCC_MISS_sum TCC_EA0_RDREQ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVES" "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum" "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"; do
+    tag=$(echo $C | tr ' ' '_')
+    timeout 300 rocprofv3 --pmc $C --kernel-include-regex "k_assign_cand|k_assign_bf16_rw" --output-format csv -d "$OUT/pmc_cand_$tag" -o pmc -- python tools/recheck_table.py 1000000 1024 0.05 > /dev/null 2>&1
+    python - "$OUT/pmc_cand_$tag" >> "$OUT/${P}_cand_pmc.txt" <<'PY'
+import csv, glob, collections, re, sys
+agg = collections.defaultdict(list)
+for f in glob.glob(sys.argv[1] + "/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = re.search(r"k_[a-z0-9_]+(<[^>]*>)?", r["Kernel_Name"])
+        agg[(k.group(0) if k else "?", r["Counter_Name"])].append(float(r["Counter_Value"]))
+for (k, c), v in sorted(agg.items()):
+    print("%-60s %-34s launches %3d  mean per launch %.0f" % (k, c, len(v), sum(v) / len(v)))
+PY
+    rm -rf "$OUT/pmc_cand_$tag"
+done
 for f in "$OUT"/${P}_*.txt; do sed -i '/amdgpu.ids/d' "$f"; done
 for f in "$OUT/${P}_mi_1m.txt" "$OUT/${P}_mi_1m_legacy.txt" "$OUT/${P}_mi_100k.txt" "$OUT/${P}_mi_lockstep8.txt" "$OUT/${P}_bench_under_rocprof.txt"; do grep "^{" "$f" | tail -1 > "$f.tmp" && mv "$f.tmp" "${f%.txt}.json" && rm -f "$f"; done
 ls -la "$OUT"
