@@ -840,7 +840,7 @@ struct Top2Rec {
     float d2;
     float xn;
 };
-template <bool NT, int NW, bool GS, int DCR = FD_DC, int SCHED = 0, bool EMIT = false>
+template <bool NT, int NW, bool GS, int DCR = FD_DC, int SCHED = 0, int EMIT = 0>
 __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__restrict__ x, int64_t n, int d,
                                                             const __bf16 *__restrict__ cb, const float *__restrict__ cn,
                                                             const float *__restrict__ counts, int K, float thr, float r,
@@ -849,11 +849,16 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
                                                             unsigned *__restrict__ recheck_count, AssignCtl *__restrict__ ctl,
                                                             Top2Rec *__restrict__ grec, CandOut out)
 {
-    // EMIT = the EMISSION PASS over the rows the (lean) filter could not decide: the rows are x[recheck_list[0 .. *recheck_count)]
-    // (a fixed grid strides over their tiles), the main loop is the filter's, and the epilogue emits every row's candidate
-    // centres (header above) instead of listing the row.  It is a separate instantiation because the emission code costs the
-    // filter 9-18 % when it merely sits in the same kernel (0.865 vs 0.94-1.035 ms per 1M x 1024 with not one row undecided).
-    if (EMIT) n = (int64_t)*recheck_count;
+    // EMIT = 2 (the default for K <= 256): the filter's epilogue emits the candidate centres of every row it cannot decide, in
+    // place -- its 128 distances per lane are still in the accumulators (header above).  The first version of this cost the
+    // filter 6-18 % with NOT ONE row undecided (0.865 -> 0.94-1.035 ms per 1M x 1024) and was therefore split off into a second
+    // pass (EMIT = 1); the cost was not the emission code but ONE register pair: the compiler computed &labels[row] in the
+    // prologue, spilled it across the stage loop and re-loaded it from scratch (+ s_waitcnt vmcnt(0)) in every tile's epilogue.
+    // With the row index laundered at its use (below) the kernel is scratch-free and as fast as the lean one (0.81-0.83 ms).
+    // EMIT = 1 (ACAV_ASSIGN_EMIT=1): the EMISSION PASS over the rows a lean filter (EMIT = 0) listed: the rows are
+    // x[recheck_list[0 .. *recheck_count)] (a fixed grid strides over their tiles), same main loop, same emission.
+    constexpr bool LISTED = EMIT == 1;
+    if (LISTED) n = (int64_t)*recheck_count;
     constexpr int XSLOT = NW * 4096;  // bytes per row-ring slot: NW x 32 rows x 32 fp32
     constexpr int CQ = 16 / NW;       // centre-stage DMA pieces (1 KB = 16 centres x 64 B) per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
@@ -869,7 +874,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
     const int nchunks = d / FD_BK;
     const int ngroups = (K + 255) / 256;
   for (int64_t tile_it = blockIdx.x;; tile_it += gridDim.x) {  // one trip, except in the emission pass
-    if (EMIT && tile_it * (NW * 32) >= n) break;
+    if (LISTED && tile_it * (NW * 32) >= n) break;
     int64_t tile = tile_it;
     int cg0 = 0, cg1 = ngroups;
     if (GS) {
@@ -897,7 +902,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
         const int rc = row0 + rr < n ? rr : (int)(n - 1 - row0);  // ragged tail: re-read the last row
         voffx[q] = (unsigned)rc * (unsigned)d * 4u + (((lane & 7) ^ ((rr >> 1) & 7)) << 4);
         ax[q] = nullptr;
-        if (EMIT)
+        if (LISTED)
             ax[q] = reinterpret_cast<const char *>(x + (size_t)recheck_list[row0 + rc] * d) + (((lane & 7) ^ ((rr >> 1) & 7)) << 4);
     }
     const unsigned xring = lds_addr(sXr) + wq * 4096, cring = lds_addr(sCb) + wq * (CQ * 1024);
@@ -926,7 +931,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
         auto issue_x = [&]() {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (EMIT) {
+                if (LISTED) {
                     if (NT) dma16_asm_v64_nt(ax[q], xring + wx * XSLOT + q * 1024);
                     else dma16_asm_v64(ax[q], xring + wx * XSLOT + q * 1024);
                     ax[q] += FD_BK * 4;
@@ -1019,7 +1024,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
                     const int q = i - CQ;
 #ifndef ACAV_ABL_NOXDMA
                     if (c + 2 < nchunks) {
-                        if (EMIT) {
+                        if (LISTED) {
                             if (NT) dma16_asm_v64_nt(ax[q], xring + wx * XSLOT + q * 1024);
                             else dma16_asm_v64(ax[q], xring + wx * XSLOT + q * 1024);
                             ax[q] += FD_BK * 4;
@@ -1157,10 +1162,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
         o.d2 = __shfl_xor(t.d2, 32);
         run = top2_merge(run, top2_merge(t, o));
 
-        if (EMIT && !GS && ngroups == 1) {
+        if (EMIT != 0 && !GS && ngroups == 1) {
             // ---- acceptance test in BOTH half-lanes of a row, and for undecided rows the candidate emission (header above)
-            const int64_t li = row0 + wq * 32 + l31;  // position in the list of undecided rows
-            const int64_t row = li < n ? (int64_t)recheck_list[li] : -1;
+            // (l31 is laundered: the compiler otherwise computes &labels[row] in the prologue, keeps it across the stage loop in a
+            // spilled register pair and reloads it from scratch in every tile's epilogue -- 6 % of the filter with not a row undecided)
+            int l31e = l31;
+            asm volatile("" : "+v"(l31e));
+            const int64_t li = row0 + wq * 32 + l31e;  // the row itself, or its position in the list of undecided rows
+            const int64_t row = li < n ? (LISTED ? (int64_t)recheck_list[li] : li) : -1;
             const float xnorm = __builtin_sqrtf(xn);
             const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
             const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
@@ -1169,7 +1178,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
             const float tagged = 1.6e-5f * (fabsf(run.d1) + fabsf(run.d2));  // > (2^-16 + 2^-22) x 1.01
             // (every listed row fails the test again: same arithmetic as the filter's; the label is already the filter's k1)
             const bool undecided = row >= 0 && !((run.d2 - run.d1) > 2.0f * E + tagged);
+            if (EMIT == 2 && h == 0 && row >= 0) labels[row] = (int64_t)run.k1;
             if (__builtin_amdgcn_ballot_w64(undecided) != 0ull) {
+                // compiler barrier: nothing of the rare block (its 128 + 128 LDS reads above all) may be hoisted in front of
+                // the branch into the path every tile takes
+                asm volatile("" ::: "memory");
+                if (EMIT == 2 && undecided && h == 0) atomicAdd(&ctl->und_count, 1u);
                 // T: every v > T satisfies v - d1 > W + c |v|, W = 2 E + c |d1|, c = 1.6e-5 (untagged v: its own tag is not
                 // charged, the slack stays).  With u = d1 + W:  v >= 0: v (1 - c) > u  <=  v > u / (1 - c) < u (1 + 2 c);
                 // v < 0 (then u < 0): v (1 + c) > u  <=  v > u (1 - 2 c).  Both are u + 2 c |u|; the last term covers the
@@ -1292,7 +1306,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
         }
         return;
     }
-    if (EMIT) continue;  // emitted inside the group loop (the accumulators live there); next tile of the list
+    if (LISTED) continue;  // emitted inside the group loop (the accumulators live there); next tile of the list
+    if (EMIT == 2) break;
     if (h == 0 && row < n) {
         const float xnorm = __builtin_sqrtf(xn);
         const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
@@ -1645,8 +1660,11 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         const char *vcand = getenv("ACAV_ASSIGN_CAND");
         const bool cand = km->K <= 256 && !(vcand && vcand[0] == '0');
         // ACAV_ASSIGN_EMIT=0: experiment -- the lean filter kernel (no emission code) even with the candidate path on
+        // ACAV_ASSIGN_EMIT: 0 = no emission at all (undecided rows -> full exact sweep), 1 = lean filter + emission pass over the
+        // undecided rows, 2 (default) = emission in place in the filter's own epilogue (one pass)
         const char *vemit = getenv("ACAV_ASSIGN_EMIT");
         const bool emit_allowed = !(vemit && vemit[0] == '0');
+        const bool emit_inplace = !(vemit && vemit[0] == '1');
         const uint64_t pair_cap64 = std::min<uint64_t>(std::max<uint64_t>(4ull * (uint64_t)n, 65536ull), 0x7fffffffull);
         unsigned pair_cap = (unsigned)pair_cap64;
         if (const char *vcap = getenv("ACAV_CAND_PAIR_CAP")) {  // tests: force the pool-overflow path
@@ -1692,6 +1710,7 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
                                   : (nt_eff ? k_assign_bf16_rw<true, 8, false, 3, 2> : k_assign_bf16_rw<false, 8, false, 3, 2>);
             else if (gs) rwk = nt_eff ? k_assign_bf16_rw<true, 4, true, 2, 0> : k_assign_bf16_rw<false, 4, true, 2, 0>;
             else if (sched == 2) rwk = nt_eff ? k_assign_bf16_rw<true, 4, false, 2, 2> : k_assign_bf16_rw<false, 4, false, 2, 2>;
+            else if (emit && emit_inplace) rwk = nt_eff ? k_assign_bf16_rw<true, 4, false, 2, 0, 2> : k_assign_bf16_rw<false, 4, false, 2, 0, 2>;
             else rwk = nt_eff ? k_assign_bf16_rw<true, 4, false, 2, 0> : k_assign_bf16_rw<false, 4, false, 2, 0>;
         }
         const int fsmem = FD_DX * nw * 4096 + dcr * FD_SLOT;
@@ -1752,13 +1771,15 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
             // emission pass: the filter's main loop once more over the undecided rows only (a fixed grid strides over the tiles
             // of the list), the epilogue emits each row's candidate centres; then the exact canonical chains of those (row,
             // centre) pairs and the labels of those rows
-            auto ek = nt ? k_assign_bf16_rw<true, 4, false, 2, 0, true> : k_assign_bf16_rw<false, 4, false, 2, 0, true>;
-            ACAV_TRY(dyn_lds_once(reinterpret_cast<const void *>(ek), km->ctx.device, fsmem));
-            const int64_t egrid = std::min<int64_t>(ntiles, 2 * (int64_t)km->num_cus);
-            hipLaunchKernelGGL(ek, dim3((unsigned)egrid), dim3(256), fsmem, st, static_cast<const float *>(dx), n, km->d,
-                               km->cb16.as<__bf16>(), km->cn.as<float>(), km->counts.as<float>(), km->K, km->threshold(),
-                               (float)km->reinit_r, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, und_list, &ctl->und_count, ctl,
-                               (Top2Rec *)nullptr, cout);
+            if (!emit_inplace) {
+                auto ek = nt ? k_assign_bf16_rw<true, 4, false, 2, 0, 1> : k_assign_bf16_rw<false, 4, false, 2, 0, 1>;
+                ACAV_TRY(dyn_lds_once(reinterpret_cast<const void *>(ek), km->ctx.device, fsmem));
+                const int64_t egrid = std::min<int64_t>(ntiles, 2 * (int64_t)km->num_cus);
+                hipLaunchKernelGGL(ek, dim3((unsigned)egrid), dim3(256), fsmem, st, static_cast<const float *>(dx), n, km->d,
+                                   km->cb16.as<__bf16>(), km->cn.as<float>(), km->counts.as<float>(), km->K, km->threshold(),
+                                   (float)km->reinit_r, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, und_list, &ctl->und_count, ctl,
+                                   (Top2Rec *)nullptr, cout);
+            }
             // (3 workgroups of 4 waves per CU: the kernel is bound by the L2 -> L1 path -- 1, 2, 3, 4, 6 per CU all measure the same)
             hipLaunchKernelGGL(k_assign_cand, dim3((unsigned)(3 * km->num_cus)), dim3(256), 0, st, static_cast<const float *>(dx),
                                km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->threshold(),

@@ -224,7 +224,7 @@ def test_bf16_filter_path_is_bit_identical(env, case):
         assert rechecked < n // 20  # centred centres: the common component costs nothing
 
 
-@pytest.mark.parametrize("mode", ["plain", "pool_overflow", "cand_off", "discounted", "many_ties"])
+@pytest.mark.parametrize("mode", ["plain", "pool_overflow", "cand_off", "discounted", "many_ties", "emission_pass"])
 def test_candidate_restricted_recheck(env, mode, monkeypatch):
     """Round 4: a row the bf16 filter cannot decide is settled by the exact canonical distances of its CANDIDATE centres only
     (those the acceptance inequality cannot rule out against the filter's minimum; k_assign_cand), not by a sweep over all
@@ -232,13 +232,15 @@ def test_candidate_restricted_recheck(env, mode, monkeypatch):
     row and == the oracle; the statistics show the candidate path did the work.  `pool_overflow`: a pair pool of 1 000
     entries -- the rows that do not fit take the full exact sweep, same labels.  `cand_off`: ACAV_ASSIGN_CAND=0 restores the
     round-3 behaviour.  `discounted`: under-used centres (distance / r, raw filter).  `many_ties`: 40 identical centres --
-    more than 16 candidates per row -> full sweep, first index wins."""
+    more than 16 candidates per row -> full sweep, first index wins.  `emission_pass`: ACAV_ASSIGN_EMIT=1, the two-pass form."""
     torch, acav, O = env
     from acav100m_amd.clustering import KMeans
     if mode == "pool_overflow":
         monkeypatch.setenv("ACAV_CAND_PAIR_CAP", "1000")
     if mode == "cand_off":
         monkeypatch.setenv("ACAV_ASSIGN_CAND", "0")
+    if mode == "emission_pass":  # lean filter + a second pass over the listed rows instead of the in-place emission
+        monkeypatch.setenv("ACAV_ASSIGN_EMIT", "1")
     n, d, K = 40_000, 1024, 256
     rs = np.random.RandomState(21)
     cen = (0.02 * rs.randn(K, d)).astype(np.float32)
@@ -262,7 +264,7 @@ def test_candidate_restricted_recheck(env, mode, monkeypatch):
         assert torch.equal(lab, exact), f"{mode}: {(lab != exact).sum().item()} labels differ from the exact sweep"
         assert rows == n and rechecked == cand_rows + full_rows
         print(f"{mode}: undecided {rechecked}/{n}: {cand_rows} rows by {cand_pairs} candidate pairs, {full_rows} by the full sweep")
-        if mode == "plain":
+        if mode in ("plain", "emission_pass"):
             assert cand_rows > n // 4 and full_rows < cand_rows // 10 and cand_pairs >= cand_rows
         if mode == "discounted":  # the raw (uncentred) filter's bound is wide: many rows exceed 16 candidates
             assert cand_rows > 0 and cand_rows + full_rows > n // 4
