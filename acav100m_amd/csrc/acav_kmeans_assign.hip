@@ -805,12 +805,23 @@ struct AssignCtl {                  // device-side control block of one assign s
     unsigned long long last_alloc;  // copies for acav_kmeans_filter_stats, written by the sweep's last kernel
     unsigned last_f32, last_pool_over;
 };
-struct CandOut {  // where the emission pass writes: candidate rows / pairs, and the list of the full exact sweep
+struct CandOut {  // where the emission writes: candidate rows / pairs, and the list of the full exact sweep
     CandRow *crow;
     CandPair *cpair;
     int *f32_list;
+    float *und_T;  // K > 256: the candidate threshold T of every listed row (k_assign_merge knows the row's minimum over all groups)
     unsigned pair_cap;
 };
+// T: every filter value v > T satisfies v - d1 > W + c |v|, W = 2 E + c |d1|, c = 1.6e-5 (untagged v: its own tag is not charged,
+// the slack stays).  With u = d1 + W:  v >= 0: v (1 - c) > u  <=  v > u / (1 - c) < u (1 + 2 c);  v < 0 (then u < 0): v (1 + c) > u
+// <=  v > u (1 - 2 c).  Both are u + 2 c |u|; the last term covers the roundings of this evaluation itself (a few 2^-24 of
+// |d1| + W) sixfold.  NaN / inf bounds give T = NaN: `!(v > T)` holds for every v -> everything is a candidate -> full exact sweep.
+__device__ __forceinline__ float cand_threshold(float d1, float E)
+{
+    const float W = 2.0f * E + 1.6e-5f * fabsf(d1);
+    const float u = d1 + W;
+    return u + 3.2e-5f * fabsf(u) + 1.6e-6f * (fabsf(d1) + W);
+}
 constexpr unsigned CAND_MAX = 16;  // candidates per row beyond which the row takes the full exact sweep
 __device__ __forceinline__ AssignCtl *ctl_of_f32_count(const unsigned *f32_count)
 {
@@ -866,6 +877,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
     __bf16 *sCb = reinterpret_cast<__bf16 *>(fd_smem + FD_DX * XSLOT);      // [FD_DC][256][32] bf16
     float *sCn = reinterpret_cast<float *>(fd_smem);  // [256] epilogue scratch, aliases the (idle) row ring
     float *sSc = sCn + 256;                           // [256] 1, or 1/r for a discounted centre
+    // emission pass only (EMIT = 1; 4.5 KB past the rings): every row's candidate list, collected over the centre groups
+    unsigned *sCandN = reinterpret_cast<unsigned *>(fd_smem + FD_DX * XSLOT + DCR * FD_SLOT);  // [NW * 32]
+    unsigned short *sCandK = reinterpret_cast<unsigned short *>(sCandN + NW * 32);              // [NW * 32][CAND_MAX]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -895,15 +909,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
     const float cn_shift = centred ? cn[0] : 0.0f;
 
     unsigned voffx[4], voffc[CQ];
-    const char *ax[4];  // EMIT: the 64-bit source address of this lane's piece of row (wq * 4 + q) * 8 + (lane >> 3)
+    const char *ax[4], *ax0[4];  // emission pass: the 64-bit source address of this lane's piece of row (wq * 4 + q) * 8 + (lane >> 3)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int rr = (wq * 4 + q) * 8 + (lane >> 3);
         const int rc = row0 + rr < n ? rr : (int)(n - 1 - row0);  // ragged tail: re-read the last row
         voffx[q] = (unsigned)rc * (unsigned)d * 4u + (((lane & 7) ^ ((rr >> 1) & 7)) << 4);
-        ax[q] = nullptr;
+        ax0[q] = nullptr;
         if (LISTED)
-            ax[q] = reinterpret_cast<const char *>(x + (size_t)recheck_list[row0 + rc] * d) + (((lane & 7) ^ ((rr >> 1) & 7)) << 4);
+            ax0[q] = reinterpret_cast<const char *>(x + (size_t)recheck_list[row0 + rc] * d) + (((lane & 7) ^ ((rr >> 1) & 7)) << 4);
     }
     const unsigned xring = lds_addr(sXr) + wq * 4096, cring = lds_addr(sCb) + wq * (CQ * 1024);
 
@@ -912,6 +926,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
     for (int e = 0; e < 16; ++e) ssq[e] = 0.f;
     Top2 run = {INFINITY, 0x7fffffff, INFINITY};
     float xn = 0.f;  // ||x||^2 of this lane's row
+    if (LISTED && h == 0) sCandN[wq * 32 + l31] = 0u;  // (wave-private entries: ordered before the wave's own appends)
 #ifdef ACAV_RW_PROF
     long long rwp[6] = {0, 0, 0, 0, 0, 0};
     const long long rw_tstart = clock64(), rw_wstart = wall_clock64();
@@ -927,6 +942,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
         const char *gx = reinterpret_cast<const char *>(x + (size_t)row0 * d);
         const char *gc = reinterpret_cast<const char *>(cb + (size_t)kbase * 32);
         const size_t cstage = (size_t)ngroups * 256 * 64;  // bytes from one stage of the centre copy to the next
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ax[q] = ax0[q];  // every centre group streams the rows from their first column
         int wx = 0, wc = 0;
         auto issue_x = [&]() {
 #pragma unroll
@@ -1162,7 +1179,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
         o.d2 = __shfl_xor(t.d2, 32);
         run = top2_merge(run, top2_merge(t, o));
 
-        if (EMIT != 0 && !GS && ngroups == 1) {
+        if (EMIT != 0 && !GS && (ngroups == 1 || LISTED)) {
             // ---- acceptance test in BOTH half-lanes of a row, and for undecided rows the candidate emission (header above)
             // (l31 is laundered: the compiler otherwise computes &labels[row] in the prologue, keeps it across the stage loop in a
             // spilled register pair and reloads it from scratch in every tile's epilogue -- 6 % of the filter with not a row undecided)
@@ -1176,22 +1193,17 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
             const float sn = xnorm + cmax;
             const float E = (e1c * cmaxc + e1r * cmax) * xnorm + e2coef * sn * sn;
             const float tagged = 1.6e-5f * (fabsf(run.d1) + fabsf(run.d2));  // > (2^-16 + 2^-22) x 1.01
-            // (every listed row fails the test again: same arithmetic as the filter's; the label is already the filter's k1)
-            const bool undecided = row >= 0 && !((run.d2 - run.d1) > 2.0f * E + tagged);
+            // (every listed row fails the test again: same arithmetic as the filter's; the label is already the filter's k1.
+            // K > 256, emission pass: the row is undecided by construction and its threshold comes from k_assign_merge, which
+            // knows the minimum over ALL groups -- this group's own running minimum would give a wider window)
+            const bool undecided = row >= 0 && (ngroups > 1 || !((run.d2 - run.d1) > 2.0f * E + tagged));
             if (EMIT == 2 && h == 0 && row >= 0) labels[row] = (int64_t)run.k1;
             if (__builtin_amdgcn_ballot_w64(undecided) != 0ull) {
                 // compiler barrier: nothing of the rare block (its 128 + 128 LDS reads above all) may be hoisted in front of
                 // the branch into the path every tile takes
                 asm volatile("" ::: "memory");
                 if (EMIT == 2 && undecided && h == 0) atomicAdd(&ctl->und_count, 1u);
-                // T: every v > T satisfies v - d1 > W + c |v|, W = 2 E + c |d1|, c = 1.6e-5 (untagged v: its own tag is not
-                // charged, the slack stays).  With u = d1 + W:  v >= 0: v (1 - c) > u  <=  v > u / (1 - c) < u (1 + 2 c);
-                // v < 0 (then u < 0): v (1 + c) > u  <=  v > u (1 - 2 c).  Both are u + 2 c |u|; the last term covers the
-                // roundings of this evaluation itself (a few 2^-24 of |d1| + W) sixfold.  NaN / inf bounds -> T = +inf via the
-                // comparison form below (everything is a candidate -> overflow -> full exact sweep).
-                const float W = 2.0f * E + 1.6e-5f * fabsf(run.d1);
-                const float u = run.d1 + W;
-                float T = u + 3.2e-5f * fabsf(u) + 1.6e-6f * (fabsf(run.d1) + W);
+                float T = ngroups > 1 ? out.und_T[li < n ? li : 0] : cand_threshold(run.d1, E);  // (derivation at cand_threshold)
                 if (!undecided) T = -INFINITY;
                 // bit (ct * 16 + g * 4 + j) of m: distance (ct, g, j) of this lane is not > T.  Branch-free: compare, 0 / 1, shift-or.
                 unsigned m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
@@ -1239,6 +1251,23 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
                     }
                 }
 #undef ACAV_CAND_MARK
+                if (LISTED) {
+                    // emission pass: the row's candidates of this group go to its list in LDS (a row may collect them over
+                    // several groups); the row is settled after the last group, below
+                    const int r = wq * 32 + l31e;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        unsigned bits = w == 0 ? m0 : w == 1 ? m1 : w == 2 ? m2 : m3;
+                        while (bits) {
+                            const int bpos = __builtin_ctz(bits);
+                            bits &= bits - 1;
+                            const unsigned idx = (unsigned)(w * 32 + bpos);  // (ct, g, j) -> centre, as for the minimum
+                            const unsigned pos = atomicAdd(&sCandN[r], 1u);
+                            if (pos < CAND_MAX)
+                                sCandK[r * CAND_MAX + pos] = (unsigned short)(kbase + 4 * h + (int)((idx >> 4) * 32 + ((idx >> 2) & 3) * 8 + (idx & 3)));
+                        }
+                    }
+                } else {
                 const unsigned m[4] = {m0, m1, m2, m3};
                 const unsigned mine = __builtin_popcount(m[0]) + __builtin_popcount(m[1]) + __builtin_popcount(m[2]) + __builtin_popcount(m[3]);
                 const unsigned other = __shfl_xor(mine, 32);
@@ -1287,6 +1316,37 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
                         }
                     }
                 }
+                }
+            }
+        }
+    }
+    if (LISTED) {
+        // ---- emission pass: settle the tile's rows from their LDS lists (the two half-lanes of a row are in one wave: their
+        // LDS appends are ordered before this read)
+        const int r = wq * 32 + l31;
+        const int64_t li = row0 + r;
+        if (h == 0 && li < n) {
+            const int row = recheck_list[li];
+            const unsigned total = sCandN[r];
+            bool full = total > CAND_MAX || total == 0u;
+            unsigned long long got = 0ull;
+            if (!full) {
+                got = atomicAdd(&ctl->alloc, ((unsigned long long)total << 32) | 1ull);
+                if ((got >> 32) + total > (unsigned long long)out.pair_cap) {  // pool exhausted (the slot stays: a "lost" row)
+                    full = true;
+                    atomicAdd(&ctl->pool_over, 1u);
+                }
+                const CandRow cr = {row, (unsigned)(got >> 32), total, xn};
+                out.crow[(unsigned)got] = cr;
+                for (unsigned q = 0; q < total; ++q) {
+                    const unsigned wpos = (unsigned)(got >> 32) + q;
+                    const CandPair cp = {(unsigned)got, (int)sCandK[r * CAND_MAX + q]};
+                    if (wpos < out.pair_cap) out.cpair[wpos] = cp;
+                }
+            }
+            if (full) {
+                const unsigned fslot = atomicAdd(&ctl->f32_count, 1u);
+                out.f32_list[fslot] = row;
             }
         }
     }
@@ -1334,8 +1394,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
 __global__ __launch_bounds__(256) void k_assign_merge(const Top2Rec *__restrict__ grec, int ngroups, int64_t n,
                                                       const CentersAux *__restrict__ aux, float e1c, float e1r, float e2coef,
                                                       int64_t *__restrict__ labels, int *__restrict__ recheck_list,
-                                                      unsigned *__restrict__ recheck_count)
+                                                      unsigned *__restrict__ recheck_count, float *__restrict__ und_T)
 {
+    // und_T != NULL: the listed rows go to the emission pass; their candidate threshold (which needs the minimum over ALL
+    // groups: only this kernel has it) travels with the list
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= n) return;
     Top2Rec r0 = grec[row];
@@ -1355,6 +1417,7 @@ __global__ __launch_bounds__(256) void k_assign_merge(const Top2Rec *__restrict_
     if (!((run.d2 - run.d1) > 2.0f * E + tagged)) {
         const unsigned slot = atomicAdd(recheck_count, 1u);
         recheck_list[slot] = (int)row;
+        if (und_T) und_T[slot] = cand_threshold(run.d1, E);
     }
 }
 
@@ -1658,7 +1721,7 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         // candidate-restricted exact re-check (K <= 256: the filter's epilogue emits the candidates); ACAV_ASSIGN_CAND=0
         // sends every undecided row to the full exact sweep as in round 3
         const char *vcand = getenv("ACAV_ASSIGN_CAND");
-        const bool cand = km->K <= 256 && !(vcand && vcand[0] == '0');
+        const bool cand = !(vcand && vcand[0] == '0');  // (K > 256: through the emission pass over the rows k_assign_merge lists)
         // ACAV_ASSIGN_EMIT=0: experiment -- the lean filter kernel (no emission code) even with the candidate path on
         // ACAV_ASSIGN_EMIT: 0 = no emission at all (undecided rows -> full exact sweep), 1 = lean filter + emission pass over the
         // undecided rows, 2 (default) = emission in place in the filter's own epilogue (one pass)
@@ -1674,11 +1737,12 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         if (cand) {
             ACAV_TRY(km->cand_rows.ensure(sizeof(CandRow) * (size_t)n));
             ACAV_TRY(km->cand_pairs.ensure(sizeof(CandPair) * (size_t)pair_cap));
+            if (km->K > 256) ACAV_TRY(km->cand_T.ensure(sizeof(float) * (size_t)n));
         }
         CandRow *crow = cand ? km->cand_rows.as<CandRow>() : (CandRow *)nullptr;
         CandPair *cpair = cand ? km->cand_pairs.as<CandPair>() : (CandPair *)nullptr;
         int *und_list = km->recheck_list.as<int>(), *f32_list = und_list + n;
-        const CandOut cout = {crow, cpair, f32_list, pair_cap};
+        const CandOut cout = {crow, cpair, f32_list, cand && km->K > 256 ? km->cand_T.as<float>() : (float *)nullptr, pair_cap};
         const double acc = 1.01 * (double)km->d * ldexp(1.0, -24);  // accumulation error of one fp32 dot, relative
         const float e1c = (float)(2.02 * (ldexp(1.0, -8) * 1.002 + acc) * 1.001);   // x ||c'|| ||x||: bf16 roundings + filter dot
         const float e1r = (float)(2.02 * (acc + ldexp(1.0, -24)) * 1.001);           // x ||c|| ||x||: canonical dot, c - mu
@@ -1704,13 +1768,17 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
                                    const CentersAux *, float, float, float, int64_t *, int *, unsigned *, AssignCtl *, Top2Rec *,
                                    CandOut);
         FilterKern rwk = nullptr;
-        const bool emit = cand && emit_allowed && rw && !gs && ngroups == 1 && nw == 4 && sched == 0;
+        // K <= 256: the filter emits in place (or, ACAV_ASSIGN_EMIT=1, lists for the emission pass); K > 256: the (tile, group) pairs
+        // cannot know a row's minimum over all groups -- k_assign_merge lists the undecided rows with their thresholds and the
+        // emission pass runs the filter's main loop once more over those rows, all groups in one workgroup
+        const bool emit_gs = cand && emit_allowed && rw && gs;
+        const bool emit = cand && emit_allowed && rw && ((!gs && ngroups == 1 && nw == 4 && sched == 0) || emit_gs);
         if (rw) {
             if (nw == 8) rwk = gs ? (nt_eff ? k_assign_bf16_rw<true, 8, true, 3, 2> : k_assign_bf16_rw<false, 8, true, 3, 2>)
                                   : (nt_eff ? k_assign_bf16_rw<true, 8, false, 3, 2> : k_assign_bf16_rw<false, 8, false, 3, 2>);
             else if (gs) rwk = nt_eff ? k_assign_bf16_rw<true, 4, true, 2, 0> : k_assign_bf16_rw<false, 4, true, 2, 0>;
             else if (sched == 2) rwk = nt_eff ? k_assign_bf16_rw<true, 4, false, 2, 2> : k_assign_bf16_rw<false, 4, false, 2, 2>;
-            else if (emit && emit_inplace) rwk = nt_eff ? k_assign_bf16_rw<true, 4, false, 2, 0, 2> : k_assign_bf16_rw<false, 4, false, 2, 0, 2>;
+            else if (emit && emit_inplace && !emit_gs) rwk = nt_eff ? k_assign_bf16_rw<true, 4, false, 2, 0, 2> : k_assign_bf16_rw<false, 4, false, 2, 0, 2>;
             else rwk = nt_eff ? k_assign_bf16_rw<true, 4, false, 2, 0> : k_assign_bf16_rw<false, 4, false, 2, 0>;
         }
         const int fsmem = FD_DX * nw * 4096 + dcr * FD_SLOT;
@@ -1731,7 +1799,8 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
                                emit ? &ctl->und_count : f32_count, ctl, gs ? km->grec.as<Top2Rec>() : (Top2Rec *)nullptr, cout);
             if (gs)
                 hipLaunchKernelGGL(k_assign_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, km->grec.as<Top2Rec>(),
-                                   ngroups, n, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, f32_list, f32_count);
+                                   ngroups, n, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, emit_gs ? und_list : f32_list,
+                                   emit_gs ? &ctl->und_count : f32_count, emit_gs ? cout.und_T : (float *)nullptr);
         } else {
             auto kern = nt ? k_assign_bf16<true> : k_assign_bf16<false>;
             ACAV_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), km->ctx.device, FD_SMEM));
@@ -1771,11 +1840,17 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
             // emission pass: the filter's main loop once more over the undecided rows only (a fixed grid strides over the tiles
             // of the list), the epilogue emits each row's candidate centres; then the exact canonical chains of those (row,
             // centre) pairs and the labels of those rows
-            if (!emit_inplace) {
-                auto ek = nt ? k_assign_bf16_rw<true, 4, false, 2, 0, 1> : k_assign_bf16_rw<false, 4, false, 2, 0, 1>;
-                ACAV_TRY(dyn_lds_once(reinterpret_cast<const void *>(ek), km->ctx.device, fsmem));
-                const int64_t egrid = std::min<int64_t>(ntiles, 2 * (int64_t)km->num_cus);
-                hipLaunchKernelGGL(ek, dim3((unsigned)egrid), dim3(256), fsmem, st, static_cast<const float *>(dx), n, km->d,
+            if (!emit_inplace || emit_gs) {
+                // one workgroup per CU either way (rings + lists do not fit twice): for K > 256 and wide rows the 8-wave /
+                // 256-row tile of the main kernel (centre ring 3, DMA pieces spread), else 4 waves / 128 rows
+                const int enw = emit_gs && nw == 8 ? 8 : 4;
+                FilterKern ek = enw == 8 ? (nt ? k_assign_bf16_rw<true, 8, false, 3, 2, 1> : k_assign_bf16_rw<false, 8, false, 3, 2, 1>)
+                                         : (nt ? k_assign_bf16_rw<true, 4, false, 2, 0, 1> : k_assign_bf16_rw<false, 4, false, 2, 0, 1>);
+                const int esmem = FD_DX * enw * 4096 + (enw == 8 ? 3 : 2) * FD_SLOT + enw * 32 * (4 + 2 * (int)CAND_MAX);  // rings + lists
+                ACAV_TRY(dyn_lds_once(reinterpret_cast<const void *>(ek), km->ctx.device, esmem));
+                const int64_t erows = (int64_t)enw * 32;
+                const int64_t egrid = std::min<int64_t>((n + erows - 1) / erows, (int64_t)km->num_cus);
+                hipLaunchKernelGGL(ek, dim3((unsigned)egrid), dim3(enw * 64), esmem, st, static_cast<const float *>(dx), n, km->d,
                                    km->cb16.as<__bf16>(), km->cn.as<float>(), km->counts.as<float>(), km->K, km->threshold(),
                                    (float)km->reinit_r, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, und_list, &ctl->und_count, ctl,
                                    (Top2Rec *)nullptr, cout);

@@ -66,7 +66,7 @@ struct acav_kmeans {
     DevBuf centers, cn, counts, scalars;
     DevBuf stage_x, stage_lab, stage_forced, keys, xn, wg_sum, minval, thr, ctl;
     DevBuf cb16, caux, cmu, recheck_list, backup, grec, split_rings;
-    DevBuf cand_ctl, cand_rows, cand_pairs;
+    DevBuf cand_ctl, cand_rows, cand_pairs, cand_T;
     unsigned ctl_pair_cap = 0;  // candidate-restricted re-check of the assign sweep (acav_kmeans_assign.hip)
     hipEvent_t ev_f0 = nullptr, ev_f1 = nullptr;  // around the last k_assign_bf16 launch (acav_kmeans_filter_time)
     bool cb16_valid = false;  // bf16 copy of the centres matches `centers`
