@@ -961,7 +961,10 @@ __device__ __forceinline__ void tpw_refresh_norms(unsigned pend8, const float *s
     if (q == 0 && mine) sCn[row0 + c8] = norm2_from_sumsq(p);
 }
 
-template <bool RAGGED, int NCP>
+// ONE_X (round 4, rows wider than 1024 columns): ONE batch-row buffer instead of two -- the rows of step t + 1 are fetched as
+// soon as the FMA phase of step t has read the buffer (they land under the exchange) -- so that 8 centres + 8 rows of up to
+// ~2400 columns fit a CU's LDS.  A wave owns the column blocks wave, wave + 4, wave + 8, ... (DMA, dot items, update).
+template <bool RAGGED, int NCP, bool ONE_X = false>
 __global__ __launch_bounds__(256) void k_train_persistent_wide(
     const float *__restrict__ x, const float *__restrict__ xn, int b, int d, int ds, int K, float *__restrict__ centers,
     float *__restrict__ cn, float *__restrict__ counts, const float *__restrict__ thr, double lr0, float r,
@@ -970,11 +973,12 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
     constexpr int NCW = 8 * NCP;  // centres per workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char tpw_smem[];
     float *sC = reinterpret_cast<float *>(tpw_smem);  // [NCW][ds]
-    float *sX0 = sC + NCW * ds;                        // [2][8][ds]
-    float *sCn = sX0 + 2 * 8 * ds;                     // [NCW]
+    const int nblk = (d + 255) >> 8;
+    float *sX0 = sC + NCW * ds;                        // [2 or 1][8][ds]
+    float *sCn = sX0 + (ONE_X ? 1 : 2) * 8 * ds;       // [NCW]
     float *sCnt = sCn + NCW;                           // [NCW]
-    float *sPart = sCnt + NCW;                         // [NCP][4][64]
-    int *sBest = reinterpret_cast<int *>(sPart + NCP * 4 * 64);  // [32]
+    float *sPart = sCnt + NCW;                         // [NCP][nblk][64]
+    int *sBest = reinterpret_cast<int *>(sPart + NCP * nblk * 64);  // [32]
     __shared__ int sDead;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -982,29 +986,35 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
     const int kk = lane >> 3, ii = lane & 7;
     const int kbase = blockIdx.x * NCW, rbase = blockIdx.y * TP_NR;
     const int nck = min(NCW, K - kbase), nrv = min(TP_NR, b - rbase);
-    const int nblk = (d + 255) >> 8;
     const int ncg = gridDim.x;
-    const bool active = wave < nblk;  // this wave has a column block (DMA and update)
-    const bool col_ok = !RAGGED || wave * 256 + (lane << 2) < d;
-    auto sX = [&](int par) { return sX0 + par * 8 * ds; };
+    auto sX = [&](int par) { return ONE_X ? sX0 : sX0 + par * 8 * ds; };
+    auto dma_rows = [&](int t) {  // this wave's share of step t's batch rows
+        if (ONE_X) {  // issued while wave 0 exchanges: waves 1 .. 3 fetch everything (a barrier follows the wait at the step start)
+            if (wave > 0)
+                for (int blk = wave - 1; blk < nblk; blk += 3) tpw_dma_block<RAGGED>(sX0, x + (size_t)t * b * d, rbase, nrv, d, ds, blk, lane);
+        } else
+            for (int blk = wave; blk < nblk; blk += 4) tpw_dma_block<RAGGED>(sX(t & 1), x + (size_t)t * b * d, rbase, nrv, d, ds, blk, lane);
+    };
 
-    if (RAGGED && active) {  // ragged last block: columns d .. 256 nblk - 1 must read as zero for good
+    if (RAGGED && wave == ((nblk - 1) & 3)) {  // ragged last block: columns d .. 256 nblk - 1 must read as zero for good
+        const int blk = nblk - 1;
         for (int row = 0; row < NCW; ++row)
-            *reinterpret_cast<float4 *>(sC + row * ds + wave * 256 + (lane << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int row = 0; row < 16; ++row)
-            *reinterpret_cast<float4 *>(sX0 + row * ds + wave * 256 + (lane << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(sC + row * ds + blk * 256 + (lane << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int row = 0; row < (ONE_X ? 8 : 16); ++row)
+            *reinterpret_cast<float4 *>(sX0 + row * ds + blk * 256 + (lane << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // before the DMA below writes the same rows
     }
-    if (active)
+    if (RAGGED && ONE_X) __syncthreads();  // (one row buffer: its blocks are fetched by other waves than the one that zeroed them)
+    for (int blk = wave; blk < nblk; blk += 4)
         for (int cp = 0; cp < NCP; ++cp)
-            if (cp * 8 < nck) tpw_dma_block<RAGGED>(sC + cp * 8 * ds, centers, kbase + cp * 8, min(8, nck - cp * 8), d, ds, wave, lane);
+            if (cp * 8 < nck) tpw_dma_block<RAGGED>(sC + cp * 8 * ds, centers, kbase + cp * 8, min(8, nck - cp * 8), d, ds, blk, lane);
     if (tid < NCW) {
         const int k = kbase + (tid < nck ? tid : 0);
         sCn[tid] = cn[k];
         sCnt[tid] = counts[k];
     }
     if (tid == 0) sDead = 0;
-    if (need < T && active) tpw_dma_block<RAGGED>(sX(need & 1), x + (size_t)need * b * d, rbase, nrv, d, ds, wave, lane);
+    if (need < T) dma_rows(need);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -1018,18 +1028,19 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
             __syncthreads();
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my block of step t's rows landed (issued one step ago)
+            if (ONE_X) __syncthreads();  // ... and everybody else's: the blocks a wave multiplies were fetched by waves 1 .. 3
             float xn_t = 0.f, thr_t = 0.f;
             if (wave == 0) {  // in flight under the FMA chain
                 xn_t = xn[(size_t)t * b + rbase + (ii < nrv ? ii : 0)];
                 thr_t = thr[t];
             }
-            if (t + 1 < T && active) tpw_dma_block<RAGGED>(sX((t + 1) & 1), x + (size_t)(t + 1) * b * d, rbase, nrv, d, ds, wave, lane);
+            if (!ONE_X && t + 1 < T) dma_rows(t + 1);
             const float *xs = sX(t & 1);
-            for (int item = wave; item < nblk * NCP; item += 4) {  // (centre pass, column block) pairs over the 4 waves
-                const int cp = item / nblk, blk = item - cp * nblk;
-                sPart[(cp * 4 + blk) * 64 + lane] =
-                    dot_blocks<1>(sC + (cp * 8 + kk) * ds + blk * 256, xs + ii * ds + blk * 256, kk << 2, ii << 2, 0.f, true);
-            }
+            // (centre pass, column block) pairs: a wave multiplies the blocks it fetched (wave, wave + 4, ...) for every pass
+            for (int blk = wave; blk < nblk; blk += 4)
+                for (int cp = 0; cp < NCP; ++cp)
+                    sPart[(cp * nblk + blk) * 64 + lane] =
+                        dot_blocks<1>(sC + (cp * 8 + kk) * ds + blk * 256, xs + ii * ds + blk * 256, kk << 2, ii << 2, 0.f, true);
             if (pend) {  // uniform: the previous update's norm refresh, off the update's critical path
                 for (int cp = 0; cp < NCP; ++cp) {
                     const unsigned p8 = (unsigned)(pend >> (cp * 8)) & 0xFFu;
@@ -1038,11 +1049,12 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                 pend = 0;
             }
             __syncthreads();
+            if (ONE_X && t + 1 < T) dma_rows(t + 1);  // the one row buffer is free: the next step's rows land under the exchange
             if (wave == 0) {
                 unsigned long long key = ~0ull;
                 for (int cp = 0; cp < NCP; ++cp) {
-                    float acc = sPart[(cp * 4) * 64 + lane];
-                    for (int w = 1; w < nblk; ++w) acc = acc + sPart[(cp * 4 + w) * 64 + lane];  // canonical left fold
+                    float acc = sPart[(cp * nblk) * 64 + lane];
+                    for (int w = 1; w < nblk; ++w) acc = acc + sPart[(cp * nblk + w) * 64 + lane];  // canonical left fold
                     const int lc = cp * 8 + kk;
                     if (lc < nck && ii < nrv) {
                         const unsigned long long kc = pack_key(dist_epilogue(acc, xn_t, sCn[lc], sCnt[lc] < thr_t, r), kbase + lc);
@@ -1135,8 +1147,13 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                 touched |= (msk[c8] ? 1u : 0u) << c8;
             }
             if (!touched) continue;  // uniform over the workgroup
-            if (active) {
-                float4 dl[8];
+            // a wave's column blocks (wave, wave + 4, wave + 8: d <= 3072) side by side -- the loads of a batch row for all of
+            // them are in flight together (one after the other the update of a 2304-wide view took three round trips)
+            for (int blk0 = wave; blk0 < nblk; blk0 += 12) {
+                bool col_ok[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) col_ok[u] = blk0 + 4 * u < nblk && (!RAGGED || (blk0 + 4 * u) * 256 + (lane << 2) < d);
+                float4 dl[8][3];
 #pragma unroll
                 for (int c8 = 0; c8 < 8; ++c8) {
                     unsigned long long m = msk[c8];
@@ -1144,20 +1161,30 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                     while (m) {  // rows of the batch with this label, ascending (torch_scatter's CPU order)
                         const int i = __ffsll((long long)m) - 1;
                         m &= m - 1;
-                        const float4 x4 = col_ok ? *reinterpret_cast<const float4 *>(xb + (size_t)i * d + wave * 256 + (lane << 2))
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-                        const float4 v = make_float4(x4.x * lr32, x4.y * lr32, x4.z * lr32, x4.w * lr32);
-                        dl[c8] = have ? make_float4(dl[c8].x + v.x, dl[c8].y + v.y, dl[c8].z + v.z, dl[c8].w + v.w) : v;
+                        float4 x4[3];
+#pragma unroll
+                        for (int u = 0; u < 3; ++u)
+                            x4[u] = col_ok[u] ? *reinterpret_cast<const float4 *>(xb + (size_t)i * d + (blk0 + 4 * u) * 256 + (lane << 2))
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) {
+                            const float4 v = make_float4(x4[u].x * lr32, x4[u].y * lr32, x4[u].z * lr32, x4[u].w * lr32);
+                            dl[c8][u] = have ? make_float4(dl[c8][u].x + v.x, dl[c8][u].y + v.y, dl[c8][u].z + v.z, dl[c8][u].w + v.w) : v;
+                        }
                         have = true;
                     }
                 }
 #pragma unroll
                 for (int c8 = 0; c8 < 8; ++c8) {
-                    if (msk[c8] && col_ok) {
+                    if (msk[c8]) {
                         const float f = 1.0f - (float)__popcll(msk[c8]) * lr32;
-                        float4 *pc4 = reinterpret_cast<float4 *>(sC + (cp * 8 + c8) * ds + wave * 256 + ((lane ^ (c8 & 7)) << 2));
-                        const float4 c4 = *pc4;
-                        *pc4 = make_float4(c4.x * f + dl[c8].x, c4.y * f + dl[c8].y, c4.z * f + dl[c8].z, c4.w * f + dl[c8].w);
+#pragma unroll
+                        for (int u = 0; u < 3; ++u)
+                            if (col_ok[u]) {
+                                float4 *pc4 = reinterpret_cast<float4 *>(sC + (cp * 8 + c8) * ds + (blk0 + 4 * u) * 256 + ((lane ^ (c8 & 7)) << 2));
+                                const float4 c4 = *pc4;
+                                *pc4 = make_float4(c4.x * f + dl[c8][u].x, c4.y * f + dl[c8][u].y, c4.z * f + dl[c8][u].z, c4.w * f + dl[c8][u].w);
+                            }
                     }
                 }
             }
@@ -1179,12 +1206,14 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
         __syncthreads();
     }
     // ---- write the owned state back (one replica per centre group)
-    if (blockIdx.y == 0 && !sDead && active) {
-        for (int c = 0; c < nck; ++c) {
-            const float4 v = *reinterpret_cast<const float4 *>(sC + c * ds + wave * 256 + ((lane ^ (c & 7)) << 2));
-            if (col_ok) *reinterpret_cast<float4 *>(centers + (size_t)(kbase + c) * d + wave * 256 + (lane << 2)) = v;
+    if (blockIdx.y == 0 && !sDead)
+        for (int blk = wave; blk < nblk; blk += 4) {
+            const bool col_ok = !RAGGED || blk * 256 + (lane << 2) < d;
+            for (int c = 0; c < nck; ++c) {
+                const float4 v = *reinterpret_cast<const float4 *>(sC + c * ds + blk * 256 + ((lane ^ (c & 7)) << 2));
+                if (col_ok) *reinterpret_cast<float4 *>(centers + (size_t)(kbase + c) * d + blk * 256 + (lane << 2)) = v;
+            }
         }
-    }
     if (blockIdx.y == 0 && !sDead && tid < nck) {
         cn[kbase + tid] = sCn[tid];
         counts[kbase + tid] = sCnt[tid];
@@ -1928,6 +1957,27 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
     // NCP whose grid fits 3/4 of the device, else the whole device, within the LDS of a CU
     int ncp = 1, ds = 0, wide_wg = 0;
     size_t wide_smem = 0;
+    bool wide = false, one_x = false;
+    // rows wider than 1024 columns (round 4: the real SlowFast widths 1408 / 2304, and d = 2048 below K = 1024): the wide kernel
+    // with ONE centre pass per workgroup (or two), its waves looping over the 256-column blocks, one batch-row buffer when two do
+    // not fit -- no column split, no hand-off between workgroups.  ACAV_TALL=0 switches it off (A/B against the split kernel /
+    // the per-step launches).
+    const char *vtall = getenv("ACAV_TALL");
+    if (!persistent && steps > 0 && !(nop && nop[0] == '1') && !(vtall && vtall[0] == '0') && (km->d % 4) == 0 && km->d > TP_DS &&
+        b <= TP_MAXB && ((uintptr_t)fx & 15) == 0) {
+        ds = ((km->d + 255) / 256) * 256;
+        const int nblk_t = ds / 256, rgroups = (int)((b + TP_NR - 1) / TP_NR);
+        for (int c : {1, 2}) {
+            for (int xrows : {16, 8}) {
+                const int groups = (km->K + 8 * c - 1) / (8 * c);
+                const size_t smem = sizeof(float) * ((size_t)(8 * c + xrows) * ds + 2 * 8 * c + 64 * c * nblk_t + 32);
+                if (!wide && groups <= 64 && smem <= 160 * 1024 - 1024 && groups * rgroups <= km->num_cus && groups * rgroups <= room) {
+                    ncp = c, wide_wg = groups * rgroups, wide_smem = smem, one_x = xrows == 8;
+                    wide = persistent = true;
+                }
+            }
+        }
+    }
     if (shape_ok && !persistent && (nwg > occ * km->num_cus || !narrow_ok)) {
         ds = ((km->d + 255) / 256) * 256;
         const int rgroups = (int)((b + TP_NR - 1) / TP_NR);
@@ -1947,7 +1997,7 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
                     break;
                 }
             }
-        if (best_ncp) ncp = best_ncp, persistent = true;
+        if (best_ncp) ncp = best_ncp, persistent = wide = true;
     }
     // 1024 < d <= 2048 (cfg4's visual view): the columns are split over pairs of workgroups (k_train_persistent_split)
     bool split = false;
@@ -1967,7 +2017,7 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
         if (occ2 >= 1 && split_wg <= occ2 * km->num_cus && split_wg <= (budget ? *budget : occ2 * km->num_cus)) split = persistent = true;
     }
     if (!persistent) return ACAV_OK;
-    tc.nwg = split ? split_wg : ncp == 1 ? nwg : wide_wg;
+    tc.nwg = split ? split_wg : wide ? wide_wg : nwg;
     if (budget) *budget -= tc.nwg;
     tc.thr.resize((size_t)steps);
     for (int64_t t = 0; t < steps; ++t)
@@ -1995,7 +2045,7 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
                            km->xn.as<float>(), (int)b, km->d, km->K, km->centers.as<float>(), km->cn.as<float>(),
                            km->counts.as<float>(), km->thr.as<float>(), lr, (float)km->reinit_r, tc.dw, (int)need, (int)steps,
                            km->ctl.as<TrainCtl>(), km->scalars.as<StepScalars>(), t0r, t0r + t0b / sizeof(unsigned long long));
-    } else if (ncp == 1) {
+    } else if (!wide) {
         hipLaunchKernelGGL(tkern, dim3((km->K + TP_NC - 1) / TP_NC, (unsigned)((b + TP_NR - 1) / TP_NR)),
                            dim3(256), 0, st, fx, km->xn.as<float>(), (int)b, km->d, km->K, km->centers.as<float>(),
                            km->cn.as<float>(), km->counts.as<float>(), km->thr.as<float>(), lr, (float)km->reinit_r,
@@ -2005,7 +2055,12 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
         using WideKernel = void (*)(const float *, const float *, int, int, int, int, float *, float *, float *, const float *,
                                     double, float, const int64_t *, int, int, TrainCtl *, StepScalars *);
         WideKernel wk = nullptr;
-        if (ragged) wk = ncp == 2 ? k_train_persistent_wide<true, 2> : ncp == 4 ? k_train_persistent_wide<true, 4> : k_train_persistent_wide<true, 8>;
+        if (km->d > TP_DS) {  // the tall forms: one or two centre passes, one or two row buffers
+            if (ragged) wk = ncp == 1 ? (one_x ? k_train_persistent_wide<true, 1, true> : k_train_persistent_wide<true, 1, false>)
+                                      : (one_x ? k_train_persistent_wide<true, 2, true> : k_train_persistent_wide<true, 2, false>);
+            else wk = ncp == 1 ? (one_x ? k_train_persistent_wide<false, 1, true> : k_train_persistent_wide<false, 1, false>)
+                               : (one_x ? k_train_persistent_wide<false, 2, true> : k_train_persistent_wide<false, 2, false>);
+        } else if (ragged) wk = ncp == 2 ? k_train_persistent_wide<true, 2> : ncp == 4 ? k_train_persistent_wide<true, 4> : k_train_persistent_wide<true, 8>;
         else wk = ncp == 2 ? k_train_persistent_wide<false, 2> : ncp == 4 ? k_train_persistent_wide<false, 4> : k_train_persistent_wide<false, 8>;
         ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_smem));
         hipLaunchKernelGGL(wk, dim3((km->K + 8 * ncp - 1) / (8 * ncp), (unsigned)((b + TP_NR - 1) / TP_NR)), dim3(256), wide_smem, st,

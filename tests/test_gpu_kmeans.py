@@ -470,6 +470,7 @@ def test_split_column_persistent_kernel(env, n, d, K, b):
     torch, acav, O = env
     from acav100m_amd.clustering import KMeans
     os.environ["ACAV_SPLIT_MINK"] = "1"  # the product takes this kernel from K = 512 on; the small shapes exercise its edges
+    os.environ["ACAV_TALL"] = "0"         # ... and where both fit, the one-workgroup tall kernel (test below) would come first
     x = _mixture(d + K, n, d, K)
     acav.manual_seed(21)
     km = KMeans(None, d, K).to("cuda:0")
@@ -495,3 +496,39 @@ def test_split_column_persistent_kernel(env, n, d, K, b):
     assert km2.fallback == ref2.fallback and (km2.fallback > 0 or K > 64)  # many centres: the batch never piles up on one
     assert np.array_equal(km2.centers.numpy(), ref2.centers)
     os.environ.pop("ACAV_SPLIT_MINK", None)
+    os.environ.pop("ACAV_TALL", None)
+
+
+@pytest.mark.parametrize("n,d,K,b", [(2048, 1408, 256, 32), (1536, 2304, 64, 32), (2048, 2048, 512, 32), (3072, 1408, 1024, 32),
+                                     (1280, 1100, 40, 20), (1024, 2304, 300, 7), (1024, 1056, 24, 32)])
+def test_tall_persistent_kernel(env, n, d, K, b):
+    """Round 4: rows wider than 1024 columns on ONE workgroup per centre group (k_train_persistent_wide with one or two centre
+    passes, its waves looping over the 256-column blocks; one batch-row buffer where two do not fit) -- the real SlowFast
+    widths 1408 / 2304, d = 2048 below K = 1024, ragged widths (d % 256 != 0, d % 32 != 0), ragged centre and row groups.
+    Two epochs (warm-up inside the first launch) == the oracle bit for bit in ONE launch per epoch, the lr fallback too."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    x = _mixture(d + K, n, d, K)
+    acav.manual_seed(23)
+    km = KMeans(None, d, K).to("cuda:0")
+    ref = O.KMeans(d, K, O.Rng(23))
+    xt = torch.from_numpy(x).cuda()
+    for e in range(2):
+        km.train_epoch(xt, b, lr=0.01)
+        ref.train_epoch(x, b, lr=0.01)
+        assert np.array_equal(km.centers.numpy(), ref.centers), f"epoch {e}"
+        assert np.array_equal(km.counts.numpy(), ref.counts)
+    assert km.count == ref.count
+    launches, gave_up = km.train_stats()
+    assert launches == 2 and gave_up == 0, f"persistent launches {launches}, fallbacks {gave_up}: the tall kernel was not taken (or gave up)"
+    lab, _ = km.calc_best(xt)
+    assert np.array_equal(lab.cpu().numpy(), ref.calc_best(x)[0])
+    km2 = KMeans(None, d, K).to("cuda:0")
+    ref2 = O.KMeans(d, K, O.Rng(13))
+    km2.centers, km2.counts, km2.count = ref2.centers, ref2.counts, 0
+    acav.manual_seed(14)
+    ref2.rng = O.Rng(14)
+    km2.train_epoch(xt, b, lr=0.3)
+    ref2.train_epoch(x, b, lr=0.3)
+    assert km2.fallback == ref2.fallback and (km2.fallback > 0 or K > 64)
+    assert np.array_equal(km2.centers.numpy(), ref2.centers)
