@@ -196,8 +196,11 @@ def read_feature_sidecar(path):
         meta = load_json(d / 'meta.json')
         if meta.get('version') != SIDECAR_VERSION or meta.get('source') != _source_stamp(path):
             return None
-        out = {'filename': meta['filename'], 'shard_name': meta['shard_name'], 'shard_size': meta['shard_size'],
-               'views': OrderedDict(), 'tags': OrderedDict()}
+        # (the shard name of every row as ONE string object, as in an unpickled shard: the assignment files written from
+        # these columns are then the same bytes -- pickle memoises by identity -- whichever source the rows came from)
+        import sys
+        out = {'filename': meta['filename'], 'shard_name': [sys.intern(str(v)) for v in meta['shard_name']],
+               'shard_size': meta['shard_size'], 'views': OrderedDict(), 'tags': OrderedDict()}
         for kind, mk, name, dataset in meta['tags']:
             out['tags'][(kind, mk)] = (name, dataset)
         for i, (kind, mk, layer, dim) in enumerate(meta['views']):
