@@ -342,8 +342,9 @@ def main():
         value = n * world * args.steps / elapsed
         st = {key: float(np.mean(v)) for key, v in stage.items()}
         vq = int(np.argmax(dims))  # the view the roofline is quoted on: the widest (cfg4: the 2048-d visual view)
-        f_ms = float(np.mean([t for vi, t in filt_ms if vi == vq]))
-        s_ms = float(np.mean([t for vi, t in sweep_ms if vi == vq]))
+        same = len(set(dims)) == 1  # views of one shape: the figures are the mean over all their sweeps
+        f_ms = float(np.mean([t for vi, t in filt_ms if same or vi == vq]))
+        s_ms = float(np.mean([t for vi, t in sweep_ms if same or vi == vq]))
         per_view = [{"d": dv, "filter_ms": float(np.mean([t for vi, t in filt_ms if vi == i])),
                      "sweep_ms": float(np.mean([t for vi, t in sweep_ms if vi == i]))} for i, dv in enumerate(dims)]
         bytes_per_launch = n * d * 4 + n * 8
