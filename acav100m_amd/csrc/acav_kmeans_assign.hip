@@ -1721,7 +1721,9 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         // candidate-restricted exact re-check (K <= 256: the filter's epilogue emits the candidates); ACAV_ASSIGN_CAND=0
         // sends every undecided row to the full exact sweep as in round 3
         const char *vcand = getenv("ACAV_ASSIGN_CAND");
-        const bool cand = !(vcand && vcand[0] == '0');  // (K > 256: through the emission pass over the rows k_assign_merge lists)
+        // (K > 256: through the emission pass over the rows k_assign_merge lists.  n < 2^27: slots and pairs -- at most 16 per row --
+        // share one 64-bit allocator word, 32 bits each)
+        const bool cand = !(vcand && vcand[0] == '0') && n < ((int64_t)1 << 27);
         // ACAV_ASSIGN_EMIT=0: experiment -- the lean filter kernel (no emission code) even with the candidate path on
         // ACAV_ASSIGN_EMIT: 0 = no emission at all (undecided rows -> full exact sweep), 1 = lean filter + emission pass over the
         // undecided rows, 2 (default) = emission in place in the filter's own epilogue (one pass)
