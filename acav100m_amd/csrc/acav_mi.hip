@@ -940,9 +940,11 @@ __device__ __forceinline__ void fy_part_body(const unsigned *__restrict__ draws,
         if (j < L) {
             int h = j;
             if (j < L - 1) h = j + (int)(mt_temper(dr[u]) % (unsigned)(L - j));
-            if (h == j) {
-                src[j] = FY_EREF | (unsigned)j;  // the content of position j just before step j
-            } else {
+            // every step leaves its reference here, in step order (coalesced): "the content of position j just before step j"
+            // when it pulls from itself, else "the ORIGINAL content of h" -- right for the FIRST puller of a position (about
+            // half of all steps); k_fy_tile overwrites it for the others only, so half of its scattered stores never happen
+            src[j] = h == j ? (FY_EREF | (unsigned)j) : (unsigned)h;
+            if (h != j) {
                 const int tile = ltab[(L - 1 - h) >> gsh];
                 tr[u] = (tile << 16) | atomicAdd(&lhist[tile], 1);
                 hh[u] = h;
@@ -1073,7 +1075,7 @@ __device__ __forceinline__ void fy_tile_body(int L, const int *__restrict__ ebou
 #ifdef ACAV_FY_ABL_SRCSEQ  // timing-only ablation: the src stores in entry order instead of step order
             FY_ST_SRC(&src[((size_t)tile * 4096 + e) % (size_t)L], pred >= 0 ? (FY_EREF | (unsigned)pred) : (unsigned)(q_lo + p));
 #else
-            FY_ST_SRC(&src[j], pred >= 0 ? (FY_EREF | (unsigned)pred) : (unsigned)(q_lo + p));
+            if (pred >= 0) FY_ST_SRC(&src[j], FY_EREF | (unsigned)pred);  // a first puller keeps k_fy_part's A-ref (= q_lo + p)
 #endif
         }
         FY_CLK(3);
