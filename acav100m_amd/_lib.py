@@ -85,6 +85,14 @@ SIGNATURES = {
     "acav_mi_sync": [vp],
     "acav_mi_timer_begin": [vp],
     "acav_mi_timer_end": [vp, C.POINTER(f32)],
+    "acav_pkl_shard_open": [C.c_char_p, pp],
+    "acav_pkl_shard_close": [vp],
+    "acav_pkl_shard_info": [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)],
+    "acav_pkl_shard_view": [vp, i32, C.POINTER(i32), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                            C.POINTER(C.c_char_p), C.POINTER(i64)],
+    "acav_pkl_shard_copy_view": [vp, i32, vp, i64],
+    "acav_pkl_shard_meta": [vp, pp, C.POINTER(i64), pp, C.POINTER(i64), pp, pp, pp],
+    "acav_pkl_load_group": [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp],
 }
 
 _lib = None

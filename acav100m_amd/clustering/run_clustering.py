@@ -167,6 +167,7 @@ class _RowGroups:
         nw = int(nw) if nw is not None else int(args.computation.num_workers or 0)
         self.workers = max(0, min(nw, os.cpu_count() or 1))
         self.sizes, self.view_dims = sizes, view_dims
+        self._pool_warm = False
         total = sum(sizes[p.stem] for p in paths) * row_bytes
         if total <= budget:
             self.groups = [list(paths)]
@@ -191,10 +192,13 @@ class _RowGroups:
         return len(self.groups) > 1
 
     def _load(self, group):
-        # streamed: every shard is read once per epoch and once more for the assign sweep -- the first pass leaves the columnar
-        # twins behind (2.0 M rows/s instead of 0.5 M from pkl, profiles/r03_streamed.txt) unless ACAV_SHARD_SIDECAR says otherwise
-        import os
-        sidecar = 'write' if self.streamed and 'ACAV_SHARD_SIDECAR' not in os.environ else None
+        # streamed: every shard is read once per epoch and once more for the assign sweep.  Since the library reads the pkl
+        # files itself (acav_pkl_load_group: 2.1 M rows/s per pass against 2.5 M from the columnar twins and 0.8 M through
+        # pickle.load, profiles/r04_streamed_native.txt) a streamed run no longer writes twins on its own: ACAV_SHARD_SIDECAR=write
+        sidecar = None
+        if self.streamed and not self._pool_warm:  # the worker processes (sidecar reading, assignment writing) start before
+            self._pool_warm = True                  # the first host block is registered with the GPU runtime (io.warm_pool)
+            io.warm_pool(self.workers)
         return io.load_feature_shards(group, model_order=self.model_order, audio_models=self.audio_models, sidecar=sidecar,
                                       workers=self.workers, expect_rows=self.sizes, expect_views=self.view_dims)
 

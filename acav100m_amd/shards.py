@@ -241,6 +241,21 @@ def _pool(workers):
         return _POOL[1]
 
 
+def _noop(_):
+    return os.getpid()
+
+
+def warm_pool(workers):
+    """Start every worker process NOW.  Even `spawn` forks this process for an instant (fork + exec), and a fork of a process
+    whose host blocks are registered with the GPU runtime write-protects those pages: every one of 40 forks then makes the
+    driver revalidate the registered ranges (measured: 12 s of worker start-up and 18 s of stalled GPU work when the pool
+    was first needed at the end of a streamed run, against 1-2 s at its start).  Called before the first block is pinned."""
+    if workers and workers > 1:
+        ex = _pool(workers)
+        for _ in range(_POOL[0]):  # one process per submit while none is idle yet; they finish starting in the background
+            ex.submit(_noop, 0)
+
+
 def _worker_load(job):
     """(path, mode, row offset, expected rows, [(view, d, shm name, total rows)]) -> per-row metadata, or a reason string"""
     from multiprocessing import shared_memory
@@ -350,7 +365,6 @@ _atexit.register(_SHM.clear)
 def _load_parallel(paths, mode, expect_rows, expect_views, workers):
     """-> FeatureTable whose views live in shared memory, or None (a shard did not have the expected layout: the caller
     reads the group the plain way).  expect_rows: path stem -> rows; expect_views: OrderedDict view -> d."""
-    import weakref
     paths = [Path(p) for p in paths]
     try:
         counts = [int(expect_rows[p.stem]) for p in paths]
@@ -375,6 +389,12 @@ def _load_parallel(paths, mode, expect_rows, expect_views, workers):
     if results is None or any(not isinstance(r, dict) for r in results):
         _SHM.release(shms)
         return None
+    return _assemble_table(paths, counts, results, expect_views, shms, total)
+
+
+def _assemble_table(paths, counts, results, expect_views, shms, total):
+    """per-shard results (metadata dicts; the rows are already in the shared blocks) -> FeatureTable"""
+    import weakref
     table = FeatureTable()
     mats = [np.ndarray((total, int(d)), np.float32, buffer=shm.buf) for (view, d), shm in zip(expect_views.items(), shms)]
     src = dst = 0
@@ -404,6 +424,171 @@ def _load_parallel(paths, mode, expect_rows, expect_views, workers):
     return table
 
 
+# ---- native shard reading (round 4).  The worker processes above still pay pickle.load: ~10 Python objects per clip and
+# view, then np.stack and the copy into the shared block -- 24 ms per 1000-clip shard in each of 40 processes on the GPU box
+# (0.5-0.9 M rows/s per pass).  libacav_hip's acav_pkl_* (csrc/acav_shardio.hip) read the file, walk the pickle opcodes once
+# and copy every vector straight into its row of the table: 3-4 ms per shard, a whole GROUP of shards per call on the
+# library's own threads (no interpreter lock, no spawn, no pipes, no result pickling: Python threads calling a per-shard
+# entry point convoyed on the GIL and on the process-wide mm lock of their mappings).  A shard outside the reader's subset is
+# read with pickle.load; the table is the same either way (tests/test_shards_io.py).
+_KINDS = ('audio', 'video')
+
+
+def _native_lib():
+    if os.environ.get('ACAV_SHARD_NATIVE', '1') == '0':
+        return None
+    try:
+        from . import _lib
+        return _lib.load_library()
+    except Exception:  # library not built: the worker processes still work
+        return None
+
+
+def _dec(b):
+    return None if b is None else b.decode('utf-8', 'surrogatepass')
+
+
+def _native_views(lib, h, nviews):
+    import ctypes as C
+    specs, tags = [], OrderedDict()
+    for v in range(nviews):
+        kind, mk, layer, ex, ds, d = C.c_int(), C.c_char_p(), C.c_char_p(), C.c_char_p(), C.c_char_p(), C.c_int64()
+        lib.acav_pkl_shard_view(h, v, C.byref(kind), C.byref(mk), C.byref(layer), C.byref(ex), C.byref(ds), C.byref(d))
+        key = (_KINDS[kind.value], _dec(mk.value), _dec(layer.value))
+        tags.setdefault(key[:2], (_dec(ex.value), _dec(ds.value)))
+        specs.append((v, key, d.value))
+    return specs, tags
+
+
+def _native_meta(lib, h, n, n_names, stem):
+    """-> filename, shard_name, shard_size lists of the handle's rows, as _shard_columns_from_rows builds them"""
+    import ctypes as C
+    if not n:
+        return [], [], []
+    fn, fl, nm, nl = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+    ids, of_row, ssz = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    lib.acav_pkl_shard_meta(h, C.byref(fn), C.byref(fl), C.byref(nm), C.byref(nl), C.byref(ids), C.byref(of_row), C.byref(ssz))
+    filename = C.string_at(fn, fl.value).decode('utf-8', 'surrogatepass').split('\n')
+    # ONE str object per shard_name object of the pickle (pickle.load gives the rows of a shard the same object; the
+    # assignment shards written from this table memoise by identity)
+    names = C.string_at(nm, nl.value).decode('utf-8', 'surrogatepass').split('\n') if n_names else []
+    by_id = dict(zip(np.frombuffer((C.c_int64 * n_names).from_address(ids.value), np.int64).tolist(), names)) if n_names else {}
+    by_id[-1] = stem
+    shard_name = [by_id[i] for i in np.frombuffer((C.c_int64 * n).from_address(of_row.value), np.int64).tolist()]
+    sizes = np.frombuffer((C.c_int64 * n).from_address(ssz.value), np.int64)
+    shard_size = np.where(sizes == np.iinfo(np.int64).min, n, sizes).tolist()
+    return filename, shard_name, shard_size
+
+
+def read_shard_native(lib, path, dest=None, base=0, n_expect=None):
+    """One pkl shard through acav_pkl_shard_*: -> columns dict as _shard_columns_from_rows builds it, or None when the
+    shard is outside the native reader's subset.  dest: {view: [total, d] matrix} -- the vectors then go straight into
+    rows [base, base + n) (and columns['views'] holds those slices); 'layout' when they do not fit."""
+    import ctypes as C
+    h = C.c_void_p()
+    if lib.acav_pkl_shard_open(os.fsencode(str(path)), C.byref(h)) != 0:
+        return None
+    try:
+        rows, nv, nn = C.c_int64(), C.c_int(), C.c_int()
+        lib.acav_pkl_shard_info(h, C.byref(rows), C.byref(nv), C.byref(nn))
+        n = rows.value
+        out = {'views': OrderedDict()}
+        specs, out['tags'] = _native_views(lib, h, nv.value)
+        if dest is not None:
+            if (n_expect is not None and n > n_expect) or {k for _, k, _ in specs} != set(dest) or \
+                    any(dest[k].shape[1] != d for _, k, d in specs):
+                return 'layout'
+        for v, key, d in specs:
+            mat = dest[key][base:base + n] if dest is not None else np.empty((n, d), np.float32)
+            if n:
+                lib.acav_pkl_shard_copy_view(h, v, mat.ctypes.data_as(C.c_void_p), mat.strides[0] // 4)
+            out['views'][key] = mat
+        out['filename'], out['shard_name'], out['shard_size'] = _native_meta(lib, h, n, nn.value, Path(path).stem)
+        return out
+    finally:
+        lib.acav_pkl_shard_close(h)
+
+
+def _load_native(paths, expect_rows, expect_views, workers):
+    """_load_parallel through acav_pkl_load_group (one call per group, the library's own threads) instead of worker
+    processes + pickle.load; same table, same fallbacks.  pkl shards only: sidecars stay with the worker processes."""
+    import ctypes as C
+    lib = _native_lib()
+    if lib is None:
+        return None
+    paths = [Path(p) for p in paths]
+    try:
+        counts = [int(expect_rows[p.stem]) for p in paths]
+    except KeyError:
+        return None
+    total, n, nv = sum(counts), len(paths), len(expect_views)
+    if total == 0:
+        return None
+    world = max(1, int(os.environ.get('WORLD_SIZE', '1') or 1))
+    threads = max(1, min(max(int(workers), 8), max(2, (os.cpu_count() or 2) // world), 64))
+    threads = int(os.environ.get('ACAV_SHARD_THREADS', threads))  # experiments (tools/exp/loader_probe.py)
+    shms = [_SHM.acquire(max(total * int(d) * 4, 1)) for d in expect_views.values()]
+    mats = [np.ndarray((total, int(d)), np.float32, buffer=shm.buf) for d, shm in zip(expect_views.values(), shms)]
+    keys = [tuple(v) for v in expect_views]
+    c_paths = (C.c_char_p * n)(*[os.fsencode(str(p)) for p in paths])
+    c_base = (C.c_int64 * n)(*np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64).tolist())
+    c_exp = (C.c_int64 * n)(*counts)
+    c_kind = (C.c_int * nv)(*[_KINDS.index(k[0]) for k in keys])
+    c_mk = (C.c_char_p * nv)(*[k[1].encode('utf-8', 'surrogatepass') for k in keys])
+    c_layer = (C.c_char_p * nv)(*[k[2].encode('utf-8', 'surrogatepass') for k in keys])
+    c_dims = (C.c_int64 * nv)(*[int(d) for d in expect_views.values()])
+    c_dest = (C.c_void_p * nv)(*[m.ctypes.data for m in mats])
+    handles, status = (C.c_void_p * n)(), (C.c_int * n)()
+    import time
+    t0 = time.perf_counter()
+    rc = lib.acav_pkl_load_group(c_paths, n, c_base, c_exp, nv, c_kind, c_mk, c_layer, c_dims, c_dest, threads, handles, status)
+    t1 = time.perf_counter()
+    results = []
+    try:
+        if rc != 0:
+            results = None
+        for i, p in enumerate(paths if results is not None else []):
+            if status[i] == 2:
+                results = None
+                break
+            if status[i] == 0:
+                h = C.c_void_p(handles[i])
+                rows, nvs, nn = C.c_int64(), C.c_int(), C.c_int()
+                lib.acav_pkl_shard_info(h, C.byref(rows), C.byref(nvs), C.byref(nn))
+                _, tags = _native_views(lib, h, nvs.value)
+                fnm, snm, ssz = _native_meta(lib, h, rows.value, nn.value, p.stem)
+                results.append({'filename': fnm, 'shard_name': snm, 'shard_size': ssz, 'tags': list(tags.items()), 'rows': rows.value})
+                continue
+            try:  # outside the native subset (or unreadable): the general reader
+                columns = _shard_columns_from_rows(load_pickle(p), p.stem)
+            except Exception as exc:
+                results.append({'skip': '{}'.format(exc)})
+                continue
+            k = len(columns['filename'])
+            if k > counts[i] or set(columns['views']) != set(keys) or \
+                    any(columns['views'][key].shape != (k, m.shape[1]) for key, m in zip(keys, mats)):
+                results = None
+                break
+            for key, m in zip(keys, mats):
+                m[c_base[i]:c_base[i] + k] = columns['views'][key]
+            results.append({'filename': columns['filename'], 'shard_name': columns['shard_name'], 'shard_size': columns['shard_size'],
+                            'tags': list(columns['tags'].items()), 'rows': k})
+    finally:
+        for i in range(n):
+            if handles[i]:
+                lib.acav_pkl_shard_close(C.c_void_p(handles[i]))
+    del mats
+    if results is None:
+        _SHM.release(shms)
+        return None
+    table = _assemble_table(paths, counts, results, expect_views, shms, total)
+    if os.environ.get('ACAV_SHARD_TIMING'):
+        t2 = time.perf_counter()
+        print('[acav] native shard group: {} shards, {} rows, {} threads: read + parse + copy {:.1f} ms, row metadata + table {:.1f} ms'.format(
+            n, len(table), threads, (t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
+    return table
+
+
 def load_feature_shards(paths, model_order=None, audio_models=(), sidecar=None, workers=0, expect_rows=None, expect_views=None):
     """Read shards in the given order (training order of a single-stream loader: sorted shards,
     rows in file order -- clustering data/clustering.py:153-186 with num_workers=0).
@@ -414,23 +599,30 @@ def load_feature_shards(paths, model_order=None, audio_models=(), sidecar=None, 
     or unreadable shard, another view set -- falls back to the plain loop below, which reports and skips as ever."""
     mode = sidecar_mode(sidecar)
     paths = list(paths)
-    if workers and workers > 1 and len(paths) >= 16 and expect_rows is not None and expect_views:  # worker start-up ~1 s
-        table = _load_parallel(paths, mode, expect_rows, expect_views, min(int(workers), len(paths)))
+    if workers and workers > 1 and expect_rows is not None and expect_views:
+        table = None
+        if mode == 'off' or (mode == 'auto' and not any(feature_sidecar_dir(p).exists() for p in paths)):
+            table = _load_native(paths, expect_rows, expect_views, int(workers))  # the library's reader and threads (above)
+        if table is None and len(paths) >= 16:  # worker processes + pickle.load / sidecars (start-up ~1 s)
+            table = _load_parallel(paths, mode, expect_rows, expect_views, min(int(workers), len(paths)))
         if table is not None:
             return table
     table = FeatureTable()
     parts = OrderedDict()
+    lib = _native_lib()
     for path in paths:
         path = Path(path)
         columns = read_feature_sidecar(path) if mode != 'off' else None
         if columns is None:
-            try:
-                rows = load_pickle(path)
-            except Exception as exc:  # EOFError and friends
-                print(exc)
-                print('Exception in shard loading: {}'.format(path.stem))
-                continue
-            columns = _shard_columns_from_rows(rows, path.stem)
+            columns = read_shard_native(lib, path) if lib is not None else None
+            if columns is None:  # outside the native reader's subset (or no library): the general reader
+                try:
+                    rows = load_pickle(path)
+                except Exception as exc:  # EOFError and friends
+                    print(exc)
+                    print('Exception in shard loading: {}'.format(path.stem))
+                    continue
+                columns = _shard_columns_from_rows(rows, path.stem)
             if mode == 'write':
                 try:
                     write_feature_sidecar(path, columns)

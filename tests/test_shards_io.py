@@ -184,3 +184,145 @@ def test_parallel_loader_keeps_going_over_short_and_broken_shards(tmp_path):
     assert os.path.basename(paths[8])[:-4] not in par.shard_rows
     for v in serial.views:
         assert par.views[v].shape == serial.views[v].shape and np.array_equal(par.views[v], serial.views[v])
+
+
+def _columns_equal(a, b):
+    assert a["filename"] == b["filename"] and a["shard_name"] == b["shard_name"] and a["shard_size"] == b["shard_size"]
+    # pickle.load gives rows that shared a str object ONE object again; the native reader reproduces the identities
+    ida = [[i for i, y in enumerate(a["shard_name"]) if y is x][0] for x in a["shard_name"]]
+    idb = [[i for i, y in enumerate(b["shard_name"]) if y is x][0] for x in b["shard_name"]]
+    assert ida == idb
+    assert list(a["tags"].items()) == list(b["tags"].items())
+    assert list(a["views"]) == list(b["views"])
+    for v in a["views"]:
+        assert a["views"][v].dtype == np.float32 and a["views"][v].shape == b["views"][v].shape
+        assert np.array_equal(a["views"][v], b["views"][v])
+
+
+def _synthetic_rows(rs, n, layout, name="shard-000007"):
+    rows = []
+    for i in range(n):
+        va, vb, vv = (rs.randn(d).astype(np.float32) for d in (8, 12, 20))
+        if layout == "dict":
+            audio, video = {"conv4": va, "fc": vb}, {"layer_0": vv}
+        elif layout == "list":
+            audio, video = [va, vb], [vv]
+        elif layout == "tuple":
+            audio, video = (va, vb), (vv,)
+        else:  # the bare vector of a non-layer extractor
+            audio, video = va, vv
+        rows.append({"video_features": [{"model_key": "vis", "extractor_name": "V", "dataset": None, "array": video}],
+                     "audio_features": [{"model_key": "aud", "extractor_name": "A", "dataset": "ds", "array": audio},
+                                        {"model_key": "aud2", "array": {"only": vb[::-1].copy()}}],
+                     "filename": "clip é中_%d.mp4" % i, "shard_size": n, "shard_name": name,
+                     "segment": (10, 20.5), "extra": {"flag": True, "none": None, "big": 1 << 40, "neg": -5, "raw": b"\x00\x01",
+                                                      "nested": [1, 2, (3,)], "long": "x" * 300}})
+    return rows
+
+
+def test_native_shard_reader_equals_pickle(tmp_path):
+    """csrc/acav_shardio.hip (acav_pkl_shard_*: the shard file mapped, its pickle opcodes walked once, every vector copied
+    straight into the table) against pickle.load + _shard_columns_from_rows -- what the reference's own loader does
+    (clustering/code/data/clustering.py:78-113, 172): every array layout, pickle protocols 3-5 (2: refused), missing keys, shared and
+    distinct shard_name objects; shards outside the reader's subset must be REFUSED (the caller then unpickles)."""
+    from acav100m_amd import _lib
+    lib = _lib.load_library()
+    rs = np.random.RandomState(0)
+    seen_native = 0
+    for layout in ("dict", "list", "tuple", "bare"):
+        for proto in (2, 3, 4, 5):
+            rows = _synthetic_rows(rs, 9, layout)
+            if layout == "list" and proto == 4:       # rows without the optional keys; distinct-but-equal name objects
+                for i, r in enumerate(rows):
+                    del r["shard_size"]
+                    if i % 2:
+                        del r["shard_name"]
+                    else:
+                        r["shard_name"] = "".join(["shard-", "x"])  # a fresh object per row
+            p = tmp_path / ("s_%s_%d.pkl" % (layout, proto))
+            with open(p, "wb") as f:
+                pickle.dump(rows, f, protocol=proto)
+            ref = io._shard_columns_from_rows(io.load_pickle(p), p.stem)
+            nat = io.read_shard_native(lib, p)
+            if proto == 2:  # Python 3 writes bytes as _codecs.encode(latin-1 text) there: not a payload to copy -- refused
+                assert nat is None
+                continue
+            assert nat is not None, (layout, proto, lib.acav_last_error())
+            seen_native += 1
+            _columns_equal(nat, ref)
+            # into a caller's table at an offset, with a wider row stride
+            dest = {v: np.full((20, m.shape[1]), 7.0, np.float32) for v, m in ref["views"].items()}
+            nat2 = io.read_shard_native(lib, p, dest, 5, 9)
+            _columns_equal(nat2, ref)
+            for v, m in dest.items():
+                assert np.array_equal(m[5:14], ref["views"][v]) and (m[:5] == 7).all() and (m[14:] == 7).all()
+            assert io.read_shard_native(lib, p, dest, 0, 8) == "layout"  # more rows than reserved
+    assert seen_native == 12
+    # outside the subset: refused, never guessed
+    base = _synthetic_rows(rs, 4, "dict")
+    cases = {}
+    r = [dict(x) for x in base]
+    r[2] = dict(r[2], audio_features=[dict(r[2]["audio_features"][0], array={"conv4": np.zeros(8, np.float64), "fc": np.zeros(12, np.float32)})]
+                + r[2]["audio_features"][1:])
+    cases["float64 vector"] = r
+    r = [dict(x) for x in base]
+    r[3] = dict(r[3], audio_features=r[3]["audio_features"][:1])
+    cases["rows with different view lists"] = r
+    r = [dict(x) for x in base]
+    r[1] = dict(r[1], video_features=[dict(r[1]["video_features"][0], array={"layer_0": np.zeros((2, 10), np.float32)})])
+    cases["2-d vector"] = r
+    r = [dict(x) for x in base]
+    r[0] = dict(r[0], video_features=[dict(r[0]["video_features"][0], array={"layer_0": np.zeros(21, np.float32)})])
+    cases["rows with different vector lengths"] = r
+    cases["big-endian vectors"] = [dict(x, video_features=[dict(x["video_features"][0], array={"layer_0": np.zeros(20, ">f4")})]) for x in base]
+    cases["not a list"] = {"rows": base}
+    for what, obj in cases.items():
+        p = tmp_path / "bad.pkl"
+        with open(p, "wb") as f:
+            pickle.dump(obj, f)
+        assert io.read_shard_native(lib, p) is None, what
+    with open(tmp_path / "bad.pkl", "wb") as f:
+        pickle.dump(base, f, protocol=0)  # text opcodes
+    assert io.read_shard_native(lib, tmp_path / "bad.pkl") is None
+    with open(tmp_path / "bad.pkl", "wb") as f:
+        f.write(pickle.dumps(base)[:-40])  # truncated
+    assert io.read_shard_native(lib, tmp_path / "bad.pkl") is None
+    assert io.read_shard_native(lib, tmp_path / "missing.pkl") is None
+
+
+def test_native_loader_equals_worker_processes(tmp_path, monkeypatch):
+    """load_feature_shards through the native group reader (acav_pkl_load_group) == the same call with ACAV_SHARD_NATIVE=0 (worker processes +
+    pickle.load) == the plain loop without the library's reader: a group with a short shard, an unreadable one and one the
+    native reader refuses (float64 vectors: read by pickle.load)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import synth
+    from collections import OrderedDict
+    glob = synth.write_feature_shards(str(tmp_path), n_shards=18, rows=10, seed=9, audio_dims=[8, 4], video_dims=[16])
+    paths = sorted(io.brace_expand(glob))
+    sizes = {os.path.basename(p)[:-4]: 10 for p in paths}
+    io.dump_pickle(io.load_pickle(paths[2])[:6], paths[2])
+    with open(paths[11], "wb") as f:
+        f.write(b"\x80\x04garbage")
+    rows = io.load_pickle(paths[5])
+    for r in rows:
+        r["audio_features"][0]["array"]["layer_1"] = r["audio_features"][0]["array"]["layer_1"].astype(np.float64)
+    io.dump_pickle(rows, paths[5])
+    monkeypatch.setenv("ACAV_SHARD_NATIVE", "0")
+    plain = io.load_feature_shards(paths, sidecar="off")
+    dims = OrderedDict((v, m.shape[1]) for v, m in plain.views.items())
+    procs = io.load_feature_shards(paths, sidecar="off", workers=3, expect_rows=sizes, expect_views=dims)
+    monkeypatch.setenv("ACAV_SHARD_NATIVE", "1")
+    calls, taken = [], []
+    orig, orig_group = io.read_shard_native, io._load_native
+    monkeypatch.setattr(io, "read_shard_native", lambda *a, **k: calls.append(1) or orig(*a, **k))
+    monkeypatch.setattr(io, "_load_native", lambda *a, **k: taken.append(orig_group(*a, **k)) or taken[-1])
+    native = io.load_feature_shards(paths, sidecar="off", workers=3, expect_rows=sizes, expect_views=dims)
+    plain_native = io.load_feature_shards(paths, sidecar="off")
+    assert len(calls) == len(paths) and taken == [native] and getattr(native, "_shm", None)  # the group call, then the plain loop
+    for t in (procs, native, plain_native):
+        assert len(t) == len(plain) == 10 * 16 + 6
+        assert t.filename == plain.filename and t.shard_name == plain.shard_name and t.shard_size == plain.shard_size
+        assert t.shard_rows == plain.shard_rows and t.tags == plain.tags and list(t.views) == list(plain.views)
+        for v in plain.views:
+            assert np.array_equal(t.views[v], plain.views[v])

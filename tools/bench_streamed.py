@@ -141,7 +141,10 @@ def main():
     os.environ["ACAV_RESIDENT_BYTES"] = str(int(budget * 1e9))
     print("data %.1f GB of fp32 rows, device budget %.1f GB -> groups of %.1f GB" % (n * d * 8 / 1e9, budget, budget / 2), flush=True)
     os.environ["ACAV_SHARD_SIDECAR"] = "off"
-    run(glob, os.path.join(root, "out_pkl"), n, k, "pkl", d)
+    # the first run of the process also pays the one-time costs (library and kernel loading, fresh shared blocks and their
+    # registration with the GPU runtime): the second run over the same pkl files is the steady state
+    run(glob, os.path.join(root, "out_pkl"), n, k, "pkl (1st)", d)
+    run(glob, os.path.join(root, "out_pkl2"), n, k, "pkl", d)
     os.environ["ACAV_SHARD_SIDECAR"] = "write"   # builds the columnar twins while it reads the pkl files
     t0 = time.perf_counter()
     from acav100m_amd import shards as io

@@ -22,13 +22,18 @@ for spread in spreads:
     gen = torch.Generator(device="cuda").manual_seed(7)
     cen = spread * torch.randn(K, d, device="cuda", generator=gen)
     comp = torch.randint(0, K, (n,), device="cuda", generator=gen)
+    if os.environ.get("RECHECK_SORTED"):  # experiment: rows grouped by component -> neighbouring rows share their candidate centres
+        comp = torch.sort(comp).values
     x = torch.empty(n, d, device="cuda")
     for s in range(0, n, 65536):
         e = min(n, s + 65536)
         x[s:e] = cen[comp[s:e]] + 0.3 * torch.randn(e - s, d, device="cuda", generator=gen)
     acav100m_amd.manual_seed(3)
     km = KMeans(None, d, K).to("cuda:0")
-    km.train_epoch(x[:262144], b, lr=0.01)
+    if os.environ.get("RECHECK_SORTED"):
+        km.train_epoch(x[torch.randperm(n, device="cuda", generator=gen)[:262144]].contiguous(), b, lr=0.01)
+    else:
+        km.train_epoch(x[:262144], b, lr=0.01)
     lib = _lib.load_library()
     lab = torch.empty(n, dtype=torch.long, device="cuda")
     best = (1e9, 1e9)
