@@ -93,6 +93,8 @@ SIGNATURES = {
     "acav_pkl_shard_copy_view": [vp, i32, vp, i64],
     "acav_pkl_shard_meta": [vp, pp, C.POINTER(i64), pp, C.POINTER(i64), pp, pp, pp],
     "acav_pkl_load_group": [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp],
+    "acav_pkl_assign_load_group": [vp, i32, i32, vp, vp],
+    "acav_pkl_shard_labels": [vp, pp],
 }
 
 _lib = None

@@ -431,10 +431,16 @@ def assign_clusters(args, groups, cl, shard_names):
 
 def run_clustering(args):
     paths = [Path(p) for p in sorted(io.brace_expand(args.data.path))]
-    sizes = io.shard_sizes_from_meta(paths, args.data.meta.path)
+    sizes = io.shard_sizes_from_meta(paths, args.data.meta.path, use_cache=True)
     rank, w = world()
-    if args.data.meta.path is not None and rank == 0:  # side effect of the reference: meta_cache.pkl in the meta dir
-        io.dump_pickle(dict(sizes), Path(args.data.meta.path) / 'meta_cache.pkl')
+    if args.data.meta.path is not None and rank == 0:  # the reference's meta_cache.pkl in the meta dir: read above, kept up to date
+        cache_path = Path(args.data.meta.path) / 'meta_cache.pkl'
+        try:
+            known = dict(io.load_pickle(cache_path)) if cache_path.is_file() else {}
+        except Exception:
+            known = {}
+        if any(k not in known for k in sizes):
+            io.dump_pickle({**known, **dict(sizes)}, cache_path)
     paths = [p for p in paths if p.stem in sizes]
     if not paths:
         print(f"All shards of {args.data.path} processing already done!")

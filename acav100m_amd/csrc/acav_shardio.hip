@@ -95,6 +95,8 @@ struct acav_pkl_shard {
     std::string names;                // the distinct shard names, '\n'-joined in order of first appearance
     std::vector<int64_t> name_ids;    // their identities, same order
     std::vector<int64_t> shard_size;  // per row, INT64_MIN = key missing
+    bool assign = false;              // an ASSIGNMENT shard (the clustering stage's output): integer labels instead of vectors
+    std::vector<int64_t> labels;      // [rows][views]
     std::string reason;               // why the shard is unsupported
 };
 
@@ -177,10 +179,11 @@ struct Parser {
         if (global_is(o.a, "numpy", nullptr, "dtype")) {
             // dtype('f4', False, True) + state (3, '<', None, None, None, -1, -1, 0)
             const Node &args = S.ar->nodes[(size_t)o.b];
-            bool ok = args.kind == N_TUPLE && args.items.size() >= 1 && str_is(args.items[0], "f4") && st.kind == N_TUPLE &&
-                      st.items.size() >= 2 && str_is(st.items[1], "<");
+            const bool le = args.kind == N_TUPLE && args.items.size() >= 1 && st.kind == N_TUPLE && st.items.size() >= 2 && str_is(st.items[1], "<");
+            const bool f4 = le && str_is(args.items[0], "f4"), i8 = le && str_is(args.items[0], "i8");
             o.kind = N_DTYPE;
-            o.flag = ok;
+            o.flag = f4;          // the vectors' dtype
+            o.len = i8 ? 8 : 0;   // numpy.int64 scalars (assignment shards)
             o.items.clear();
             return;
         }
@@ -214,6 +217,18 @@ struct Parser {
     void frombuffer(int obj)
     {
         Node &o = S.ar->nodes[(size_t)obj];
+        if (global_is(o.a, "numpy.core.multiarray", "numpy._core.multiarray", "scalar")) {
+            // numpy.int64(label) of an assignment shard: scalar(dtype('i8'), 8 bytes) -> a plain integer
+            const Node &args = S.ar->nodes[(size_t)o.b];
+            if (args.kind != N_TUPLE || args.items.size() != 2) return;
+            const Node &dt = S.ar->nodes[(size_t)args.items[0]], &raw = S.ar->nodes[(size_t)args.items[1]];
+            if (dt.kind != N_DTYPE || dt.len != 8 || raw.kind != N_BYTES || raw.len != 8) return;
+            int64_t v;
+            memcpy(&v, S.base + raw.i, 8);
+            o.kind = N_INT;
+            o.i = v;
+            return;
+        }
         if (!global_is(o.a, "numpy.core.numeric", "numpy._core.numeric", "_frombuffer")) return;
         o.kind = N_NDARRAY;
         o.flag = false;
@@ -444,6 +459,8 @@ std::string str_of(const acav_pkl_shard &S, int id)
 
 // the shard's layout as shards.py:_shard_columns_from_rows builds it: views in the order of the FIRST row's walk (audio
 // features, then video features; feature list order; layer order), every later row with exactly the same sequence
+// S.assign: the same walk over an ASSIGNMENT shard -- what subset_selection/code/dataloader.py:17-69 (format_row /
+// format_assignments) reads: 'audio_assignments' / 'video_assignments' entries whose 'array' maps layers to integer labels
 bool extract(acav_pkl_shard &S, Parser &P, int root)
 {
     const Node &top = S.ar->nodes[(size_t)root];
@@ -451,7 +468,7 @@ bool extract(acav_pkl_shard &S, Parser &P, int root)
     S.rows = (int64_t)top.items.size();
     S.name_id.assign((size_t)S.rows, -1);
     S.shard_size.assign((size_t)S.rows, INT64_MIN);
-    static const char *const feature_keys[2] = {"audio_features", "video_features"};
+    static const char *const feature_keys[2][2] = {{"audio_features", "video_features"}, {"audio_assignments", "video_assignments"}};
     for (int64_t r = 0; r < S.rows; ++r) {
         const Node &row = S.ar->nodes[(size_t)top.items[(size_t)r]];
         if (row.kind != N_DICT) return P.fail("a row is not a dict");
@@ -475,14 +492,15 @@ bool extract(acav_pkl_shard &S, Parser &P, int root)
                 S.name_ids.push_back(nm.i);
             }
         }
+        if (S.assign && sn < 0) return P.fail("an assignment row without shard_name");
         const int ss = dict_get(S, P, row, "shard_size");
         if (ss >= 0) {
-            if (S.ar->nodes[(size_t)ss].kind != N_INT) return P.fail("shard_size is not an int");
-            S.shard_size[(size_t)r] = S.ar->nodes[(size_t)ss].i;
+            if (S.ar->nodes[(size_t)ss].kind != N_INT && !S.assign) return P.fail("shard_size is not an int");
+            if (S.ar->nodes[(size_t)ss].kind == N_INT) S.shard_size[(size_t)r] = S.ar->nodes[(size_t)ss].i;
         }
         size_t vi = 0;
         for (int kind = 0; kind < 2; ++kind) {
-            const int fl = dict_get(S, P, row, feature_keys[kind]);
+            const int fl = dict_get(S, P, row, feature_keys[S.assign ? 1 : 0][kind]);
             if (fl < 0) continue;
             const Node &feats = S.ar->nodes[(size_t)fl];
             if (feats.kind != N_LIST && feats.kind != N_TUPLE) return P.fail("a feature list is not a list");
@@ -505,11 +523,13 @@ bool extract(acav_pkl_shard &S, Parser &P, int root)
                 } else if (a.kind == N_LIST || a.kind == N_TUPLE) {
                     for (size_t q = 0; q < a.items.size(); ++q) layers.emplace_back("layer_" + std::to_string(q), a.items[q]);
                 } else {
+                    if (S.assign) return P.fail("scalar assignment arrays are not supported by the reference");
                     layers.emplace_back("model", arr);
                 }
                 for (auto &lv : layers) {
                     const Node &vec = S.ar->nodes[(size_t)lv.second];
-                    if (vec.kind != N_NDARRAY || !vec.flag) return P.fail("a feature vector is not a plain float32 ndarray");
+                    if (S.assign ? vec.kind != N_INT : (vec.kind != N_NDARRAY || !vec.flag))
+                        return P.fail(S.assign ? "a label is not an integer" : "a feature vector is not a plain float32 ndarray");
                     if (r == 0) {
                         View v;
                         v.kind = kind;
@@ -519,19 +539,21 @@ bool extract(acav_pkl_shard &S, Parser &P, int root)
                         v.has_dataset = ds >= 0 && S.ar->nodes[(size_t)ds].kind == N_STR;
                         if (v.has_extractor) v.extractor = str_of(S, ex);
                         if (v.has_dataset) v.dataset = str_of(S, ds);
-                        v.d = vec.len;
+                        v.d = S.assign ? 1 : vec.len;
                         v.off.reserve((size_t)S.rows);
-                        for (const View &o : S.views)
-                            if (o.kind == v.kind && o.model_key == v.model_key && o.layer == v.layer) return P.fail("a view appears twice in a row");
+                        for (const View &o : S.views)  // (an assignment row is keyed by (model key, layer) alone)
+                            if ((S.assign || o.kind == v.kind) && o.model_key == v.model_key && o.layer == v.layer)
+                                return P.fail("a view appears twice in a row");
                         S.views.push_back(std::move(v));
                     }
                     if (vi >= S.views.size()) return P.fail("rows with different view lists");
                     View &v = S.views[vi];
                     const Node &mkn = S.ar->nodes[(size_t)mk];
-                    if (v.kind != kind || v.d != vec.len || (size_t)mkn.len != v.model_key.size() ||
+                    if (v.kind != kind || v.d != (S.assign ? 1 : vec.len) || (size_t)mkn.len != v.model_key.size() ||
                         memcmp(S.base + mkn.i, v.model_key.data(), v.model_key.size()) != 0 || v.layer != lv.first)
                         return P.fail("rows with different view lists");
-                    v.off.push_back(vec.i);
+                    if (S.assign) S.labels.push_back(vec.i);
+                    else v.off.push_back(vec.i);
                     ++vi;
                 }
             }
@@ -737,5 +759,62 @@ ACAV_EXPORT int acav_pkl_load_group(const char *const *paths, int n, const int64
     worker();
     for (std::thread &t : pool) t.join();
     ACAV_REQUIRE(!oom.load(), ACAV_ENOMEM, "acav_pkl_load_group: out of memory");
+    return ACAV_OK;
+}
+
+// ASSIGNMENT shards (the clustering stage's output, the selection stage's input): n shards parsed on `threads` threads.
+// status[i] 0: handles[i] holds rows, views ((model key, layer) in the order of the first row's walk: acav_pkl_shard_view,
+// d = 1), filenames / shard names (acav_pkl_shard_meta) and the labels (acav_pkl_shard_labels); 1: outside the subset.
+ACAV_EXPORT int acav_pkl_assign_load_group(const char *const *paths, int n, int threads, acav_pkl_shard **handles, int *status)
+{
+    ACAV_REQUIRE(paths && handles && status && n >= 0, ACAV_EINVAL, "acav_pkl_assign_load_group: bad argument");
+    if (threads < 1) threads = 1;
+    if (threads > n) threads = n;
+    std::atomic<int> next(0);
+    std::atomic<bool> oom(false);
+    auto worker = [&]() {
+        std::vector<unsigned char> buf;
+        Arena ar;
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n) break;
+            handles[i] = nullptr;
+            status[i] = 1;
+            acav_pkl_shard *S = new (std::nothrow) acav_pkl_shard();
+            if (!S) {
+                oom = true;
+                continue;
+            }
+            S->assign = true;
+            try {
+                if (read_file(paths[i], buf, S->size)) {
+                    S->base = buf.data();
+                    if (parse_shard(S, ar)) status[i] = 0;
+                }
+            } catch (const std::bad_alloc &) {
+                oom = true;
+                status[i] = 1;
+            }
+            S->base = nullptr;
+            if (status[i] == 0) handles[i] = S;
+            else delete S;
+        }
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+    } catch (...) {
+    }
+    worker();
+    for (std::thread &t : pool) t.join();
+    ACAV_REQUIRE(!oom.load(), ACAV_ENOMEM, "acav_pkl_assign_load_group: out of memory");
+    return ACAV_OK;
+}
+
+// labels of an assignment-shard handle: int64 [rows][views], alive as long as the handle
+ACAV_EXPORT int acav_pkl_shard_labels(const acav_pkl_shard *S, const int64_t **labels)
+{
+    ACAV_REQUIRE(S && labels && S->assign, ACAV_EINVAL, "acav_pkl_shard_labels: not an assignment-shard handle");
+    *labels = S->labels.data();
     return ACAV_OK;
 }

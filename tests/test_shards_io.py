@@ -57,6 +57,10 @@ def test_feature_table_and_assignment_schema(tmp_path, golden_dir):
     t2 = io.load_feature_shards(paths + [str(tmp_path / "features" / "shard-000002.pkl")])
     assert len(t2) == 16
     assert io.shard_sizes_from_meta(paths, tmp_path / "videos") == {"shard-000000": 8, "shard-000001": 8}
+    # the reference's meta_cache.pkl is trusted for the shards it lists, the others are counted from their json (data/meta.py:11-20)
+    io.dump_pickle({"shard-000001": 5}, tmp_path / "videos" / "meta_cache.pkl")
+    assert io.shard_sizes_from_meta(paths, tmp_path / "videos", use_cache=True) == {"shard-000000": 8, "shard-000001": 5}
+    assert io.shard_sizes_from_meta(paths, tmp_path / "videos") == {"shard-000000": 8, "shard-000001": 8}
 
 
 def test_partitions_metas_and_output_csv(tmp_path, golden_dir):
@@ -326,3 +330,56 @@ def test_native_loader_equals_worker_processes(tmp_path, monkeypatch):
         assert t.shard_rows == plain.shard_rows and t.tags == plain.tags and list(t.views) == list(plain.views)
         for v in plain.views:
             assert np.array_equal(t.views[v], plain.views[v])
+
+
+def test_native_assignment_reader_equals_pickle(tmp_path, monkeypatch):
+    """acav_pkl_assign_load_group (the selection stage's input shards parsed by the library) against the reference's row walk
+    (subset_selection/code/dataloader.py:17-69 as restated in _assignment_rows_to_lists): dict and list 'array's, numpy.int64
+    and plain-int labels, protocols 3-5, an empty shard; shards it must refuse fall back to pickle.load -- same result."""
+    rs = np.random.RandomState(4)
+    paths = []
+    for s, proto in enumerate((3, 4, 5, 4)):
+        n = 0 if s == 3 else 7 + s
+        cols = [(("audio", "am", "layer_1"), rs.randint(0, 999, n)), (("audio", "am", "layer_0"), rs.randint(0, 999, n)),
+                (("video", "vm", "layer_0"), rs.randint(0, 1 << 40, n))]
+        rows = io._assignment_rows_from_columns(["clip_%d_%d é.mp4" % (s, i) for i in range(n)], [n] * n, ["shard-%06d" % s] * n,
+                                                [(("audio", "am"), ("A", "ds")), (("video", "vm"), ("V", None))], cols)
+        if s == 1:   # list arrays and plain ints
+            for r in rows:
+                r["audio_assignments"][0]["array"] = [int(v) for v in r["audio_assignments"][0]["array"].values()]
+                r["video_assignments"][0]["array"] = [int(v) for v in r["video_assignments"][0]["array"].values()]
+        p = tmp_path / ("shard-%06d.pkl" % s)
+        with open(p, "wb") as f:
+            pickle.dump(rows, f, protocol=proto)
+        paths.append(p)
+    nat = io._assignment_shards_native(paths)
+    assert sorted(nat) == [0, 1, 2, 3]
+    for i, p in enumerate(paths):
+        per_row, sn, fn = io._assignment_rows_to_lists(io.load_pickle(p))
+        mat, ty = io.rows_to_matrix(per_row)
+        if per_row:
+            assert nat[i][1] == ty
+        assert np.array_equal(nat[i][0].reshape(mat.shape), mat) and nat[i][0].dtype == np.int64
+        assert nat[i][2] == sn and nat[i][3] == fn
+    # shards 0 and 2 share their clusterings: the loader's result with and without the library's reader
+    monkeypatch.setenv("ACAV_SHARD_NATIVE", "0")
+    ref = io.load_assignment_shards([paths[0], paths[2], paths[3]], sidecar="off")
+    monkeypatch.setenv("ACAV_SHARD_NATIVE", "1")
+    got = io.load_assignment_shards([paths[0], paths[2], paths[3]], sidecar="off")
+    assert np.array_equal(ref[0], got[0]) and ref[1:] == got[1:]
+    with pytest.raises(KeyError):  # list arrays name their layers layer_0 / layer_1: other clusterings than shard 0's? no: same names
+        io.load_assignment_shards([paths[0], tmp_path / "other.pkl"], sidecar="off") if _write_other(tmp_path) else None
+    # refused: float labels, rows with different clusterings, a missing shard_name
+    rows = io.load_pickle(paths[0])
+    bad = {"float label": [dict(r, video_assignments=[dict(r["video_assignments"][0], array={"layer_0": 1.5})]) for r in rows],
+           "differing rows": [dict(r) if i else dict(r, audio_assignments=[]) for i, r in enumerate(rows)],
+           "no shard_name": [{k: v for k, v in r.items() if k != "shard_name"} for r in rows]}
+    for what, obj in bad.items():
+        io.dump_pickle(obj, tmp_path / "bad.pkl")
+        assert io._assignment_shards_native([tmp_path / "bad.pkl"]) == {}, what
+
+
+def _write_other(tmp_path):
+    rows = io._assignment_rows_from_columns(["x.mp4"], [1], ["other"], [(("audio", "zz"), ("A", "ds"))], [(("audio", "zz", "layer_0"), np.array([3]))])
+    io.dump_pickle(rows, tmp_path / "other.pkl")
+    return True

@@ -111,7 +111,14 @@ def run(glob, out, n, k, label, d=1024):
                             **{"clustering.ncentroids": k, "computation.num_gpus": 1})
         args.data.output.path.mkdir(parents=True, exist_ok=True)
         t0 = time.perf_counter()
-        saved = rc.run_clustering(args)
+        if os.environ.get("ACAV_BENCH_CPROFILE") == label:  # where the main thread's python time goes
+            import cProfile
+            import pstats
+            prof = cProfile.Profile()
+            saved = prof.runcall(rc.run_clustering, args)
+            pstats.Stats(prof).sort_stats("tottime").print_stats(22)
+        else:
+            saved = rc.run_clustering(args)
         wall = time.perf_counter() - t0
     finally:
         io.load_feature_shards, KMeans.train_epoch_multi, KMeans.calc_best, io.dump_pickle = orig_load, orig_multi, orig_best, orig_dump
