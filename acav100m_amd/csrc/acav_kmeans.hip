@@ -964,34 +964,47 @@ __device__ __forceinline__ void tpw_refresh_norms(unsigned pend8, const float *s
 // ONE_X (round 4, rows wider than 1024 columns): ONE batch-row buffer instead of two -- the rows of step t + 1 are fetched as
 // soon as the FMA phase of step t has read the buffer (they land under the exchange) -- so that 8 centres + 8 rows of up to
 // ~2400 columns fit a CU's LDS.  A wave owns the column blocks wave, wave + 4, wave + 8, ... (DMA, dot items, update).
-template <bool RAGGED, int NCP, bool ONE_X = false>
+//
+// NRP = 2 (round 4, late; NCP = 2, ONE_X, ds = 1024): TWO row passes -- the workgroup labels 16 batch rows against its 16 centres,
+// the four (centre half, row half) quadrants of a column block as four interleaved FMA chains (dot_quad, as the column-split
+// kernel).  K = 1024 at 768 < d <= 1024 then takes 64 x 2 = 128 workgroups of 132 KB instead of 64 x 4 = 256: the centres are
+// replicated twice instead of four times and TWO clusterings (the audio and the visual view of cfg5) train side by side.
+__device__ __forceinline__ void dot_quad(const float *pc, const float *px, int scz, int sxz, float out[4]);
+
+template <bool RAGGED, int NCP, bool ONE_X = false, int NRP = 1>
 __global__ __launch_bounds__(256) void k_train_persistent_wide(
     const float *__restrict__ x, const float *__restrict__ xn, int b, int d, int ds, int K, float *__restrict__ centers,
     float *__restrict__ cn, float *__restrict__ counts, const float *__restrict__ thr, double lr0, float r,
     const int64_t *__restrict__ forced, int need, int T, TrainCtl *__restrict__ ctl, StepScalars *__restrict__ sc)
 {
     constexpr int NCW = 8 * NCP;  // centres per workgroup
+    constexpr int NRW = 8 * NRP;  // batch rows per workgroup
+    static_assert(NRP == 1 || (NRP == 2 && NCP == 2 && ONE_X), "two row passes: 16 centres x 16 rows, one row buffer");
     extern __shared__ __attribute__((aligned(16))) unsigned char tpw_smem[];
     float *sC = reinterpret_cast<float *>(tpw_smem);  // [NCW][ds]
     const int nblk = (d + 255) >> 8;
     float *sX0 = sC + NCW * ds;                        // [2 or 1][8][ds]
-    float *sCn = sX0 + (ONE_X ? 1 : 2) * 8 * ds;       // [NCW]
+    float *sCn = sX0 + (ONE_X ? NRP : 2) * 8 * ds;     // [NCW]
     float *sCnt = sCn + NCW;                           // [NCW]
-    float *sPart = sCnt + NCW;                         // [NCP][nblk][64]
-    int *sBest = reinterpret_cast<int *>(sPart + NCP * nblk * 64);  // [32]
+    float *sPart = sCnt + NCW;                         // [NCP * NRP][nblk][64] (NRP = 2: quadrant 2 cp + rp)
+    int *sBest = reinterpret_cast<int *>(sPart + NCP * NRP * nblk * 64);  // [32]
     __shared__ int sDead;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kk = lane >> 3, ii = lane & 7;
-    const int kbase = blockIdx.x * NCW, rbase = blockIdx.y * TP_NR;
-    const int nck = min(NCW, K - kbase), nrv = min(TP_NR, b - rbase);
+    const int kbase = blockIdx.x * NCW, rbase = blockIdx.y * NRW;
+    const int nck = min(NCW, K - kbase), nrv = min(NRW, b - rbase);
     const int ncg = gridDim.x;
     auto sX = [&](int par) { return ONE_X ? sX0 : sX0 + par * 8 * ds; };
     auto dma_rows = [&](int t) {  // this wave's share of step t's batch rows
         if (ONE_X) {  // issued while wave 0 exchanges: waves 1 .. 3 fetch everything (a barrier follows the wait at the step start)
             if (wave > 0)
-                for (int blk = wave - 1; blk < nblk; blk += 3) tpw_dma_block<RAGGED>(sX0, x + (size_t)t * b * d, rbase, nrv, d, ds, blk, lane);
+                for (int it = wave - 1; it < nblk * NRP; it += 3) {
+                    const int rp = NRP == 1 ? 0 : it / nblk, blk = NRP == 1 ? it : it - rp * nblk;
+                    if (nrv > rp * 8)  // (a row pass without a valid row is never read into a key)
+                        tpw_dma_block<RAGGED>(sX0 + rp * 8 * ds, x + (size_t)t * b * d, rbase + rp * 8, min(8, nrv - rp * 8), d, ds, blk, lane);
+                }
         } else
             for (int blk = wave; blk < nblk; blk += 4) tpw_dma_block<RAGGED>(sX(t & 1), x + (size_t)t * b * d, rbase, nrv, d, ds, blk, lane);
     };
@@ -1000,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
         const int blk = nblk - 1;
         for (int row = 0; row < NCW; ++row)
             *reinterpret_cast<float4 *>(sC + row * ds + blk * 256 + (lane << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int row = 0; row < (ONE_X ? 8 : 16); ++row)
+        for (int row = 0; row < (ONE_X ? NRW : 16); ++row)
             *reinterpret_cast<float4 *>(sX0 + row * ds + blk * 256 + (lane << 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // before the DMA below writes the same rows
     }
@@ -1029,18 +1042,29 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my block of step t's rows landed (issued one step ago)
             if (ONE_X) __syncthreads();  // ... and everybody else's: the blocks a wave multiplies were fetched by waves 1 .. 3
-            float xn_t = 0.f, thr_t = 0.f;
+            float xn_t[NRP], thr_t = 0.f;
+#pragma unroll
+            for (int rp = 0; rp < NRP; ++rp) xn_t[rp] = 0.f;
             if (wave == 0) {  // in flight under the FMA chain
-                xn_t = xn[(size_t)t * b + rbase + (ii < nrv ? ii : 0)];
+#pragma unroll
+                for (int rp = 0; rp < NRP; ++rp) xn_t[rp] = xn[(size_t)t * b + rbase + (rp * 8 + ii < nrv ? rp * 8 + ii : 0)];
                 thr_t = thr[t];
             }
             if (!ONE_X && t + 1 < T) dma_rows(t + 1);
             const float *xs = sX(t & 1);
             // (centre pass, column block) pairs: a wave multiplies the blocks it fetched (wave, wave + 4, ...) for every pass
-            for (int blk = wave; blk < nblk; blk += 4)
-                for (int cp = 0; cp < NCP; ++cp)
-                    sPart[(cp * nblk + blk) * 64 + lane] =
-                        dot_blocks<1>(sC + (cp * 8 + kk) * ds + blk * 256, xs + ii * ds + blk * 256, kk << 2, ii << 2, 0.f, true);
+            if constexpr (NRP == 2) {  // ds == TS_COLS: the four quadrants of a block as four chains
+                for (int blk = wave; blk < nblk; blk += 4) {
+                    float q4[4];
+                    dot_quad(sC + kk * ds + blk * 256, xs + ii * ds + blk * 256, kk << 2, ii << 2, q4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sPart[(q * nblk + blk) * 64 + lane] = q4[q];
+                }
+            } else
+                for (int blk = wave; blk < nblk; blk += 4)
+                    for (int cp = 0; cp < NCP; ++cp)
+                        sPart[(cp * nblk + blk) * 64 + lane] =
+                            dot_blocks<1>(sC + (cp * 8 + kk) * ds + blk * 256, xs + ii * ds + blk * 256, kk << 2, ii << 2, 0.f, true);
             if (pend) {  // uniform: the previous update's norm refresh, off the update's critical path
                 for (int cp = 0; cp < NCP; ++cp) {
                     const unsigned p8 = (unsigned)(pend >> (cp * 8)) & 0xFFu;
@@ -1051,22 +1075,31 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
             __syncthreads();
             if (ONE_X && t + 1 < T) dma_rows(t + 1);  // the one row buffer is free: the next step's rows land under the exchange
             if (wave == 0) {
-                unsigned long long key = ~0ull;
-                for (int cp = 0; cp < NCP; ++cp) {
-                    float acc = sPart[(cp * nblk) * 64 + lane];
-                    for (int w = 1; w < nblk; ++w) acc = acc + sPart[(cp * nblk + w) * 64 + lane];  // canonical left fold
-                    const int lc = cp * 8 + kk;
-                    if (lc < nck && ii < nrv) {
-                        const unsigned long long kc = pack_key(dist_epilogue(acc, xn_t, sCn[lc], sCnt[lc] < thr_t, r), kbase + lc);
-                        key = kc < key ? kc : key;
+                unsigned long long keys[NRP];
+                unsigned long long o;
+#pragma unroll
+                for (int rp = 0; rp < NRP; ++rp) {
+                    unsigned long long key = ~0ull;
+                    for (int cp = 0; cp < NCP; ++cp) {
+                        const int q = NRP == 1 ? cp : 2 * cp + rp;
+                        float acc = sPart[(q * nblk) * 64 + lane];
+                        for (int w = 1; w < nblk; ++w) acc = acc + sPart[(q * nblk + w) * 64 + lane];  // canonical left fold
+                        const int lc = cp * 8 + kk;
+                        if (lc < nck && rp * 8 + ii < nrv) {
+                            const unsigned long long kc = pack_key(dist_epilogue(acc, xn_t[rp], sCn[lc], sCnt[lc] < thr_t, r), kbase + lc);
+                            key = kc < key ? kc : key;
+                        }
                     }
+                    o = __shfl_xor(key, 8);
+                    key = o < key ? o : key;
+                    o = __shfl_xor(key, 16);
+                    key = o < key ? o : key;
+                    o = __shfl_xor(key, 32);
+                    key = o < key ? o : key;
+                    keys[rp] = key;
                 }
-                unsigned long long o = __shfl_xor(key, 8);
-                key = o < key ? o : key;
-                o = __shfl_xor(key, 16);
-                key = o < key ? o : key;
-                o = __shfl_xor(key, 32);
-                key = o < key ? o : key;
+                // lane l < 8 NRP holds the key of row l: its ii is l & 7 and every lane of an ii column holds that row's minimum
+                const unsigned long long key = (NRP == 2 && (lane >> 3) == 1) ? keys[NRP - 1] : keys[0];
                 const unsigned long long tag = (unsigned long long)((nsync % 65535u) + 1u) << 48;
                 unsigned long long(*ring)[TP_MAXB] = ctl->gran[nsync % TP_RING];
                 if (lane < nrv) {
@@ -1955,7 +1988,7 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
     bool persistent = shape_ok && narrow_ok && nwg <= room && nwg <= occ * km->num_cus;
     // more 8-centre groups than CUs (K = 1024): NCP x 8 centres per workgroup (k_train_persistent_wide) -- the smallest
     // NCP whose grid fits 3/4 of the device, else the whole device, within the LDS of a CU
-    int ncp = 1, ds = 0, wide_wg = 0;
+    int ncp = 1, nrp = 1, ds = 0, wide_wg = 0;
     size_t wide_smem = 0;
     bool wide = false, one_x = false;
     // rows wider than 1024 columns (round 4: the real SlowFast widths 1408 / 2304, and d = 2048 below K = 1024): the wide kernel
@@ -1997,6 +2030,19 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
                     break;
                 }
             }
+        // K = 1024 at 768 < d <= 1024 (cfg5): NCP = 2 needs the whole device (64 centre groups x 4 row groups) and more centres
+        // per workgroup do not fit next to two row buffers -- with SEVERAL clusterings in the call the two-row-pass form
+        // (16 centres x 16 rows, one row buffer, 64 x 2 = 128 workgroups) lets two of them run side by side: 14.x us per step of
+        // the PAIR instead of 2 x 13.1.  ACAV_WIDE_NRP=2 forces it for a single clustering, =1 switches it off (A/B).
+        const char *fnrp = getenv("ACAV_WIDE_NRP");
+        const bool nrp_forced = fnrp && fnrp[0] == '2', nrp_off = fnrp && fnrp[0] == '1';
+        if (ds == TS_COLS && !nrp_off && !fncp && (nrp_forced || (budget && (!best_ncp || wide_wg > (3 * km->num_cus) / 4)))) {
+            const int groups = (km->K + 15) / 16, rg2 = (int)((b + 15) / 16);
+            const size_t smem = sizeof(float) * ((size_t)(16 + 16) * ds + 2 * 16 + 4 * 64 * (ds / 256) + 32);
+            if (groups <= 64 && smem <= 160 * 1024 - 1024 && groups * rg2 <= (3 * km->num_cus) / 4 && groups * rg2 <= room) {
+                best_ncp = 2, nrp = 2, one_x = true, wide_wg = groups * rg2, wide_smem = smem;
+            }
+        }
         if (best_ncp) ncp = best_ncp, persistent = wide = true;
     }
     // 1024 < d <= 2048 (cfg4's visual view): the columns are split over pairs of workgroups (k_train_persistent_split)
@@ -2060,10 +2106,11 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
                                       : (one_x ? k_train_persistent_wide<true, 2, true> : k_train_persistent_wide<true, 2, false>);
             else wk = ncp == 1 ? (one_x ? k_train_persistent_wide<false, 1, true> : k_train_persistent_wide<false, 1, false>)
                                : (one_x ? k_train_persistent_wide<false, 2, true> : k_train_persistent_wide<false, 2, false>);
-        } else if (ragged) wk = ncp == 2 ? k_train_persistent_wide<true, 2> : ncp == 4 ? k_train_persistent_wide<true, 4> : k_train_persistent_wide<true, 8>;
+        } else if (nrp == 2) wk = ragged ? k_train_persistent_wide<true, 2, true, 2> : k_train_persistent_wide<false, 2, true, 2>;
+        else if (ragged) wk = ncp == 2 ? k_train_persistent_wide<true, 2> : ncp == 4 ? k_train_persistent_wide<true, 4> : k_train_persistent_wide<true, 8>;
         else wk = ncp == 2 ? k_train_persistent_wide<false, 2> : ncp == 4 ? k_train_persistent_wide<false, 4> : k_train_persistent_wide<false, 8>;
         ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_smem));
-        hipLaunchKernelGGL(wk, dim3((km->K + 8 * ncp - 1) / (8 * ncp), (unsigned)((b + TP_NR - 1) / TP_NR)), dim3(256), wide_smem, st,
+        hipLaunchKernelGGL(wk, dim3((km->K + 8 * ncp - 1) / (8 * ncp), (unsigned)((b + 8 * nrp - 1) / (8 * nrp))), dim3(256), wide_smem, st,
                            fx, km->xn.as<float>(), (int)b, km->d, ds, km->K, km->centers.as<float>(), km->cn.as<float>(),
                            km->counts.as<float>(), km->thr.as<float>(), lr, (float)km->reinit_r, tc.dw, (int)need, (int)steps,
                            km->ctl.as<TrainCtl>(), km->scalars.as<StepScalars>());
@@ -2170,8 +2217,11 @@ ACAV_EXPORT int acav_kmeans_train_multi(acav_kmeans *const *kms, int count, cons
         int budget = prop.multiProcessorCount, last = first;
         for (; last < count; ++last) {
             const int before = budget;
+            // (the last clustering of the call with nothing else in flight is a call for ONE clustering: it gets the form that is
+            // fastest alone, not the one that leaves room for a neighbour)
+            int *bp = (last == first && last + 1 == count) ? nullptr : &budget;
             ACAV_TRY(train_launch(kms[last], calls[(size_t)last], xs[last], ns[last], b, lr,
-                                  warm_best ? warm_best[last] : nullptr, n_warm[last], &budget));
+                                  warm_best ? warm_best[last] : nullptr, n_warm[last], bp));
             if (calls[(size_t)last].active && !calls[(size_t)last].launched && last > first && before < prop.multiProcessorCount) {
                 // did not fit beside the ones already in flight: finish those first, then it gets the whole device
                 break;
@@ -2183,9 +2233,9 @@ ACAV_EXPORT int acav_kmeans_train_multi(acav_kmeans *const *kms, int count, cons
             ACAV_TRY(kms[i]->prepare_filter());
         }
         if (retry) {
-            int whole = prop.multiProcessorCount;
+            // alone on the device (it is finished before the next group starts): as a call for one clustering
             ACAV_TRY(train_launch(kms[last], calls[(size_t)last], xs[last], ns[last], b, lr,
-                                  warm_best ? warm_best[last] : nullptr, n_warm[last], &whole));
+                                  warm_best ? warm_best[last] : nullptr, n_warm[last], nullptr));
             ACAV_TRY(train_finish(kms[last], calls[(size_t)last]));
             ACAV_TRY(kms[last]->prepare_filter());
             ++last;

@@ -532,3 +532,69 @@ def test_tall_persistent_kernel(env, n, d, K, b):
     ref2.train_epoch(x, b, lr=0.3)
     assert km2.fallback == ref2.fallback and (km2.fallback > 0 or K > 64)
     assert np.array_equal(km2.centers.numpy(), ref2.centers)
+
+
+@pytest.mark.parametrize("n,d,K,b", [(3072, 1024, 1024, 32), (2048, 1000, 520, 32), (1536, 800, 300, 20), (1024, 1024, 1024, 7),
+                                     (1280, 900, 264, 9)])
+def test_two_row_pass_wide_kernel(env, n, d, K, b):
+    """Round 4 (late): the wide persistent kernel with TWO row passes (16 centres x 16 rows per workgroup, one row buffer, the four
+    quadrants of a column block as four interleaved chains) -- K = 1024 at 768 < d <= 1024 on 128 workgroups instead of 256, so that
+    cfg5's two views train side by side.  Forced here for ONE clustering (ACAV_WIDE_NRP=2): two epochs == the oracle bit for bit in
+    one launch per epoch; ragged widths, ragged centre groups (K = 520 / 300 / 264), ragged row groups (b = 20: 16 + 4, b = 9: 8 + 1
+    valid row in the second pass, b = 7: none), the lr fallback."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    os.environ["ACAV_WIDE_NRP"] = "2"
+    try:
+        x = _mixture(d + K, n, d, K)
+        acav.manual_seed(29)
+        km = KMeans(None, d, K).to("cuda:0")
+        ref = O.KMeans(d, K, O.Rng(29))
+        xt = torch.from_numpy(x).cuda()
+        for e in range(2):
+            km.train_epoch(xt, b, lr=0.01)
+            ref.train_epoch(x, b, lr=0.01)
+            assert np.array_equal(km.centers.numpy(), ref.centers), f"epoch {e}"
+            assert np.array_equal(km.counts.numpy(), ref.counts)
+        assert km.count == ref.count
+        launches, gave_up = km.train_stats()
+        assert launches == 2 and gave_up == 0, f"persistent launches {launches}, fallbacks {gave_up}"
+        km2 = KMeans(None, d, K).to("cuda:0")
+        ref2 = O.KMeans(d, K, O.Rng(13))
+        km2.centers, km2.counts, km2.count = ref2.centers, ref2.counts, 0
+        acav.manual_seed(14)
+        ref2.rng = O.Rng(14)
+        km2.train_epoch(xt, b, lr=0.3)
+        ref2.train_epoch(x, b, lr=0.3)
+        assert km2.fallback == ref2.fallback
+        assert np.array_equal(km2.centers.numpy(), ref2.centers)
+    finally:
+        os.environ.pop("ACAV_WIDE_NRP", None)
+
+
+def test_two_wide_clusterings_side_by_side(env):
+    """cfg5's pair: two K = 1024 clusterings of 1024-d rows in one acav_kmeans_train_multi call take the two-row-pass form (128
+    workgroups each) and are in flight together; each == its own oracle, one persistent launch per epoch and handle."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    n, d, K, b = 4096, 1024, 1024, 32
+    xs = [_mixture(70 + i, n, d, K) for i in range(2)]
+    xts = [torch.from_numpy(x).cuda() for x in xs]
+    acav.manual_seed(31)
+    kms = [KMeans(None, d, K).to("cuda:0") for _ in range(2)]
+    refs = [O.KMeans(d, K, O.Rng(0), centers=km._centers0.copy()) for km in kms]
+    lab_rs = np.random.RandomState(3)
+    for epoch in range(2):
+        warm = [lab_rs.randint(0, K, (km.warmup_steps(b, n // b), b)).astype(np.int64) for km in kms]
+        KMeans.train_epoch_multi(kms, xts, b, lr=0.01, warm_bests=warm)
+        for km, ref, x, w in zip(kms, refs, xs, warm):
+            for t in range(n // b):
+                xb = x[t * b:(t + 1) * b]
+                if t < len(w):
+                    ref.apply_update(xb, w[t], 0.01)
+                else:
+                    ref.lr = 0.01
+                    ref.add(xb)
+            assert np.array_equal(km.centers.numpy(), ref.centers), f"epoch {epoch}"
+            assert np.array_equal(km.counts.numpy(), ref.counts) and km.count == ref.count
+    assert [km.train_stats() for km in kms] == [(2, 0), (2, 0)]

@@ -1,0 +1,48 @@
+"""Do two clusterings of one shape really train side by side?  One epoch through acav_kmeans_train (one handle) against one
+epoch of TWO handles through acav_kmeans_train_multi, same shape, same box.  BENCH_D / BENCH_K / BENCH_N select the shape.
+side by side: the pair takes about as long as one; not side by side: twice as long."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import acav100m_amd
+from acav100m_amd.clustering import KMeans
+
+n = int(os.environ.get("BENCH_N", "262144"))
+d = int(os.environ.get("BENCH_D", "1024"))
+k = int(os.environ.get("BENCH_K", "1024"))
+b = 32
+g = torch.Generator(device="cuda").manual_seed(0)
+xs = []
+for v in range(2):
+    cen = torch.randn(k, d, device="cuda", generator=g) * 4
+    xs.append(cen[torch.randint(0, k, (n,), device="cuda", generator=g)] + 0.3 * torch.randn(n, d, device="cuda", generator=g))
+torch.cuda.synchronize()
+acav100m_amd.manual_seed(0)
+kms = [KMeans(None, d, k).to("cuda:0") for _ in range(2)]
+
+
+def one():
+    t0 = time.perf_counter()
+    kms[0].train_epoch(xs[0], b, lr=0.01)
+    kms[0].synchronize()
+    return time.perf_counter() - t0
+
+
+def pair():
+    t0 = time.perf_counter()
+    KMeans.train_epoch_multi(kms, xs, b, lr=0.01)
+    for km in kms:
+        km.synchronize()
+    return time.perf_counter() - t0
+
+
+one(), pair()
+steps = n // b
+for rep in range(3):
+    t1, t2 = one(), pair()
+    print(f"d={d} K={k}: one handle {t1 / steps * 1e6:.2f} us/step; two handles in one call {t2 / steps * 1e6:.2f} us per step of the pair "
+          f"({t2 / (2 * steps) * 1e6:.2f} effective); launches / fallbacks {[km.train_stats() for km in kms]}")
