@@ -598,3 +598,34 @@ def test_two_wide_clusterings_side_by_side(env):
             assert np.array_equal(km.centers.numpy(), ref.centers), f"epoch {epoch}"
             assert np.array_equal(km.counts.numpy(), ref.counts) and km.count == ref.count
     assert [km.train_stats() for km in kms] == [(2, 0), (2, 0)]
+
+
+def test_cfg4_pair_in_one_multi_call(env):
+    """cfg4's pair in one acav_kmeans_train_multi call: the column-split kernel of the 2048-d view (one workgroup on every CU)
+    and the 128-d view's K = 1024 clustering, which has to wait its turn (the split kernel's waves take a SIMD's whole register file:
+    nothing becomes resident beside it -- tools/exp/NOTES_r04.md section 12).  Each == its own oracle, one persistent launch per epoch
+    and handle, none given up."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    n, K, b = 3072, 1024, 32
+    dims = [2048, 128]
+    xs = [_mixture(80 + i, n, d, K) for i, d in enumerate(dims)]
+    xts = [torch.from_numpy(x).cuda() for x in xs]
+    acav.manual_seed(37)
+    kms = [KMeans(None, d, K).to("cuda:0") for d in dims]
+    refs = [O.KMeans(d, K, O.Rng(0), centers=km._centers0.copy()) for d, km in zip(dims, kms)]
+    lab_rs = np.random.RandomState(5)
+    for epoch in range(2):
+        warm = [lab_rs.randint(0, K, (km.warmup_steps(b, n // b), b)).astype(np.int64) for km in kms]
+        KMeans.train_epoch_multi(kms, xts, b, lr=0.01, warm_bests=warm)
+        for km, ref, x, w in zip(kms, refs, xs, warm):
+            for t in range(n // b):
+                xb = x[t * b:(t + 1) * b]
+                if t < len(w):
+                    ref.apply_update(xb, w[t], 0.01)
+                else:
+                    ref.lr = 0.01
+                    ref.add(xb)
+            assert np.array_equal(km.centers.numpy(), ref.centers), f"epoch {epoch}"
+            assert np.array_equal(km.counts.numpy(), ref.counts) and km.count == ref.count
+    assert [km.train_stats() for km in kms] == [(2, 0), (2, 0)]

@@ -14,21 +14,22 @@ from acav100m_amd.clustering import KMeans
 n = int(os.environ.get("BENCH_N", "262144"))
 d = int(os.environ.get("BENCH_D", "1024"))
 k = int(os.environ.get("BENCH_K", "1024"))
+d2 = int(os.environ.get("BENCH_D2", str(d)))  # the second clustering's width (cfg4: 2048 + 128)
 b = 32
 g = torch.Generator(device="cuda").manual_seed(0)
 xs = []
-for v in range(2):
-    cen = torch.randn(k, d, device="cuda", generator=g) * 4
-    xs.append(cen[torch.randint(0, k, (n,), device="cuda", generator=g)] + 0.3 * torch.randn(n, d, device="cuda", generator=g))
+for dv in (d, d2):
+    cen = torch.randn(k, dv, device="cuda", generator=g) * 4
+    xs.append(cen[torch.randint(0, k, (n,), device="cuda", generator=g)] + 0.3 * torch.randn(n, dv, device="cuda", generator=g))
 torch.cuda.synchronize()
 acav100m_amd.manual_seed(0)
-kms = [KMeans(None, d, k).to("cuda:0") for _ in range(2)]
+kms = [KMeans(None, dv, k).to("cuda:0") for dv in (d, d2)]
 
 
-def one():
+def one(i=0):
     t0 = time.perf_counter()
-    kms[0].train_epoch(xs[0], b, lr=0.01)
-    kms[0].synchronize()
+    kms[i].train_epoch(xs[i], b, lr=0.01)
+    kms[i].synchronize()
     return time.perf_counter() - t0
 
 
@@ -40,9 +41,9 @@ def pair():
     return time.perf_counter() - t0
 
 
-one(), pair()
+one(0), one(1), pair()
 steps = n // b
 for rep in range(3):
-    t1, t2 = one(), pair()
-    print(f"d={d} K={k}: one handle {t1 / steps * 1e6:.2f} us/step; two handles in one call {t2 / steps * 1e6:.2f} us per step of the pair "
-          f"({t2 / (2 * steps) * 1e6:.2f} effective); launches / fallbacks {[km.train_stats() for km in kms]}")
+    t1, t1b, t2 = one(0), one(1), pair()
+    print(f"d={d}/{d2} K={k}: one handle {t1 / steps * 1e6:.2f} / {t1b / steps * 1e6:.2f} us/step; two handles in one call {t2 / steps * 1e6:.2f} "
+          f"us per step of the pair ({t2 / (2 * steps) * 1e6:.2f} effective); launches / fallbacks {[km.train_stats() for km in kms]}")
