@@ -105,6 +105,12 @@ def stress(seed=0, budget=60.0, max_cases=None):
             b = int(rs.choice([16, 32, 32, 64]))
             steps = int(rs.randint(20, 80))
             shapes = [(int(rs.choice([64, 128, 352, 704, 1024, 2048])), int(rs.choice([16, 64, 256, 300]))) for _ in range(ncl)]
+            if rs.rand() < 0.35:  # wide pairs: K > 256 at 768 < d <= 1024 takes the two-row-pass form when another clustering shares the call
+                ncl = int(rs.randint(2, 4))
+                b = int(rs.choice([9, 20, 32, 32]))
+                wide = [(1024, 1024), (1000, 520), (896, 1024), (800, 300), (128, 1024), (1024, 512), (2048, 1024)]
+                shapes = [wide[int(rs.randint(len(wide)))] for _ in range(ncl)]
+                steps = (10 * max(k for _, k in shapes)) // b + int(rs.randint(2, 12))  # a few synced steps beyond the longest warm-up
             xs = [mixture(steps * b, d, k, 3.0) for d, k in shapes]
             s = int(rs.randint(1 << 30))
             acav100m_amd.manual_seed(s)
