@@ -195,10 +195,13 @@ def _run_chunks_lockstep(args, chunk_args, mine, rank, width):
     from ..rng import Generator
     from .measures.batch import EfficientBatchMI
     assert chunk_args.measure_name == 'batch_mi', "lockstep chunks are implemented for the batch_mi measure"
+    from concurrent.futures import ThreadPoolExecutor
     base_seed = int(chunk_args.computation.random_seed or 0)
     written = []
-    for g0 in range(0, len(mine), width):
-        group = mine[g0:g0 + width]
+
+    def prepare_group(group):
+        """Host side of a group: shard loading, candidate shuffle, tables, device handles.  Runs on a helper thread under the
+        PREVIOUS group's greedy loop (the library call releases the GIL; per-chunk generators: nothing is shared)."""
         prepared = []
         for num, chunk in group:
             print("loading chunk {}".format(num))
@@ -212,6 +215,15 @@ def _run_chunks_lockstep(args, chunk_args, mine, rank, width):
                                               chunk_args.clustering.pairing, chunk_args.shuffle_candidates,
                                               chunk_args.verbose, generator=Generator(base_seed + 1 + num))
             prepared.append((measure, start, subset, shard_names, filenames, metas))
+        return prepared
+
+    groups = [mine[g0:g0 + width] for g0 in range(0, len(mine), width)]
+    pool = ThreadPoolExecutor(1)
+    nxt = pool.submit(prepare_group, groups[0]) if groups else None
+    for gi, group in enumerate(groups):
+        g0 = gi * width
+        prepared = nxt.result()
+        nxt = pool.submit(prepare_group, groups[gi + 1]) if gi + 1 < len(groups) else None
         live = [p for p in prepared if p is not None]
         print("running chunks {} in lockstep".format([num for num, _ in group]))
         results = EfficientBatchMI.run_greedy_multi([p[0] for p in live], [p[2] for p in live], [p[1] for p in live],
@@ -229,6 +241,7 @@ def _run_chunks_lockstep(args, chunk_args, mine, rank, width):
             cache_out = Path(args.data.output.path).parent / 'caches' / Path(args.data.output.path).name
             out_path, _ = io.append_output_csv(res, metas, cache_out, name + '_')
             written.append(out_path)
+    pool.shutdown()
     return written
 
 

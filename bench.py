@@ -182,18 +182,28 @@ def select_chunked(a, types, chunk, width, seed0=1):
     from acav100m_amd.rng import Generator
     from acav100m_amd.subset_selection.measures.batch import EfficientBatchMI
     from acav100m_amd.subset_selection.run_greedy import _prepare
+    from concurrent.futures import ThreadPoolExecutor
     sargs = select_args()
     n = a.shape[0]
     out = []
-    with contextlib.redirect_stdout(io.StringIO()):
-        for g0 in range(0, n, chunk * width):
-            prepared = []
-            for i, c0 in enumerate(range(g0, min(n, g0 + chunk * width), chunk)):
-                prepared.append(_prepare(sargs, a[c0:c0 + chunk], types, None, RATIO, "batch_mi", "combination", True, False,
-                                         generator=Generator(seed0 + g0 // chunk + i)))
+
+    def prepare_group(g0):  # host work of a group (candidate shuffle, tables, device handles): under the previous group's greedy loop
+        return [_prepare(sargs, a[c0:c0 + chunk], types, None, RATIO, "batch_mi", "combination", True, False,
+                         generator=Generator(seed0 + g0 // chunk + i))
+                for i, c0 in enumerate(range(g0, min(n, g0 + chunk * width), chunk))]
+
+    groups = list(range(0, n, chunk * width))
+    with contextlib.redirect_stdout(io.StringIO()), ThreadPoolExecutor(1) as pool:
+        nxt = pool.submit(prepare_group, groups[0])
+        for gi, g0 in enumerate(groups):
+            prepared = nxt.result()
+            if gi + 1 < len(groups):
+                nxt = pool.submit(prepare_group, groups[gi + 1])
             res = EfficientBatchMI.run_greedy_multi([p[0] for p in prepared], [p[2] for p in prepared],
                                                     [p[1] for p in prepared])
             out.extend((r[0], r[1]) for r in res)
+            pool.submit(list.clear, prepared)  # the handles' device blocks are released on the helper thread too (a free syncs)
+            del prepared
     return out
 
 
