@@ -527,6 +527,9 @@ constexpr unsigned TP_SPIN_LIMIT = 1u << 24;
 #endif
 constexpr int TP_FIRST_SWEEP_PAUSE = ACAV_TP_FIRST_SLEEP;  // x 64 clocks between a workgroup's publish and its first sweep
 
+#if defined(ACAV_WIDE_PROF) && !defined(ACAV_EXPERIMENT_BUILD)
+#error "ACAV_WIDE_PROF is a diagnostic switch of experiment builds (add -DACAV_EXPERIMENT_BUILD)"
+#endif
 constexpr int TP_RING = 4;
 struct TrainCtl {
     unsigned err;          // 1 = a bounded spin gave up
@@ -1033,7 +1036,16 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
 
     unsigned nsync = 0;
     unsigned long long pend = 0;  // centres whose ||c||^2 is stale: refreshed under the next step's FMA phase
+#ifdef ACAV_WIDE_PROF  // experiment builds: shader-clock cycles per phase of workgroup (1, 0), as k_train_persistent's PROF
+#define TPW_CLK() ((long long)clock64())
+    long long wpr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+#define TPW_CLK() 0ll
+#endif
     for (int t = 0; t < T; ++t) {
+        const long long wc0 = TPW_CLK();
+        long long wc1 = wc0, wc2 = wc0, wc3 = wc0;
+        (void)wc1, (void)wc2, (void)wc3;
         const float *xb = x + (size_t)t * b * d;
         if (t < need) {
             __syncthreads();  // every wave has read the previous step's labels (an untouched workgroup has no other barrier)
@@ -1042,6 +1054,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my block of step t's rows landed (issued one step ago)
             if (ONE_X) __syncthreads();  // ... and everybody else's: the blocks a wave multiplies were fetched by waves 1 .. 3
+            wc1 = TPW_CLK();
             float xn_t[NRP], thr_t = 0.f;
 #pragma unroll
             for (int rp = 0; rp < NRP; ++rp) xn_t[rp] = 0.f;
@@ -1073,6 +1086,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                 pend = 0;
             }
             __syncthreads();
+            wc2 = TPW_CLK();
             if (ONE_X && t + 1 < T) dma_rows(t + 1);  // the one row buffer is free: the next step's rows land under the exchange
             if (wave == 0) {
                 unsigned long long keys[NRP];
@@ -1116,6 +1130,9 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                 for (int u = 0; u < TPW_SW; ++u)
                     if (srow < b && half + 2 * u < ncg) needm |= 1u << u;
                 for (unsigned spins = 0;; ++spins) {
+#ifdef ACAV_WIDE_PROF
+                    wpr[7] += 1;  // sweep passes
+#endif
 #pragma unroll
                     for (int u = 0; u < TPW_SW; ++u)
                         if ((needm >> u) & 1u)
@@ -1149,6 +1166,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
             }
             ++nsync;
             __syncthreads();
+            wc3 = TPW_CLK();
             if (sDead) break;  // uniform
         }
         // ---- update: every replica of a centre group does the same arithmetic; wave w owns column block w
@@ -1170,7 +1188,15 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
         }
         const float lr32 = (float)lr;
         if (fell && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) sc->fallback += 1;
-        if (__ballot(lane < b && best >= kbase && best < kbase + nck) == 0ull) continue;  // uniform: nothing of mine was hit
+#ifdef ACAV_WIDE_PROF
+        if (t >= need) wpr[0] += wc1 - wc0, wpr[1] += wc2 - wc1, wpr[2] += wc3 - wc2, wpr[5] += 1;
+#endif
+        if (__ballot(lane < b && best >= kbase && best < kbase + nck) == 0ull) {  // uniform: nothing of mine was hit
+#ifdef ACAV_WIDE_PROF
+            if (t >= need) wpr[3] += TPW_CLK() - wc3, wpr[4] += TPW_CLK() - wc0;
+#endif
+            continue;
+        }
         for (int cp = 0; cp < NCP; ++cp) {
             unsigned long long msk[8];
             unsigned touched = 0;
@@ -1230,7 +1256,15 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
             pend |= (unsigned long long)touched << (cp * 8);
         }
         __syncthreads();  // the updated centres and counts are in place before the next step reads them
+#ifdef ACAV_WIDE_PROF
+        if (t >= need) wpr[3] += TPW_CLK() - wc3, wpr[4] += TPW_CLK() - wc0, wpr[6] += 1;
+#endif
     }
+#ifdef ACAV_WIDE_PROF
+    if (blockIdx.x == 1 && blockIdx.y == 0 && tid == 0)
+        for (int q = 0; q < 8; ++q) ctl->prof[q] = (unsigned long long)wpr[q];
+#endif
+#undef TPW_CLK
     if (pend) {  // uniform
         for (int cp = 0; cp < NCP; ++cp) {
             const unsigned p8 = (unsigned)(pend >> (cp * 8)) & 0xFFu;
@@ -2148,6 +2182,17 @@ static int train_finish(acav_kmeans *km, TrainCall &tc)
             fprintf(stderr, "[acav]   over workgroups: wait %.0f..%.0f fma %.0f..%.0f exch %.0f..%.0f upd %.0f..%.0f; sweep passes/step %.2f\n", mn[0],
                     mx[0], mn[1], mx[1], mn[2], mx[2], mn[3], mx[3], head.prof[7] / den);
         }
+#ifdef ACAV_WIDE_PROF
+        {
+            struct { unsigned err, pad[3]; unsigned long long prof[8]; } hw{};
+            ACAV_HIP_TRY(hipMemcpy(&hw, km->ctl.p, sizeof(hw), hipMemcpyDeviceToHost));
+            const double den = (double)(hw.prof[5] ? hw.prof[5] : 1);
+            if (hw.prof[5])
+                fprintf(stderr, "[acav] wide epoch (%d workgroups): cycles/step of workgroup (1, 0): row wait %.0f, fma %.0f, keys + exchange %.0f, update %.0f, "
+                                "total %.0f; sweep passes/step %.2f; steps with an update of mine %.3f\n", tc.nwg, hw.prof[0] / den, hw.prof[1] / den,
+                        hw.prof[2] / den, hw.prof[3] / den, hw.prof[4] / den, hw.prof[7] / den, hw.prof[6] / den);
+        }
+#endif
         if (tc.split_prof) {
             struct { unsigned err, pad[3]; unsigned long long prof[8]; unsigned long long wg0[8]; } hs{};
             ACAV_HIP_TRY(hipMemcpy(&hs, km->ctl.p, sizeof(hs), hipMemcpyDeviceToHost));

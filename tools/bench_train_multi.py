@@ -9,7 +9,11 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import acav100m_amd
+from acav100m_amd import _lib
 from acav100m_amd.clustering import KMeans
+
+if os.environ.get("ACAV_LIB"):  # A/B of another build of the library (tools only, as tools/ab_train.py)
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.__file__), os.environ["ACAV_LIB"])
 
 n = int(os.environ.get("BENCH_N", "262144"))
 d = int(os.environ.get("BENCH_D", "1024"))
