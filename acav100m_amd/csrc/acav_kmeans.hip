@@ -1039,6 +1039,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
 #ifdef ACAV_WIDE_PROF  // experiment builds: shader-clock cycles per phase of workgroup (1, 0), as k_train_persistent's PROF
 #define TPW_CLK() ((long long)clock64())
     long long wpr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long wup[4] = {0, 0, 0, 0};  // touched steps: lr / labels, row loads issued -> landed, the rest of the update, closing barrier
 #else
 #define TPW_CLK() 0ll
 #endif
@@ -1197,6 +1198,49 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
 #endif
             continue;
         }
+#ifdef ACAV_WIDE_PROF
+        const long long wu0 = TPW_CLK();
+        long long wu1 = 0, wacc1 = 0;
+#endif
+        // d <= 1024 (a wave owns at most ONE column block): a COMPACT loop over the centres that were hit, one at a time -- the general
+        // form below is ~1000 straight-line instructions (8 centres x 3 blocks unrolled) that run once per step in a third of the
+        // workgroups, i.e. out of a cold instruction cache: 4.8k cycles per touched step for ~300 cycles of work (ACAV_WIDE_PROF),
+        // on the chain of the slowest publisher of the next step.  Same arithmetic: rows ascending within a centre, v = x * lr,
+        // dl = v0 (+ v1 ...), c = c * f + dl; the order of the CENTRES does not matter (disjoint rows of sC, sCnt, bits of pend).
+        if (nblk <= 4) {
+            const int li = best - kbase;  // this lane's batch row -> local centre (valid: lane < b and 0 <= li < nck)
+            unsigned long long rem = __ballot(lane < b && li >= 0 && li < nck);
+            const bool own = wave < nblk;
+            const int col = wave * 256 + (lane << 2);
+            const bool ok = own && (!RAGGED || col < d);
+            while (rem) {  // uniform
+                const int lead = __ffsll((long long)rem) - 1;
+                const int c = __builtin_amdgcn_readlane(li, lead);
+                unsigned long long m = __ballot(lane < b && li == c);
+                rem &= ~m;
+                const int cnt = __popcll(m);
+                if (own) {
+                    float4 dl = make_float4(0.f, 0.f, 0.f, 0.f);
+                    bool have = false;
+                    while (m) {  // rows of the batch with this label, ascending (torch_scatter's CPU order)
+                        const int i = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const float4 x4 = ok ? *reinterpret_cast<const float4 *>(xb + (size_t)i * d + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 v = make_float4(x4.x * lr32, x4.y * lr32, x4.z * lr32, x4.w * lr32);
+                        dl = have ? make_float4(dl.x + v.x, dl.y + v.y, dl.z + v.z, dl.w + v.w) : v;
+                        have = true;
+                    }
+                    if (ok) {
+                        const float f = 1.0f - (float)cnt * lr32;
+                        float4 *pc4 = reinterpret_cast<float4 *>(sC + c * ds + wave * 256 + ((lane ^ (c & 7)) << 2));
+                        const float4 c4 = *pc4;
+                        *pc4 = make_float4(c4.x * f + dl.x, c4.y * f + dl.y, c4.z * f + dl.z, c4.w * f + dl.w);
+                    }
+                }
+                if (tid == 0) sCnt[c] = sCnt[c] + (float)cnt;
+                pend |= 1ull << c;
+            }
+        } else
         for (int cp = 0; cp < NCP; ++cp) {
             unsigned long long msk[8];
             unsigned touched = 0;
@@ -1213,6 +1257,9 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
 #pragma unroll
                 for (int u = 0; u < 3; ++u) col_ok[u] = blk0 + 4 * u < nblk && (!RAGGED || (blk0 + 4 * u) * 256 + (lane << 2) < d);
                 float4 dl[8][3];
+#ifdef ACAV_WIDE_PROF
+                wu1 = TPW_CLK();
+#endif
 #pragma unroll
                 for (int c8 = 0; c8 < 8; ++c8) {
                     unsigned long long m = msk[c8];
@@ -1233,6 +1280,10 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                         have = true;
                     }
                 }
+#ifdef ACAV_WIDE_PROF
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the rows have landed: what lies before this is their round trip)
+                wacc1 += TPW_CLK() - wu1;
+#endif
 #pragma unroll
                 for (int c8 = 0; c8 < 8; ++c8) {
                     if (msk[c8]) {
@@ -1255,14 +1306,23 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
             }
             pend |= (unsigned long long)touched << (cp * 8);
         }
+#ifdef ACAV_WIDE_PROF
+        const long long wu3 = TPW_CLK();
+#endif
         __syncthreads();  // the updated centres and counts are in place before the next step reads them
 #ifdef ACAV_WIDE_PROF
-        if (t >= need) wpr[3] += TPW_CLK() - wc3, wpr[4] += TPW_CLK() - wc0, wpr[6] += 1;
+        if (t >= need) {
+            wpr[3] += TPW_CLK() - wc3, wpr[4] += TPW_CLK() - wc0, wpr[6] += 1;
+            wup[0] += wu0 - wc3, wup[1] += wacc1, wup[2] += wu3 - wu0 - wacc1, wup[3] += TPW_CLK() - wu3;
+        }
 #endif
     }
 #ifdef ACAV_WIDE_PROF
     if (blockIdx.x == 1 && blockIdx.y == 0 && tid == 0)
+    {
         for (int q = 0; q < 8; ++q) ctl->prof[q] = (unsigned long long)wpr[q];
+        for (int q = 0; q < 4; ++q) ctl->prof_wg[0][q] = (unsigned long long)wup[q];
+    }
 #endif
 #undef TPW_CLK
     if (pend) {  // uniform
@@ -2184,13 +2244,18 @@ static int train_finish(acav_kmeans *km, TrainCall &tc)
         }
 #ifdef ACAV_WIDE_PROF
         {
-            struct { unsigned err, pad[3]; unsigned long long prof[8]; } hw{};
+            struct { unsigned err, pad[3]; unsigned long long prof[8]; unsigned long long up[8]; } hw{};
             ACAV_HIP_TRY(hipMemcpy(&hw, km->ctl.p, sizeof(hw), hipMemcpyDeviceToHost));
             const double den = (double)(hw.prof[5] ? hw.prof[5] : 1);
             if (hw.prof[5])
                 fprintf(stderr, "[acav] wide epoch (%d workgroups): cycles/step of workgroup (1, 0): row wait %.0f, fma %.0f, keys + exchange %.0f, update %.0f, "
                                 "total %.0f; sweep passes/step %.2f; steps with an update of mine %.3f\n", tc.nwg, hw.prof[0] / den, hw.prof[1] / den,
                         hw.prof[2] / den, hw.prof[3] / den, hw.prof[4] / den, hw.prof[7] / den, hw.prof[6] / den);
+            if (hw.prof[6]) {
+                const double dt = (double)hw.prof[6];
+                fprintf(stderr, "[acav]   per step WITH an update of mine: lr / labels %.0f, row loads issued -> landed %.0f, ballots + accumulate + centre rows "
+                                "rewritten %.0f, closing barrier %.0f\n", hw.up[0] / dt, hw.up[1] / dt, hw.up[2] / dt, hw.up[3] / dt);
+            }
         }
 #endif
         if (tc.split_prof) {
