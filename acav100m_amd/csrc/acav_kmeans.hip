@@ -1687,47 +1687,48 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
             if (PROF) pr[5] += TS_CLK() - c0;
             continue;
         }
-        for (int cp = 0; cp < 2; ++cp) {
-            unsigned long long msk[8];
-            unsigned touched = 0;
+        {  // COMPACT update (as k_train_persistent / k_train_persistent_wide): the hit centres four at a time, first rows in flight together
+            const int li = best - kbase;  // this lane's batch row -> local centre (valid: lane < b, 0 <= li < nck)
+            unsigned long long rem = __ballot(lane < b && li >= 0 && li < nck);
+            while (rem) {  // uniform
+                int cs[4];
+                unsigned long long ms[4];
+                float4 x0[4];
 #pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) {
-                msk[c8] = (cp * 8 + c8 < nck) ? __ballot(lane < b && best == kbase + cp * 8 + c8) : 0ull;
-                touched |= (msk[c8] ? 1u : 0u) << c8;
-            }
-            if (!touched) continue;  // uniform over the workgroup
-            if (active) {
-                float4 dl[8];
-#pragma unroll
-                for (int c8 = 0; c8 < 8; ++c8) {
-                    unsigned long long m = msk[c8];
-                    bool have = false;
-                    while (m) {  // rows of the batch with this label, ascending (torch_scatter's CPU order)
-                        const int i = __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        const float4 x4 = *reinterpret_cast<const float4 *>(xb + (size_t)i * d + coff + wave * 256 + (lane << 2));
-                        const float4 v = make_float4(x4.x * lr32, x4.y * lr32, x4.z * lr32, x4.w * lr32);
-                        dl[c8] = have ? make_float4(dl[c8].x + v.x, dl[c8].y + v.y, dl[c8].z + v.z, dl[c8].w + v.w) : v;
-                        have = true;
+                for (int q = 0; q < 4; ++q) {
+                    cs[q] = 0, ms[q] = 0ull, x0[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (rem) {
+                        cs[q] = __builtin_amdgcn_readlane(li, __ffsll((long long)rem) - 1);
+                        ms[q] = __ballot(lane < b && li == cs[q]);
+                        rem &= ~ms[q];
+                        const int i0 = __ffsll((long long)ms[q]) - 1;
+                        if (active) x0[q] = *reinterpret_cast<const float4 *>(xb + (size_t)i0 * d + coff + wave * 256 + (lane << 2));
                     }
                 }
 #pragma unroll
-                for (int c8 = 0; c8 < 8; ++c8) {
-                    if (msk[c8]) {
-                        const float f = 1.0f - (float)__popcll(msk[c8]) * lr32;
-                        float4 *pc4 = reinterpret_cast<float4 *>(sC + (cp * 8 + c8) * TS_COLS + wave * 256 + ((lane ^ (c8 & 7)) << 2));
-                        const float4 c4 = *pc4;
-                        *pc4 = make_float4(c4.x * f + dl[c8].x, c4.y * f + dl[c8].y, c4.z * f + dl[c8].z, c4.w * f + dl[c8].w);
+                for (int q = 0; q < 4; ++q) {
+                    if (ms[q]) {  // uniform
+                        const int c = cs[q], cnt = __popcll(ms[q]);
+                        if (active) {
+                            float4 dl = make_float4(x0[q].x * lr32, x0[q].y * lr32, x0[q].z * lr32, x0[q].w * lr32);
+                            unsigned long long m = ms[q] & (ms[q] - 1);
+                            while (m) {  // further rows of the batch with this label, ascending (torch_scatter's CPU order)
+                                const int i = __ffsll((long long)m) - 1;
+                                m &= m - 1;
+                                const float4 x4 = *reinterpret_cast<const float4 *>(xb + (size_t)i * d + coff + wave * 256 + (lane << 2));
+                                const float4 v = make_float4(x4.x * lr32, x4.y * lr32, x4.z * lr32, x4.w * lr32);
+                                dl = make_float4(dl.x + v.x, dl.y + v.y, dl.z + v.z, dl.w + v.w);
+                            }
+                            const float f = 1.0f - (float)cnt * lr32;
+                            float4 *pc4 = reinterpret_cast<float4 *>(sC + c * TS_COLS + wave * 256 + ((lane ^ (c & 7)) << 2));
+                            const float4 c4 = *pc4;
+                            *pc4 = make_float4(c4.x * f + dl.x, c4.y * f + dl.y, c4.z * f + dl.z, c4.w * f + dl.w);
+                        }
+                        if (tid == 0) sCnt[c] = sCnt[c] + (float)cnt;
+                        pend |= 1u << c;
                     }
                 }
             }
-            if (tid < 8 && ((touched >> tid) & 1u)) {
-                int cnt = 0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) cnt = (e == (int)tid) ? __popcll(msk[e]) : cnt;
-                sCnt[cp * 8 + tid] = sCnt[cp * 8 + tid] + (float)cnt;
-            }
-            pend |= touched << (cp * 8);
         }
         __syncthreads();  // the updated centres and counts are in place before the next step reads them
         if (PROF) {
