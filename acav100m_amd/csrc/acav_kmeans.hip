@@ -1211,32 +1211,42 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
         }
 #ifdef ACAV_WIDE_PROF
         const long long wu0 = TPW_CLK();
-        long long wu1 = 0, wacc1 = 0;
+        const long long wacc1 = 0;  // (the row round trip is no longer timed apart: the compact loop overlaps it)
 #endif
-        // d <= 1024 (a wave owns at most ONE column block): a COMPACT loop over the centres that were hit, one at a time -- the general
-        // form below is ~1000 straight-line instructions (8 centres x 3 blocks unrolled) that run once per step in a third of the
-        // workgroups, i.e. out of a cold instruction cache: 4.8k cycles per touched step for ~300 cycles of work (ACAV_WIDE_PROF),
-        // on the chain of the slowest publisher of the next step.  Same arithmetic: rows ascending within a centre, v = x * lr,
-        // dl = v0 (+ v1 ...), c = c * f + dl; the order of the CENTRES does not matter (disjoint rows of sC, sCnt, bits of pend).
-        if (nblk <= 4) {
+        // A COMPACT loop over the centres that were hit, four at a time (round 4).  The form it replaced walked every centre pass with
+        // 8 centres x 3 column blocks unrolled: ~1000 straight-line instructions that ran once per step in a third of the workgroups,
+        // i.e. out of a cold instruction cache -- 4.8k cycles per touched step for ~300 cycles of work (ACAV_WIDE_PROF), on the chain
+        // of the next step's slowest publisher.  Same arithmetic: rows ascending within a centre, v = x * lr, dl = v0 (+ v1 ...),
+        // c = c * f + dl; the order of the CENTRES does not matter (disjoint rows of sC, sCnt, bits of pend).
+        {
             const int li = best - kbase;  // this lane's batch row -> local centre (valid: lane < b and 0 <= li < nck)
             unsigned long long rem = __ballot(lane < b && li >= 0 && li < nck);
+            // a wave's column blocks: wave, wave + 4, wave + 8 (d <= 3072); the loads of a row for all of them are in flight together
+            bool okb[3];
+            int colb[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                colb[u] = (wave + 4 * u) * 256 + (lane << 2);
+                okb[u] = wave + 4 * u < nblk && (!RAGGED || colb[u] < d);
+            }
             const bool own = wave < nblk;
-            const int col = wave * 256 + (lane << 2);
-            const bool ok = own && (!RAGGED || col < d);
             while (rem) {  // uniform: up to four centres per trip, the first row of each in flight together (one round trip)
                 int cs[4];
                 unsigned long long ms[4];
-                float4 x0[4];
+                float4 x0[4][3];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    cs[q] = 0, ms[q] = 0ull, x0[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    cs[q] = 0, ms[q] = 0ull;
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) x0[q][u] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (rem) {
                         cs[q] = __builtin_amdgcn_readlane(li, __ffsll((long long)rem) - 1);
                         ms[q] = __ballot(lane < b && li == cs[q]);
                         rem &= ~ms[q];
                         const int i0 = __ffsll((long long)ms[q]) - 1;
-                        if (ok) x0[q] = *reinterpret_cast<const float4 *>(xb + (size_t)i0 * d + col);
+#pragma unroll
+                        for (int u = 0; u < 3; ++u)
+                            if (okb[u]) x0[q][u] = *reinterpret_cast<const float4 *>(xb + (size_t)i0 * d + colb[u]);
                     }
                 }
 #pragma unroll
@@ -1244,92 +1254,37 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                     if (ms[q]) {  // uniform
                         const int c = cs[q], cnt = __popcll(ms[q]);
                         if (own) {
-                            float4 dl = make_float4(x0[q].x * lr32, x0[q].y * lr32, x0[q].z * lr32, x0[q].w * lr32);
+                            float4 dl[3];
+#pragma unroll
+                            for (int u = 0; u < 3; ++u) dl[u] = make_float4(x0[q][u].x * lr32, x0[q][u].y * lr32, x0[q][u].z * lr32, x0[q][u].w * lr32);
                             unsigned long long m = ms[q] & (ms[q] - 1);
                             while (m) {  // further rows of the batch with this label, ascending (torch_scatter's CPU order)
                                 const int i = __ffsll((long long)m) - 1;
                                 m &= m - 1;
-                                const float4 x4 = ok ? *reinterpret_cast<const float4 *>(xb + (size_t)i * d + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-                                const float4 v = make_float4(x4.x * lr32, x4.y * lr32, x4.z * lr32, x4.w * lr32);
-                                dl = make_float4(dl.x + v.x, dl.y + v.y, dl.z + v.z, dl.w + v.w);
+                                float4 x4[3];
+#pragma unroll
+                                for (int u = 0; u < 3; ++u)
+                                    x4[u] = okb[u] ? *reinterpret_cast<const float4 *>(xb + (size_t)i * d + colb[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                                for (int u = 0; u < 3; ++u) {
+                                    const float4 v = make_float4(x4[u].x * lr32, x4[u].y * lr32, x4[u].z * lr32, x4[u].w * lr32);
+                                    dl[u] = make_float4(dl[u].x + v.x, dl[u].y + v.y, dl[u].z + v.z, dl[u].w + v.w);
+                                }
                             }
-                            if (ok) {
-                                const float f = 1.0f - (float)cnt * lr32;
-                                float4 *pc4 = reinterpret_cast<float4 *>(sC + c * ds + wave * 256 + ((lane ^ (c & 7)) << 2));
-                                const float4 c4 = *pc4;
-                                *pc4 = make_float4(c4.x * f + dl.x, c4.y * f + dl.y, c4.z * f + dl.z, c4.w * f + dl.w);
-                            }
+                            const float f = 1.0f - (float)cnt * lr32;
+#pragma unroll
+                            for (int u = 0; u < 3; ++u)
+                                if (okb[u]) {
+                                    float4 *pc4 = reinterpret_cast<float4 *>(sC + c * ds + (wave + 4 * u) * 256 + ((lane ^ (c & 7)) << 2));
+                                    const float4 c4 = *pc4;
+                                    *pc4 = make_float4(c4.x * f + dl[u].x, c4.y * f + dl[u].y, c4.z * f + dl[u].z, c4.w * f + dl[u].w);
+                                }
                         }
                         if (tid == 0) sCnt[c] = sCnt[c] + (float)cnt;
                         pend |= 1ull << c;
                     }
                 }
             }
-        } else
-        for (int cp = 0; cp < NCP; ++cp) {
-            unsigned long long msk[8];
-            unsigned touched = 0;
-#pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) {
-                msk[c8] = (cp * 8 + c8 < nck) ? __ballot(lane < b && best == kbase + cp * 8 + c8) : 0ull;
-                touched |= (msk[c8] ? 1u : 0u) << c8;
-            }
-            if (!touched) continue;  // uniform over the workgroup
-            // a wave's column blocks (wave, wave + 4, wave + 8: d <= 3072) side by side -- the loads of a batch row for all of
-            // them are in flight together (one after the other the update of a 2304-wide view took three round trips)
-            for (int blk0 = wave; blk0 < nblk; blk0 += 12) {
-                bool col_ok[3];
-#pragma unroll
-                for (int u = 0; u < 3; ++u) col_ok[u] = blk0 + 4 * u < nblk && (!RAGGED || (blk0 + 4 * u) * 256 + (lane << 2) < d);
-                float4 dl[8][3];
-#ifdef ACAV_WIDE_PROF
-                wu1 = TPW_CLK();
-#endif
-#pragma unroll
-                for (int c8 = 0; c8 < 8; ++c8) {
-                    unsigned long long m = msk[c8];
-                    bool have = false;
-                    while (m) {  // rows of the batch with this label, ascending (torch_scatter's CPU order)
-                        const int i = __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        float4 x4[3];
-#pragma unroll
-                        for (int u = 0; u < 3; ++u)
-                            x4[u] = col_ok[u] ? *reinterpret_cast<const float4 *>(xb + (size_t)i * d + (blk0 + 4 * u) * 256 + (lane << 2))
-                                              : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int u = 0; u < 3; ++u) {
-                            const float4 v = make_float4(x4[u].x * lr32, x4[u].y * lr32, x4[u].z * lr32, x4[u].w * lr32);
-                            dl[c8][u] = have ? make_float4(dl[c8][u].x + v.x, dl[c8][u].y + v.y, dl[c8][u].z + v.z, dl[c8][u].w + v.w) : v;
-                        }
-                        have = true;
-                    }
-                }
-#ifdef ACAV_WIDE_PROF
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the rows have landed: what lies before this is their round trip)
-                wacc1 += TPW_CLK() - wu1;
-#endif
-#pragma unroll
-                for (int c8 = 0; c8 < 8; ++c8) {
-                    if (msk[c8]) {
-                        const float f = 1.0f - (float)__popcll(msk[c8]) * lr32;
-#pragma unroll
-                        for (int u = 0; u < 3; ++u)
-                            if (col_ok[u]) {
-                                float4 *pc4 = reinterpret_cast<float4 *>(sC + (cp * 8 + c8) * ds + (blk0 + 4 * u) * 256 + ((lane ^ (c8 & 7)) << 2));
-                                const float4 c4 = *pc4;
-                                *pc4 = make_float4(c4.x * f + dl[c8][u].x, c4.y * f + dl[c8][u].y, c4.z * f + dl[c8][u].z, c4.w * f + dl[c8][u].w);
-                            }
-                    }
-                }
-            }
-            if (tid < 8 && ((touched >> tid) & 1u)) {
-                int cnt = 0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) cnt = (e == (int)tid) ? __popcll(msk[e]) : cnt;
-                sCnt[cp * 8 + tid] = sCnt[cp * 8 + tid] + (float)cnt;
-            }
-            pend |= (unsigned long long)touched << (cp * 8);
         }
 #ifdef ACAV_WIDE_PROF
         const long long wu3 = TPW_CLK();
