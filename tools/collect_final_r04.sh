@@ -24,3 +24,11 @@ tools/exp/colds_probe_bench 135744 240 > "$OUT/${P}_colds_probe.txt" 2>&1
 for f in "$OUT"/${P}_*.txt; do sed -i '/amdgpu.ids/d' "$f"; done
 for f in "$OUT/${P}_mi_1m.txt" "$OUT/${P}_bench_under_rocprof.txt"; do grep "^{" "$f" | tail -1 > "$f.tmp" && mv "$f.tmp" "${f%.txt}.json" && rm -f "$f"; done
 ls -la "$OUT"
+# SGD step per shape after the compact update
+: > "$OUT/${P}_train_shapes_compact.txt"
+for shape in "1024 256" "512 64" "1024 1024" "128 1024" "2048 1024" "2048 512" "2048 256" "1408 256" "2304 256" "1408 1024"; do
+    set -- $shape
+    echo -n "d=$1 K=$2: " >> "$OUT/${P}_train_shapes_compact.txt"
+    BENCH_D=$1 BENCH_K=$2 timeout 300 python tools/bench_train_b.py 32 2> /dev/null | tail -1 >> "$OUT/${P}_train_shapes_compact.txt"
+done
+ACAV_PROFILE_STEPS=1 BENCH_D=1024 BENCH_K=256 timeout 300 python tools/bench_train_b.py 32 2>&1 | grep -a "acav\|us/step" > "$OUT/${P}_train_phase_cycles_compact.txt"
