@@ -53,6 +53,7 @@ SIGNATURES = {
     "acav_kmeans_allreduce_init": [vp, vp],
     "acav_kmeans_train_dp": [vp, vp, vp, i64, i64, f64, vp, i64, i64, i32],
     "acav_kmeans_train_dp_multi": [vp, vp, i32, vp, i64, i64, f64, vp, vp, i64, vp],
+    "acav_kmeans_train_plan_multi": [vp, vp, i32, vp, i64, i32, i64, vp, i64, i64, f64, vp, vp, i64, vp],
     "acav_kmeans_broadcast_state": [vp, vp, i32],
     "acav_kmeans_timer_begin": [vp],
     "acav_kmeans_timer_end": [vp, C.POINTER(f32)],

@@ -8,7 +8,8 @@ Same observable behaviour as the reference with a single-stream loader (--comput
   * KMeans objects are created in args.models order, layer by layer (RNG order of run_clustering.py:32-44)
   * per batch of 32 consecutive rows, every clustering takes one add() -- the warm-up draws are
     interleaved across clusterings exactly like the reference's per-batch loop (:229-241)
-  * lr = 0.1 ** (2 + epoch // 5), epochs = ceil(epochs / num_gpus), drop_last batches
+  * lr = 0.1 ** (2 + epoch // 5), drop_last batches; several GPUs: clustering.multi_gpu (config.py) -- `views` keeps the
+    one-GPU batch stream and epoch count, `reference` is the reference's own N-GPU stream with ceil(epochs / num_gpus) epochs
   * cache_epoch_{e}_{name} checkpoints, skip of already written shards, log_*.json manifest
 """
 import math
@@ -277,21 +278,22 @@ def _device_budget(args):
     return int(free * 0.6)
 
 
-def train_clusters(args, probe, groups):
+def train_clusters(args, probe, groups, shard_stems=()):
     import torch
     cl, loaded = load_clusterings(args, probe)
     if loaded and not args.clustering.resume_training:
         return cl
     pre = args.clustering.cached_epoch if loaded else 0
     rank, w = world()
-    # The reference divides the epochs by the number of GPUs because its DDP step consumes num_gpus batches
-    # (run_clustering.py:146); here several GPUs split the CLUSTERINGS, every one of which still sees every batch
-    # of every epoch -- the N-GPU run produces the files of the one-GPU run.
+    # `views` (default): several GPUs split the CLUSTERINGS, every one of which still sees every batch of every epoch with
+    # the one-GPU arithmetic -- the N-GPU run produces the files of the one-GPU run.  (The reference divides the epochs by
+    # the number of GPUs, run_clustering.py:146, and has every rank stream every shard with a per-rank batch of
+    # batch_size / N: that run is `clustering.multi_gpu=reference`, _train_clusters_planned.)
     epochs = int(args.clustering.epochs)
     b = int(args.data.batch_size)
     print("training sgd kmeans for views: {}".format([v[1:] for v in cl]))
-    if w > 1 and multi_gpu_mode(args) == 'rows':
-        return _train_clusters_rows(args, cl, groups, pre, epochs, b)
+    if w > 1 and multi_gpu_mode(args) != 'views':
+        return _train_clusters_planned(args, cl, groups, pre, epochs, b, multi_gpu_mode(args), shard_stems)
     for epoch in range(pre, pre + epochs):
         lr = 0.1 ** (2 + epoch // 5)
         for km in cl.values():
@@ -340,48 +342,75 @@ def train_clusters(args, probe, groups):
 
 
 def multi_gpu_mode(args):
-    """clustering.multi_gpu: 'views' (default) or 'rows' -- see config.py"""
+    """clustering.multi_gpu: 'views' (default), 'reference' or 'rows' -- see config.py"""
     mode = str(args.clustering.multi_gpu or 'views')
-    if mode not in ('views', 'rows'):
-        raise ValueError("clustering.multi_gpu must be 'views' or 'rows', not {!r}".format(mode))
+    if mode not in ('views', 'reference', 'rows'):
+        raise ValueError("clustering.multi_gpu must be 'views', 'reference' or 'rows', not {!r}".format(mode))
     return mode
 
 
-def _train_clusters_rows(args, cl, groups, pre, epochs, b):
-    """The reference's multi-GPU training (sgd_clustering.py:94-129 under is_distributed, run_clustering.py:146): `groups`
-    holds THIS rank's shards (rank::world, mps/distributed.py:439) -- the node's aggregate HBM holds the rows, nothing
-    streams through one GPU -- step t's global batch is the rank-major concatenation of every rank's rows
-    [t b, (t + 1) b), and the epochs are divided by the number of GPUs (ceil), because a step consumes world batches.
-    What bench.py --gpus N measures: KMeans.train_epoch_distributed_multi (rows of 1 024 steps at a time to the rank that
-    runs a view's chain, no collective on the step path), then the trainers hand out their states."""
-    import math
+def _train_clusters_planned(args, cl, groups, pre, epochs, b, mode, shard_stems):
+    """Multi-GPU training with the rows PARTITIONED over the ranks: `groups` holds THIS rank's shards (rank::world,
+    mps/distributed.py:439 -- the node's aggregate HBM holds the rows, nothing streams through one GPU) and a plan
+    (parallel/row_plan.py) says which rows form which step's global batch:
+
+      reference   the reference's own N-GPU run (sgd_clustering.py:94-129 under is_distributed): rank q feeds
+                  int(batch_size / N) rows per step (data/clustering.py:25) of ITS stream over ALL shards in the rotated
+                  order full[q::N] + full[q+1::N] + ... (mps/distributed.py:433-437), ceil(epochs / N) epochs
+                  (run_clustering.py:146).  Global batch = batch_size; N * rows / batch_size steps per epoch.
+      rows        large batch: every rank feeds batch_size rows of its OWN shards per step (global batch N x batch_size),
+                  ceil(epochs / N) epochs -- N x N fewer SGD steps than `reference`; not the reference's run.
+
+    KMeans.train_epoch_plan_multi: the rows of 1 024 steps at a time travel to the rank that runs a clustering's chain
+    (clustering v -> rank v % N), no collective on the step path; then the trainers hand out their states.  The state
+    equals ONE process fed the same global batches (tests/test_gpu_cli.py); the reference's own all-reduce of per-rank
+    deltas differs from that by fp32 re-association in an order NCCL does not promise."""
     import torch
     import torch.distributed as dist
-    from ..parallel.kmeans_dp import _collective_device
+    from ..parallel import make_plan, plan_warmup_labels
     rank, w = world()
     if groups.streamed:
-        raise RuntimeError("clustering.multi_gpu=rows keeps every rank's rows resident: {} groups do not fit the device budget "
-                           "(raise data.resident_bytes, use more GPUs, or clustering.multi_gpu=views)".format(len(groups.groups)))
-    epochs = math.ceil(epochs / w)  # run_clustering.py:146
-    (_gi, _table, rows), = list(groups.iterate())
-    n_local = next(iter(rows.values())).shape[0] if rows else 0
-    steps = torch.tensor([n_local // b], dtype=torch.int64, device=_collective_device())
-    dist.all_reduce(steps, op=dist.ReduceOp.MIN)  # every rank feeds every step: the shortest rank decides (drop_last)
-    steps = int(steps.item())
-    print("rank {}: {} local rows, {} steps of {} x {} rows per epoch, {} epochs".format(rank, n_local, steps, w, b, epochs))
+        raise RuntimeError("clustering.multi_gpu={} keeps every rank's rows resident: {} groups do not fit the device budget "
+                           "(raise data.resident_bytes, use more GPUs, or clustering.multi_gpu=views)".format(mode, len(groups.groups)))
+    (_gi, table, rows), = list(groups.iterate())
+    # rows every shard REALLY delivered (an unreadable shard was reported and skipped by the loader: 0 rows), from its owner
+    mine = {stem: len(table.shard_rows.get(stem) or ()) for stem in shard_stems[rank::w]}
+    everyone = [None] * w
+    dist.all_gather_object(everyone, mine)
+    have = {}
+    for part in everyone:
+        have.update(part)
+    shard_rows = [int(have.get(stem, 0)) for stem in shard_stems]
+    plan = make_plan(mode, shard_rows, w, b, epochs)
+    seg = [sum(shard_rows[r::w]) for r in range(w)]
+    # the reference clamps num_gpus to the number of shards (script.py:22,37); a rank without rows (more GPUs than shards,
+    # or every shard of a rank unreadable) or an epoch without a single step would leave untrained clusterings behind
+    if min(seg) == 0 or plan.steps == 0:
+        raise RuntimeError("clustering.multi_gpu={}: rows per rank {} give {} steps of {} rows -- fewer shards than GPUs, or "
+                           "unreadable shards; lower computation.num_gpus".format(mode, seg, plan.steps, plan.global_batch))
+    print("rank {}: {} local rows; mode {}: {} steps of {} x {} rows per epoch, {} epochs".format(
+        rank, seg[rank], mode, plan.steps, plan.slots, plan.lb, plan.epochs))
     kms = list(cl.values())
-    for epoch in range(pre, pre + epochs):
+    xs = [rows[v] for v in cl]
+    for epoch in range(pre, pre + plan.epochs):
         lr = 0.1 ** (2 + epoch // 5)
         for km in kms:
             km.lr = lr
-        gen = kms[0]._generator  # the DataLoader iterator's seed draw, as in the one-GPU loop
+        gen = kms[0]._generator  # the DataLoader iterator's seed draw, as in the one-GPU loop (every rank creates its own)
         gen.u32()
         gen.u32()
-        if steps > 0:
-            xs = [rows[v][:steps * b] for v in cl]
-            trainers = KMeans.train_epoch_distributed_multi(kms, xs, b, lr=lr)
+        # warm-up labels of this rank's slot, drawn batch by batch across the clusterings like the reference loop
+        # (run_clustering.py:170-175 steps every clustering per batch), then exchanged once per clustering
+        need = [km.warmup_steps(plan.global_batch, plan.steps) for km in kms]
+        local = [np.empty((nd, plan.lb), np.int64) for nd in need]
+        for t in range(max(need, default=0)):
             for i, km in enumerate(kms):
-                km.broadcast_state_from(trainers[i], comm_slot=i)
+                if t < need[i]:
+                    local[i][t] = km.draw_warmup(plan.lb)
+        warm = [plan_warmup_labels(km, plan, device=xs[i].device, mine=local[i], comm_slot=i) for i, km in enumerate(kms)]
+        trainers = KMeans.train_epoch_plan_multi(kms, xs, plan, lr=lr, warm_bests=warm)
+        for i, km in enumerate(kms):
+            km.broadcast_state_from(trainers[i], comm_slot=i)
         if rank == 0:
             save_clusterings(args, epoch, cl)
     return cl
@@ -458,10 +487,13 @@ def run_clustering(args):
         return []
     row_bytes = 4 * sum(m.shape[1] for m in probe.views.values())
     view_dims = OrderedDict((v, m.shape[1]) for v, m in probe.views.items())
-    rows_mode = w > 1 and multi_gpu_mode(args) == 'rows'
-    # rows mode: a rank reads, holds and labels its own shards only (rank::world) -- training included
-    groups = _RowGroups(args, paths[rank::w] if rows_mode else paths, sizes, row_bytes, _device_budget(args), view_dims)
-    cl = train_clusters(args, probe, groups)
+    partitioned = w > 1 and multi_gpu_mode(args) != 'views'
+    if partitioned and w > len(paths):  # the reference clamps num_gpus to the number of shards (script.py:22,37)
+        raise RuntimeError("clustering.multi_gpu={}: {} GPUs for {} shards -- a rank without shards holds no rows to feed the "
+                           "steps; lower computation.num_gpus".format(multi_gpu_mode(args), w, len(paths)))
+    # reference / rows mode: a rank reads, holds and labels its own shards only (rank::world) -- training included
+    groups = _RowGroups(args, paths[rank::w] if partitioned else paths, sizes, row_bytes, _device_budget(args), view_dims)
+    cl = train_clusters(args, probe, groups, [p.stem for p in paths])
     mine = [p.stem for p in paths][rank::w]  # assign: shards strided over ranks (mps/distributed.py:439)
     return assign_clusters(args, groups, cl, mine)
 

@@ -385,8 +385,9 @@ class KMeans:
 
     def train_epoch_distributed(self, x_local, batch_size, lr=None, chunk_steps=1024, train_here=True, comm_slot=0, wait=True,
                                 trainer=None):
-        """One epoch of the reference's multi-GPU add() loop (global batch = world * batch_size rows, rank-major)
-        without a collective per step: see acav100m_amd/parallel/kmeans_dp.py:train_epoch_dp."""
+        """One epoch in the large-batch mode (global batch = world * batch_size rows, rank-major: every rank feeds
+        batch_size of its own rows per step -- not the reference's N-GPU run, see train_epoch_plan_multi) without a
+        collective per step: acav100m_amd/parallel/kmeans_dp.py:train_epoch_dp."""
         lr = self.lr if lr is None else lr
         from ..parallel.rccl_comm import default_comm
         comm = default_comm(comm_slot) if hasattr(x_local, "is_cuda") and x_local.is_cuda else None
@@ -450,6 +451,64 @@ class KMeans:
         here = np.asarray([(1 if t == rank else 0) | 4 | (t << 8) for t in trainers], np.int32)
         _lib.check(_lib._lib.acav_kmeans_train_dp_multi(h_arr, c_arr, cnt, x_arr, int(n_local), int(batch_size), float(lr), w_arr,
                                                         _lib.ptr(nw_arr), int(chunk_steps), _lib.ptr(here)))
+        return trainers
+
+    @staticmethod
+    def train_epoch_plan_multi(clusterings, xs_local, plan, lr=None, chunk_steps=1024, trainers=None, warm_bests=None):
+        """One epoch of several clusterings over the global batches of `plan` (parallel/row_plan.py: `reference` = the
+        reference's own N-GPU batch stream, `views` = the one-GPU stream over partitioned rows, `rows` = large batch) with
+        the rows living on the ranks that own them: acav_kmeans_train_plan_multi.  Every rank feeds every clustering's row
+        exchange (communicator slot = position in the list); the chain of clustering v runs on rank trainers[v] only
+        (default v % world): different ranks train different clusterings at the same time.  Follow with
+        broadcast_state_from(trainers[v], comm_slot=v).  warm_bests[v]: [need, global batch] warm-up labels (None: drawn
+        and exchanged here, clustering by clustering -- parallel.plan_warmup_labels).  Without RCCL (gloo / host tensors:
+        CPU tests, several ranks on one GPU) the clusterings go one after the other through torch.distributed
+        (parallel.train_epoch_plan)."""
+        kms = list(clusterings)
+        if not kms:
+            return []
+        from ..parallel.collectives import world as _world
+        from ..parallel.kmeans_dp import plan_warmup_labels, train_epoch_plan
+        from ..parallel.rccl_comm import default_comm
+        rank, w = _world()
+        trainers = [v % w for v in range(len(kms))] if trainers is None else [int(t) for t in trainers]
+        lr = kms[0].lr if lr is None else lr
+        on_gpu = all(hasattr(x, "is_cuda") and x.is_cuda for x in xs_local)
+        comms = [default_comm(v) for v in range(len(kms))] if on_gpu else [None] * len(kms)
+        warms = []
+        for v, (km, x) in enumerate(zip(kms, xs_local)):  # drawn in clustering order on every rank: the shared generator advances alike
+            wb = None if warm_bests is None else warm_bests[v]
+            if wb is None:
+                wb = plan_warmup_labels(km, plan, device=getattr(x, "device", None), comm=comms[v] if w > 1 else None)
+            warms.append(None if wb is None else np.ascontiguousarray(wb, np.int64))
+        if any(c is None for c in comms):
+            for v, (km, x) in enumerate(zip(kms, xs_local)):
+                train_epoch_plan(km, x, plan, lr, trainers[v], chunk_steps=chunk_steps, warm=warms[v])
+            return trainers
+        keep, ptrs = [], []
+        n_local = None
+        for km, x in zip(kms, xs_local):
+            k, xp, n, _ = _as_f32_2d(x, km._shape[1])
+            assert n_local is None or n == n_local, "the clusterings of one call share the local rows"
+            n_local = n
+            keep.append(k)
+            ptrs.append(xp.value)
+        cnt = len(kms)
+        ext = np.ascontiguousarray(plan.table(), np.int64)
+        needs = np.asarray([0 if wm is None else len(wm) for wm in warms], np.int64)
+        for v, wm in enumerate(warms):
+            assert wm is None or wm.shape == (needs[v], plan.global_batch), (wm.shape, needs[v], plan.global_batch)
+        h_arr = (C.c_void_p * cnt)(*[km._require_handle().value for km in kms])
+        c_arr = (C.c_void_p * cnt)(*[c._h.value for c in comms])
+        x_arr = (C.c_void_p * cnt)(*ptrs)
+        w_arr = (C.c_void_p * cnt)(*[None if wm is None else wm.ctypes.data for wm in warms])
+        here = np.asarray([(1 if t == rank else 0) | 4 | (t << 8) for t in trainers], np.int32)  # ACAV_DP_TRAIN | ACAV_DP_ROOTED | root << 8
+        _lib.check(_lib._lib.acav_kmeans_train_plan_multi(h_arr, c_arr, cnt, x_arr, int(n_local), int(plan.slots), int(plan.lb),
+                                                          _lib.ptr(ext), int(ext.shape[0]), int(plan.steps), float(lr), w_arr,
+                                                          _lib.ptr(needs), int(chunk_steps), _lib.ptr(here)))
+        for v, km in enumerate(kms):  # a rank that only fed the exchange keeps `count` in step until the state arrives
+            if trainers[v] != rank:
+                km.skip_epoch(plan.steps * plan.global_batch)
         return trainers
 
     def broadcast_state_from(self, root, comm_slot=0):

@@ -103,10 +103,15 @@ CLUSTERING_DEFAULTS = {
         'cached_epoch': None,
         'resume_training': False,
         'load_cache_from_shard_subset': True,
-        # ours: what several GPUs do in training.  'views': the clusterings are dealt out over the GPUs, every GPU trains
-        # its share over ALL rows with the one-GPU arithmetic and epoch count (files identical to a one-GPU run).
-        # 'rows': the reference's DDP (sgd_clustering.py:94-129, run_clustering.py:146): every GPU holds the rows of its own
-        # shards (rank::world), a step's global batch is batch_size rows from every GPU, epochs = ceil(epochs / num_gpus)
+        # ours: what several GPUs do in training (acav100m_amd/parallel/row_plan.py).
+        # 'views' (default): the clusterings are dealt out over the GPUs, every GPU trains its share over ALL rows with the
+        #   one-GPU batch stream and epoch count: the N-GPU run writes the files of the one-GPU run.
+        # 'reference': the reference's own N-GPU run -- every GPU holds the rows of its own shards (rank::N), rank q feeds
+        #   int(batch_size / N) rows per step (data/clustering.py:25) of its rotated stream over ALL shards
+        #   (mps/distributed.py:433-437), epochs = ceil(epochs / N) (run_clustering.py:146): the global batch stays
+        #   batch_size, N * rows / batch_size steps per epoch.
+        # 'rows': a LARGE-BATCH operating point, not the reference's run: batch_size rows of every GPU's own shards per step
+        #   (global batch N x batch_size), ceil(epochs / N) epochs -- N x N fewer SGD steps than 'reference' (64 x at N = 8).
         'multi_gpu': 'views',
     },
     'debug': False,

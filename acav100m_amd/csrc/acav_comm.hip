@@ -4,9 +4,11 @@
 //
 // What the path really exchanges between GPUs (one process per GPU, xGMI):
 //   initialize()      one all-reduce of [centres | counts]                       (K d + K floats, once)
-//   DDP training      the ROWS of the steps ahead, all-gathered in bulk (acav_kmeans_train_dp): step t's global batch
-//                     is the rank-major concatenation of every rank's rows [t b, (t+1) b); the SGD chain itself runs
-//                     replicated and device-resident on every rank -- no collective on the 4-7 us step path
+//   multi-GPU training  the ROWS of the steps ahead, in bulk, to the one rank that runs a clustering's SGD chain -- which rows
+//                     form a step's global batch is a plan (acav_kmeans_train_plan_multi: the reference's own N-GPU batch
+//                     stream, the one-GPU stream over partitioned rows, or the large-batch layout of acav_kmeans_train_dp:
+//                     rank-major concatenation of every rank's rows [t b, (t+1) b)); the chain itself is device-resident
+//                     -- no collective on the 4-7 us step path
 //   view-parallel     broadcast of a clustering's state from the rank that trained it (K d + K floats per epoch)
 // RCCL is resolved at run time (dlopen of the librccl the process already has -- torch's -- else the ROCm one): the
 // library loads and every other entry point works on a box without RCCL; only acav_comm_* report ACAV_ESTATE there.
@@ -118,6 +120,84 @@ static int rows_to_trainers(const Rccl &R, const void *send, void *recv, size_t 
     return ACAV_OK;
 }
 
+// acav_kmeans_train_plan_multi: a destination row finds its source row through a sorted table of row ranges ("pieces").
+//   PLACE = false  packing on the sending side: destination row R of the packed block <- local row src + (R - key)
+//                  of the piece with the largest key <= R (one group)
+//   PLACE = true   the trainer's global batches [step][slot][row]: destination row R = (t, q, j) reads position
+//                  key = t * lb + j of slot q's stream within this chunk; group q holds that slot's pieces, whose `src`
+//                  is a row of the landing buffer (the ranks' packed blocks one after the other)
+struct PlanPiece {
+    int64_t key, src, len;
+};
+
+template <bool PLACE>
+__global__ __launch_bounds__(256) void k_rows_by_table(const PlanPiece *__restrict__ pieces, const int *__restrict__ group_begin,
+                                                       const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t rows,
+                                                       int d4, int slots, int lb, int lanes_per_row)
+{
+    const int rpb = 256 / lanes_per_row, sub = (int)threadIdx.x / lanes_per_row, lane = (int)threadIdx.x % lanes_per_row;
+    for (int64_t R = (int64_t)blockIdx.x * rpb + sub; R < rows; R += (int64_t)gridDim.x * rpb) {
+        int g = 0;
+        int64_t key = R;
+        if (PLACE) {
+            const int64_t bg = (int64_t)slots * lb, t = R / bg;
+            const int rem = (int)(R - t * bg);
+            g = rem / lb;
+            key = t * lb + (rem - g * lb);
+        }
+        int lo = group_begin[g], hi = group_begin[g + 1] - 1;  // the last piece of the group whose key is <= `key`
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pieces[mid].key <= key) lo = mid;
+            else hi = mid - 1;
+        }
+        const PlanPiece p = pieces[lo];
+        const float4 *s = src + (p.src + (key - p.key)) * d4;
+        float4 *o = dst + R * d4;
+        for (int c = lane; c < d4; c += lanes_per_row) o[c] = s[c];
+    }
+}
+
+static void launch_rows_by_table(bool place, const PlanPiece *pieces, const int *group_begin, const float *src, float *dst,
+                                 int64_t rows, int d, int slots, int lb, hipStream_t st)
+{
+    if (rows <= 0) return;
+    const int d4 = d / 4;
+    const int lpr = d4 >= 256 ? 256 : d4 >= 128 ? 128 : d4 >= 64 ? 64 : 32;
+    const int rpb = 256 / lpr;
+    int64_t blocks = (rows + rpb - 1) / rpb;
+    if (blocks > 65536) blocks = 65536;
+    if (place)
+        hipLaunchKernelGGL(k_rows_by_table<true>, dim3((unsigned)blocks), dim3(256), 0, st, pieces, group_begin,
+                           reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), rows, d4, slots, lb, lpr);
+    else
+        hipLaunchKernelGGL(k_rows_by_table<false>, dim3((unsigned)blocks), dim3(256), 0, st, pieces, group_begin,
+                           reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), rows, d4, slots, lb, lpr);
+}
+
+// every rank's packed rows of a chunk -> the trainer `root`: one grouped send / receive round; a rank without rows in
+// this chunk sends nothing and the root posts no receive for it (both sides read that off the same plan)
+static int packed_rows_to_root(const Rccl &R, const void *send, int64_t my_rows, void *recv, const int64_t *from, size_t row_bytes,
+                               int root, int rank, int world, ncclComm_t comm, hipStream_t st)
+{
+    if (root >= world) return ACAV_OK;  // the trainer is outside this communicator (single-rank tests): nothing to move
+    ACAV_NCCL_TRY(R.GroupStart());
+    ncclResult_t r1 = ncclSuccess, r2 = ncclSuccess;
+    if (my_rows > 0) r1 = R.Send(send, (size_t)my_rows * row_bytes, ncclInt8, root, comm, st);
+    if (rank == root) {
+        size_t off = 0;
+        for (int r = 0; r < world && r2 == ncclSuccess; ++r) {
+            if (from[r] > 0) r2 = R.Recv(static_cast<char *>(recv) + off, (size_t)from[r] * row_bytes, ncclInt8, r, comm, st);
+            off += (size_t)from[r] * row_bytes;
+        }
+    }
+    ncclResult_t r3 = R.GroupEnd();
+    ACAV_NCCL_TRY(r1);
+    ACAV_NCCL_TRY(r2);
+    ACAV_NCCL_TRY(r3);
+    return ACAV_OK;
+}
+
 __global__ void k_scale_f32(float *__restrict__ v, int64_t n, float s)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -130,7 +210,8 @@ struct acav_comm {
     StreamCtx ctx;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
-    DevBuf gather[2], batches[2], flat;
+    DevBuf gather[2], batches[2], pack[2], flat;
+    DevBuf plan_pieces, plan_groups;  // acav_kmeans_train_plan_multi: the epoch's piece tables (read-only once uploaded)
     hipEvent_t ev_gathered[2] = {nullptr, nullptr}, ev_trained[2] = {nullptr, nullptr};
 };
 
@@ -406,6 +487,201 @@ ACAV_EXPORT int acav_kmeans_train_dp_multi(acav_kmeans *const *kms, acav_comm *c
         const int64_t s = steps - c0 < chunk_steps ? steps - c0 : chunk_steps;
         if (c0 + s < steps)
             for (int v = 0; v < count; ++v) ACAV_TRY(gather(v, c0 + s, par ^ 1));  // next chunk travels while this one trains
+        lk.clear(), lx.clear(), ln.clear(), lnw.clear(), lw.clear();
+        for (int v = 0; v < count; ++v) {
+            if (!here[(size_t)v]) continue;
+            ACAV_HIP_TRY(hipStreamWaitEvent((hipStream_t)st_train[(size_t)v], comms[v]->ev_gathered[par], 0));
+            int64_t nw = (n_warm ? n_warm[v] : 0) - warm_done[(size_t)v];
+            nw = nw < 0 ? 0 : (nw > s ? s : nw);
+            lk.push_back(kms[v]);
+            lx.push_back(comms[v]->batches[par].as<float>());
+            ln.push_back(s * bg);
+            lnw.push_back(nw);
+            lw.push_back(nw ? warm_global[v] + warm_done[(size_t)v] * bg : nullptr);
+            warm_done[(size_t)v] += nw;
+        }
+        if (!lk.empty()) {
+            ACAV_TRY(acav_kmeans_train_multi(lk.data(), (int)lk.size(), lx.data(), ln.data(), bg, lr, lw.data(), lnw.data()));
+            for (int v = 0; v < count; ++v)
+                if (here[(size_t)v]) ACAV_HIP_TRY(hipEventRecord(comms[v]->ev_trained[par], (hipStream_t)st_train[(size_t)v]));
+        }
+    }
+    for (int v = 0; v < count; ++v) {
+        ACAV_HIP_TRY(hipStreamSynchronize(comms[v]->ctx.stream));
+        ACAV_TRY(acav_kmeans_sync(kms[v]));
+    }
+    return ACAV_OK;
+}
+
+// One training epoch whose global batches are put together from rows that live on DIFFERENT ranks, by a plan
+// (acav100m_amd/parallel/row_plan.py): step t's batch = for slot q = 0 .. slots-1 the rows [t lb, (t+1) lb) of slot q's
+// stream, and a stream is a list of extents (owner rank, first local row, rows).  The reference's own N-GPU stream
+// (mps/distributed.py:433-437 rotated shard order, data/clustering.py:25 per-rank batch), the one-GPU stream over
+// partitioned rows and the large-batch mode of acav_kmeans_train_dp_multi are three plans.  Mechanics as there: per chunk
+// of `chunk_steps` steps every rank packs the rows it owns (k_rows_by_table), sends them to the ONE rank that runs the
+// clustering's chain (grouped ncclSend / ncclRecv on the clustering's own communicator and stream, a chunk ahead of the
+// training), which places them into global batches and trains (acav_kmeans_train_multi: its clusterings side by side).
+// ext: int64 [n_ext][4] = (slot, owner, first row, rows), the extents of a slot in stream order.  The same `ext`, `steps`,
+// `chunk_steps` and `train_here` roots on every rank.  train_here[v]: ACAV_DP_TRAIN | ACAV_DP_ROOTED | root << 8.
+ACAV_EXPORT int acav_kmeans_train_plan_multi(acav_kmeans *const *kms, acav_comm *const *comms, int count,
+                                             const float *const *x_local_dev, int64_t n_local, int slots, int64_t lb,
+                                             const int64_t *ext, int64_t n_ext, int64_t steps, double lr,
+                                             const int64_t *const *warm_global, const int64_t *n_warm, int64_t chunk_steps,
+                                             const int *train_here)
+{
+    ACAV_REQUIRE(kms && comms && x_local_dev && train_here && count > 0 && count <= 64, ACAV_EINVAL, "bad argument");
+    ACAV_REQUIRE(n_local >= 0 && slots > 0 && slots <= 4096 && lb > 0 && lb * slots <= (1 << 20) && chunk_steps > 0 && steps >= 0 &&
+                     n_ext >= 0 && (ext || n_ext == 0),
+                 ACAV_EINVAL, "bad sizes");
+    ACAV_REQUIRE(rccl().p2p, ACAV_ESTATE, "this RCCL has no ncclSend / ncclRecv: the plan-driven row exchange needs them");
+    if (steps == 0) return ACAV_OK;
+    const int w = comms[0] ? comms[0]->world : 1, me = comms[0] ? comms[0]->rank : 0;
+    const int64_t bg = (int64_t)slots * lb;
+    std::vector<int> dv((size_t)count, 0), here((size_t)count, 0), roots((size_t)count, -1);
+    std::vector<void *> st_train((size_t)count, nullptr);
+    for (int v = 0; v < count; ++v) {
+        here[(size_t)v] = (train_here[v] & 1) != 0;
+        ACAV_REQUIRE(train_here[v] & 4, ACAV_EINVAL, "clustering %d: the plan-driven epoch has exactly one trainer (ACAV_DP_ROOTED)", v);
+        roots[(size_t)v] = train_here[v] >> 8;
+        ACAV_REQUIRE(kms[v] && comms[v] && (x_local_dev[v] || n_local == 0), ACAV_EINVAL, "clustering %d: NULL argument", v);
+        ACAV_REQUIRE(comms[v]->world == w && comms[v]->rank == me, ACAV_EINVAL, "communicators of different shapes");
+        ACAV_REQUIRE(here[(size_t)v] == (me == roots[(size_t)v]), ACAV_EINVAL,
+                     "clustering %d: ACAV_DP_ROOTED root %d does not match ACAV_DP_TRAIN on rank %d", v, roots[(size_t)v], me);
+        ACAV_REQUIRE(n_local == 0 || is_device_ptr(x_local_dev[v]), ACAV_EINVAL, "x_local must be device memory");
+        ACAV_REQUIRE(!n_warm || n_warm[v] == 0 || (warm_global && warm_global[v]), ACAV_EINVAL, "clustering %d: warm-up labels missing", v);
+        for (int e = 0; e < v; ++e) ACAV_REQUIRE(comms[e] != comms[v] && kms[e] != kms[v], ACAV_EINVAL, "one communicator and one handle per clustering");
+        int K = 0;
+        ACAV_TRY(acav_kmeans_shape(kms[v], &K, &dv[(size_t)v]));
+        ACAV_REQUIRE((dv[(size_t)v] & 3) == 0, ACAV_EINVAL, "d = %d must be a multiple of 4 for the bulk exchange", dv[(size_t)v]);
+        ACAV_TRY(acav_kmeans_stream(kms[v], &st_train[(size_t)v]));
+    }
+    // ---- the plan: per slot its extents with their stream offsets
+    struct Ext { int owner; int64_t first, rows, pos; };
+    std::vector<std::vector<Ext>> streams((size_t)slots);
+    for (int64_t i = 0; i < n_ext; ++i) {
+        const int64_t q = ext[4 * i], owner = ext[4 * i + 1], first = ext[4 * i + 2], rows = ext[4 * i + 3];
+        ACAV_REQUIRE(q >= 0 && q < slots && owner >= 0 && first >= 0 && rows >= 0, ACAV_EINVAL, "extent %lld is malformed", (long long)i);
+        ACAV_REQUIRE(owner < w, ACAV_EINVAL, "extent %lld: owner %lld outside the communicator", (long long)i, (long long)owner);
+        ACAV_REQUIRE(owner != me || first + rows <= n_local, ACAV_EINVAL, "extent %lld reaches past this rank's %lld rows", (long long)i, (long long)n_local);
+        if (rows == 0) continue;
+        auto &sv = streams[(size_t)q];
+        sv.push_back({(int)owner, first, rows, sv.empty() ? 0 : sv.back().pos + sv.back().rows});
+    }
+    for (int q = 0; q < slots; ++q) {
+        const int64_t have = streams[(size_t)q].empty() ? 0 : streams[(size_t)q].back().pos + streams[(size_t)q].back().rows;
+        ACAV_REQUIRE(have >= steps * lb, ACAV_EINVAL, "slot %d's stream holds %lld rows, the epoch needs %lld", q, (long long)have, (long long)(steps * lb));
+    }
+    // ---- per chunk: the pieces every rank packs (in (slot, position) order) and where they land at the trainer
+    struct Chunk { int64_t s, pack_off, pack_n, place_off, gb_off, my_rows, all_rows; std::vector<int64_t> from; };
+    const int64_t n_chunks = (steps + chunk_steps - 1) / chunk_steps;
+    std::vector<Chunk> chunks((size_t)n_chunks);
+    std::vector<PlanPiece> table;
+    std::vector<int> groups;
+    std::vector<size_t> cursor((size_t)slots, 0);
+    struct Pc { int slot, owner; int64_t rel, first, rows; };
+    std::vector<Pc> pcs;
+    int64_t max_my = 0, max_all = 0;
+    for (int64_t ci = 0; ci < n_chunks; ++ci) {
+        Chunk &ch = chunks[(size_t)ci];
+        const int64_t c0 = ci * chunk_steps;
+        ch.s = steps - c0 < chunk_steps ? steps - c0 : chunk_steps;
+        const int64_t lo = c0 * lb, hi = (c0 + ch.s) * lb;
+        pcs.clear();
+        for (int q = 0; q < slots; ++q) {
+            const auto &sv = streams[(size_t)q];
+            size_t &e = cursor[(size_t)q];
+            while (e < sv.size() && sv[e].pos + sv[e].rows <= lo) ++e;
+            for (size_t k = e; k < sv.size() && sv[k].pos < hi; ++k) {
+                const int64_t a = sv[k].pos > lo ? sv[k].pos : lo, b = sv[k].pos + sv[k].rows < hi ? sv[k].pos + sv[k].rows : hi;
+                if (a < b) pcs.push_back({q, sv[k].owner, a - lo, sv[k].first + (a - sv[k].pos), b - a});
+            }
+        }
+        ch.from.assign((size_t)w, 0);
+        for (const Pc &p : pcs) ch.from[(size_t)p.owner] += p.rows;
+        std::vector<int64_t> block((size_t)ch.from.size(), 0), fill((size_t)ch.from.size(), 0);
+        for (size_t r = 1; r < block.size(); ++r) block[r] = block[r - 1] + ch.from[r - 1];
+        ch.all_rows = ch.s * bg;
+        ch.my_rows = ch.from[(size_t)me];
+        // packing table of THIS rank (one group): key = row of the packed block
+        ch.pack_off = (int64_t)table.size();
+        int64_t filled = 0;
+        for (const Pc &p : pcs)
+            if (p.owner == me) {
+                table.push_back({filled, p.first, p.rows});
+                filled += p.rows;
+            }
+        ch.pack_n = (int64_t)table.size() - ch.pack_off;
+        // placement table (groups = slots): key = position within the slot's chunk, src = row of the landing buffer
+        ch.place_off = (int64_t)table.size();
+        ch.gb_off = (int64_t)groups.size();
+        int cur = -1;
+        for (const Pc &p : pcs) {
+            while (cur < p.slot) groups.push_back((int)((int64_t)table.size() - ch.place_off)), ++cur;
+            const size_t r = (size_t)p.owner;
+            table.push_back({p.rel, block[r] + fill[r], p.rows});
+            fill[r] += p.rows;
+        }
+        while (cur < slots) groups.push_back((int)((int64_t)table.size() - ch.place_off)), ++cur;  // slots + 1 entries
+        max_my = ch.my_rows > max_my ? ch.my_rows : max_my;
+        max_all = ch.all_rows > max_all ? ch.all_rows : max_all;
+    }
+    // the tables of the whole epoch go to the device once (a few hundred KB), before anything is enqueued
+    acav_comm *c0 = comms[0];
+    ACAV_HIP_TRY(hipSetDevice(c0->ctx.device));
+    ACAV_TRY(c0->plan_pieces.ensure(sizeof(PlanPiece) * (table.size() + 1)));
+    // groups: per chunk [slots + 1] placement offsets, then per chunk [2] = {0, pack_n} for the packing launch
+    const size_t gb_pack0 = groups.size();
+    for (const Chunk &ch : chunks) groups.push_back(0), groups.push_back((int)ch.pack_n);
+    ACAV_TRY(c0->plan_groups.ensure(sizeof(int) * (groups.size() + 1)));
+    if (!table.empty()) ACAV_HIP_TRY(hipMemcpy(c0->plan_pieces.p, table.data(), sizeof(PlanPiece) * table.size(), hipMemcpyHostToDevice));
+    ACAV_HIP_TRY(hipMemcpy(c0->plan_groups.p, groups.data(), sizeof(int) * groups.size(), hipMemcpyHostToDevice));
+    const PlanPiece *tab_dev = c0->plan_pieces.as<PlanPiece>();
+    const int *grp_dev = c0->plan_groups.as<int>();
+    for (int v = 0; v < count; ++v) {
+        const size_t row_bytes = sizeof(float) * (size_t)dv[(size_t)v];
+        for (int q = 0; q < 2; ++q) {
+            ACAV_TRY(comms[v]->pack[q].ensure(row_bytes * (size_t)(max_my > 0 ? max_my : 1)));
+            if (here[(size_t)v]) {  // a rank that only sends needs no landing buffers
+                ACAV_TRY(comms[v]->gather[q].ensure(row_bytes * (size_t)max_all));
+                ACAV_TRY(comms[v]->batches[q].ensure(row_bytes * (size_t)max_all));
+            }
+        }
+    }
+    auto gather = [&](int v, int64_t ci, int par) -> int {  // chunk ci of every owner -> batches[par] of clustering v
+        acav_comm *c = comms[v];
+        const Chunk &ch = chunks[(size_t)ci];
+        const int d = dv[(size_t)v];
+        hipStream_t sc = c->ctx.stream;
+        if (here[(size_t)v]) ACAV_HIP_TRY(hipStreamWaitEvent(sc, c->ev_trained[par], 0));  // the chunk trained from this buffer is done
+        launch_rows_by_table(false, tab_dev + ch.pack_off, grp_dev + gb_pack0 + 2 * (size_t)ci, x_local_dev[v], c->pack[par].as<float>(),
+                             ch.my_rows, d, 1, 1, sc);
+        ACAV_HIP_TRY(hipGetLastError());
+        ACAV_TRY(packed_rows_to_root(rccl(), c->pack[par].p, ch.my_rows, c->gather[par].p, ch.from.data(), sizeof(float) * (size_t)d,
+                                     roots[(size_t)v], me, w, c->comm, sc));
+        if (here[(size_t)v]) {
+            launch_rows_by_table(true, tab_dev + ch.place_off, grp_dev + ch.gb_off, c->gather[par].as<float>(), c->batches[par].as<float>(),
+                                 ch.all_rows, d, slots, (int)lb, sc);
+            ACAV_HIP_TRY(hipGetLastError());
+        }
+        ACAV_HIP_TRY(hipEventRecord(c->ev_gathered[par], sc));
+        return ACAV_OK;
+    };
+    for (int v = 0; v < count; ++v) {
+        ACAV_HIP_TRY(hipSetDevice(comms[v]->ctx.device));
+        if (here[(size_t)v])
+            for (int q = 0; q < 2; ++q) ACAV_HIP_TRY(hipEventRecord(comms[v]->ev_trained[q], (hipStream_t)st_train[(size_t)v]));  // both buffers free
+        ACAV_TRY(gather(v, 0, 0));
+    }
+    std::vector<int64_t> warm_done((size_t)count, 0);
+    std::vector<acav_kmeans *> lk;
+    std::vector<const float *> lx;
+    std::vector<int64_t> ln, lnw;
+    std::vector<const int64_t *> lw;
+    int par = 0;
+    for (int64_t ci = 0; ci < n_chunks; ++ci, par ^= 1) {
+        const int64_t s = chunks[(size_t)ci].s;
+        if (ci + 1 < n_chunks)
+            for (int v = 0; v < count; ++v) ACAV_TRY(gather(v, ci + 1, par ^ 1));  // next chunk travels while this one trains
         lk.clear(), lx.clear(), ln.clear(), lnw.clear(), lw.clear();
         for (int v = 0; v < count; ++v) {
             if (!here[(size_t)v]) continue;

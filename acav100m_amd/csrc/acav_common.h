@@ -73,6 +73,12 @@ struct DevBuf {
     int ensure(size_t n)
     {
         if (n <= bytes) return ACAV_OK;
+        // Growing a buffer that kernels already in flight may still read or write (an asynchronous assign / step enqueued
+        // with the old block): hipFree used to synchronise the device implicitly, a PARKED block is handed to the next
+        // request at once -- possibly another handle on another stream.  Growth is rare (first use of a larger shape), so
+        // it pays for the synchronisation the free no longer does.  Destructors run after the owner's *_destroy has
+        // synchronised its stream.
+        if (p) (void)hipDeviceSynchronize();
         release();
         return devbuf_alloc(&p, &bytes, n);
     }

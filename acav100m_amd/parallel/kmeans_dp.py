@@ -1,11 +1,14 @@
-"""Data-parallel KMeans.add() -- the reference's DDP branch (sgd_clustering.py:94-129 with
-is_distributed) re-designed for exactness and xGMI.
+"""Multi-GPU KMeans training -- the host side of the exchanges (torch.distributed: RCCL on the GPUs, gloo in the CPU
+tests).  The library's own RCCL path (csrc/acav_comm.hip) does the same inside one C call; this module is what runs when
+the group's backend is not RCCL, and what defines the semantics.
 
-Reference per step and clustering: all_gather([batch]) (only to take len()), all_reduce([counts]),
-all_reduce([deltas]) = 2 x K*d*4 bytes of ring traffic.  Here each rank labels its local rows,
-ONE all-gather moves the rows and labels (b*d*4 + b*8 bytes), and every rank applies the same
-global-batch update with the deterministic in-order kernel.  The resulting state is bit-identical on
-all ranks and equal to a single process fed the rank-major concatenation of the local batches.
+Reference per step and clustering (sgd_clustering.py:94-129 under is_distributed): all_gather([batch]) (only to take
+len()), all_reduce([counts]), all_reduce([deltas]) = 2 x K*d*4 bytes of ring traffic, every rank labelling its own
+int(batch_size / world) rows (data/clustering.py:25).  Here the rows travel instead (b*d*4 bytes) and ONE process applies
+the whole global batch with the deterministic in-order update kernel: the state equals a single process fed the same
+global batches (the reference's own sum of per-rank deltas differs from that by fp32 re-association only, in an order
+NCCL does not promise).  WHICH rows form a step's global batch is a plan (row_plan.py): `reference` = the reference's own
+N-GPU stream, `views` = the one-GPU stream, `rows` = a large-batch mode (global batch world x batch_size).
 
 `engine` is anything with calc_best(batch) -> (labels, mean) and apply_update(x, labels, lr): the GPU
 KMeans in production; the multi-process CPU tests plug a host stand-in to exercise the
@@ -40,9 +43,9 @@ def distributed_add(engine, batch, lr):
 
 
 def train_epoch_dp(engine, x_local, b_local, lr, chunk_steps=1024, force_collective=False, trainer=None):
-    """One training epoch with the reference's DDP semantics (sgd_clustering.py:94-129 under is_distributed):
-    step t's global batch is the rank-major concatenation of every rank's rows [t*b_local, (t+1)*b_local), and
-    every rank applies the same update.
+    """One training epoch in the LARGE-BATCH mode (row_plan.plan_rows; not the reference's N-GPU run, whose global batch
+    stays batch_size -- train_epoch_plan with plan_reference): step t's global batch is the rank-major concatenation of
+    every rank's rows [t*b_local, (t+1)*b_local), and every rank applies the same update.
 
     The SGD chain is latency-bound (each step needs the centres of the previous one), so a per-step collective
     would cost more than the step itself.  But the ROWS of future steps do not depend on the state: they are
@@ -106,6 +109,105 @@ def train_epoch_dp(engine, x_local, b_local, lr, chunk_steps=1024, force_collect
             engine.train_epoch(cur, bg, lr, warm_best=wb if need else None)  # asynchronous on the engine's stream
         if c0 + s < steps:  # gather the next chunk while this one trains
             nxt = gather(c0 + s, min(chunk_steps, steps - c0 - s))
+    engine.synchronize()
+    if not here:
+        engine.skip_epoch(steps * bg)
+
+
+def plan_warmup_labels(engine, plan, device=None, comm=None, mine=None, comm_slot=None):
+    """labels of the warm-up steps of a planned epoch, [need, slots * lb] in batch order (None when there are none).
+    slots == world (reference / rows): slot q's rows are labelled by rank q -- calc_best(local batch) draws
+    torch.rand(k, local_b) from the rank's own generator (sgd_clustering.py:67-68,111) -- and the labels are exchanged
+    once.  One slot (views): the one-GPU run's draws, torch.rand(k, batch_size) per step from this process's generator
+    (every rank draws them: generators seeded alike stay in step; the trainer's are used).
+    mine: this rank's labels [need, lb] drawn by the caller (several clusterings sharing one generator draw batch by
+    batch across the clusterings).  comm_slot: take the library's communicator of that slot when RCCL is the backend."""
+    rank, w = world()
+    need = engine.warmup_steps(plan.global_batch, plan.steps)
+    if not need:
+        return None
+    import numpy as np
+    if plan.slots != w or w == 1:
+        if mine is not None and plan.slots == 1:
+            return np.ascontiguousarray(mine, np.int64)
+        per = [np.asarray(engine.draw_warmup(plan.global_batch)).astype(np.int64) for _ in range(need)]
+        return np.ascontiguousarray(np.stack(per))
+    if comm is None and comm_slot is not None and device is not None and getattr(device, "type", str(device)[:4]) == "cuda":
+        from .rccl_comm import default_comm
+        comm = default_comm(comm_slot)
+    if mine is None:
+        mine = [_as_tensor(engine.draw_warmup(plan.lb)).to(torch.long) for _ in range(need)]
+        mine = torch.stack(mine).contiguous()
+    else:
+        mine = torch.as_tensor(np.ascontiguousarray(mine, np.int64))
+        assert tuple(mine.shape) == (need, plan.lb), (tuple(mine.shape), need, plan.lb)
+    if comm is not None:  # the library's communicator (RCCL)
+        send = mine.to(device)
+        recv = torch.empty((w, need, plan.lb), dtype=torch.long, device=device)
+        comm.allgather(send, recv)
+        comm.synchronize()
+    else:
+        send = mine.to(device if device is not None else "cpu")
+        recv = torch.empty((w * need, plan.lb), dtype=torch.long, device=send.device)
+        dist.all_gather_into_tensor(recv, send)
+        recv = recv.view(w, need, plan.lb)
+    return np.ascontiguousarray(recv.cpu().numpy().transpose(1, 0, 2).reshape(need, w * plan.lb))  # [step, slot-major rows]
+
+
+def train_epoch_plan(engine, x_local, plan, lr, trainer, chunk_steps=1024, warm=None):
+    """One training epoch over the global batches of `plan` (row_plan.RowPlan) with the rows living on their owners: per
+    chunk of `chunk_steps` steps every rank packs the rows it owns, they are gathered to rank `trainer` (dist.gather, a
+    chunk ahead of the training), which places them into global batches [step][slot][row] and trains
+    (engine.train_epoch at the global batch size).  What acav_kmeans_train_plan_multi does inside the library over
+    RCCL; this form runs under any torch.distributed backend (gloo: CPU tests, several ranks on one GPU).  A rank that only sends keeps `count` in step (engine.skip_epoch) and takes the
+    trainer's state afterwards (broadcast_state).  warm: plan_warmup_labels() (drawn here when None)."""
+    rank, w = world()
+    x_local = _as_tensor(x_local)
+    d = x_local.shape[1]
+    here = int(trainer) == rank
+    steps, bg, lb = plan.steps, plan.global_batch, plan.lb
+    if warm is None:
+        warm = plan_warmup_labels(engine, plan, device=x_local.device)
+    need = 0 if warm is None else len(warm)
+    if steps == 0:
+        return
+
+    def gather(t0, t1):
+        pcs = plan.pieces(t0, t1)
+        by = [sum(p.rows for p in pcs if p.owner == r) for r in range(w)]
+        cap = max(by) if by else 0
+        send = torch.zeros((max(cap, 1), d), dtype=x_local.dtype, device=x_local.device)  # dist.gather wants equal shapes
+        mine = [x_local[p.first:p.first + p.rows] for p in pcs if p.owner == rank]
+        if mine:
+            send[:by[rank]] = torch.cat(mine)
+        if w > 1:
+            parts = [torch.empty_like(send) for _ in range(w)] if here else None
+            dist.gather(send, parts, dst=int(trainer))
+        else:
+            parts = [send]
+        if not here:
+            return None
+        out = torch.empty(((t1 - t0) * bg, d), dtype=x_local.dtype, device=x_local.device)
+        fill = [0] * w
+        for p in pcs:
+            rel = torch.arange(p.rel, p.rel + p.rows, device=x_local.device)
+            out[(rel // lb) * bg + p.slot * lb + rel % lb] = parts[p.owner][fill[p.owner]:fill[p.owner] + p.rows]
+            fill[p.owner] += p.rows
+        return out
+
+    done_warm = 0
+    nxt = gather(0, min(chunk_steps, steps))
+    for c0 in range(0, steps, chunk_steps):
+        s = min(chunk_steps, steps - c0)
+        cur = nxt
+        engine.synchronize()  # the chunk trained before `cur` is finished: its buffer may be recycled
+        nw = min(max(need - done_warm, 0), s)
+        wb = warm[done_warm:done_warm + nw] if need else None
+        done_warm += nw
+        if here:
+            engine.train_epoch(cur, bg, lr, warm_best=wb)  # asynchronous on the engine's stream
+        if c0 + s < steps:  # gather the next chunk while this one trains
+            nxt = gather(c0 + s, c0 + s + min(chunk_steps, steps - c0 - s))
     engine.synchronize()
     if not here:
         engine.skip_epoch(steps * bg)

@@ -560,10 +560,13 @@ def _load_native(paths, expect_rows, expect_views, workers):
                 results.append({'filename': fnm, 'shard_name': snm, 'shard_size': ssz, 'tags': list(tags.items()), 'rows': rows.value})
                 continue
             try:  # outside the native subset (or unreadable): the general reader
-                columns = _shard_columns_from_rows(load_pickle(p), p.stem)
-            except Exception as exc:
+                shard_rows = load_pickle(p)
+            except Exception as exc:  # an unreadable FILE is reported and skipped (data/clustering.py:167-182) ...
                 results.append({'skip': '{}'.format(exc)})
                 continue
+            # ... inconsistent CONTENT (a view missing in some rows) is not: the ValueError propagates exactly as it does
+            # from the plain loop of load_feature_shards and from the worker processes, whichever loader ran
+            columns = _shard_columns_from_rows(shard_rows, p.stem)
             k = len(columns['filename'])
             if k > counts[i] or set(columns['views']) != set(keys) or \
                     any(columns['views'][key].shape != (k, m.shape[1]) for key, m in zip(keys, mats)):
@@ -573,11 +576,15 @@ def _load_native(paths, expect_rows, expect_views, workers):
                 m[c_base[i]:c_base[i] + k] = columns['views'][key]
             results.append({'filename': columns['filename'], 'shard_name': columns['shard_name'], 'shard_size': columns['shard_size'],
                             'tags': list(columns['tags'].items()), 'rows': k})
+    except Exception:  # corrupt content: the blocks go back before the error leaves (the caller does not see them)
+        del mats
+        _SHM.release(shms)
+        raise
     finally:
         for i in range(n):
             if handles[i]:
                 lib.acav_pkl_shard_close(C.c_void_p(handles[i]))
-    del mats
+    mats = None
     if results is None:
         _SHM.release(shms)
         return None

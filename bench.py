@@ -28,10 +28,21 @@ Other workloads (`--workload`, never the default: the driver's line stays on con
          chunks of 100 shards = 100k clips, 10 chunks in lockstep (computation.concurrent_chunks)
 Their `roofline` is quoted on the K = 1024 filter against the bf16 MFMA roof that binds there (intensity K/2 = 512 flop/B).
 
-N > 1 (weak scaling): every rank holds its own 1M-clip partition.  k-means training is one global clustering per view with
-the reference's DDP semantics (global batch = 32 N rows per step, rows all-gathered in bulk ahead of the SGD chain, no
-collective on the step path; the replicated chain of a view runs on one rank, which broadcasts its state); assign is local; the MI selection runs per rank on its own partition -- the reference's
-chunked mode with one chunk per GPU (chunk.py:21-53) -- no exchange.
+N > 1 (weak scaling: every rank holds its own 1M-clip partition, N million clips in all).  Assign is local and the MI
+selection runs per rank on its own partition -- the reference's chunked mode with one chunk per GPU (chunk.py:21-53) -- no
+exchange.  k-means TRAINING is one global clustering per view, and its SGD chain is sequential by construction (a step
+needs the centres of the step before): what N GPUs do there is a choice, `--multi-gpu` (acav100m_amd/parallel/row_plan.py):
+  views      (default) the ONE-GPU arithmetic over all N million rows: batch 32, 2 epochs, shards in global order -- the
+             result (and the files of the CLI) of a one-GPU run over the union; the two views' chains run on two
+             different ranks, the rows travel to them in bulk (no collective on the step path).  Comparable with the
+             N = 1 line row for row; the chain grows with N, so this stage does NOT weak-scale (about 0.4 s x N).
+  reference  the reference's own N-GPU run: per-rank batch int(32 / N) of a rotated stream over ALL shards
+             (data/clustering.py:25, mps/distributed.py:433-437), ceil(2 / N) epochs (run_clustering.py:146): global batch
+             32, N * (N million) / 32 steps per epoch -- N = 8: 2 M steps against the 62.5 k of N = 1.
+  rows       large batch, NOT the reference's run: 32 rows of every rank per step (global batch 32 N), ceil(2 / N) epochs:
+             N x N fewer steps than `reference`; a different operating point (what earlier rounds timed).
+`config` names the mode, the global batch and the SGD steps per epoch.  `--verify` (any N): after the timed region every
+rank hashes every clustering's state (all ranks must agree) and rank 0 re-labels 16 384 of its rows with the oracle.
 
 The JSON line also carries
   roofline      k_assign_bf16_rw, the HBM-bound kernel of the path: algorithmic bytes N*d*4 + N*8 per launch over the
@@ -77,15 +88,18 @@ WORKLOADS = {
 }
 
 
-def synth_views(torch, n, d, k, seed, device, views=2, rho=0.5):
+def synth_views(torch, n, d, k, seed, device, views=2, rho=0.5, part=0):
     """SURVEY 8(d) generator: K Gaussian components per view, component centres ~ N(0,1)^d, row = centre + 0.3 N(0,1);
-    the views share the component id with probability rho, else draw their own (gives the MI selection a signal)."""
-    gen = torch.Generator(device=device).manual_seed(seed)
-    shared = torch.randint(0, k, (n,), device=device, generator=gen)
+    the views share the component id with probability rho, else draw their own (gives the MI selection a signal).
+    The component centres depend on `seed` alone, the rows on (seed, part): the partitions of a multi-GPU run are draws
+    from ONE mixture (their union is what a one-GPU run over all rows would cluster)."""
+    gen_c = torch.Generator(device=device).manual_seed(seed)
+    gen = torch.Generator(device=device).manual_seed(seed + 1 + 1000003 * part)
     dims = [d] * views if isinstance(d, int) else list(d)
+    cens = [torch.randn(k, dv, device=device, generator=gen_c) for dv in dims]
+    shared = torch.randint(0, k, (n,), device=device, generator=gen)
     out = []
-    for d in dims:
-        cen = torch.randn(k, d, device=device, generator=gen)
+    for d, cen in zip(dims, cens):
         own = torch.randint(0, k, (n,), device=device, generator=gen)
         comp = torch.where(torch.rand(n, device=device, generator=gen) < rho, shared, own)
         x = torch.empty(n, d, device=device, dtype=torch.float32)
@@ -217,6 +231,8 @@ def main():
     ap.add_argument("--d", type=int, default=None)   # overrides (tests): one width for both views
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--multi-gpu", dest="multi_gpu", choices=("views", "reference", "rows"), default="views")  # N > 1: see the docstring
+    ap.add_argument("--verify", action="store_true")  # cross-rank state hashes + an oracle sample on rank 0, outside the timed region
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     args = ap.parse_args()
@@ -258,7 +274,7 @@ def main():
     chunk = wl["chunk"] if wl["chunk"] and wl["chunk"] < n else None
     b, nviews = args.batch, len(dims)
     d = max(dims)  # the view the roofline is quoted on
-    xs = synth_views(torch, n, dims, k, 1234 + rank, dev)
+    xs = synth_views(torch, n, dims, k, 1234, dev, part=rank)
     torch.cuda.synchronize()
 
     cargs = _NS(computation=_NS(device="cuda", num_gpus=world))
@@ -273,6 +289,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    plan = None
+    if world > 1:  # every rank's n rows = shards of 1000 clips, dealt rank::world like the CLI's shards
+        from acav100m_amd.parallel import make_plan
+        per_rank = [min(1000, n - s0) for s0 in range(0, n, 1000)]
+        plan = make_plan(args.multi_gpu, [rows for rows in per_rank for _ in range(world)], world, b, EPOCHS)
     labels = [torch.empty(n, dtype=torch.long, device=dev) for _ in range(nviews)]
     stage = {"train": [], "assign": [], "handoff": [], "mi": []}
     filt_ms, sweep_ms, filt_stats = [], [], []
@@ -285,17 +306,16 @@ def main():
         for km in kms:
             km.initialize()
         t0 = time.perf_counter()
-        for epoch in range(EPOCHS):
+        for epoch in range(EPOCHS if plan is None else plan.epochs):
             lr = 0.1 ** (2 + epoch // 5)
             if world == 1:  # the two views' SGD chains are independent: side by side on the GPU (run_clustering does the same)
                 KMeans.train_epoch_multi(kms, xs, b, lr=lr)
             else:
-                # reference DDP semantics: global batch = world * b rows per step, rows all-gathered in bulk by every rank;
-                # the (replicated, device-resident) SGD chain of view v runs on rank v % world only, which then hands out
-                # its state -- instead of every rank running both chains one after the other.  Chunk by chunk across the
-                # views (acav_kmeans_train_dp_multi: one communicator per view, every rank feeds every exchange before it
-                # blocks in its own chain): the views train on different ranks at the same time
-                trainers = KMeans.train_epoch_distributed_multi(kms, xs, b, lr=lr)
+                # the rows of 1 024 steps at a time travel to the rank that runs a view's chain (view v -> rank v % world),
+                # chunk by chunk across the views (acav_kmeans_train_plan_multi: one communicator per view, every rank feeds
+                # every exchange before it blocks in its own chain): the views train on different ranks at the same time,
+                # then the trainers hand out their states.  WHICH rows form a step's batch: `plan` (--multi-gpu)
+                trainers = KMeans.train_epoch_plan_multi(kms, xs, plan, lr=lr)
                 for v, km in enumerate(kms):
                     km.broadcast_state_from(trainers[v], comm_slot=v)
         for km in kms:
@@ -327,6 +347,8 @@ def main():
             S = [c0 * chunk + i for c0, (Sc, _) in enumerate(res) for i in Sc]
             assert len(S) == subset and len(set(S)) == subset
         last["S"], last["a"] = S, a
+        if args.verify:
+            last["states"] = [km.state_arrays() for km in kms]
         if timed:
             stage["train"].append(t1 - t0)
             stage["assign"].append(t2 - t1)
@@ -347,6 +369,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    verify = None
+    if args.verify:
+        verify = run_verify(torch, dist, world, rank, last, xs, labels, dims, k)
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = n * world * args.steps / elapsed
@@ -365,14 +391,15 @@ def main():
         traffic_profile = None
         pdir = os.path.join(ROOT, "profiles")
         for name in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
-            if name.endswith("_pmc_assign.json") or name.endswith("_pmc_assign_k1024.json"):  # summaries of the separate rocprofv3 --pmc passes
+            if name.endswith(".json") and "_pmc_assign" in name:  # summaries of the separate rocprofv3 --pmc passes (tools/summarize_pmc.py)
                 pm = json.load(open(os.path.join(pdir, name)))
                 if (pm.get("d"), pm.get("K")) == (d, k) and pm.get("kernel", "").startswith("k_assign_bf16"):
                     scale = n / pm["rows"]  # per-row traffic of the same kernel shape, scaled to this launch's rows
                     traffic_profile = {"file": "profiles/" + name, "rows_in_profile": pm["rows"],
                                        "bytes_per_launch": pm["traffic_bytes_per_launch"] * scale}
                     break
-        train_steps = EPOCHS * nviews * (n // b)
+        steps_per_epoch, train_epochs = (n // b, EPOCHS) if plan is None else (plan.steps, plan.epochs)
+        train_steps = train_epochs * nviews * steps_per_epoch
         if chunk is None:
             perm_bytes = sum(16 * (n - 1 - SELECT_K * t) for t in range(iters))
         else:
@@ -410,10 +437,14 @@ def main():
             "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{wl['name']}: {n} clips x {nviews} views ({views_txt}), K={k}: per view {EPOCHS} training "
-                                   f"epochs at b={b} ({n // b} SGD steps each) + 1 assign sweep, then {sel_txt}, end to end "
-                                   f"on 1 GPU per partition",
-                       "global_batch": b * world, "rows_per_gpu": n, "views": nviews, "view_dims": list(dims), "epochs": EPOCHS,
+            "config": {"workload": f"{wl['name']}: {n} clips{' per GPU' if world > 1 else ''} x {nviews} views ({views_txt}), K={k}: per view "
+                                   f"{train_epochs} training epochs of {steps_per_epoch} SGD steps at a global batch of "
+                                   f"{b if plan is None else plan.global_batch} rows"
+                                   + (f" (multi-GPU training mode '{plan.mode}': see bench.py's docstring)" if plan is not None else "")
+                                   + f" + 1 assign sweep, then {sel_txt}, end to end on 1 GPU per partition",
+                       "global_batch": b if plan is None else plan.global_batch, "sgd_steps_per_epoch": steps_per_epoch,
+                       "train_epochs": train_epochs, "multi_gpu_mode": None if plan is None else plan.mode,
+                       "rows_per_gpu": n, "views": nviews, "view_dims": list(dims), "epochs": EPOCHS,
                        "select": subset, "mi_chunks": 1 if chunk is None else -(-n // chunk)},
             "stages": {"train_s": st["train"], "assign_s": st["assign"], "handoff_s": st["handoff"], "mi_s": st["mi"],
                        "train_us_per_sgd_step": st["train"] * 1e6 / train_steps,
@@ -428,8 +459,9 @@ def main():
                             "note": "16 L bytes per iteration (int64 candidate permutation read + write, SURVEY 8(d)) over "
                                     "the whole selection incl. its host part (python shuffle, table set-up)"},
             "train_kernel": {"kernel": "persistent epoch kernels (the views' launches side by side: acav_kmeans_train_multi)" if world == 1 else
-                             "k_step_dist_dma + k_step_update (global batch %d)" % (b * world),
-                             "bound": "latency (dependent chain of %d steps per epoch and view)" % (n // b),
+                             "persistent epoch kernels per 1 024-step chunk at the trainer rank of each view (global batch %d; per-step "
+                             "launches k_step_dist_dma + k_step_update beyond batch 32)" % plan.global_batch,
+                             "bound": "latency (dependent chain of %d steps per epoch and view)" % steps_per_epoch,
                              "us_per_step": st["train"] * 1e6 / train_steps,
                              "persistent_launches_and_fallbacks": last.get("train_stats")},
         }
@@ -441,10 +473,53 @@ def main():
             out["variants"] = dict(out.get("variants", {}), assign_hard_data=assign_hard_variant(torch, lib, n, d, k, b, dev))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, dims, k, b, 1234, chunk)
+        if verify is not None:
+            out["verify"] = verify
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_verify(torch, dist, world, rank, last, xs, labels, dims, k, sample=16384):
+    """--verify, outside the timed region: (i) every rank hashes every clustering's final state (centres, usage counts,
+    count) -- after the trainers' hand-out all ranks must hold the same bytes; (ii) rank 0 re-labels the first `sample`
+    rows of its partition with the ORACLE (oracle/, the checker) from that state and compares with the labels the assign
+    sweep wrote; (iii) the selection's size / uniqueness was asserted in the pass itself.  Returns the verdict (rank 0)
+    and raises on every rank when something differs, so that a first multi-GPU contact ends in a verdict, not a hang."""
+    import hashlib
+    digests = []
+    for centers, counts, count, fallback in last["states"]:
+        h = hashlib.sha256()
+        h.update(np.ascontiguousarray(centers, np.float32).tobytes())
+        h.update(np.ascontiguousarray(counts, np.float32).tobytes())
+        h.update(str((int(count), int(fallback))).encode())
+        digests.append(h.hexdigest())
+    everyone = [digests]
+    if world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, digests)
+    same = all(d == everyone[0] for d in everyone)
+    verdict = {"state_sha256": everyone[0], "ranks_agree": bool(same), "oracle_sample_rows": 0, "oracle_labels_equal": None}
+    ok = same
+    if rank == 0:
+        from oracle import oracle as O
+        m = min(sample, xs[0].shape[0])
+        equal = []
+        for (centers, counts, count, _fb), x, lab, d in zip(last["states"], xs, labels, dims):
+            ref = O.KMeans(d, k, O.Rng(0), centers=np.ascontiguousarray(centers, np.float32))
+            ref.set_state(None, np.ascontiguousarray(counts, np.float32), int(count))
+            want = ref.calc_best(x[:m].cpu().numpy())[0]
+            equal.append(bool(np.array_equal(want, lab[:m].cpu().numpy())))
+        verdict.update(oracle_sample_rows=int(m), oracle_labels_equal=equal)
+        ok = ok and all(equal)
+    if world > 1:
+        flag = [ok]
+        dist.broadcast_object_list(flag, src=0)
+        ok = bool(flag[0]) and same
+    if not ok:
+        raise SystemExit("bench.py --verify FAILED on rank {}: {}".format(rank, verdict))
+    return verdict
 
 
 def assign_hard_variant(torch, lib, n, d, k, b, dev):

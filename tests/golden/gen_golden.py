@@ -7,7 +7,7 @@ this script and the tiny stand-in modules under _stubs/ for the reference's un-v
 imports (torch_scatter, diffdist, wget, braceexpand).
 
     python tests/golden/gen_golden.py            # all three groups
-    python tests/golden/gen_golden.py kmeans|kmeans_big|mi|mi_exact|mi_ami|rng|cli|contrastive
+    python tests/golden/gen_golden.py kmeans|kmeans_big|mi|mi_exact|mi_ami|rng|cli|contrastive|ddp_stream
 
 Groups:
   rng.npz     torch.manual_seed/rand/randperm and random.shuffle streams (G6)
@@ -18,6 +18,8 @@ Groups:
               parameters, infer() scores
   cli_clustering.npz / cli_output.csv   the reference's two CLIs end to end on synthetic shards
               regenerated from a seed by tests/golden/synth.py (G5)
+  ddp_stream.npz   the reference's N-GPU training batch stream: per-rank shard order (node_selection), per-rank batch,
+              samples per epoch (get_length), epochs -- what clustering.multi_gpu=reference reproduces
 The two reference stages have clashing top-level module names, so each group runs in its own
 interpreter.
 """
@@ -554,6 +556,43 @@ def gen_contrastive():
         print(f"contrastive_{name}.npz written: loss {losses[0]:.4f} -> {losses[-1]:.4f}")
 
 
+def gen_ddp_stream():
+    """The reference's multi-GPU TRAINING batch stream, from its own code (no process group needed): which shards rank r
+    streams in which order -- mps.distributed.node_selection(urls, r, total=W, is_train=True), the call of
+    data/shards.py:36 -- the per-rank batch size int(batch_size / world_size) (data/clustering.py:25), the samples per
+    rank and epoch mps.distributed.get_length(..., is_train=True) (data/clustering.py:50-52; it reads WORLD_SIZE), and the
+    epoch count math.ceil(epochs / num_gpus) (run_clustering.py:146)."""
+    import math
+    sys.path.insert(0, STUBS)
+    sys.path.insert(1, os.path.join(REF, "clustering", "code"))
+    import mps.distributed as du  # noqa: E402  (the reference)
+    cases = {
+        # name: (rows per shard in global order, world, data.batch_size, clustering.epochs)
+        "w2_even": ([256, 256, 256, 256], 2, 32, 2),           # tests/test_gpu_cli.py's shards
+        "w2_ragged": ([96, 64, 80, 96, 64], 2, 32, 2),
+        "w3_ragged": ([40, 24, 56, 32, 48, 16, 40], 3, 32, 2),  # per-rank batch int(32 / 3) = 10: global batch 30
+        "w4_even": ([64] * 8, 4, 32, 2),
+        "w8_epochs": ([32] * 16, 8, 32, 10),
+    }
+    out = {"cases": np.array(sorted(cases))}
+    for name, (sizes, w, b, epochs) in cases.items():
+        urls = ["shard-%06d.pkl" % i for i in range(len(sizes))]
+        os.environ["WORLD_SIZE"] = str(w)
+        lb = int(b / w)  # data/clustering.py:25
+        out[name + "_sizes"] = np.array(sizes, np.int64)
+        out[name + "_world"], out[name + "_batch_size"], out[name + "_epochs_in"] = w, b, epochs
+        out[name + "_local_batch"] = lb
+        out[name + "_epochs"] = math.ceil(epochs / w)  # run_clustering.py:146
+        out[name + "_length"] = du.get_length(list(sizes), lb, 0, is_train=True)
+        for r in range(w):
+            order = du.node_selection(list(urls), r, total=w, is_train=True)
+            out[name + "_order_rank%d" % r] = np.array([urls.index(u) for u in order], np.int64)
+            out[name + "_assign_rank%d" % r] = np.array([urls.index(u) for u in du.node_selection(list(urls), r, total=w, is_train=False)], np.int64)
+    os.environ.pop("WORLD_SIZE", None)
+    np.savez_compressed(os.path.join(HERE, "ddp_stream.npz"), **out)
+    print("ddp_stream.npz written")
+
+
 def gen_cli():
     import tempfile
     root = tempfile.mkdtemp(prefix="acav_golden_")
@@ -568,10 +607,10 @@ if __name__ == "__main__":
     if sys.argv[1:2] == ["cli_subset"]:
         gen_cli_subset(sys.argv[2])
         sys.exit(0)
-    which = sys.argv[1:] or ["rng", "kmeans", "kmeans_big", "mi", "mi_exact", "mi_ami", "cli", "contrastive"]
+    which = sys.argv[1:] or ["rng", "kmeans", "kmeans_big", "mi", "mi_exact", "mi_ami", "cli", "contrastive", "ddp_stream"]
     if len(which) > 1:
         for w in which:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
         {"rng": gen_rng, "kmeans": gen_kmeans, "kmeans_big": gen_kmeans_big, "mi": gen_mi, "mi_exact": gen_mi_exact, "mi_ami": gen_mi_ami, "cli": gen_cli,
-         "contrastive": gen_contrastive}[which[0]]()
+         "contrastive": gen_contrastive, "ddp_stream": gen_ddp_stream}[which[0]]()

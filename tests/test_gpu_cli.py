@@ -240,11 +240,11 @@ def test_cluster_cli_spawns_one_process_per_gpu(workdir):
 
 
 def test_cluster_cli_rows_mode_two_workers(workdir):
-    """`cli.py cluster --clustering.multi_gpu=rows --computation.num_gpus=2`: the reference's DDP training through the CLI
-    (sgd_clustering.py:94-129, run_clustering.py:146) -- every worker holds the rows of its own shards (rank::2), a step's
-    global batch is 32 rows of worker 0 followed by 32 rows of worker 1, ceil(2 / 2) = 1 epoch -- the same call bench.py
-    --gpus N times.  Two workers on the one GPU of this box (gloo).  Checked against the ORACLE fed that batch stream:
-    the saved centres of all ten clusterings bit for bit, and every written label."""
+    """`cli.py cluster --clustering.multi_gpu=rows --computation.num_gpus=2`: the LARGE-BATCH multi-GPU mode through the CLI
+    (not the reference's N-GPU run -- that is test_cluster_cli_reference_mode_two_workers): every worker holds the rows of
+    its own shards (rank::2), a step's global batch is 32 rows of worker 0 followed by 32 rows of worker 1 (global batch
+    64), ceil(2 / 2) = 1 epoch.  Two workers on the one GPU of this box (gloo).  Checked against the ORACLE fed that batch
+    stream: the saved centres of all ten clusterings bit for bit, and every written label."""
     import torch
     from oracle import oracle as O
     from acav100m_amd import shards as io
@@ -253,7 +253,7 @@ def test_cluster_cli_rows_mode_two_workers(workdir):
     log = _run_cli("acav100m_amd.clustering.cli",
                    ["cluster", "--feature_path=" + glob, "--meta_path=" + os.path.join(root, "videos"), "--out_path=" + out,
                     "--computation.num_gpus=2", "--clustering.multi_gpu=rows"], {"ACAV_SEED": "0", "ACAV_DIST_BACKEND": "gloo"})
-    assert log.count("done") == 2 and "16 steps of 2 x 32 rows per epoch, 1 epochs" in log
+    assert log.count("done") == 2 and "mode rows: 16 steps of 2 x 32 rows per epoch, 1 epochs" in log
     caches = sorted(f for f in os.listdir(out) if f.startswith("cache_epoch_"))
     assert len(caches) == 1  # ceil(epochs / num_gpus) = 1 epoch, written by worker 0
     saved = torch.load(os.path.join(out, caches[0]), weights_only=False)
@@ -268,9 +268,14 @@ def test_cluster_cli_rows_mode_two_workers(workdir):
     refs = [O.KMeans(tabs[0].views[v].shape[1], K, rng) for v in views]  # ten inits in view order (run_clustering.py:32-44)
     rng.u32(), rng.u32()                                                   # the DataLoader iterator's seed draw
     steps = min(len(t) for t in tabs) // b
-    for ref, v in zip(refs, views):  # warm-up labels: drawn clustering by clustering; both workers draw the same stream
-        need = min(steps, -(-(10 * K) // (2 * b)))
-        warm = [np.argmin(rng.rand(K, b), axis=0) for _ in range(need)]
+    # warm-up labels: each worker draws the labels of ITS rows batch by batch across the clusterings (the reference loop
+    # steps every clustering per batch); both workers are seeded alike and draw the same stream
+    need = min(steps, -(-(10 * K) // (2 * b)))
+    warms = [[None] * need for _ in views]
+    for t in range(need):
+        for i in range(len(views)):
+            warms[i][t] = np.argmin(rng.rand(K, b), axis=0)
+    for ref, v, warm in zip(refs, views, warms):
         for t in range(steps):
             xg = np.concatenate([tabs[r].views[v][t * b:(t + 1) * b] for r in range(2)])
             if t < need:
@@ -293,6 +298,80 @@ def test_cluster_cli_rows_mode_two_workers(workdir):
             key = "audio_assignments" if kind == "audio" else "video_assignments"
             got = np.array([int(r[key][0]["array"][layer]) for r in rows])
             assert np.array_equal(got, want), (s, mk, layer)
+
+
+def test_cluster_cli_reference_mode_two_workers(workdir, golden_dir):
+    """`cli.py cluster --clustering.multi_gpu=reference --computation.num_gpus=2`: the reference's OWN two-GPU training run
+    (sgd_clustering.py:94-129 under is_distributed) -- every worker feeds int(32 / 2) = 16 rows per step
+    (data/clustering.py:25) of its stream over ALL four shards in the rotated order of mps/distributed.py:433-437
+    (worker 0: shards 0 2 1 3, worker 1: 1 3 0 2 -- read from tests/golden/ddp_stream.npz, which the reference's own
+    node_selection produced), ceil(2 / 2) = 1 epoch of 2 * 1024 / 32 = 64 steps at the global batch of 32.  Two workers on
+    the one GPU of this box (gloo), each HOLDING only its own shards.  Checked against the ORACLE fed the reference's
+    batch stream: the saved centres of all ten clusterings bit for bit, and every written label."""
+    import torch
+    from pathlib import Path
+    from oracle import oracle as O
+    from acav100m_amd import shards as io
+    root, glob = workdir
+    out = os.path.join(root, "cl_reference")
+    log = _run_cli("acav100m_amd.clustering.cli",
+                   ["cluster", "--feature_path=" + glob, "--meta_path=" + os.path.join(root, "videos"), "--out_path=" + out,
+                    "--computation.num_gpus=2", "--clustering.multi_gpu=reference"], {"ACAV_SEED": "0", "ACAV_DIST_BACKEND": "gloo"})
+    assert log.count("done") == 2 and "mode reference: 64 steps of 2 x 16 rows per epoch, 1 epochs" in log
+    caches = sorted(f for f in os.listdir(out) if f.startswith("cache_epoch_"))
+    assert len(caches) == 1  # ceil(epochs / num_gpus) = 1 epoch, written by worker 0
+    saved = torch.load(os.path.join(out, caches[0]), weights_only=False)
+    g = np.load(os.path.join(golden_dir, "ddp_stream.npz"))
+    case = "w2_even"
+    assert [int(x) for x in g[case + "_sizes"]] == [256] * 4 and int(g[case + "_world"]) == 2
+    lb, epochs = int(g[case + "_local_batch"]), int(g[case + "_epochs"])
+    paths = [Path(q) for q in sorted(io.brace_expand(glob))]
+    models, audio = ['layer_vggish', 'layer_slow_fast'], ('vggish', 'layer_vggish')
+    shard_tabs = [io.load_feature_shards([q], model_order=models, audio_models=audio) for q in paths]
+    views = list(shard_tabs[0].views)
+    K, lr = 32, 0.1 ** 2  # run_clustering.py:168: lr = 0.1 ** (2 + epoch // 5)
+    rng = O.Rng(0)
+    refs = [O.KMeans(shard_tabs[0].views[v].shape[1], K, rng) for v in views]  # ten inits in view order (run_clustering.py:32-44)
+    rng.u32(), rng.u32()                                                         # the DataLoader iterator's seed draw
+    steps = 1024 // lb
+    assert epochs == 1 and steps * lb == int(g[case + "_length"])
+    need = min(steps, -(-(10 * K) // (2 * lb)))
+    warms = [[None] * need for _ in views]
+    for t in range(need):  # each worker labels its own 16 rows (calc_best(batch): torch.rand(k, 16)); same seed, same draws
+        for i in range(len(views)):
+            warms[i][t] = np.argmin(rng.rand(K, lb), axis=0)
+    for ref, v, warm in zip(refs, views, warms):
+        streams = [np.concatenate([shard_tabs[int(s)].views[v] for s in g[case + "_order_rank%d" % r]]) for r in range(2)]
+        for t in range(steps):
+            xg = np.concatenate([streams[r][t * lb:(t + 1) * lb] for r in range(2)])  # all_gather order: rank-major
+            if t < need:
+                ref.apply_update(xg, np.concatenate([warm[t], warm[t]]), lr)
+            else:
+                ref.lr = lr
+                ref.add(xg)
+    for ref, (kind, mk, layer) in zip(refs, views):
+        got = saved[mk][layer]
+        assert np.array_equal(np.asarray(got["centers"]), ref.centers), (mk, layer)
+        assert got["count"] == ref.count == steps * 2 * lb
+    for s in range(4):
+        rows = pickle.load(open(os.path.join(out, "shard-%06d.pkl" % s), "rb"))
+        assert len(rows) == 256
+        for ref, view in zip(refs, views):
+            kind, mk, layer = view
+            want = ref.calc_best(shard_tabs[s].views[view])[0]
+            key = "audio_assignments" if kind == "audio" else "video_assignments"
+            got = np.array([int(r[key][0]["array"][layer]) for r in rows])
+            assert np.array_equal(got, want), (s, mk, layer)
+    # more GPUs than shards: the reference clamps num_gpus (script.py:22,37); here the run refuses instead of writing
+    # checkpoints and labels of untrained clusterings
+    one = os.path.join(os.path.dirname(glob), "shard-{000000..000000}.pkl")
+    with pytest.raises(AssertionError):
+        _run_cli("acav100m_amd.clustering.cli",
+                 ["cluster", "--feature_path=" + one, "--meta_path=" + os.path.join(root, "videos"),
+                  "--out_path=" + os.path.join(root, "cl_reference_none"), "--computation.num_gpus=2",
+                  "--clustering.multi_gpu=reference"], {"ACAV_SEED": "0", "ACAV_DIST_BACKEND": "gloo"})
+    assert not os.path.isdir(os.path.join(root, "cl_reference_none")) or not any(
+        f.startswith("cache_epoch_") or f.endswith(".pkl") for f in os.listdir(os.path.join(root, "cl_reference_none")))
 
 
 def test_subset_cli_chunks_spawn_per_gpu(workdir):

@@ -202,11 +202,75 @@ def test_comm_c_abi_world1():
     assert np.array_equal(kb.centers.numpy(), before[0]) and kb.count == before[1] and ka.count == before[2] + steps * b
 
 
+def test_plan_driven_epoch_c_abi_world1():
+    """acav_kmeans_train_plan_multi (the row exchange of clustering.multi_gpu=reference / bench.py --gpus N inside the
+    library: pack kernel, grouped send / receive on the clustering's communicator, placement kernel, chunk pipeline,
+    device-resident chain) on the one GPU of this box: a communicator of ONE rank, but plans with SEVERAL slots whose
+    extents all name rank 0 -- rotated streams over four ragged "segments" of the local rows, as plan_reference lays them
+    out, and the one-slot shard-order stream of plan_views.  Two clusterings per call (communicator per clustering),
+    chunks of 7 steps (the warm-up spans chunks; pieces are cut by chunk AND extent boundaries).  The state must equal the
+    oracle fed the plan's global batches row for row."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import acav100m_amd
+    from acav100m_amd.clustering import KMeans
+    from acav100m_amd.parallel.rccl_comm import default_comm
+    from acav100m_amd.parallel.row_plan import RowPlan
+    from oracle import oracle as O
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if default_comm(0) is None:
+        pytest.skip("RCCL not available")
+    rs = np.random.RandomState(2)
+    k, b = 24, 32
+    seg = [200, 136, 168, 152]  # four ragged segments laid out one after the other in this rank's rows
+    first = np.concatenate([[0], np.cumsum(seg)[:-1]])
+    n = sum(seg)
+    dims = (256, 128)
+    xs = [(rs.randn(k, d)[rs.randint(0, k, n)] * 3 + rs.randn(n, d)).astype(np.float32) for d in dims]
+    xt = [torch.from_numpy(x).cuda() for x in xs]
+    plans = []
+    lb = b // 4
+    rot = [[(0, int(first[i % 4]), seg[i % 4]) for i in range(q, q + 4)] for q in range(4)]
+    plans.append(RowPlan("reference-like", 1, 4, lb, rot, n // lb, 1))
+    plans.append(RowPlan("views-like", 1, 1, b, [[(0, int(first[i]), seg[i]) for i in (2, 0, 3, 1)]], n // b, 1))
+    plans.append(RowPlan("rows-like", 1, 2, b, [[(0, 0, 336)], [(0, 336, 320)]], 320 // b, 1))
+    for plan in plans:
+        acav100m_amd.manual_seed(21)
+        kms = [KMeans(None, d, k).to("cuda:0") for d in dims]
+        rng = O.Rng(21)
+        refs = [O.KMeans(d, k, rng) for d in dims]
+        for epoch in range(2):
+            # one rank: the labels of a warm-up step are argmin torch.rand(k, global batch), clustering by clustering
+            tr = KMeans.train_epoch_plan_multi(kms, xt, plan, lr=0.01, chunk_steps=7)
+            assert tr == [0, 0]
+            for v, km in enumerate(kms):
+                km.broadcast_state_from(0, comm_slot=v)
+            for ref, x in zip(refs, xs):
+                need = min(plan.steps, max(0, -(-(10 * k - ref.count) // plan.global_batch)))
+                warm = [np.argmin(rng.rand(k, plan.global_batch), axis=0) for _ in range(need)]
+                for t in range(plan.steps):
+                    xb = np.stack([x[row] for _owner, row in plan.batch_sources(t)])
+                    if t < need:
+                        ref.apply_update(xb, warm[t].astype(np.int64), 0.01)
+                    else:
+                        ref.add(xb, 0.01)
+            for km, ref in zip(kms, refs):
+                assert np.array_equal(km.centers.numpy(), ref.centers), (plan.mode, epoch)
+                assert np.array_equal(km.counts.numpy(), ref.counts) and km.count == ref.count, (plan.mode, epoch)
+        # a clustering whose trainer is another rank (nobody in a world of one) only feeds its exchange
+        before = (kms[1].centers.numpy().copy(), kms[1].count, kms[0].count)
+        KMeans.train_epoch_plan_multi(kms, xt, plan, lr=0.01, chunk_steps=16, trainers=[0, 1])
+        assert np.array_equal(kms[1].centers.numpy(), before[0]) and kms[1].count == before[1] + plan.steps * plan.global_batch
+        assert kms[0].count == before[2] + plan.steps * plan.global_batch
+
+
 def test_bench_two_ranks_on_one_gpu():
     """bench.py's N > 1 path end to end, launched the way the driver launches it (torch.distributed.run, one process per
     rank) with two ranks sharing the one GPU of this box (ACAV_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device):
-    DDP training epochs with the bulk row exchange, the state hand-out, per-rank assign and selection, the MAX-over-ranks
-    timing and ONE JSON line from rank 0."""
+    plan-driven training epochs with the bulk row exchange (every --multi-gpu mode), the state hand-out, per-rank assign
+    and selection, the MAX-over-ranks timing, --verify (state hashes agree across the ranks, rank 0's labels == the
+    oracle's on 16 384 rows) and ONE JSON line from rank 0."""
     import json
     import socket
     import subprocess
@@ -214,19 +278,44 @@ def test_bench_two_ranks_on_one_gpu():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, ACAV_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-           "--rows", "65536", "--no-cpu-baseline", "--no-variants"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    rows = 65536
+    want = {"views": (32, 2 * rows // 32, 2), "reference": (32, 2 * 2 * rows // 32, 1), "rows": (64, rows // 32, 1)}
+    for mode, (gb, steps, epochs) in want.items():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, ACAV_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+               "--rows", str(rows), "--no-cpu-baseline", "--no-variants", "--verify", "--multi-gpu", mode]
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["steps"] == 1 and out["scaling"] == "weak" and out["unit"] == "clips/s"
+        cfg = out["config"]
+        assert cfg["multi_gpu_mode"] == mode and cfg["rows_per_gpu"] == rows
+        assert (cfg["global_batch"], cfg["sgd_steps_per_epoch"], cfg["train_epochs"]) == (gb, steps, epochs), cfg
+        assert mode in cfg["workload"]
+        assert out["value"] > 0 and abs(out["value"] - 2 * rows / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+        assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["rows"] == rows
+        v = out["verify"]
+        assert v["ranks_agree"] and v["oracle_sample_rows"] == 16384 and v["oracle_labels_equal"] == [True, True], v
+
+
+def test_bench_verify_one_gpu():
+    """bench.py --verify on one GPU (the driver's N = 1 launch shape, small): the verdict object is in the line"""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--rows", "65536", "--no-cpu-baseline",
+           "--no-variants", "--verify"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["scaling"] == "weak" and out["unit"] == "clips/s"
-    assert out["config"]["global_batch"] == 64 and out["config"]["rows_per_gpu"] == 65536
-    assert out["value"] > 0 and abs(out["value"] - 2 * 65536 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
-    assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["rows"] == 65536
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["config"]["multi_gpu_mode"] is None and out["config"]["global_batch"] == 32
+    assert out["verify"]["ranks_agree"] and out["verify"]["oracle_labels_equal"] == [True, True]

@@ -4,7 +4,7 @@
 # Separate runs, as the MI355X guide prescribes: kernel trace + stats, then one --pmc pass per counter (never combined
 # with a trace domain).  Copy the results into profiles/ afterwards.
 set -u
-P=${1:-r04}
+P=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profiles
 mkdir -p "$OUT"
@@ -40,6 +40,10 @@ stats assign_k1024 python tools/run_assign_only.py 1000000 3 filter 1024 1024
 pmc fetch_k1024 "k_assign" FETCH_SIZE python tools/run_assign_only.py 1000000 3 filter 1024 1024
 pmc write_k1024 "k_assign" WRITE_SIZE python tools/run_assign_only.py 1000000 3 filter 1024 1024
 python tools/summarize_pmc.py "$OUT" "$P" _k1024 1000000 1024 1024
+# cfg4's widest view (d = 2048, K = 1024, the per-GPU partition of 1.25M rows): the `traffic` of bench.py --workload cfg4
+pmc fetch_k1024_d2048 "k_assign" FETCH_SIZE python tools/run_assign_only.py 1250000 3 filter 2048 1024
+pmc write_k1024_d2048 "k_assign" WRITE_SIZE python tools/run_assign_only.py 1250000 3 filter 2048 1024
+python tools/summarize_pmc.py "$OUT" "$P" _k1024_d2048 1250000 2048 1024
 # cfg4's per-GPU partition (10M clips over 8 GPUs): 1.25M rows, 2048-d visual / 128-d audio, K = 1024
 (python tools/run_assign_only.py 1250000 3 filter 2048 1024; python tools/run_assign_only.py 1250000 3 filter 128 1024) > "$OUT/${P}_assign_cfg4.txt" 2> /dev/null
 # 3. MI greedy: one chunk at V = 1M (3000 iterations) and V = 100k, legacy global-atomic kernels for the A/B, 8 chunks in lockstep
