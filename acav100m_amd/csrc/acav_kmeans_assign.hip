@@ -948,6 +948,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
         auto issue_x = [&]() {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+#if defined(ACAV_ABL_NOXDMA_G123)  // timing-only bounds of a bf16-row hand-off between the pair workgroups of a tile:
+                if (GS && cg > 0) continue;  // groups 1.. get their rows for free
+#elif defined(ACAV_ABL_XHALF_G123)
+                if (GS && cg > 0 && (q & 1)) continue;  // groups 1.. move half the row bytes (what bf16 rows would)
+#endif
                 if (LISTED) {
                     if (NT) dma16_asm_v64_nt(ax[q], xring + wx * XSLOT + q * 1024);
                     else dma16_asm_v64(ax[q], xring + wx * XSLOT + q * 1024);
@@ -994,8 +999,20 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
 #else
             // what stays in flight behind stage c: DCR 2 -- the 4 row pieces of stage c+1 (issued last, after the
             // centres of stage c); DCR 3 -- the CQ centre + 4 row pieces of stage c+1
+#if defined(ACAV_ABL_NOXDMA_G123) || defined(ACAV_ABL_XHALF_G123)
+            // (fewer row pieces in flight behind stage c for groups 1..: the counted wait follows)
+            if (c + 1 >= nchunks) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (GS && cg > 0) {
+#ifdef ACAV_ABL_NOXDMA_G123
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DCR == 2 ? 0 : CQ) : "memory");
+#else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DCR == 2 ? 2 : CQ + 2) : "memory");
+#endif
+            } else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DCR == 2 ? 4 : CQ + 4) : "memory");
+#else
             if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DCR == 2 ? 4 : CQ + 4) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 #endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             RW_T(t1);
@@ -1040,7 +1057,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
                 } else {
                     const int q = i - CQ;
 #ifndef ACAV_ABL_NOXDMA
+#if defined(ACAV_ABL_NOXDMA_G123)
+                    if (c + 2 < nchunks && !(GS && cg > 0)) {
+#elif defined(ACAV_ABL_XHALF_G123)
+                    if (c + 2 < nchunks && !(GS && cg > 0 && (q & 1))) {
+#else
                     if (c + 2 < nchunks) {
+#endif
                         if (LISTED) {
                             if (NT) dma16_asm_v64_nt(ax[q], xring + wx * XSLOT + q * 1024);
                             else dma16_asm_v64(ax[q], xring + wx * XSLOT + q * 1024);
@@ -1586,6 +1609,20 @@ __global__ __launch_bounds__(256, 3) void k_assign_cand(const float *__restrict_
     }
 }
 
+// out [n][dp] <- in [n][d], columns d .. dp-1 zero: a view whose width is not a multiple of the filter's 32-column stage
+// (SlowFast's 88-wide layer, clustering/code/models/slowfast.py:31) takes the filter on a padded copy.  Zero columns change
+// nothing in the canonical arithmetic: fmaf(0, 0, s) == s in every dot and norm chain, for the filter AND for the exact
+// re-check of the rows it cannot decide (both run on the padded rows and centres).
+__global__ __launch_bounds__(256) void k_pad_rows(const float *__restrict__ in, float *__restrict__ out, int64_t n, int d, int dp)
+{
+    const int64_t total = n * dp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / dp;
+        const int j = (int)(i - r * dp);
+        out[i] = j < d ? in[r * d + j] : 0.0f;
+    }
+}
+
 }  // namespace
 
 // The filter's copy of the centres: bf16 of c (or of c - mu when no centre is under-used), the mean centre, and the
@@ -1595,16 +1632,25 @@ __global__ __launch_bounds__(256, 3) void k_assign_cand(const float *__restrict_
 int acav_kmeans::prepare_filter()
 {
     if (cb16_valid) return ACAV_OK;
-    if ((d % FD_BK) != 0 || K < 2 || warm()) return ACAV_OK;  // the filter does not run on this shape / state
+    if (K < 2 || warm()) return ACAV_OK;  // the filter does not run on this shape / state
     hipStream_t st = ctx.stream;
     const int Kp = (K + 255) / 256 * 256;  // whole groups of 256 centre slots (stage-major copy: k_centers_bf16)
-    ACAV_TRY(cb16.ensure(sizeof(unsigned short) * (size_t)Kp * d));
+    // a width that is not a multiple of the 32-column stage: the filter (and its exact re-check) run on zero-padded copies
+    const int dp = filter_d();
+    const float *fc = centers.as<float>();
+    if (dp != d) {
+        ACAV_TRY(cpad.ensure(sizeof(float) * (size_t)K * dp));
+        hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)std::min<int64_t>(((int64_t)K * dp + 255) / 256, 4096)), dim3(256), 0, st,
+                           centers.as<float>(), cpad.as<float>(), (int64_t)K, d, dp);
+        fc = cpad.as<float>();
+    }
+    ACAV_TRY(cb16.ensure(sizeof(unsigned short) * (size_t)Kp * dp));
     ACAV_TRY(caux.ensure(sizeof(CentersAux)));
     ACAV_HIP_TRY(hipMemsetAsync(caux.p, 0, sizeof(CentersAux), st));
-    ACAV_TRY(cmu.ensure(sizeof(float) * (size_t)d));
-    hipLaunchKernelGGL(k_centers_mu, dim3((unsigned)((d + 31) / 32)), dim3(256), 0, st, centers.as<float>(), cn.as<float>(),
-                       counts.as<float>(), K, d, threshold(), cmu.as<float>(), caux.as<CentersAux>());
-    hipLaunchKernelGGL(k_centers_bf16, dim3((unsigned)Kp), dim3(256), 0, st, centers.as<float>(), cmu.as<float>(), d, K, Kp,
+    ACAV_TRY(cmu.ensure(sizeof(float) * (size_t)dp));
+    hipLaunchKernelGGL(k_centers_mu, dim3((unsigned)((dp + 31) / 32)), dim3(256), 0, st, fc, cn.as<float>(),
+                       counts.as<float>(), K, dp, threshold(), cmu.as<float>(), caux.as<CentersAux>());
+    hipLaunchKernelGGL(k_centers_bf16, dim3((unsigned)Kp), dim3(256), 0, st, fc, cmu.as<float>(), dp, K, Kp,
                        cb16.as<__bf16>(), caux.as<CentersAux>());
     ACAV_HIP_TRY(hipGetLastError());
     cb16_valid = true;
@@ -1706,10 +1752,23 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
     // bf16 filter + exact re-check (bit-identical labels, HBM-bound when the clusters are separated): taken when
     // the caller does not need the mean distance (the filter's distances are approximate)
     const char *noflt = getenv("ACAV_ASSIGN_EXACT_ONLY");
-    const bool filter = !mean_dist && fast && (km->d % FD_BK) == 0 && km->K >= 2 && n >= FB_ROWS &&
+    // d % 32 != 0 (88-wide SlowFast layer): the filter sweep runs on zero-padded copies of the rows and the centres (k_pad_rows;
+    // ACAV_FILTER_PAD=0: the guarded exact sweep as before)
+    const char *vpad = getenv("ACAV_FILTER_PAD");
+    const bool ragged = (km->d % FD_BK) != 0;
+    const bool filter = !mean_dist && (ragged ? !(vpad && vpad[0] == '0') : fast) && km->K >= 2 && n >= FB_ROWS &&
                         !(noflt && noflt[0] == '1') && n < 0x7fffffff;
     if (filter) {
         ACAV_TRY(km->prepare_filter());
+        const int fd = km->filter_d();  // the width the sweep runs at
+        const float *fc = km->centers.as<float>();
+        if (ragged) {
+            ACAV_TRY(km->xpad.ensure(sizeof(float) * (size_t)n * fd));
+            hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)std::min<int64_t>((n * fd + 255) / 256, 65536)), dim3(256), 0, st,
+                               static_cast<const float *>(dx), km->xpad.as<float>(), n, fd, fd);
+            dx = km->xpad.p;
+            fc = km->cpad.as<float>();
+        }
         ACAV_TRY(km->recheck_list.ensure(sizeof(int) * (size_t)n * 2));  // [undecided rows | rows for the full exact sweep]
         // control block of the sweep: zero when a sweep starts -- zeroed here once, and by the last kernel of every sweep
         if (!km->cand_ctl.p) {
@@ -1745,7 +1804,7 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         CandPair *cpair = cand ? km->cand_pairs.as<CandPair>() : (CandPair *)nullptr;
         int *und_list = km->recheck_list.as<int>(), *f32_list = und_list + n;
         const CandOut cout = {crow, cpair, f32_list, cand && km->K > 256 ? km->cand_T.as<float>() : (float *)nullptr, pair_cap};
-        const double acc = 1.01 * (double)km->d * ldexp(1.0, -24);  // accumulation error of one fp32 dot, relative
+        const double acc = 1.01 * (double)fd * ldexp(1.0, -24);  // accumulation error of one fp32 dot, relative
         const float e1c = (float)(2.02 * (ldexp(1.0, -8) * 1.002 + acc) * 1.001);   // x ||c'|| ||x||: bf16 roundings + filter dot
         const float e1r = (float)(2.02 * (acc + ldexp(1.0, -24)) * 1.001);           // x ||c|| ||x||: canonical dot, c - mu
         // rows are read exactly once: non-temporal DMA policy (ACAV_FILTER_NT=0 restores the default policy);
@@ -1762,7 +1821,7 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         const bool gs = rw && ngroups > 1 && !(vgs && vgs[0] == '0');
         // (narrow views, d <= 256: a pair is only 4-8 stages long and its ring fill and epilogue weigh as much as its stage loop
         // -- two 128-row workgroups per CU hide them under each other: d = 128, K = 1024: 0.59 vs 0.72 ms per 1.25M rows)
-        const int nw = !rw ? 4 : (vnw && vnw[0] == '8') ? 8 : (vnw && vnw[0] == '4') ? 4 : (gs ? (km->d <= 256 ? 4 : 8) : FILTER_NW_DEFAULT);
+        const int nw = !rw ? 4 : (vnw && vnw[0] == '8') ? 8 : (vnw && vnw[0] == '4') ? 4 : (gs ? (fd <= 256 ? 4 : 8) : FILTER_NW_DEFAULT);
         const bool nt_eff = gs ? !(vnt && vnt[0] == '0') : nt;  // nt rows are still found in L2 by the tile's other groups (PMC)
         const int dcr = nw == 8 ? 3 : 2;  // centre ring depth (3 only fits the one-workgroup-per-CU tile)
         const int sched = nw == 8 ? 2 : (vsc ? (vsc[0] == '2' ? 2 : 0) : FILTER_SCHED_DEFAULT);
@@ -1795,7 +1854,7 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         if (rw) {
             ACAV_TRY(dyn_lds_once(reinterpret_cast<const void *>(rwk), km->ctx.device, fsmem));
             ACAV_HIP_TRY(hipEventRecord(km->ev_f0, st));
-            hipLaunchKernelGGL(rwk, dim3((unsigned)fgrid), dim3(nw * 64), fsmem, st, static_cast<const float *>(dx), n, km->d,
+            hipLaunchKernelGGL(rwk, dim3((unsigned)fgrid), dim3(nw * 64), fsmem, st, static_cast<const float *>(dx), n, fd,
                                km->cb16.as<__bf16>(), km->cn.as<float>(), km->counts.as<float>(), km->K, km->threshold(),
                                (float)km->reinit_r, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, emit ? und_list : f32_list,
                                emit ? &ctl->und_count : f32_count, ctl, gs ? km->grec.as<Top2Rec>() : (Top2Rec *)nullptr, cout);
@@ -1808,7 +1867,7 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
             ACAV_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), km->ctx.device, FD_SMEM));
             ACAV_HIP_TRY(hipEventRecord(km->ev_f0, st));
             hipLaunchKernelGGL(kern, dim3((unsigned)((n + FB_ROWS - 1) / FB_ROWS)), dim3(256), FD_SMEM, st,
-                               static_cast<const float *>(dx), n, km->d, km->cb16.as<__bf16>(), km->cn.as<float>(),
+                               static_cast<const float *>(dx), n, fd, km->cb16.as<__bf16>(), km->cn.as<float>(),
                                km->counts.as<float>(), km->K, km->threshold(), (float)km->reinit_r, km->caux.as<CentersAux>(), e1c,
                                e1r, e2, dlab, f32_list, f32_count);
         }
@@ -1852,20 +1911,20 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
                 ACAV_TRY(dyn_lds_once(reinterpret_cast<const void *>(ek), km->ctx.device, esmem));
                 const int64_t erows = (int64_t)enw * 32;
                 const int64_t egrid = std::min<int64_t>((n + erows - 1) / erows, (int64_t)km->num_cus);
-                hipLaunchKernelGGL(ek, dim3((unsigned)egrid), dim3(enw * 64), esmem, st, static_cast<const float *>(dx), n, km->d,
+                hipLaunchKernelGGL(ek, dim3((unsigned)egrid), dim3(enw * 64), esmem, st, static_cast<const float *>(dx), n, fd,
                                    km->cb16.as<__bf16>(), km->cn.as<float>(), km->counts.as<float>(), km->K, km->threshold(),
                                    (float)km->reinit_r, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, und_list, &ctl->und_count, ctl,
                                    (Top2Rec *)nullptr, cout);
             }
             // (3 workgroups of 4 waves per CU: the kernel is bound by the L2 -> L1 path -- 1, 2, 3, 4, 6 per CU all measure the same)
             hipLaunchKernelGGL(k_assign_cand, dim3((unsigned)(3 * km->num_cus)), dim3(256), 0, st, static_cast<const float *>(dx),
-                               km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->threshold(),
+                               fd, fc, km->cn.as<float>(), km->counts.as<float>(), km->threshold(),
                                (float)km->reinit_r, ctl, crow, cpair, pair_cap, dlab);
         }
         // full exact sweep of the rows on the f32 list (more than CAND_MAX candidates, pool overflow, K > 256); also the
         // sweep's last kernel: its last workgroup resets the control block
         hipLaunchKernelGGL(k_assign_f32<false>, dim3((unsigned)rgrid), dim3(256), 0, st, static_cast<const float *>(dx), n,
-                           km->d, km->centers.as<float>(), km->cn.as<float>(), km->counts.as<float>(), km->K,
+                           fd, fc, km->cn.as<float>(), km->counts.as<float>(), km->K,
                            km->threshold(), (float)km->reinit_r, dlab, (float *)nullptr, km->wg_sum.as<double>(),
                            f32_list, f32_count);
         km->n_filter_launches += 1;

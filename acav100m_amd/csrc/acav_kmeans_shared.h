@@ -67,6 +67,7 @@ struct acav_kmeans {
     DevBuf stage_x, stage_lab, stage_forced, keys, xn, wg_sum, minval, thr, ctl;
     DevBuf cb16, caux, cmu, recheck_list, backup, grec, split_rings;
     DevBuf cand_ctl, cand_rows, cand_pairs, cand_T;
+    DevBuf cpad, xpad;  // zero-padded centres / rows of the assign filter when d % 32 != 0 (acav_kmeans_assign.hip)
     unsigned ctl_pair_cap = 0;  // candidate-restricted re-check of the assign sweep (acav_kmeans_assign.hip)
     hipEvent_t ev_f0 = nullptr, ev_f1 = nullptr;  // around the last k_assign_bf16 launch (acav_kmeans_filter_time)
     bool cb16_valid = false;  // bf16 copy of the centres matches `centers`
@@ -80,6 +81,7 @@ struct acav_kmeans {
 
     float threshold() const { return (float)pow((double)count / (double)K, reinit_p); }
     bool warm() const { return count < (int64_t)initial_rounds * K; }
+    int filter_d() const { return (d + 31) / 32 * 32; }  // the width the assign filter runs at (d padded to its 32-column stage)
     int refresh_cn();          // acav_kmeans.hip (k_row_norm2 over the centres)
     int prepare_filter();      // acav_kmeans_assign.hip: bf16 / centred copy of the centres for the filter
 };

@@ -20,6 +20,15 @@
 
 using namespace acav;
 
+// Experiment builds only (-DACAV_EXPERIMENT_BUILD -DACAV_MI_ABL_EMPTY, tools/exp/build_empty_mi.sh): every kernel of the greedy
+// loop returns at once, so that ACAV_MI_TIMING=1 shows what the HOST side of the loop costs per iteration with the same launch
+// pattern (grids, streams, events, generator bookkeeping) and an idle GPU.  Results are garbage by construction.
+#ifdef ACAV_MI_ABL_EMPTY
+#define ACAV_MI_EMPTY_RETURN return;
+#else
+#define ACAV_MI_EMPTY_RETURN
+#endif
+
 namespace {
 
 struct MiScalars {
@@ -678,6 +687,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_mt_generate(unsigned *__restrict
 __global__ __launch_bounds__(MT_THREADS) void k_mt_generate_lanes(unsigned *__restrict__ states, unsigned *__restrict__ out0,
                                                                  long long blk, long long head)
 {
+    ACAV_MI_EMPTY_RETURN
     const long long lane = blockIdx.x;
     const long long extra = lane == 0 ? head : 0;  // leftover draws of the host block, placed right before block 0
     mt_generate_body<false>(states + lane * 625, out0 + lane * blk - extra, blk + extra);  // the state stays at the block start
@@ -691,6 +701,7 @@ constexpr int MJ_WORDS = MT_BACK + MT_WIDE * 32;  // 21014 >= 624 + 19937
 __global__ __launch_bounds__(MT_THREADS) void k_mt_jump(unsigned *__restrict__ states, int src0, int dst0,
                                                        const unsigned *__restrict__ poly)
 {
+    ACAV_MI_EMPTY_RETURN
     __shared__ unsigned X[MJ_WORDS];
     const unsigned tid = threadIdx.x;
     const unsigned *src = states + (size_t)(src0 + blockIdx.x) * 625;
@@ -1128,6 +1139,7 @@ __device__ __forceinline__ const unsigned *chunk_draw_ptr(const TileChunk &c, in
 template <bool STAGED>
 __global__ __launch_bounds__(FYA_THREADS) void k_fy_part_multi(const TileChunk *__restrict__ cd, int it0, int dl)
 {
+    ACAV_MI_EMPTY_RETURN
     const TileChunk &c = cd[blockIdx.y];
     const int z = (int)blockIdx.z, it = it0 + z;
     const int L = c.L0 - it * dl;
@@ -1139,6 +1151,7 @@ __global__ __launch_bounds__(FYA_THREADS) void k_fy_part_multi(const TileChunk *
 
 __global__ __launch_bounds__(FYT_THREADS) void k_fy_tile_multi(const TileChunk *__restrict__ cd, int it0, int dl)
 {
+    ACAV_MI_EMPTY_RETURN
     const TileChunk &c = cd[blockIdx.y];
     const int z = (int)blockIdx.z, it = it0 + z;
     if (it >= c.iters || (int)blockIdx.x >= c.NT) return;
@@ -1150,6 +1163,7 @@ __global__ __launch_bounds__(FYT_THREADS) void k_fy_tile_multi(const TileChunk *
 // here, beside the content path -- the gather that waits for the previous selection is then one indexed copy
 __global__ __launch_bounds__(256) void k_fy_resolve_multi(const TileChunk *__restrict__ cd, int it0, int dl, int nreq)
 {
+    ACAV_MI_EMPTY_RETURN
     // one element per thread: a wave waits for the longest of its chains, and four elements per thread (256 chains per
     // wave) made the kernel 1.5x slower
     const TileChunk &c = cd[blockIdx.y];
@@ -1187,6 +1201,7 @@ __global__ __launch_bounds__(256) void k_fy_resolve_multi(const TileChunk *__res
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fy_gather_select_multi(
     const TileChunk *__restrict__ cd, int it, int dl, int B, int k, int mode, int keep_unselected)
 {
+    ACAV_MI_EMPTY_RETURN
     const TileChunk &c = cd[blockIdx.y];
     const int L = c.L0 - it * dl;  // list length of iteration `it`
     const int nreq = keep_unselected ? B - k : 0;

@@ -27,6 +27,9 @@ Other workloads (`--workload`, never the default: the driver's line stays on con
   cfg5   configs[4]: 100M clips / 8 = 12.5M clips per GPU, two 1024-d views (102 GB resident), K = 1024, selection in
          chunks of 100 shards = 100k clips, 10 chunks in lockstep (computation.concurrent_chunks)
 Their `roofline` is quoted on the K = 1024 filter against the bf16 MFMA roof that binds there (intensity K/2 = 512 flop/B).
+  real10 the reference's REAL pipeline shape: ten clusterings over the 5 + 5 layer outputs of VGGish (64 / 128 / 256 / 512 / 128,
+         models/vggish.py:20) and SlowFast (88 / 352 / 704 / 1408 / 2304, models/slowfast.py:31), K = 32 (config.py:41; --k 256),
+         `combination` pairing P = 45, one chunk of 1M clips; `roofline` on the widest view's filter (2304-d, HBM-bound)
 
 N > 1 (weak scaling: every rank holds its own 1M-clip partition, N million clips in all).  Assign is local and the MI
 selection runs per rank on its own partition -- the reference's chunked mode with one chunk per GPU (chunk.py:21-53) -- no
@@ -85,6 +88,11 @@ WORKLOADS = {
     "cfg4": dict(name="BASELINE configs[3], per-GPU slice (10M clips / 8)", n=1_250_000, dims=(2048, 128), k=1024, chunk=None, width=1),
     "cfg5": dict(name="BASELINE configs[4], per-GPU slice (100M clips / 8)", n=12_500_000, dims=(1024, 1024), k=1024,
                  chunk=100_000, width=10),
+    # the reference's REAL pipeline: ten clusterings over the 5 + 5 layer outputs of its two extractors (clustering/code/
+    # models/vggish.py:20: 64 / 128 / 256 / 512 / 128; models/slowfast.py:31: 88 / 352 / 704 / 1408 / 2304), K = 32
+    # (clustering/code/config.py:41; --k 256 for the larger point), `combination` pairing over D = 10 -> P = 45, one chunk
+    "real10": dict(name="the reference's real 5 + 5 layer pipeline (VGGish + SlowFast layer widths)", n=1_000_000,
+                   dims=(64, 128, 256, 512, 128, 88, 352, 704, 1408, 2304), k=32, chunk=None, width=1, audio_views=5),
 }
 
 
@@ -130,7 +138,9 @@ def cpu_baseline(n, dims, k, b, seed, chunk=None):
     rs = np.random.RandomState(seed)
     views = len(dims)
     n_steps, n_assign_rows = 256, 65536
-    mi_iters = 1500 if k <= 256 else 300  # dense [B,P,C,C] scoring is 16x the work at C = 1024; ~15 s of CPU work in all
+    # dense [B,P,C,C] scoring: work per iteration ~ P C^2 (16x at C = 1024, 45x at the real pipeline's P = 45); ~15 s of CPU work in all
+    pairs_n = views * (views - 1) // 2
+    mi_iters = max(300 if pairs_n == 1 else 20, min(1500, int(1500 * 65536 / (max(k, 64) ** 2 * pairs_n))))
     cores = os.cpu_count() or 1
     train_threads = min(cores, 16)
     per_d = {}
@@ -279,7 +289,9 @@ def main():
 
     cargs = _NS(computation=_NS(device="cuda", num_gpus=world))
     sargs = select_args()
-    types = [("audio_model", "layer_0"), ("visual_model", "layer_0")]
+    n_audio = wl.get("audio_views", 1)  # clustering types as dataloader.py:17-69 builds them: sorted (model_key, layer)
+    types = [("audio_model", f"layer_{i}") for i in range(n_audio)] + [("visual_model", f"layer_{i}") for i in range(nviews - n_audio)]
+    npairs = nviews * (nviews - 1) // 2  # `combination` pairing (pairing.py:5-41)
     subset = round(RATIO * n) if chunk is None else sum(round(RATIO * min(chunk, n - c0)) for c0 in range(0, n, chunk))
     iters = -(-subset // SELECT_K) if chunk is None else sum(-(-round(RATIO * min(chunk, n - c0)) // SELECT_K) for c0 in range(0, n, chunk))
 
@@ -433,7 +445,7 @@ def main():
             "sweep_over_launch": s_ms / f_ms,
             "rows_rechecked_exact": [int(f[2]) for f in filt_stats[-nviews:]], "rows": n, "per_view": per_view})
         out = {
-            "metric": "clips/sec curated (k-means train + assign, 2 views) + MI greedy selection of 20 %",
+            "metric": f"clips/sec curated (k-means train + assign, {nviews} views) + MI greedy selection of 20 %",
             "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -445,7 +457,7 @@ def main():
                        "global_batch": b if plan is None else plan.global_batch, "sgd_steps_per_epoch": steps_per_epoch,
                        "train_epochs": train_epochs, "multi_gpu_mode": None if plan is None else plan.mode,
                        "rows_per_gpu": n, "views": nviews, "view_dims": list(dims), "epochs": EPOCHS,
-                       "select": subset, "mi_chunks": 1 if chunk is None else -(-n // chunk)},
+                       "select": subset, "mi_chunks": 1 if chunk is None else -(-n // chunk), "mi_pairs": npairs},
             "stages": {"train_s": st["train"], "assign_s": st["assign"], "handoff_s": st["handoff"], "mi_s": st["mi"],
                        "train_us_per_sgd_step": st["train"] * 1e6 / train_steps,
                        "assign_sweep_ms": s_ms, "mi_us_per_iteration": st["mi"] * 1e6 / iters,

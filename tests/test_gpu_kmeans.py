@@ -224,6 +224,63 @@ def test_bf16_filter_path_is_bit_identical(env, case):
         assert rechecked < n // 20  # centred centres: the common component costs nothing
 
 
+@pytest.mark.parametrize("d,K,kind", [(88, 32, "clustered"), (88, 256, "clustered"), (88, 64, "unstructured"), (200, 48, "tiny_gap"),
+                                      (100, 300, "clustered"), (36, 16, "discounted"), (2308, 32, "clustered")])
+def test_filter_on_widths_that_are_not_stage_multiples(env, d, K, kind, monkeypatch):
+    """Round 5: a view whose width is not a multiple of the filter's 32-column stage -- SlowFast's 88-wide layer
+    (clustering/code/models/slowfast.py:31) -- used to take the guarded exact sweep.  Now calc_best(need_mean=False) runs the
+    bf16 filter + candidate / exact re-check on zero-padded copies of the rows and the centres (88 -> 96; fmaf(0, 0, s) == s in
+    every canonical chain).  Labels must equal the oracle's on the UNPADDED data: separated clusters (filter decides), unstructured
+    rows and centre pairs 1e-4 apart (the re-check decides, on the padded copies), K > 256 (group pairs + merge), under-used
+    centres (no centring), a width past 2304; and equal what the guarded exact sweep gives (ACAV_FILTER_PAD=0)."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    rs = np.random.RandomState(d + K)
+    n = 3000
+    if kind == "unstructured":
+        x = rs.randn(n, d).astype(np.float32)
+        centers = rs.randn(K, d).astype(np.float32)
+    elif kind == "tiny_gap":
+        x = _mixture(4, n, d, K // 2)
+        base = np.stack([x[rs.randint(0, n)] for _ in range(K // 2)]).astype(np.float32)
+        centers = np.concatenate([base, base + (1e-4 * rs.randn(K // 2, d)).astype(np.float32)])
+    else:
+        cen = (2.0 * rs.randn(K, d)).astype(np.float32)
+        x = (cen[rs.randint(0, K, n)] + 0.3 * rs.randn(n, d)).astype(np.float32)
+        centers = (cen + 0.05 * rs.randn(K, d)).astype(np.float32)
+    counts = np.full(K, 1000, np.float32)
+    if kind == "discounted":
+        counts = rs.randint(0, 80, K).astype(np.float32)
+    count = 10 * K + 2000
+    km = KMeans(None, d, K)
+    km.centers, km.counts, km.count = centers, counts, count
+    km.to("cuda:0")
+    ref = O.KMeans(d, K, O.Rng(0), centers=centers)
+    ref.set_state(None, counts, count)
+    lab_ref, _ = ref.calc_best(x)
+    xt = torch.from_numpy(x).cuda()
+    lab, mean = km.calc_best(xt, need_mean=False)
+    assert mean is None
+    launches, rows, rechecked = km.filter_stats()
+    assert launches == 1 and rows == n, "the padded filter did not run"
+    assert np.array_equal(lab.cpu().numpy(), lab_ref), f"{(lab.cpu().numpy() != lab_ref).sum()} labels differ"
+    print(f"d={d} K={K} {kind}: {rechecked}/{n} rows needed the exact re-check")
+    if kind == "clustered":
+        assert rechecked < n // 10
+    if kind in ("unstructured", "tiny_gap"):
+        assert rechecked > n // 2
+    # host rows go through the same path; a second sweep after a state change rebuilds the padded copies
+    lab_h, _ = km.calc_best(x, need_mean=False)
+    assert np.array_equal(lab_h.numpy(), lab_ref)
+    km.centers = centers[::-1].copy()
+    ref2 = O.KMeans(d, K, O.Rng(0), centers=centers[::-1].copy())
+    ref2.set_state(None, counts, count)
+    assert np.array_equal(km.calc_best(xt, need_mean=False)[0].cpu().numpy(), ref2.calc_best(x)[0])
+    monkeypatch.setenv("ACAV_FILTER_PAD", "0")  # the guarded exact sweep, as before round 5
+    assert np.array_equal(km.calc_best(xt, need_mean=False)[0].cpu().numpy(), ref2.calc_best(x)[0])
+    assert km.filter_stats()[0] == 3
+
+
 @pytest.mark.parametrize("mode", ["plain", "pool_overflow", "cand_off", "discounted", "many_ties", "emission_pass"])
 def test_candidate_restricted_recheck(env, mode, monkeypatch):
     """Round 4: a row the bf16 filter cannot decide is settled by the exact canonical distances of its CANDIDATE centres only
