@@ -1765,7 +1765,7 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         if (ragged) {
             ACAV_TRY(km->xpad.ensure(sizeof(float) * (size_t)n * fd));
             hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)std::min<int64_t>((n * fd + 255) / 256, 65536)), dim3(256), 0, st,
-                               static_cast<const float *>(dx), km->xpad.as<float>(), n, fd, fd);
+                               static_cast<const float *>(dx), km->xpad.as<float>(), n, km->d, fd);
             dx = km->xpad.p;
             fc = km->cpad.as<float>();
         }

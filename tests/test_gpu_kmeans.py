@@ -267,7 +267,9 @@ def test_filter_on_widths_that_are_not_stage_multiples(env, d, K, kind, monkeypa
     print(f"d={d} K={K} {kind}: {rechecked}/{n} rows needed the exact re-check")
     if kind == "clustered":
         assert rechecked < n // 10
-    if kind in ("unstructured", "tiny_gap"):
+    if kind == "unstructured":
+        assert rechecked > n // 20  # the re-check (on the padded copies) really decided rows
+    if kind == "tiny_gap":
         assert rechecked > n // 2
     # host rows go through the same path; a second sweep after a state change rebuilds the padded copies
     lab_h, _ = km.calc_best(x, need_mean=False)
