@@ -94,6 +94,13 @@ for (k, c), v in sorted(agg.items()):
 PY
     rm -rf "$OUT/pmc_cand_$tag"
 done
+# 7. round 5: the real pipeline's shape (ten clusterings, P = 45) as bench lines, ten clusterings alone vs in one call, the driver's
+#    command with --verify, the cfg4 pair and the K = d = 1024 pair side by side
+timeout 900 python bench.py --workload real10 --steps 2 --warmup 1 > "$OUT/${P}_real10_k32.json" 2> /dev/null
+timeout 900 python bench.py --workload real10 --k 256 --steps 2 --warmup 1 > "$OUT/${P}_real10_k256.json" 2> /dev/null
+(BENCH_K=32 python tools/bench_train_real10.py; BENCH_K=256 python tools/bench_train_real10.py) > "$OUT/${P}_train_real10.txt" 2>&1
+timeout 600 python bench.py --steps 2 --warmup 1 --verify --no-cpu-baseline --no-variants > "$OUT/${P}_bench_verify.json" 2> /dev/null
+(python tools/bench_train_multi.py; BENCH_D=2048 BENCH_D2=128 python tools/bench_train_multi.py; BENCH_K=256 python tools/bench_train_multi.py) > "$OUT/${P}_train_multi.txt" 2>&1
 for f in "$OUT"/${P}_*.txt; do sed -i '/amdgpu.ids/d' "$f"; done
 for f in "$OUT/${P}_mi_1m.txt" "$OUT/${P}_mi_1m_legacy.txt" "$OUT/${P}_mi_100k.txt" "$OUT/${P}_mi_lockstep8.txt" "$OUT/${P}_bench_under_rocprof.txt"; do grep "^{" "$f" | tail -1 > "$f.tmp" && mv "$f.tmp" "${f%.txt}.json" && rm -f "$f"; done
 ls -la "$OUT"
