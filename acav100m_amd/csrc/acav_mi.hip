@@ -164,6 +164,36 @@ __device__ double ami_pair_score(const int *__restrict__ asg, int D, int C, int 
     return (mi - emi) / den;
 }
 
+// EfficientNMI._calc_score (mi.py:262-271) for pair p: 2 MI / max(mean entropy, eps) -- the MI and entropy terms of the
+// adjusted score without the EMI; the canonical form of oracle nmi_score_canon (same running sums, same operations)
+__device__ __forceinline__ double nmi_pair_score(const int *__restrict__ asg, int D, int C, int p, const int *__restrict__ pairs, int id,
+                                                 const int *__restrict__ Nc, const int *__restrict__ ac, const int *__restrict__ bc,
+                                                 const double *__restrict__ SN, const double *__restrict__ Sa, const double *__restrict__ Sb,
+                                                 const double *__restrict__ phi, const double *__restrict__ lnk, long long nc)
+{
+    const int *row = asg + (size_t)id * D;
+    const int i = row[pairs[2 * p]], j = row[pairs[2 * p + 1]];
+    const long long n1i = nc + 1;
+    const double n1 = (double)n1i, ln_n = lnk[n1i];
+    const int cN = Nc[((size_t)p * C + i) * C + j], ca = ac[(size_t)p * C + j], cb = bc[(size_t)p * C + i];
+    const double sN = SN[p] - phi[cN] + phi[cN + 1];
+    const double sa = Sa[p] - phi[ca] + phi[ca + 1];
+    const double sb = Sb[p] - phi[cb] + phi[cb + 1];
+    if ((long long)cN + 1 == n1i) {
+        // DEGENERATE (every sample in ONE cell: MI = entropies = 0 over integer counts): the reference returns the ratio of its eps
+        // artefacts, a closed form of C and n -- derivation in oracle/acav_oracle.c nmi_score_canon; the same operations here
+        const double ln_eps = -36.043653389117154, ln_c = lnk[C];
+        const double num = (double)(C - 1) * ((ln_n - ln_eps) - 2.0 * ln_c) - 2.0 * ln_c;
+        const double dd = (double)C * ((ln_n - ln_c) - ln_eps);
+        return (2.0 * num) / dd;
+    }
+    const double mi = (((sN - sa) - sb) + phi[n1i]) / n1;
+    const double ha = ln_n - sa / n1, hb = ln_n - sb / n1;
+    double den = (ha + hb) / 2.0;
+    if (den < 2.220446049250313e-16) den = 2.220446049250313e-16;  // ensure_nonzero (mi.py:194-199)
+    return (2.0 * mi) / den;
+}
+
 constexpr int SEL_MAXB = 64;
 constexpr int SEL_MAXBP = 8192;
 
@@ -482,10 +512,13 @@ __global__ __launch_bounds__(256) void k_mi_exact_iter(
     double *__restrict__ trace_scores, int *__restrict__ trace_argmax, int measure, const double *__restrict__ lnk,
     const double *__restrict__ lf)
 {
-    // measure 0: calc_MI ('mi' / 'mem_mi'); 1: calc_AMI ('ami')
+    // measure 0: calc_MI ('mi' / 'mem_mi'); 1: calc_AMI ('ami'); 2: calc_NMI (mi.py:262-271); 3: ConstantMeasure (mi.py:274-281:
+    // every candidate scores 1, the first remaining one is taken)
     auto pair_score = [&](int p, int id, long long n) -> double {
-        return measure == 1 ? ami_pair_score(asg, D, C, p, pairs, id, Nc, ac, bc, SN, Sa, Sb, phi, lnk, lf, n)
-                            : mi_pair_score(asg, D, C, p, pairs, id, Nc, ac, bc, SN, Sa, Sb, phi, n);
+        if (measure == 1) return ami_pair_score(asg, D, C, p, pairs, id, Nc, ac, bc, SN, Sa, Sb, phi, lnk, lf, n);
+        if (measure == 2) return nmi_pair_score(asg, D, C, p, pairs, id, Nc, ac, bc, SN, Sa, Sb, phi, lnk, n);
+        if (measure == 3) return 1.0;
+        return mi_pair_score(asg, D, C, p, pairs, id, Nc, ac, bc, SN, Sa, Sb, phi, n);
     };
     __shared__ double sS[4];
     __shared__ int sP[4];
@@ -1354,7 +1387,7 @@ struct acav_mi {
     DevBuf chunk_desc;                         // descriptor array of a multi-chunk run (lead handle)
     DevBuf lane_states, ring, polys;           // MT19937 lanes of the single-chunk greedy (MtStream)
     DevBuf lnk, lf;   // ln k and ln k! tables of the `ami` score (acav_mi_set_measure)
-    int measure = 0;  // exact greedy: 0 = calc_MI, 1 = calc_AMI
+    int measure = 0;  // exact greedy: 0 = calc_MI, 1 = calc_AMI, 2 = calc_NMI, 3 = constant
     DevBuf fy_table, fy_bounds, fy_bucket, fy_count, fy_src[FY_GROUP], fy_g[FY_GROUP], fy_perm[FY_NBUF], fy_tail, fy_err;  // tiled Fisher-Yates
     hipStream_t st_fy = nullptr;               // the position kernels of group g+1 run beside the gathers of group g
     hipEvent_t ev_tile[FY_NBUF] = {}, ev_gather[FY_NBUF] = {};
@@ -2096,12 +2129,15 @@ ACAV_EXPORT int acav_mi_run_greedy_multi(acav_mi **mis, int nchunks, const int64
 }
 
 // which score the exact greedy (acav_mi_run_exact) maximises: 0 = calc_MI ('mi', 'mem_mi'; mi.py:85-91), 1 = calc_AMI ('ami',
-// mi.py:212-259).  The adjusted score reads two more host-built tables, ln k and ln k! for k <= V + 1.
+// mi.py:212-259), 2 = calc_NMI (EfficientNMI, mi.py:262-271), 3 = ConstantMeasure (mi.py:274-281).  The adjusted and normalised
+// scores read two more host-built tables, ln k and ln k! for k <= V + 1.
 ACAV_EXPORT int acav_mi_set_measure(acav_mi *mi, int measure)
 {
     ACAV_REQUIRE(mi, ACAV_EINVAL, "handle is NULL");
-    ACAV_REQUIRE(measure == 0 || measure == 1, ACAV_EINVAL, "unknown measure %d", measure);
-    if (measure == 1 && !mi->lnk.p) {
+    ACAV_REQUIRE(measure >= 0 && measure <= 3, ACAV_EINVAL, "unknown measure %d", measure);
+    ACAV_REQUIRE(measure != 2 || (int64_t)mi->C <= mi->V + 1, ACAV_EINVAL, "nmi: ncentroids %d exceeds the ln k table (V + 1 = %lld)",
+                 mi->C, (long long)(mi->V + 1));
+    if ((measure == 1 || measure == 2) && !mi->lnk.p) {
         ACAV_HIP_TRY(hipSetDevice(mi->ctx.device));
         std::vector<double> lnk((size_t)mi->V + 2), lf((size_t)mi->V + 2);
         lnk[0] = 0.0, lf[0] = 0.0;

@@ -89,3 +89,23 @@ class EfficientAMI(EfficientMI):
         assert self.average_method == 'arithmetic', "ami: only the reference's default average_method is built"
         super().init(clustering_combinations, candidates)
         _lib.check(_lib._lib.acav_mi_set_measure(self._h, 1))
+
+
+class EfficientNMI(EfficientAMI):
+    """normalised MI (mi.py:262-271): the exact greedy on 2 MI / max(mean entropy, eps).  The reference defines the class but
+    its registry (measures/__init__.py:5-14) does not name it; here it is reachable as 'nmi'.  Same kernel, score 2
+    (acav_mi_set_measure); float64 over integer counts, pinned on the reference class's own run (tests/golden/mi_nmi_*.npz)."""
+
+    def init(self, clustering_combinations, candidates):
+        assert self.average_method == 'arithmetic', "nmi: only the reference's default average_method is built"
+        EfficientMI.init(self, clustering_combinations, candidates)
+        _lib.check(_lib._lib.acav_mi_set_measure(self._h, 2))
+
+
+class ConstantMeasure(EfficientMI):
+    """mi.py:274-281: every candidate scores 1, so the exact greedy takes the first remaining candidate every iteration and
+    every gain is 1.0 -- the reference's "no measure" control ('constant' here; not in the reference's registry either)."""
+
+    def init(self, clustering_combinations, candidates):
+        super().init(clustering_combinations, candidates)
+        _lib.check(_lib._lib.acav_mi_set_measure(self._h, 3))

@@ -239,8 +239,9 @@ class BatchMI:
         return out
 
     def set_measure(self, name):
-        """exact greedy scores: 'mi' / 'mem_mi' (calc_MI) or 'ami' (calc_AMI, mi.py:212-259)"""
-        lib().orc_mi_set_measure(self.h, 1 if name == "ami" else 0)
+        """exact greedy scores: 'mi' / 'mem_mi' (calc_MI), 'ami' (calc_AMI, mi.py:212-259), 'nmi' (calc_NMI, :262-271) or
+        'constant' (ConstantMeasure, :274-281)"""
+        lib().orc_mi_set_measure(self.h, {"ami": 1, "nmi": 2, "constant": 3}.get(name, 0))
 
     def scores_ami(self, ids):
         ids = _i64(ids)

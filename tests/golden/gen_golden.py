@@ -7,7 +7,7 @@ this script and the tiny stand-in modules under _stubs/ for the reference's un-v
 imports (torch_scatter, diffdist, wget, braceexpand).
 
     python tests/golden/gen_golden.py            # all three groups
-    python tests/golden/gen_golden.py kmeans|kmeans_big|mi|mi_exact|mi_ami|rng|cli|contrastive|ddp_stream
+    python tests/golden/gen_golden.py kmeans|kmeans_big|mi|mi_exact|mi_ami|mi_nmi|rng|cli|contrastive|ddp_stream
 
 Groups:
   rng.npz     torch.manual_seed/rand/randperm and random.shuffle streams (G6)
@@ -593,6 +593,65 @@ def gen_ddp_stream():
     print("ddp_stream.npz written")
 
 
+def gen_mi_nmi():
+    """The reference's EfficientNMI (mi.py:262-271) and ConstantMeasure (mi.py:274-281) -- classes its get_measure registry does
+    not name -- through its own _run_greedy (run_greedy.py:9-54) with the registry look-up pointed at the class: per-iteration
+    score vectors, picks, S, GAIN of the exact greedy."""
+    sys.path.insert(0, os.path.join(REF, "subset_selection", "code"))
+    import torch
+    import run_greedy as ref_run_greedy  # noqa: E402  (the reference)
+    from measures.mi import ConstantMeasure, EfficientMI, EfficientNMI  # noqa: E402
+
+    cases = {
+        # name: (class, tag, seed, V, D, C, subset)
+        "nmi_a": (EfficientNMI, 0, 240, 2, 6, 50),
+        "nmi_b": (EfficientNMI, 1, 200, 3, 5, 40),
+        "nmi_c": (EfficientNMI, 2, 320, 2, 12, 36),
+        "constant_a": (ConstantMeasure, 3, 120, 2, 5, 30),
+    }
+    for name, (cls, seed, v, dd, c, subset) in cases.items():
+        rs = np.random.RandomState(500 + seed)
+        comp = rs.randint(0, c, size=v)
+        cols = []
+        for _ in range(dd):
+            indep = rs.randint(0, c, size=v)
+            share = rs.rand(v) < 0.5
+            cols.append(np.where(share, comp, indep))
+        assignments = np.stack(cols, 1).astype(np.int64)
+        assignments[0, :] = c - 1
+        types = [("m%d" % i, "layer_0") for i in range(dd)]
+        rec = dict(scores=[], idx=[])
+        orig, orig_get = EfficientMI.calc_score, ref_run_greedy.get_measure
+
+        def calc_score(self, *a, **k):
+            sc = self._calc_score(*a, **k).mean(dim=-1)
+            score, idx = sc.max(dim=0)
+            rec["scores"].append(sc.cpu().numpy().astype(np.float32).copy())
+            rec["idx"].append(int(idx.item()))
+            return score.item(), idx.item()
+
+        EfficientMI.calc_score = calc_score
+        ref_run_greedy.get_measure = lambda _name, cls=cls: cls
+        args = _NS(batch=_NS(batch_size=20, selection_size=4, keep_unselected=True),
+                   computation=_NS(device="cpu"), log_every=10 ** 9, log_times=None,
+                   node_rank=None, parent_pid=None)
+        random.seed(seed)
+        torch.manual_seed(seed)
+        S, GAIN, _ = ref_run_greedy._run_greedy(args, assignments, types, subset, None, "unregistered", "combination", True, False)
+        EfficientMI.calc_score, ref_run_greedy.get_measure = orig, orig_get
+        w0 = len(rec["scores"][0])
+        sc = np.full((len(rec["scores"]), w0), np.nan, np.float32)
+        for t, row in enumerate(rec["scores"]):
+            sc[t, :len(row)] = row
+        random.seed(seed)
+        cand = list(range(v))
+        random.shuffle(cand)
+        np.savez_compressed(os.path.join(HERE, f"mi_{name}.npz"), assignments=assignments, seed=seed, C=c, subset=subset,
+                            S=np.array(S, np.int64), GAIN=np.array(GAIN, np.float64), scores=sc,
+                            idx=np.array(rec["idx"], np.int64), shuffled=np.array(cand, np.int64))
+        print(f"mi_{name}.npz written: {len(S)} selected, score range {np.nanmin(sc):.4f} .. {np.nanmax(sc):.4f}")
+
+
 def gen_cli():
     import tempfile
     root = tempfile.mkdtemp(prefix="acav_golden_")
@@ -607,10 +666,10 @@ if __name__ == "__main__":
     if sys.argv[1:2] == ["cli_subset"]:
         gen_cli_subset(sys.argv[2])
         sys.exit(0)
-    which = sys.argv[1:] or ["rng", "kmeans", "kmeans_big", "mi", "mi_exact", "mi_ami", "cli", "contrastive", "ddp_stream"]
+    which = sys.argv[1:] or ["rng", "kmeans", "kmeans_big", "mi", "mi_exact", "mi_ami", "cli", "contrastive", "ddp_stream", "mi_nmi"]
     if len(which) > 1:
         for w in which:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
         {"rng": gen_rng, "kmeans": gen_kmeans, "kmeans_big": gen_kmeans_big, "mi": gen_mi, "mi_exact": gen_mi_exact, "mi_ami": gen_mi_ami, "cli": gen_cli,
-         "contrastive": gen_contrastive, "ddp_stream": gen_ddp_stream}[which[0]]()
+         "contrastive": gen_contrastive, "ddp_stream": gen_ddp_stream, "mi_nmi": gen_mi_nmi}[which[0]]()

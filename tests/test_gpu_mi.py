@@ -252,6 +252,45 @@ def test_ami_exact_greedy_golden_and_free_running(env, golden_dir, name):
     assert S2[1:] == free["S"].tolist() and np.array_equal(np.array(G2), free["GAIN"])
 
 
+@pytest.mark.parametrize("name", ["nmi_a", "nmi_b", "nmi_c", "constant_a"])
+def test_nmi_and_constant_golden_and_free_running(env, golden_dir, name):
+    """'nmi' / 'constant' (EfficientNMI / ConstantMeasure, measures/mi.py:262-281) on the GPU: replaying the reference's recorded
+    picks, S / GAIN / every score vector equal the oracle's canonical float64 form bit for bit (hence, test_oracle_golden, the
+    reference's fp32 scores to 1e-5); free-running == the oracle, pick for pick."""
+    torch, acav, O = env
+    from acav100m_amd.subset_selection import get_measure
+    g = np.load(os.path.join(golden_dir, f"mi_{name}.npz"))
+    a, c, subset, cand = g["assignments"], int(g["C"]), int(g["subset"]), g["shuffled"]
+    pairs = list(itertools.combinations(range(a.shape[1]), 2))
+    idx = g["idx"]
+    measure = name.split("_")[0]
+    L = len(cand) - 1
+    m = get_measure(measure)(a, ncentroids=c, batch_size=20, selection_size=4, device="cuda:0", keep_unselected=True)
+    m.init(pairs, [int(i) for i in cand[1:]])
+    S, GAIN, _, _ = m.run_greedy(subset, [int(cand[0])], None, record_trace=True, forced_pos=_remaining_to_original(idx, L))
+    assert S == g["S"].tolist()
+    om = O.BatchMI(a, c, pairs)
+    om.set_measure(measure)
+    ref = om.run_exact(cand[1:], cand[:1], subset, forced_idx=idx, trace=True)
+    assert np.array_equal(np.array(GAIN), ref["GAIN"])  # float64, bit for bit
+    alive = list(range(L))
+    for t in range(subset - 2):
+        row = m.trace["scores"][t]
+        assert np.array_equal(row[alive], ref["scores"][t, :len(alive)])
+        assert m.trace["argmax"][t] == alive[int(ref["argmax"][t])]
+        alive.pop(int(idx[t]))
+    np.testing.assert_allclose(np.array(GAIN), g["GAIN"], rtol=1e-5, atol=1e-7)  # the reference's own fp32 gains
+    m2 = get_measure(measure)(a, ncentroids=c, device="cuda:0")
+    m2.init(pairs, [int(i) for i in cand[1:]])
+    S2, G2, _, _ = m2.run_greedy(subset, [int(cand[0])])
+    om2 = O.BatchMI(a, c, pairs)
+    om2.set_measure(measure)
+    free = om2.run_exact(cand[1:], cand[:1], subset)
+    assert S2[1:] == free["S"].tolist() and np.array_equal(np.array(G2), free["GAIN"])
+    if measure == "constant":
+        assert S2 == g["S"].tolist() and all(v == 1.0 for v in G2)
+
+
 def test_ami_larger_tables_free_running_equals_oracle(env):
     """ami beyond the golden sizes: D = 4 (P = 6), C = 24, 2 000 candidates, 80 picks -- GPU == oracle bit for bit"""
     torch, acav, O = env

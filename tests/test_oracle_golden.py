@@ -321,3 +321,39 @@ def test_contrastive_oracle_vs_reference(golden_dir, name):
         ref = g["p1_" + k]
         np.testing.assert_allclose(v[:len(ref)], ref, rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(m.infer(visual, audio), g["infer"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["nmi_a", "nmi_b", "nmi_c", "constant_a"])
+def test_nmi_and_constant_exact_greedy_golden(golden_dir, name):
+    """EfficientNMI (2 MI / max(mean entropy, eps), measures/mi.py:262-271) and ConstantMeasure (every candidate scores 1,
+    mi.py:274-281): classes of the reference that its get_measure registry does not name, run through its own _run_greedy
+    (tests/golden/gen_golden.py mi_nmi).  Teacher-forced on the reference's picks: the canonical float64 scores equal its fp32
+    score vectors to 1e-5 relative at every iteration, every reference pick is within that band of the canonical maximum, S and
+    GAIN follow; the constant measure takes the first remaining candidate every time, free-running too."""
+    g = np.load(os.path.join(golden_dir, f"mi_{name}.npz"))
+    a, c, subset, cand = g["assignments"], int(g["C"]), int(g["subset"]), g["shuffled"]
+    pairs = list(itertools.combinations(range(a.shape[1]), 2))
+    idx, ref_sc = g["idx"], g["scores"]
+    measure = name.split("_")[0]
+    m = O.BatchMI(a, c, pairs)
+    m.set_measure(measure)
+    r = m.run_exact(cand[1:], cand[:1], subset, forced_idx=idx, trace=True)
+    n = subset - 2
+    assert r["iters"] == n == len(idx)
+    assert np.array_equal(r["S"], g["S"][1:]) and g["S"][0] == cand[0]
+    np.testing.assert_allclose(r["GAIN"], g["GAIN"], rtol=1e-5, atol=1e-7)
+    worst = 0.0
+    for t in range(n):
+        L = ref_sc.shape[1] - t
+        mine, ref = r["scores"][t, :L], ref_sc[t, :L].astype(np.float64)
+        rel = np.abs(mine - ref) / np.maximum(np.abs(ref), 1e-6)
+        worst = max(worst, float(rel.max()))
+        assert rel.max() <= 1e-5
+        assert mine.max() - mine[idx[t]] <= 1e-5 * max(1e-6, abs(mine.max()))
+    print(f"{name}: max relative score difference from the reference {worst:.2e}")
+    if measure == "constant":
+        assert (idx == 0).all() and np.array_equal(g["S"][1:], cand[1:subset - 1])
+        m2 = O.BatchMI(a, c, pairs)
+        m2.set_measure("constant")
+        free = m2.run_exact(cand[1:], cand[:1], subset)
+        assert np.array_equal(free["S"], g["S"][1:]) and (free["GAIN"] == 1.0).all()
