@@ -1423,7 +1423,8 @@ struct MtStream {
     int64_t freed = 0;     // superblocks [0, freed) are no longer read by any iteration still to be enqueued
 
     // L: the longest list (one iteration reads at most L - 1 contiguous draws); span: the most draws one acquire() covers
-    int plan(acav_mi *mi, hipStream_t consumer, const uint32_t *mtbuf, int idx, int64_t total_draws, int64_t L, int64_t span)
+    int plan(acav_mi *mi, hipStream_t consumer, const uint32_t *mtbuf, int idx, int64_t total_draws, int64_t L, int64_t span,
+             hipStream_t generator = nullptr)
     {
         T = total_draws;
         p0 = idx;
@@ -1450,7 +1451,7 @@ struct MtStream {
         nsuper = nblocks ? (nblocks + W - 1) / W : 0;
         wraps = nsuper > NSLOT;
         st = consumer;
-        smt = mi->st_mt;
+        smt = generator ? generator : mi->st_mt;
         for (int q = 0; q < NSLOT; ++q) ev_mt[q] = mi->ev_mt[q], ev_used[q] = mi->ev_used[q];
         const int64_t slots = nsuper < NSLOT ? nsuper : NSLOT;
         ACAV_TRY(mi->ring.ensure(sizeof(unsigned) * (size_t)(PAD + slots * S + (wraps ? lmax : 0) + 8)));
@@ -1845,7 +1846,14 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
         int idx = 0;
         ACAV_TRY(acav_rng_get_state(rngs[c], mtbuf, &idx));
         MtStream &ms = streams[(size_t)c];
-        ACAV_TRY(ms.plan(mi, sf, mtbuf, idx, draws, L[c], (int64_t)FY_GROUP * L[c]));
+        // Chunks in lockstep: ALL their generators run on the lead handle's generator stream (round 5).  A generator launch is rare
+        // (a superblock of 82 M words lasts ~800 iterations of a 100k-clip chunk) and off the critical path, but ten generator
+        // streams are ten more queues for the runtime to service: with GPU_MAX_HW_QUEUES = 16 (which ten clusterings training
+        // side by side need, acav100m_amd/__init__.py) the lockstep loop ran at 7.4 us per chunk-iteration instead of 3.8;
+        // on one shared stream 3.66 at either setting.  ACAV_MI_SHARE_GEN=0: a stream per chunk again, =n: n streams (A/B).
+        const char *vsh = getenv("ACAV_MI_SHARE_GEN");
+        const int nshare = vsh ? atoi(vsh) : 1;
+        ACAV_TRY(ms.plan(mi, sf, mtbuf, idx, draws, L[c], (int64_t)FY_GROUP * L[c], nshare > 0 ? mis[c % nshare]->st_mt : nullptr));
         TileChunk &d = desc[(size_t)c];
         d.ring = ms.ring + MtStream::PAD;
         d.head = ms.head;
@@ -1959,7 +1967,7 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
     }
     ACAV_HIP_TRY(hipStreamSynchronize(st));
     for (int c = 0; c < nchunks; ++c) {  // every generator continues on the host where its chunk stopped drawing
-        ACAV_HIP_TRY(hipStreamSynchronize(mis[c]->st_mt));
+        ACAV_HIP_TRY(hipStreamSynchronize(streams[(size_t)c].smt ? streams[(size_t)c].smt : mis[c]->st_mt));
         unsigned mtbuf[625];
         int idx = 0;
         ACAV_TRY(acav_rng_get_state(rngs[c], mtbuf, &idx));
