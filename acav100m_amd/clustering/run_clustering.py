@@ -342,10 +342,10 @@ def train_clusters(args, probe, groups, shard_stems=()):
 
 
 def multi_gpu_mode(args):
-    """clustering.multi_gpu: 'views' (default), 'reference' or 'rows' -- see config.py"""
+    """clustering.multi_gpu: 'views' (default), 'striped', 'reference' or 'rows' -- see config.py"""
     mode = str(args.clustering.multi_gpu or 'views')
-    if mode not in ('views', 'reference', 'rows'):
-        raise ValueError("clustering.multi_gpu must be 'views', 'reference' or 'rows', not {!r}".format(mode))
+    if mode not in ('views', 'striped', 'reference', 'rows'):
+        raise ValueError("clustering.multi_gpu must be 'views', 'striped', 'reference' or 'rows', not {!r}".format(mode))
     return mode
 
 
@@ -354,6 +354,9 @@ def _train_clusters_planned(args, cl, groups, pre, epochs, b, mode, shard_stems)
     mps/distributed.py:439 -- the node's aggregate HBM holds the rows, nothing streams through one GPU) and a plan
     (parallel/row_plan.py) says which rows form which step's global batch:
 
+      striped     the ONE-GPU batch stream over partitioned rows: one slot, the shards in their global order,
+                  batch_size rows per step, `epochs` epochs -- the files of the one-GPU run (and of the default `views` mode,
+                  which reads every shard on the training rank instead), the rows resident on the ranks that own them.
       reference   the reference's own N-GPU run (sgd_clustering.py:94-129 under is_distributed): rank q feeds
                   int(batch_size / N) rows per step (data/clustering.py:25) of ITS stream over ALL shards in the rotated
                   order full[q::N] + full[q+1::N] + ... (mps/distributed.py:433-437), ceil(epochs / N) epochs

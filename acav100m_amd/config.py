@@ -106,6 +106,8 @@ CLUSTERING_DEFAULTS = {
         # ours: what several GPUs do in training (acav100m_amd/parallel/row_plan.py).
         # 'views' (default): the clusterings are dealt out over the GPUs, every GPU trains its share over ALL rows with the
         #   one-GPU batch stream and epoch count: the N-GPU run writes the files of the one-GPU run.
+        # 'striped': the same one-GPU batch stream and epoch count (hence the same files) with the ROWS partitioned: every GPU holds
+        #   the rows of its own shards (rank::N) and they travel in bulk to the GPU that runs a clustering's chain.
         # 'reference': the reference's own N-GPU run -- every GPU holds the rows of its own shards (rank::N), rank q feeds
         #   int(batch_size / N) rows per step (data/clustering.py:25) of its rotated stream over ALL shards
         #   (mps/distributed.py:433-437), epochs = ceil(epochs / N) (run_clustering.py:146): the global batch stays

@@ -14,9 +14,10 @@ the one rank that runs a clustering's SGD chain -- KMeans.train_epoch_plan_multi
               with a per-rank batch of int(batch_size / W) rows (data/clustering.py:25), for ceil(epochs / W) epochs
               (run_clustering.py:146).  The global batch stays batch_size rows; an epoch has W * N / batch_size steps.
   views       the one-GPU run's own stream: ONE slot, the shards in their global order, batch_size rows per step,
-              `epochs` epochs -- the arithmetic (and the files) of a one-GPU run over all rows, with the rows living on
-              the ranks that own them (bench.py --gpus N; the CLI's `views` mode reads every shard on the training rank
-              instead and needs no plan).
+  (striped)   `epochs` epochs -- the arithmetic (and the files) of a one-GPU run over all rows, with the rows living on
+              the ranks that own them: SURVEY 8(e)'s row-striped partition (bench.py --gpus N; the CLI's
+              `clustering.multi_gpu=striped`.  The CLI's default `views` mode reaches the same result by reading every
+              shard on the training rank and needs no plan).
   rows        a LARGE-BATCH operating point, not the reference's run: slot q = rank q's own segment only, batch_size rows
               of every rank per step (global batch W * batch_size), ceil(epochs / W) epochs: W * W fewer SGD steps than
               `reference` (64 x at 8 GPUs).
@@ -133,7 +134,7 @@ def plan_rows(shard_rows, world, batch_size, epochs):
                    math.ceil(epochs / world))
 
 
-PLANS = {"reference": plan_reference, "views": plan_views, "rows": plan_rows}
+PLANS = {"reference": plan_reference, "views": plan_views, "striped": plan_views, "rows": plan_rows}
 
 
 def make_plan(mode, shard_rows, world, batch_size, epochs):

@@ -239,6 +239,42 @@ def test_cluster_cli_spawns_one_process_per_gpu(workdir):
     assert len(logs) == 2  # one manifest per process, each listing its own shards (save.py:9-17)
 
 
+def test_cluster_cli_striped_mode_two_workers(workdir):
+    """`cli.py cluster --clustering.multi_gpu=striped --computation.num_gpus=2`: SURVEY 8(e)'s row-striped partition -- every
+    worker HOLDS only the rows of its own shards (rank::2), the global batch stream is the one-GPU run's (shards in global order,
+    32 rows per step, 2 epochs), the rows travel in bulk to the worker that runs a clustering's chain.  The files must be those
+    of the one-process run (and of the default `views` mode): every label, and the checkpoints' centres / counts bit for bit."""
+    import torch
+    root, glob = workdir
+    out1 = os.path.join(root, "cl_one")
+    if not os.path.isfile(os.path.join(out1, "shard-000000.pkl")):
+        pytest.skip("the one-process run of the spawn test is missing")
+    out = os.path.join(root, "cl_striped")
+    log = _run_cli("acav100m_amd.clustering.cli",
+                   ["cluster", "--feature_path=" + glob, "--meta_path=" + os.path.join(root, "videos"), "--out_path=" + out,
+                    "--computation.num_gpus=2", "--clustering.multi_gpu=striped"], {"ACAV_SEED": "0", "ACAV_DIST_BACKEND": "gloo"})
+    assert log.count("done") == 2 and "mode striped: 32 steps of 1 x 32 rows per epoch, 2 epochs" in log
+    for s in range(4):
+        name = "shard-%06d.pkl" % s
+        a = pickle.load(open(os.path.join(out1, name), "rb"))
+        b = pickle.load(open(os.path.join(out, name), "rb"))
+        assert len(a) == len(b) == 256
+        for ra, rb in zip(a, b):
+            assert ra["filename"] == rb["filename"]
+            for key in ("audio_assignments", "video_assignments"):
+                assert {k: int(v) for k, v in ra[key][0]["array"].items()} == {k: int(v) for k, v in rb[key][0]["array"].items()}
+    caches = sorted(f for f in os.listdir(out) if f.startswith("cache_epoch_"))
+    assert len(caches) == 2
+    for name in caches:
+        c1 = torch.load(os.path.join(out1, name), weights_only=False)
+        c2 = torch.load(os.path.join(out, name), weights_only=False)
+        for mk in c1:
+            for layer in c1[mk]:
+                assert np.array_equal(c1[mk][layer]["centers"], c2[mk][layer]["centers"]), (name, mk, layer)
+                assert np.array_equal(c1[mk][layer]["counts"], c2[mk][layer]["counts"])
+                assert c1[mk][layer]["count"] == c2[mk][layer]["count"]
+
+
 def test_cluster_cli_rows_mode_two_workers(workdir):
     """`cli.py cluster --clustering.multi_gpu=rows --computation.num_gpus=2`: the LARGE-BATCH multi-GPU mode through the CLI
     (not the reference's N-GPU run -- that is test_cluster_cli_reference_mode_two_workers): every worker holds the rows of
