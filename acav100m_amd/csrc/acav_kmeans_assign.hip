@@ -243,9 +243,11 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
   if (row_idx != nullptr && tid == 0) assign_ctl_finish(ctl_of_f32_count(row_cnt), gridDim.x);
 }
 
-// --------------------------------------------------------------------------- k_assign_bf16
-// HBM-bound calc_best: a bf16-MFMA FILTER followed by an exact fp32 re-check of the ambiguous rows.
-//   1. distances with centres and rows rounded to bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate), the
+// --------------------------------------------------------------------------- the filter (k_assign_f16_rw)
+// HBM-bound calc_best: a reduced-precision MFMA FILTER followed by an exact fp32 re-check of the ambiguous rows.
+// (Rounds 1-4: bf16 operands, kernel k_assign_bf16_rw.  Round 5: IEEE half -- see the ROUND 5 notes below; read "bf16" in the
+// older remarks of this file as "the filter's 16-bit operand type".)
+//   1. distances with centres and rows rounded to 16 bits (v_mfma_f32_32x32x16_f16, fp32 accumulate), the
 //      same fused epilogue; per row the best (d1, k1) and the runner-up value d2 are tracked
 //   2. |D~ - D| <= E_i for every centre (E_i: rigorous bound, see below), so d2 - d1 > 2 E_i proves that k1
 //      is the argmin of the canonical fp32 distances -- first-index ties included, because the inequality
@@ -253,34 +255,69 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
 //   3. every other row is appended to a list and re-labelled by the exact kernel (k_assign_f32)
 // The result is therefore bit-identical to the exact kernel for ANY input; only the speed depends on how
 // well separated the clusters are.
-// Error bound (per row i, any centre k):  dot~ uses c~ = c(1+a), x~ = x(1+b), |a|,|b| <= 2^-9 (RNE to 8
-// significant bits), products exact in fp32, accumulation error <= d 2^-24 sum|c~x~|; the canonical dot has
-// error <= d 2^-24 sum|cx|; sum|cx| <= ||c|| ||x||.  Hence |dot~ - dot| <= ||c|| ||x|| (2^-8 (1+2^-10) + 2.02 d 2^-24)
+// Error bound (per row i, any centre k):  dot~ uses c~ = c(1+a), x~ = x(1+b), |a|,|b| <= 2^-8 (RNE to bf16's 8
+// significant bits: unit roundoff 2^-p = 2^-8; 1 + 2^-8 rounds to 1), products exact in fp32, accumulation error
+// <= d 2^-24 sum|c~x~|; the canonical dot has error <= d 2^-24 sum|cx|; sum|cx| <= ||c|| ||x||.
+// Hence |dot~ - dot| <= ||c|| ||x|| (2^-7 (1 + 2^-9) + 2.02 d 2^-24)
 // and, through -2 dot + ||x||^2 + ||c||^2 (three fp32 roundings of magnitude <= (||x||+||c||)^2):
-//   E_i = 2.02 (2^-8 1.002 + 2.02 d 2^-24) cmax ||x_i|| + 2^-17 (||x_i|| + cmax)^2,   cmax = max_k ||c_k||
+//   E_i = 2.02 (2^-7 1.002 + 2.02 d 2^-24) cmax ||x_i|| + 2^-17 (||x_i|| + cmax)^2,   cmax = max_k ||c_k||
+// (ROUND 5 CORRECTION: rounds 1-4 charged 2^-9 per operand -- half of bf16's unit roundoff -- so the leading term of E
+// was half of what the proof needs.  No test or stress run ever produced a wrong label: a real dot's rounding errors add
+// up like a random walk, ~sqrt(d) below this worst case.  But the claim is a PROOF, and the window is now the proven one.)
+// ROUND 5, HALF-PRECISION OPERANDS.  With the proven 2^-8 the bf16 window doubled (62 % undecided rows became 84 % on the hard
+// data of bench.py's variants, 2.0 -> 3.7 ms), so the operands moved to IEEE half: 11 significant bits, unit roundoff 2^-11, the
+// same MFMA rate and bytes:
+//   |dot~ - dot| <= ||c'|| ||x|| (2^-10 (1 + 2^-12) + 2.02 d 2^-24) + the underflow terms of k_centers_scale (eA, eB)
+// -- a window 8 x narrower than bf16's proven one (4 x narrower than what rounds 1-4 ran with): 27 % undecided, 1.40 ms.  On
+// well separated data the kernel is 2-5 % SLOWER than with bf16 (0.81-0.84 -> 0.85-0.86 ms per 1M x 1024 on the same box, also
+// with the legacy RTZ pack conversion: not the conversion).  Half's narrow exponent range is handled by exact power-of-two
+// scales (CentersAux) and by filter_bound() refusing rows that could overflow.
 // CENTRED CENTRES.  With c = c' + mu for ANY common vector mu, -2 x.c = -2 x.c' - 2 x.mu and the last term is the
 // same for every centre of a row: it moves d1 and d2 alike.  The filter therefore multiplies by c' = fl(c - mu)
 // (mu = the mean centre) and its bf16 error scales with cmax' = max_k ||c'_k|| -- the SPREAD of the centres -- instead
 // of their norm; embeddings with a large common component (post-ReLU features) would otherwise send almost every
 // row to the exact re-check.  Only the accumulation error of the canonical dot keeps the raw norm:
-//   E_i = 2.02 [ (2^-8 1.002 + 1.01 d 2^-24) cmax' + (1.01 d 2^-24 + 2^-24) cmax ] ||x_i|| + 2^-17 (||x_i|| + cmax)^2
+//   E_i = 2.02 [ (u2 1.002 + 1.01 d 2^-24) cmax' + (1.01 d 2^-24 + 2^-24) cmax ] ||x_i|| + 2^-17 (||x_i|| + cmax)^2
+//   (u2 = both operands' unit roundoffs: 2^-7 for bf16, 2^-10 for half; + eA ||x_i|| + eB with half)
 // (2^-24 ||x|| cmax' covers the rounding of c - mu; mu = 0 gives back the formula above).  A row constant does not
 // survive the under-use division by r, so the centres are only centred when no centre is under-used.
 // The second term also covers what the filter's epilogue does differently from the exact one: it multiplies by
 // fl(1/r) where the exact path divides by r (< 2 ulp), and it overwrites the 5 low mantissa bits of a distance
 // with the centre's position in the lane (< 2^-18 relative) -- together < 2^-17 (||x_i|| + cmax)^2 with room to
 // spare.  (The under-use scaling by 1/r < 1 only shrinks both sides.)
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// Operand type of the filter's MFMA.  Rounds 1-4: bf16 (8 significant bits, unit roundoff 2^-8).  Round 5: IEEE half (11 bits,
+// 2^-11) at the same MFMA rate and the same bytes -- the acceptance window is 8 x narrower for the same data.  Half has a
+// narrow exponent range, so both operands are scaled by exact powers of two first (below); bf16 needed no such care.
+typedef _Float16 fl16;
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));  // (8 operand elements of one lane: the historical name stays)
 
 constexpr int FB_ROWS = 128;  // rows per workgroup (4 MFMA row tiles)
-constexpr int FILTER_NW_DEFAULT = 4, FILTER_SCHED_DEFAULT = 0;  // K <= 256 defaults of k_assign_bf16_rw (see acav_kmeans_assign)
+constexpr int FILTER_NW_DEFAULT = 4, FILTER_SCHED_DEFAULT = 0;  // K <= 256 defaults of k_assign_f16_rw (see acav_kmeans_assign)
 
 struct CentersAux {
     unsigned cmax_bits;   // bits of max_k ||c_k||^2 (non-negative floats order like unsigned)
     unsigned cmaxc_bits;  // bits of (an upper bound of) max_k ||c'_k||^2 of the copy the filter multiplies by
     unsigned any_disc;    // some centre is under-used (distance / r): no centring
-    unsigned pad;
+    unsigned amax_bits;   // bits of max_kj |c_kj| of the RAW centres: sets the scale of the rows (rows look like centres)
+    unsigned amaxc_bits;  // bits of max_kj |c'_kj| of what the filter multiplies by (centred or raw): sets the centres' scale
+    float sx, sc;         // exact powers of two: the filter computes with fl16(sx x) and fl16(sc c'); amax sx, amaxc sc in [2^9, 2^10)
+    float inv_ss;         // 1 / (sx sc), exact: the accumulated dot is scaled back in the epilogue's fma
+    float eA, eB;         // underflow terms of the acceptance bound: E += eA ||x|| + eB (k_centers_scale)
 };
+
+// The acceptance bound of the filter (header of k_assign_f16_rw; derivation at CentersAux / k_centers_scale):
+//   E = (e1c cmax' + e1r cmax + eA) ||x|| + eB + e2 (||x|| + cmax)^2
+// NaN when an element of the scaled row could leave half's range (max_j |x_j| <= ||x||): RNE would turn it into +-inf and a
+// single +inf product can make ONE distance -inf and the gap to the runner-up +inf -- "decided", wrongly.  Every comparison
+// against a NaN bound fails, so such a row is undecided and takes the exact path.
+__device__ __forceinline__ float filter_bound(const CentersAux *__restrict__ aux, float xnorm, float e1c, float e1r, float e2coef)
+{
+    const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
+    const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
+    const float s = xnorm + cmax;
+    const float E = (e1c * cmaxc + e1r * cmax + aux->eA) * xnorm + aux->eB + e2coef * s * s;
+    return xnorm * aux->sx < 60000.0f ? E : __builtin_nanf("");
+}
 
 // mu[j] = mean over the centres of column j (any vector would do, see the bound): 32 columns x 8 centre lanes per block
 // Block 0 also scans the per-centre scalars: max ||c_k||^2 and whether any centre is under-used.
@@ -296,9 +333,14 @@ __global__ __launch_bounds__(256) void k_centers_mu(const float *__restrict__ c,
         }
     const int cj = threadIdx.x & 31, ky = threadIdx.x >> 5;
     const int j = blockIdx.x * 32 + cj;
-    float s = 0.f;
+    float s = 0.f, am = 0.f;
     if (j < d)
-        for (int k = ky; k < K; k += 8) s = s + c[(size_t)k * d + j];
+        for (int k = ky; k < K; k += 8) {
+            const float v = c[(size_t)k * d + j];
+            s = s + v;
+            am = fmaxf(am, fabsf(v));
+        }
+    if (am > 0.f) atomicMax(&aux->amax_bits, __float_as_uint(am));  // (a NaN centre element: fmaxf drops it; the bound's norms carry it)
     sp[ky][cj] = s;
     __syncthreads();
     if (ky == 0 && j < d) {
@@ -309,25 +351,77 @@ __global__ __launch_bounds__(256) void k_centers_mu(const float *__restrict__ c,
     }
 }
 
-// one block per centre slot: the bf16 copy of c_k (or of c_k - mu) and the largest squared norm of what was rounded.
+// max_kj |c'_kj| of what the filter multiplies by (c - mu when no centre is under-used, else c): one block per centre
+__global__ __launch_bounds__(256) void k_centers_amaxc(const float *__restrict__ c, const float *__restrict__ mu, int d, int K,
+                                                       CentersAux *__restrict__ aux)
+{
+    const bool centred = aux->any_disc == 0u;
+    const size_t base = (size_t)blockIdx.x * d;
+    float am = 0.f;
+    for (int j = threadIdx.x; j < d; j += blockDim.x) am = fmaxf(am, fabsf(centred ? c[base + j] - mu[j] : c[base + j]));
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) am = fmaxf(am, __shfl_xor(am, dlt));
+    if ((threadIdx.x & 63) == 0 && am > 0.f) atomicMax(&aux->amaxc_bits, __float_as_uint(am));
+}
+
+// The scales of the half-precision filter and the underflow terms of its bound (one thread).
+//   sx = 2^(9 - floor(log2 amax)), sc likewise from amaxc: the largest centre element lands in [2^9, 2^10) -- a row element may be
+//   64 x larger than the largest centre element before sx x leaves half's range (then filter_bound() refuses the row).
+// With x~ = fl16(sx x), c~ = fl16(sc c'):  an element inside half's NORMAL range [2^-14, 65504] is rounded with relative error
+// <= 2^-11; below 2^-14 the hardware may keep a subnormal (error <= 2^-25) or flush to zero (error < 2^-14): the bound charges
+// 2^-14 ABSOLUTE per such element, on either operand.  Hence, divided by sx sc,
+//   |dot~ - dot| <= (2^-10 + 2^-22) ||c'|| ||x||                       both roundings (e1c on the host side, with the fp32 accumulation)
+//                 + 2^-14 1.001 (||c'||_1 / sx  +  ||x||_1 / sc)        one operand under the normal range, the other rounded
+//                 + d 2^-28 / (sx sc)                                   both
+// and with ||v||_1 <= sqrt(d) ||v||, doubled for the -2 of the distance (2.02 as everywhere in the bound):
+//   eA = 2.02 * 2^-14 * 1.001 * sqrt(d) / sc                                   (x ||x||)
+//   eB = 2.02 * (2^-14 * 1.001 * sqrt(d) * cmax' / sx  +  d 2^-28 / (sx sc))
+// At the working point (amax sx ~ 2^9.5) these are 2^-23.5 sqrt(d) amax-sized: three to four orders below the rounding term.
+__global__ void k_centers_scale(CentersAux *__restrict__ aux, int d)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    auto pow2_for = [](unsigned bits) -> float {
+        const float a = __uint_as_float(bits);
+        if (!(a > 0.f) || !(a < 3.0e38f)) return 1.0f;
+        int e;
+        (void)frexpf(a, &e);          // a = m 2^e, m in [0.5, 1): floor(log2 a) = e - 1
+        int p = 9 - (e - 1);
+        p = p > 100 ? 100 : (p < -100 ? -100 : p);
+        return ldexpf(1.0f, p);
+    };
+    // rows: no scaling (sx = 1: the multiply costs the filter 4-6 %) while the largest RAW centre element sits in [2^-5, 2^11] --
+    // a row element may then be 32 x larger before it leaves half's range, and elements below 2^-14 (< amax / 512) are charged
+    // through eA / eB like any other underflow.  Outside that window the rows are scaled like the centres.
+    const float amax = __uint_as_float(aux->amax_bits);
+    const float sx = (amax >= 0.03125f && amax <= 2048.0f) ? 1.0f : pow2_for(aux->amax_bits);
+    const float sc = pow2_for(aux->amaxc_bits);
+    const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
+    const float sd = __builtin_sqrtf((float)d) * 1.0001f;
+    aux->sx = sx, aux->sc = sc;
+    aux->inv_ss = (1.0f / sx) * (1.0f / sc);  // powers of two: exact
+    aux->eA = 2.02f * 6.1035156e-5f * 1.002f * sd / sc;
+    aux->eB = 2.02f * (6.1035156e-5f * 1.002f * sd * cmaxc / sx + (float)d * 3.7252903e-9f * 1.01f * (1.0f / sx) * (1.0f / sc));
+}
+
+// one block per centre slot: the half-precision copy of sc c_k (or of sc (c_k - mu)) and the largest squared norm of what was
+// rounded (in UNSCALED units: cmax').
 // LAYOUT (round 4): STAGE-MAJOR -- out[(j / 32) * Kp + k][j % 32], Kp = K rounded up to whole groups of 256 (the slots past K
 // repeat the last centre; the filter gives them an unbeatable norm).  The filter's centre stage (32 columns of 256 centres) is
 // then ONE contiguous 16 KB block: a DMA instruction covers 1 KB of whole 128-byte lines instead of 16 half lines 2 d bytes
 // apart -- half the L2 requests of the centre stream (the path runs at ~100 G L2 requests/s whatever the bytes).
-__global__ __launch_bounds__(256) void k_centers_bf16(const float *__restrict__ c, const float *__restrict__ mu, int d, int K,
-                                                      int Kp, __bf16 *__restrict__ out, CentersAux *__restrict__ aux)
+// Two passes over the slot's row: the norm first (k_centers_scale needs the max before anything is scaled), the copy in
+// k_centers_f16 below.
+__global__ __launch_bounds__(256) void k_centers_norm(const float *__restrict__ c, const float *__restrict__ mu, int d, int K,
+                                                      CentersAux *__restrict__ aux)
 {
     __shared__ float sred[4];
     const bool centred = aux->any_disc == 0u;
-    const int k = (int)blockIdx.x;
-    const size_t base = (size_t)(k < K ? k : K - 1) * d;
+    const size_t base = (size_t)blockIdx.x * d;
     float ss = 0.f;
     for (int j = threadIdx.x; j < d; j += blockDim.x) {
         const float v = centred ? c[base + j] - mu[j] : c[base + j];
-        out[((size_t)(j >> 5) * Kp + k) * 32 + (j & 31)] = (__bf16)v;
         ss = __builtin_fmaf(v, v, ss);
     }
-    if (k >= K) return;
 #pragma unroll
     for (int dlt = 1; dlt < 64; dlt <<= 1) ss = ss + __shfl_xor(ss, dlt);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = ss;
@@ -335,6 +429,19 @@ __global__ __launch_bounds__(256) void k_centers_bf16(const float *__restrict__ 
     if (threadIdx.x == 0) {
         const float tot = ((sred[0] + sred[1]) + (sred[2] + sred[3])) * (1.0f + 2.0f * (float)d * 5.9604645e-8f);  // >= exact
         atomicMax(&aux->cmaxc_bits, __float_as_uint(tot));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_centers_f16(const float *__restrict__ c, const float *__restrict__ mu, int d, int K,
+                                                     int Kp, fl16 *__restrict__ out, const CentersAux *__restrict__ aux)
+{
+    const bool centred = aux->any_disc == 0u;
+    const float sc = aux->sc;
+    const int k = (int)blockIdx.x;
+    const size_t base = (size_t)(k < K ? k : K - 1) * d;
+    for (int j = threadIdx.x; j < d; j += blockDim.x) {
+        const float v = centred ? c[base + j] - mu[j] : c[base + j];
+        out[((size_t)(j >> 5) * Kp + k) * 32 + (j & 31)] = (fl16)(v * sc);  // v * sc exact (power of two), then RNE to half
     }
 }
 
@@ -422,322 +529,41 @@ __device__ __forceinline__ void dma16_asm_v64_nt(const char *addr, unsigned lds)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(addr), "s"(lds) : "memory", "m0");
 }
 
-__device__ __forceinline__ bf16x8 cvt_bf16x8(float4 lo, float4 hi)
+// eight row elements -> half (4 v_cvt_pk_f16_f32, RNE), scaled by the exact power of two sx first when sx != 1 (4 v_pk_mul_f32
+// more: measured +4.5 % on the K = 256 filter, +6 % at K = 1024 -- k_centers_scale therefore keeps sx = 1 whenever the data's
+// own scale sits well inside half's range, and the branch is wave-uniform)
+__device__ __forceinline__ bf16x8 cvt_bf16x8(float4 lo, float4 hi, float sx, bool scaled)
 {
-    bf16x8 r = {(__bf16)lo.x, (__bf16)lo.y, (__bf16)lo.z, (__bf16)lo.w, (__bf16)hi.x, (__bf16)hi.y, (__bf16)hi.z, (__bf16)hi.w};
+    typedef float f32x2s __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    f32x2s p0 = {lo.x, lo.y}, p1 = {lo.z, lo.w}, p2 = {hi.x, hi.y}, p3 = {hi.z, hi.w};
+    if (scaled) {
+        const f32x2s s2 = {sx, sx};
+        p0 = p0 * s2, p1 = p1 * s2, p2 = p2 * s2, p3 = p3 * s2;
+    }
+#ifdef ACAV_CVT_RTZ  // experiment: the legacy round-toward-zero pack conversion (is v_cvt_pk_f16_f32 the 5 %?)
+    typedef __fp16 g2 __attribute__((ext_vector_type(2)));
+    const g2 q0 = __builtin_amdgcn_cvt_pkrtz(p0.x, p0.y), q1 = __builtin_amdgcn_cvt_pkrtz(p1.x, p1.y);
+    const g2 q2 = __builtin_amdgcn_cvt_pkrtz(p2.x, p2.y), q3 = __builtin_amdgcn_cvt_pkrtz(p3.x, p3.y);
+    bf16x8 r = {(_Float16)q0.x, (_Float16)q0.y, (_Float16)q1.x, (_Float16)q1.y, (_Float16)q2.x, (_Float16)q2.y, (_Float16)q3.x, (_Float16)q3.y};
     return r;
+#else
+    const h2 q0 = __builtin_convertvector(p0, h2), q1 = __builtin_convertvector(p1, h2);
+    const h2 q2 = __builtin_convertvector(p2, h2), q3 = __builtin_convertvector(p3, h2);
+    bf16x8 r = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+    return r;
+#endif
 }
 
-#ifdef ACAV_RW_PROF  // tools/exp/assign_bench.hip only: per-stage phase cycles of k_assign_bf16_rw (s_memtime)
+#ifdef ACAV_RW_PROF  // tools/exp/assign_bench.hip only: per-stage phase cycles of k_assign_f16_rw (s_memtime)
 __device__ unsigned long long g_rw_prof[16];
 #define RW_T(v) const long long v = clock64()
 #else
 #define RW_T(v)
 #endif
-#ifdef ACAV_FD_PROF
-__device__ unsigned long long g_fd_prof[20];
-#define FD_T(v) const long long v = clock64()
-#else
-#define FD_T(v)
-#endif
 
-template <bool NT>
-__global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict__ x, int64_t n, int d,
-                                                            const __bf16 *__restrict__ cb, const float *__restrict__ cn,
-                                                            const float *__restrict__ counts, int K, float thr, float r,
-                                                            const CentersAux *__restrict__ aux, float e1c, float e1r, float e2coef,
-                                                            int64_t *__restrict__ labels, int *__restrict__ recheck_list,
-                                                            unsigned *__restrict__ recheck_count)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
-    float *sXr = reinterpret_cast<float *>(fd_smem);                        // [FD_DX][128][32] fp32
-    __bf16 *sCb = reinterpret_cast<__bf16 *>(fd_smem + FD_DX * FD_SLOT);    // [FD_DC][256][32] bf16
-    // epilogue scratch ALIASES the row ring (the rings are idle between the last stage and the next group's first DMA)
-    float *sXn = reinterpret_cast<float *>(fd_smem);  // [128]
-    float *sCn = sXn + 128;                           // [256]
-    float *sSc = sCn + 256;                           // [256] 1, or 1/r for a discounted centre
-    float *sD1 = sSc + 256;                           // [4][128]
-    int *sK1 = reinterpret_cast<int *>(sD1 + 512);    // [4][128]
-    float *sD2 = reinterpret_cast<float *>(sK1 + 512);  // [4][128]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = centre quarter (64 centres)
-    const int l31 = lane & 31, h = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * 128;
-    const int nchunks = d / FD_BK;
-    const int ngroups = (K + 255) / 256;
-    const float inv_r = 1.0f / r;
-
-    // DMA share of this wave: instructions 4 wq .. 4 wq + 3 of the 16 per slot, for rows and for centres.
-    // Source = uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset; destination = slot + (4 wq + q) KB.
-    unsigned voffx[4], voffc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int rr = (wq * 4 + q) * 8 + (lane >> 3);
-        const int rc = row0 + rr < n ? rr : (int)(n - 1 - row0);  // ragged tail: re-read the last row
-        voffx[q] = (unsigned)rc * (unsigned)d * 4u + (((lane & 7) ^ ((rr >> 1) & 7)) << 4);
-    }
-    const unsigned xring = lds_addr(sXr) + wq * 4096, cring = lds_addr(sCb) + wq * 4096;
-
-    float ssq[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) ssq[e] = 0.f;
-    Top2 run = {INFINITY, 0x7fffffff, INFINITY};
-    float my_xn = 0.f;                         // ||x||^2 of row tid (tid < 128), kept across centre groups
-    float xn_rt[4] = {0.f, 0.f, 0.f, 0.f};     // ... and of this lane's four fragment rows
-#ifdef ACAV_FD_PROF
-    long long fdp0 = 0, fdp1 = 0, fdp2 = 0, fdp3 = 0, fdp4 = 0, fdp5 = 0, fdp6 = 0;
-    const long long fd_tstart = clock64(), fd_wstart = wall_clock64();
-#endif
-
-    for (int cg = 0; cg < ngroups; ++cg) {
-        const int kbase = cg * 256;
-#ifdef ACAV_FD_PROF
-        const long long fd_tgrp = clock64();
-#endif
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int rr = (wq * 4 + q) * 16 + (lane >> 2);
-            voffc[q] = (unsigned)rr * 64u + (((lane & 3) ^ ((rr >> 2) & 3)) << 4);  // stage-major copy: 64 B per centre and stage
-        }
-        const char *gx = reinterpret_cast<const char *>(x + (size_t)row0 * d);
-        const char *gc = reinterpret_cast<const char *>(cb + (size_t)kbase * 32);
-        const size_t cstage = (size_t)ngroups * 256 * 64;  // bytes from one stage of the centre copy to the next
-        int wx = 0, wc = 0;  // ring slots the next issue fills
-        auto issue_x = [&]() {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (NT) dma16_asm_nt(gx, voffx[q], xring + wx * FD_SLOT + q * 1024);
-                else dma16_asm(gx, voffx[q], xring + wx * FD_SLOT + q * 1024);
-            }
-            gx += FD_BK * 4;
-            wx = wx + 1 == FD_DX ? 0 : wx + 1;
-        };
-        auto issue_c = [&]() {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dma16_asm(gc, voffc[q], cring + wc * FD_SLOT + q * 1024);
-            gc += cstage;
-            wc = wc + 1 == FD_DC ? 0 : wc + 1;
-        };
-
-        f32x16 acc[2][4];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave is done with the previous centre group's epilogue scratch
-        issue_x();                     // rows 0, centres 0, rows 1: the steady-state order (centres c+1, rows c+2)
-        issue_c();
-        if (nchunks > 1) issue_x();
-        int rx = 0, rcs = 0;  // ring slots stage c is read from
-#ifdef ACAV_FD_PROF
-        const long long fd_tloop0 = clock64();
-#endif
-        for (int c = 0; c < nchunks; ++c) {
-            FD_T(t0);
-            // retire rows c and centres c; rows c+1 (the 4 newest loads) may stay in flight
-            if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            FD_T(t1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            FD_T(t2);
-            const float *px = sXr + rx * (128 * 32);
-            const __bf16 *pc = sCb + rcs * (256 * 32);
-            rx = rx + 1 == FD_DX ? 0 : rx + 1;
-            rcs = rcs + 1 == FD_DC ? 0 : rcs + 1;
-            const int swz = (l31 >> 1) & 7;  // ((rowX >> 1) & 7) for every row tile (32 rows = 2 swizzle periods)
-            const float *pxl = px + l31 * 32;
-            const __bf16 *pcl = pc + (wq * 64 + l31) * 32;
-            const int swa = (l31 >> 2) & 3;  // ((rowA >> 2) & 3), likewise
-#define FD_LOAD_A(ks, A)                                                                          \
-    A[0] = *reinterpret_cast<const bf16x8 *>(pcl + (((2 * (ks) + h) ^ swa) << 3));                \
-    A[1] = *reinterpret_cast<const bf16x8 *>(pcl + 32 * 32 + (((2 * (ks) + h) ^ swa) << 3));
-            // accumulator slot j of this wave holds row tile (j + wq) & 3: slot 0 is always the wave's OWN tile, the
-            // one whose canonical ||x||^2 it accumulates -- from the fragments it reads anyway, no branch, no re-read
-            const float *pxj[4] = {pxl + ((0 + wq) & 3) * 1024, pxl + ((1 + wq) & 3) * 1024, pxl + ((2 + wq) & 3) * 1024,
-                                   pxl + ((3 + wq) & 3) * 1024};
-#define FD_LOAD_X(ks, j, F0, F1)                                                                               \
-    const float4 F0 = *reinterpret_cast<const float4 *>(pxj[j] + (((4 * (ks) + 2 * h) ^ swz) << 2));          \
-    const float4 F1 = *reinterpret_cast<const float4 *>(pxj[j] + (((4 * (ks) + 2 * h + 1) ^ swz) << 2));
-#define FD_SSQ(ks, F0, F1)                                           \
-    ssq[8 * (ks) + 0] = __builtin_fmaf(F0.x, F0.x, ssq[8 * (ks) + 0]); \
-    ssq[8 * (ks) + 1] = __builtin_fmaf(F0.y, F0.y, ssq[8 * (ks) + 1]); \
-    ssq[8 * (ks) + 2] = __builtin_fmaf(F0.z, F0.z, ssq[8 * (ks) + 2]); \
-    ssq[8 * (ks) + 3] = __builtin_fmaf(F0.w, F0.w, ssq[8 * (ks) + 3]); \
-    ssq[8 * (ks) + 4] = __builtin_fmaf(F1.x, F1.x, ssq[8 * (ks) + 4]); \
-    ssq[8 * (ks) + 5] = __builtin_fmaf(F1.y, F1.y, ssq[8 * (ks) + 5]); \
-    ssq[8 * (ks) + 6] = __builtin_fmaf(F1.z, F1.z, ssq[8 * (ks) + 6]); \
-    ssq[8 * (ks) + 7] = __builtin_fmaf(F1.w, F1.w, ssq[8 * (ks) + 7]);
-#define FD_MMA(A, rt, B)                                                                            \
-    acc[0][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B, acc[0][rt], 0, 0, 0);              \
-    acc[1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B, acc[1][rt], 0, 0, 0);
-            // k-step 0 operands of the first two row tiles are read BEFORE the DMA issue: the issue stalls while the
-            // memory pipe accepts 8 KB, which hides this LDS latency
-            bf16x8 a0[2], a1[2];
-            FD_LOAD_A(0, a0)
-            FD_LOAD_X(0, 0, p00, p01)
-            FD_LOAD_X(0, 1, p10, p11)
-            if (c + 1 < nchunks) issue_c();  // into the slots stage c-1 just vacated
-            if (c + 2 < nchunks) issue_x();
-            FD_T(t3);
-            {
-                const bf16x8 b0 = cvt_bf16x8(p00, p01), b1 = cvt_bf16x8(p10, p11);
-                FD_LOAD_X(0, 2, p20, p21)
-                FD_LOAD_X(0, 3, p30, p31)
-                FD_MMA(a0, 0, b0)
-                FD_MMA(a0, 1, b1)
-                const bf16x8 b2 = cvt_bf16x8(p20, p21), b3 = cvt_bf16x8(p30, p31);
-                FD_LOAD_A(1, a1)
-                FD_LOAD_X(1, 0, q00, q01)
-                FD_LOAD_X(1, 1, q10, q11)
-                FD_MMA(a0, 2, b2)
-                FD_MMA(a0, 3, b3)
-                const bf16x8 d0 = cvt_bf16x8(q00, q01), d1 = cvt_bf16x8(q10, q11);
-                FD_LOAD_X(1, 2, q20, q21)
-                FD_LOAD_X(1, 3, q30, q31)
-                FD_MMA(a1, 0, d0)
-                FD_MMA(a1, 1, d1)
-                const bf16x8 d2 = cvt_bf16x8(q20, q21), d3 = cvt_bf16x8(q30, q31);
-                FD_MMA(a1, 2, d2)
-                FD_MMA(a1, 3, d3)
-                if (cg == 0) {  // uniform: this wave's share of the canonical ||x||^2 (row tile wq, classes 16 ks + 8 h + e)
-                    FD_SSQ(0, p00, p01)
-                    FD_SSQ(1, q00, q01)
-                }
-            }
-#undef FD_LOAD_A
-#undef FD_LOAD_X
-#undef FD_SSQ
-#undef FD_MMA
-#ifdef ACAV_FD_PROF
-            {
-                const long long t4 = clock64();
-                fdp0 += t1 - t0, fdp1 += t2 - t1, fdp2 += t3 - t2, fdp3 += t4 - t3, fdp4 += 1;
-            }
-#endif
-        }
-#ifdef ACAV_FD_PROF
-        const long long fd_tloop1 = clock64();
-        fdp5 += fd_tloop0 - fd_tgrp;
-        fdp6 += fd_tloop1 - fd_tloop0;
-#endif
-        // beyond K: a huge FINITE norm -- such a centre never wins and never becomes the runner-up.  (+inf would turn
-        // into a NaN under the position tag, and fmaxf(s1, NaN) = s1 makes the runner-up collapse onto the minimum: every
-        // lane that mixes real and padding centres would send its row to the re-check.)
-        float my_cn = 3.0e38f, my_sc = 1.0f;
-        if (kbase + tid < K) {
-            my_cn = cn[kbase + tid];
-            my_sc = counts[kbase + tid] < thr ? inv_r : 1.0f;
-        }
-        __syncthreads();  // every wave has read its last fragments: the row ring becomes epilogue scratch
-        sCn[tid] = my_cn;
-        sSc[tid] = my_sc;
-        if (cg == 0) {
-            // lane (i, h) of wave w holds classes 16 ks + 8 h + e of row 32 w + i.  Canonical tree: (p0+p1)+(p2+p3)
-            // per group of 4 classes, then ((g0+g1)+(g2+g3)) + ((g4+g5)+(g6+g7)): g0,g1 = (ks 0, h 0), g2,g3 =
-            // (ks 0, h 1), g4,g5 = (ks 1, h 0), g6,g7 = (ks 1, h 1).
-            float ta = ((ssq[0] + ssq[1]) + (ssq[2] + ssq[3])) + ((ssq[4] + ssq[5]) + (ssq[6] + ssq[7]));
-            float tb = ((ssq[8] + ssq[9]) + (ssq[10] + ssq[11])) + ((ssq[12] + ssq[13]) + (ssq[14] + ssq[15]));
-            ta = ta + __shfl_xor(ta, 32);
-            tb = tb + __shfl_xor(tb, 32);
-            if (h == 0) sXn[wq * 32 + l31] = norm2_from_sumsq(ta + tb);
-        }
-        __syncthreads();
-        if (cg == 0) {
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt) xn_rt[rt] = sXn[((rt + wq) & 3) * 32 + l31];  // slot rt = row tile (rt + wq) & 3
-            if (tid < 128) my_xn = sXn[tid];
-        }
-        // Scan of this lane's 4 x 32 distances without a single compare: the low 5 mantissa bits of every distance
-        // are replaced by its position (ct, g, j) in the lane, so min() carries the argmin along and
-        // d2 = min(d2, max(d1, v)) tracks the runner-up.  The perturbation (< 2^-18 relative) is part of the e2
-        // term of the acceptance bound; exact ties, NaNs and infinities end in a zero / NaN margin -> re-check.
-        float s1[4], s2[4];
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) s1[rt] = INFINITY, s2[rt] = INFINITY;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int kl = wq * 64 + ct * 32 + 4 * h + 8 * g;
-                const float4 cnv = *reinterpret_cast<const float4 *>(sCn + kl);
-                const float4 scv = *reinterpret_cast<const float4 *>(sSc + kl);
-                const float cn4[4] = {cnv.x, cnv.y, cnv.z, cnv.w};
-                const float sc4[4] = {scv.x, scv.y, scv.z, scv.w};
-#pragma unroll
-                for (int rt = 0; rt < 4; ++rt) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = __builtin_fmaf(-2.0f, acc[ct][rt][4 * g + j], xn_rt[rt]);  // == (-2 dot) + xn
-                        v = v + cn4[j];
-                        v = v * sc4[j];  // * (1/r) where the exact path divides by r
-                        v = __uint_as_float((__float_as_uint(v) & 0xFFFFFFE0u) | (unsigned)(ct * 16 + g * 4 + j));
-                        s2[rt] = fminf(s2[rt], fmaxf(s1[rt], v));
-                        s1[rt] = fminf(s1[rt], v);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-            const int row = ((rt + wq) & 3) * 32 + l31;
-            const unsigned c5 = __float_as_uint(s1[rt]) & 31u;  // (ct, g, j) of the lane's minimum
-            Top2 t = {s1[rt], kbase + wq * 64 + 4 * h + (int)((c5 >> 4) * 32 + ((c5 >> 2) & 3) * 8 + (c5 & 3)), s2[rt]}, o;
-            o.d1 = __shfl_xor(t.d1, 32);
-            o.k1 = __shfl_xor(t.k1, 32);
-            o.d2 = __shfl_xor(t.d2, 32);
-            t = top2_merge(t, o);
-            if (h == 0) {
-                sD1[wq * 128 + row] = t.d1;
-                sK1[wq * 128 + row] = t.k1;
-                sD2[wq * 128 + row] = t.d2;
-            }
-        }
-        __syncthreads();
-        if (tid < 128) {
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                Top2 o = {sD1[w * 128 + tid], sK1[w * 128 + tid], sD2[w * 128 + tid]};
-                run = top2_merge(run, o);
-            }
-        }
-    }
-#ifdef ACAV_FD_PROF
-    if (lane == 0 && (blockIdx.x & 31) == 0 && (wq == 0 || wq == 3)) {
-        const int o = wq == 0 ? 0 : 8;
-        atomicAdd(&g_fd_prof[o + 0], (unsigned long long)fdp0);
-        atomicAdd(&g_fd_prof[o + 1], (unsigned long long)fdp1);
-        atomicAdd(&g_fd_prof[o + 2], (unsigned long long)fdp2);
-        atomicAdd(&g_fd_prof[o + 3], (unsigned long long)fdp3);
-        atomicAdd(&g_fd_prof[o + 4], (unsigned long long)fdp4);
-        atomicAdd(&g_fd_prof[o + 5], (unsigned long long)(clock64() - fd_tstart));
-        atomicAdd(&g_fd_prof[o + 6], (unsigned long long)(wall_clock64() - fd_wstart));
-        atomicAdd(&g_fd_prof[o + 7], 1ull);
-        atomicAdd(&g_fd_prof[16 + o / 8 * 2], (unsigned long long)fdp5);
-        atomicAdd(&g_fd_prof[17 + o / 8 * 2], (unsigned long long)fdp6);
-    }
-#endif
-    if (tid < 128 && row0 + tid < n) {
-        const float xnorm = __builtin_sqrtf(my_xn);
-        const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
-        const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
-        const float s = xnorm + cmax;
-        const float E = (e1c * cmaxc + e1r * cmax) * xnorm + e2coef * s * s;
-        labels[row0 + tid] = (int64_t)run.k1;
-        if (!((run.d2 - run.d1) > 2.0f * E)) {  // also catches NaN / inf
-            const unsigned slot = atomicAdd(recheck_count, 1u);
-            recheck_list[slot] = (int)(row0 + tid);
-        }
-    }
-}
-
-// k_assign_bf16_rw -- the same filter with the waves cut the other way ("row waves"): wave w owns ROWS 32 w .. 32 w + 31
+// k_assign_f16_rw (k_assign_bf16_rw until round 5) -- "row waves": wave w owns ROWS 32 w .. 32 w + 31
+// (round 1's layout -- wave = centre quarter, every wave re-converting all rows -- was kept as k_assign_bf16 for A/B runs until round 5)
 // of the workgroup's 128 against ALL 256 centres of the group (8 accumulator tiles of 32x32).
 //   * a wave reads and converts only its own rows' fp32 fragments: 8 v_cvt_pk_bf16_f32 per 32-column stage instead of
 //     32 (in the centre-quarter layout every wave re-read and re-converted all 128 rows); the bf16 centre fragments,
@@ -748,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void k_assign_bf16(const float *__restrict_
 //   * the position tag needs 7 bits (128 distances per lane): 128 ulp = 2^-16 of the tagged distance.  That is charged
 //     to the two distances the acceptance test compares (|d1| + |d2|) instead of to (||x|| + cmax)^2; what is left in the
 //     e2 term are the 3 + 3 fp32 roundings of the two epilogues (< 6 x 2^-24 (||x|| + cmax)^2): e2 = 2^-20 here
-// Rings, swizzles, DMA shares, counted waits and the one raw barrier per stage are those of k_assign_bf16.
+// Rings, swizzles, DMA shares, counted waits and the one raw barrier per stage are those of round 1's kernel.
 // Ablations of this kernel on one MI355X (1M x 1024, K = 256; wrong labels, timing only): full 0.93 ms; without the
 // centre DMA 0.71 ms; DMA only (no fragment reads, no MFMA) 0.78 ms -- the bf16 centre stage (16 KB from L2 per 16 KB of
 // rows from HBM) is the largest single cost.  A persistent 256-row workgroup (eight row waves sharing one centre stage,
@@ -851,9 +677,12 @@ struct Top2Rec {
     float d2;
     float xn;
 };
-template <bool NT, int NW, bool GS, int DCR = FD_DC, int SCHED = 0, int EMIT = 0>
-__global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__restrict__ x, int64_t n, int d,
-                                                            const __bf16 *__restrict__ cb, const float *__restrict__ cn,
+// XS (round 5): the rows are multiplied by the power of two aux->sx before their conversion to half (data whose own scale sits
+// outside half's comfortable range: k_centers_scale); XS = false carries no trace of it -- the multiply and the registers behind
+// it cost the K = 256 filter 4.5 % and pushed the product instantiation into scratch.
+template <bool NT, int NW, bool GS, int DCR = FD_DC, int SCHED = 0, int EMIT = 0, bool XS = false>
+__global__ __launch_bounds__(NW * 64, 2) void k_assign_f16_rw(const float *__restrict__ x, int64_t n, int d,
+                                                            const fl16 *__restrict__ cb, const float *__restrict__ cn,
                                                             const float *__restrict__ counts, int K, float thr, float r,
                                                             const CentersAux *__restrict__ aux, float e1c, float e1r, float e2coef,
                                                             int64_t *__restrict__ labels, int *__restrict__ recheck_list,
@@ -874,7 +703,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
     constexpr int CQ = 16 / NW;       // centre-stage DMA pieces (1 KB = 16 centres x 64 B) per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char fd_smem[];
     float *sXr = reinterpret_cast<float *>(fd_smem);                        // [FD_DX][NW * 32][32] fp32
-    __bf16 *sCb = reinterpret_cast<__bf16 *>(fd_smem + FD_DX * XSLOT);      // [FD_DC][256][32] bf16
+    fl16 *sCb = reinterpret_cast<fl16 *>(fd_smem + FD_DX * XSLOT);          // [FD_DC][256][32] half
     float *sCn = reinterpret_cast<float *>(fd_smem);  // [256] epilogue scratch, aliases the (idle) row ring
     float *sSc = sCn + 256;                           // [256] 1, or 1/r for a discounted centre
     // emission pass only (EMIT = 1; 4.5 KB past the rings): every row's candidate list, collected over the centre groups
@@ -907,6 +736,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
     // squared norms.  With an under-used centre the division by r does not commute with a row constant: full values.
     const bool centred = aux->any_disc == 0u;
     const float cn_shift = centred ? cn[0] : 0.0f;
+    // half-precision operands: rows are multiplied by the exact power of two sx before the conversion, the centre copy holds
+    // sc c'; the accumulated dot comes back through m2s = -2 / (sx sc) in the epilogue's fma (a power of two: exact)
+    const float sxrow = XS ? aux->sx : 1.0f;
 
     unsigned voffx[4], voffc[CQ];
     const char *ax[4], *ax0[4];  // emission pass: the 64-bit source address of this lane's piece of row (wq * 4 + q) * 8 + (lane >> 3)
@@ -1019,7 +851,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
             __builtin_amdgcn_s_barrier();
             RW_T(t2);
             const float *pxl = sXr + rx * (XSLOT / 4) + wq * 1024 + l31 * 32;  // this lane's row of the wave's own tile
-            const __bf16 *pcl = sCb + rcs * (256 * 32) + l31 * 32;            // row l31 of centre tile 0 (+ 1024 per tile)
+            const fl16 *pcl = sCb + rcs * (256 * 32) + l31 * 32;              // row l31 of centre tile 0 (+ 1024 per tile)
             rx = rx + 1 == FD_DX ? 0 : rx + 1;
             rcs = rcs + 1 == DCR ? 0 : rcs + 1;
 #define RW_LDB(ks, F0, F1)                                                                         \
@@ -1035,7 +867,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
 #ifdef ACAV_ABL_NOMFMA
 #define RW_MFMA(a, b, cc) cc[0] += (float)(a)[0] + (float)(b)[0]
 #else
-#define RW_MFMA(a, b, cc) cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, cc, 0, 0, 0)
+#define RW_MFMA(a, b, cc) cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, cc, 0, 0, 0)
 #endif
             // SCHED: when a wave issues its CQ + 4 DMA pieces of the stage (an issue costs the wave 60-120 cycles while the
             // path is busy: tools/exp/assign_bench.hip -DACAV_RW_PROF).  0: all of them in one burst before the MFMAs.
@@ -1089,14 +921,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
             }
             RW_T(t4);
             RW_LDB(1, q0, q1)
-            const bf16x8 b0 = cvt_bf16x8(p0, p1);
+            const bf16x8 b0 = cvt_bf16x8(p0, p1, sxrow, XS);
 #pragma unroll
             for (int ct = 0; ct < 8; ++ct) {
                 RW_MFMA(a0[ct], b0, acc[ct]);
                 a1[ct] = RW_LDA(1, RW_CT(ct));
                 if (SCHED == 2 && (ct & 1) == 0 && ct / 2 < NP1) piece(ct / 2);
             }
-            const bf16x8 b1 = cvt_bf16x8(q0, q1);
+            const bf16x8 b1 = cvt_bf16x8(q0, q1, sxrow, XS);
 #pragma unroll
             for (int ct = 0; ct < 8; ++ct) {
                 RW_MFMA(a1[ct], b1, acc[ct]);
@@ -1152,6 +984,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
         }
         __syncthreads();
         // compare-free top-2 scan of this lane's 8 x 16 distances: the 7 low mantissa bits carry the position
+        const float m2s = -2.0f * aux->inv_ss;  // (read here, not held across the stage loop: a scalar load per tile)
         float s1 = INFINITY, s2 = INFINITY;
         if (centred) {
             // no centre is under-used: every scale is 1 and ||x||^2 is left out -- v = fl(-2 dot + ||c||^2') is ONE fma (-2 dot is
@@ -1164,7 +997,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
                     const float cn4[4] = {cnv.x, cnv.y, cnv.z, cnv.w};
 #pragma unroll
                     for (int j = 0; j < 4; j += 2) {  // two distances per v_pk_fma_f32 (each half is one IEEE fma)
-                        const f32x2 a2 = {acc[ct][4 * g + j], acc[ct][4 * g + j + 1]}, c2 = {cn4[j], cn4[j + 1]}, m2 = {-2.0f, -2.0f};
+                        const f32x2 a2 = {acc[ct][4 * g + j], acc[ct][4 * g + j + 1]}, c2 = {cn4[j], cn4[j + 1]}, m2 = {m2s, m2s};
                         const f32x2 v2 = __builtin_elementwise_fma(m2, a2, c2);
                         top2_push(s1, s2, __uint_as_float((__float_as_uint(v2.x) & 0xFFFFFF80u) | (unsigned)(ct * 16 + g * 4 + j)));
                         top2_push(s1, s2, __uint_as_float((__float_as_uint(v2.y) & 0xFFFFFF80u) | (unsigned)(ct * 16 + g * 4 + j + 1)));
@@ -1184,7 +1017,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
                     const float sc4[4] = {scv.x, scv.y, scv.z, scv.w};
 #pragma unroll
                     for (int j = 0; j < 4; j += 2) {  // packed: each half is the same three IEEE operations as the scalar form
-                        const f32x2 a2 = {acc[ct][4 * g + j], acc[ct][4 * g + j + 1]}, m2 = {-2.0f, -2.0f}, x2 = {xoff, xoff};
+                        const f32x2 a2 = {acc[ct][4 * g + j], acc[ct][4 * g + j + 1]}, m2 = {m2s, m2s}, x2 = {xoff, xoff};
                         const f32x2 c2 = {cn4[j], cn4[j + 1]}, sc2 = {sc4[j], sc4[j + 1]};
                         f32x2 v2 = __builtin_elementwise_fma(m2, a2, x2);  // == (-2 dot) + xn
                         v2 = v2 + c2;
@@ -1210,11 +1043,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
             asm volatile("" : "+v"(l31e));
             const int64_t li = row0 + wq * 32 + l31e;  // the row itself, or its position in the list of undecided rows
             const int64_t row = li < n ? (LISTED ? (int64_t)recheck_list[li] : li) : -1;
-            const float xnorm = __builtin_sqrtf(xn);
-            const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
-            const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
-            const float sn = xnorm + cmax;
-            const float E = (e1c * cmaxc + e1r * cmax) * xnorm + e2coef * sn * sn;
+            const float E = filter_bound(aux, __builtin_sqrtf(xn), e1c, e1r, e2coef);  // NaN: the row cannot be decided here
             const float tagged = 1.6e-5f * (fabsf(run.d1) + fabsf(run.d2));  // > (2^-16 + 2^-22) x 1.01
             // (every listed row fails the test again: same arithmetic as the filter's; the label is already the filter's k1.
             // K > 256, emission pass: the row is undecided by construction and its threshold comes from k_assign_merge, which
@@ -1247,7 +1076,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
                             const float cn4[4] = {cnv.x, cnv.y, cnv.z, cnv.w};
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const float v = __builtin_fmaf(-2.0f, acc[ct][4 * g + j], cn4[j]);
+                                const float v = __builtin_fmaf(m2s, acc[ct][4 * g + j], cn4[j]);
                                 ACAV_CAND_MARK(v, ct * 16 + g * 4 + j)
                             }
                         }
@@ -1265,7 +1094,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
                             const float sc4[4] = {scv.x, scv.y, scv.z, scv.w};
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                float v = __builtin_fmaf(-2.0f, acc[ct][4 * g + j], xoff);
+                                float v = __builtin_fmaf(m2s, acc[ct][4 * g + j], xoff);
                                 v = v + cn4[j];
                                 v = v * sc4[j];
                                 ACAV_CAND_MARK(v, ct * 16 + g * 4 + j)
@@ -1392,11 +1221,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
     if (LISTED) continue;  // emitted inside the group loop (the accumulators live there); next tile of the list
     if (EMIT == 2) break;
     if (h == 0 && row < n) {
-        const float xnorm = __builtin_sqrtf(xn);
-        const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
-        const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
-        const float s = xnorm + cmax;
-        const float E = (e1c * cmaxc + e1r * cmax) * xnorm + e2coef * s * s;
+        const float E = filter_bound(aux, __builtin_sqrtf(xn), e1c, e1r, e2coef);
         labels[row] = (int64_t)run.k1;
         // the position tag perturbs a distance by < 2^-16 of ITS OWN magnitude (and fl(1/r) by 2 ulp more): charged to the
         // two distances that are compared instead of to (||x|| + cmax)^2 -- with a large common component the distances
@@ -1413,7 +1238,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_assign_bf16_rw(const float *__re
 
 // Folds the per-group records of the group-split filter (ascending group order = the order of the single-workgroup loop;
 // top2_merge breaks distance ties towards the lower centre index, so the fold is order-independent anyway) and applies
-// k_assign_bf16_rw's acceptance test.  One thread per row; 16-byte records, coalesced.
+// k_assign_f16_rw's acceptance test.  One thread per row; 16-byte records, coalesced.
 __global__ __launch_bounds__(256) void k_assign_merge(const Top2Rec *__restrict__ grec, int ngroups, int64_t n,
                                                       const CentersAux *__restrict__ aux, float e1c, float e1r, float e2coef,
                                                       int64_t *__restrict__ labels, int *__restrict__ recheck_list,
@@ -1430,11 +1255,7 @@ __global__ __launch_bounds__(256) void k_assign_merge(const Top2Rec *__restrict_
         const Top2 o = {rg.d1, rg.k1, rg.d2};
         run = top2_merge(run, o);
     }
-    const float xnorm = __builtin_sqrtf(r0.xn);
-    const float cmax = __builtin_sqrtf(__uint_as_float(aux->cmax_bits));
-    const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
-    const float s = xnorm + cmax;
-    const float E = (e1c * cmaxc + e1r * cmax) * xnorm + e2coef * s * s;
+    const float E = filter_bound(aux, __builtin_sqrtf(r0.xn), e1c, e1r, e2coef);
     labels[row] = (int64_t)run.k1;
     const float tagged = 1.6e-5f * (fabsf(run.d1) + fabsf(run.d2));
     if (!((run.d2 - run.d1) > 2.0f * E + tagged)) {
@@ -1634,7 +1455,7 @@ int acav_kmeans::prepare_filter()
     if (cb16_valid) return ACAV_OK;
     if (K < 2 || warm()) return ACAV_OK;  // the filter does not run on this shape / state
     hipStream_t st = ctx.stream;
-    const int Kp = (K + 255) / 256 * 256;  // whole groups of 256 centre slots (stage-major copy: k_centers_bf16)
+    const int Kp = (K + 255) / 256 * 256;  // whole groups of 256 centre slots (stage-major copy: k_centers_f16)
     // a width that is not a multiple of the 32-column stage: the filter (and its exact re-check) run on zero-padded copies
     const int dp = filter_d();
     const float *fc = centers.as<float>();
@@ -1650,9 +1471,20 @@ int acav_kmeans::prepare_filter()
     ACAV_TRY(cmu.ensure(sizeof(float) * (size_t)dp));
     hipLaunchKernelGGL(k_centers_mu, dim3((unsigned)((dp + 31) / 32)), dim3(256), 0, st, fc, cn.as<float>(),
                        counts.as<float>(), K, dp, threshold(), cmu.as<float>(), caux.as<CentersAux>());
-    hipLaunchKernelGGL(k_centers_bf16, dim3((unsigned)Kp), dim3(256), 0, st, fc, cmu.as<float>(), dp, K, Kp,
-                       cb16.as<__bf16>(), caux.as<CentersAux>());
+    hipLaunchKernelGGL(k_centers_amaxc, dim3((unsigned)K), dim3(256), 0, st, fc, cmu.as<float>(), dp, K, caux.as<CentersAux>());
+    hipLaunchKernelGGL(k_centers_norm, dim3((unsigned)K), dim3(256), 0, st, fc, cmu.as<float>(), dp, K, caux.as<CentersAux>());
+    hipLaunchKernelGGL(k_centers_scale, dim3(1), dim3(64), 0, st, caux.as<CentersAux>(), dp);
+    hipLaunchKernelGGL(k_centers_f16, dim3((unsigned)Kp), dim3(256), 0, st, fc, cmu.as<float>(), dp, K, Kp, cb16.as<fl16>(),
+                       caux.as<CentersAux>());
     ACAV_HIP_TRY(hipGetLastError());
+    {   // which instantiation the sweeps launch (rows scaled before the conversion or not) is decided on the device: 4 bytes back.
+        // Every caller of prepare_filter has just synchronised the stream (end of a training call, set_state) or is about to
+        // run a sweep: ~10 us, once per change of state.
+        float sx_host = 1.0f;
+        ACAV_HIP_TRY(hipMemcpyAsync(&sx_host, &caux.as<CentersAux>()->sx, sizeof(float), hipMemcpyDeviceToHost, st));
+        ACAV_HIP_TRY(hipStreamSynchronize(st));
+        filter_rows_scaled = sx_host != 1.0f;
+    }
     cb16_valid = true;
     // the sweep's one-time objects, so that the first sweep of a handle does not create them inside its own timing
     if (!ev_f0) {
@@ -1805,14 +1637,14 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         int *und_list = km->recheck_list.as<int>(), *f32_list = und_list + n;
         const CandOut cout = {crow, cpair, f32_list, cand && km->K > 256 ? km->cand_T.as<float>() : (float *)nullptr, pair_cap};
         const double acc = 1.01 * (double)fd * ldexp(1.0, -24);  // accumulation error of one fp32 dot, relative
-        const float e1c = (float)(2.02 * (ldexp(1.0, -8) * 1.002 + acc) * 1.001);   // x ||c'|| ||x||: bf16 roundings + filter dot
+        const float e1c = (float)(2.02 * (ldexp(1.0, -10) * 1.002 + acc) * 1.001);  // x ||c'|| ||x||: half roundings (2^-11 per operand) + filter dot
         const float e1r = (float)(2.02 * (acc + ldexp(1.0, -24)) * 1.001);           // x ||c|| ||x||: canonical dot, c - mu
-        // rows are read exactly once: non-temporal DMA policy (ACAV_FILTER_NT=0 restores the default policy);
-        // ACAV_FILTER_V1=1 selects the round-1 wave layout (wave = centre quarter) for A/B measurements
-        const char *vnt = getenv("ACAV_FILTER_NT"), *v1 = getenv("ACAV_FILTER_V1");
-        const bool nt = !(vnt && vnt[0] == '0'), rw = !(v1 && v1[0] == '1');
-        const float e2 = (float)ldexp(1.0, rw ? -20 : -17);  // row waves: epilogue roundings only, the tag is charged separately
-        // Tile shape and DMA schedule of k_assign_bf16_rw (template parameters there).  K > 256: one workgroup per (row tile,
+        // rows are read exactly once: non-temporal DMA policy (ACAV_FILTER_NT=0 restores the default policy)
+        const char *vnt = getenv("ACAV_FILTER_NT");
+        const bool nt = !(vnt && vnt[0] == '0');
+        constexpr bool rw = true;  // (round 1's wave layout, ACAV_FILTER_V1, went with the move to half-precision operands)
+        const float e2 = (float)ldexp(1.0, -20);  // epilogue roundings only, the tag is charged separately
+        // Tile shape and DMA schedule of k_assign_f16_rw (template parameters there).  K > 256: one workgroup per (row tile,
         // centre group) pair, the pairs of a tile side by side on one XCD, 256-row tiles (8 waves), centre ring of 3, DMA
         // pieces spread between the MFMAs -- rows from HBM once.  Knobs for A/B runs: ACAV_FILTER_GS=0 (loop over the groups
         // inside one workgroup), ACAV_FILTER_NW=4|8, ACAV_FILTER_SCHED=0|2.
@@ -1825,7 +1657,7 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         const bool nt_eff = gs ? !(vnt && vnt[0] == '0') : nt;  // nt rows are still found in L2 by the tile's other groups (PMC)
         const int dcr = nw == 8 ? 3 : 2;  // centre ring depth (3 only fits the one-workgroup-per-CU tile)
         const int sched = nw == 8 ? 2 : (vsc ? (vsc[0] == '2' ? 2 : 0) : FILTER_SCHED_DEFAULT);
-        typedef void (*FilterKern)(const float *, int64_t, int, const __bf16 *, const float *, const float *, int, float, float,
+        typedef void (*FilterKern)(const float *, int64_t, int, const fl16 *, const float *, const float *, int, float, float,
                                    const CentersAux *, float, float, float, int64_t *, int *, unsigned *, AssignCtl *, Top2Rec *,
                                    CandOut);
         FilterKern rwk = nullptr;
@@ -1835,12 +1667,15 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
         const bool emit_gs = cand && emit_allowed && rw && gs;
         const bool emit = cand && emit_allowed && rw && ((!gs && ngroups == 1 && nw == 4 && sched == 0) || emit_gs);
         if (rw) {
-            if (nw == 8) rwk = gs ? (nt_eff ? k_assign_bf16_rw<true, 8, true, 3, 2> : k_assign_bf16_rw<false, 8, true, 3, 2>)
-                                  : (nt_eff ? k_assign_bf16_rw<true, 8, false, 3, 2> : k_assign_bf16_rw<false, 8, false, 3, 2>);
-            else if (gs) rwk = nt_eff ? k_assign_bf16_rw<true, 4, true, 2, 0> : k_assign_bf16_rw<false, 4, true, 2, 0>;
-            else if (sched == 2) rwk = nt_eff ? k_assign_bf16_rw<true, 4, false, 2, 2> : k_assign_bf16_rw<false, 4, false, 2, 2>;
-            else if (emit && emit_inplace && !emit_gs) rwk = nt_eff ? k_assign_bf16_rw<true, 4, false, 2, 0, 2> : k_assign_bf16_rw<false, 4, false, 2, 0, 2>;
-            else rwk = nt_eff ? k_assign_bf16_rw<true, 4, false, 2, 0> : k_assign_bf16_rw<false, 4, false, 2, 0>;
+            // (rows scaled before the conversion: the XS instantiations, non-temporal rows only)
+            const bool xs = km->filter_rows_scaled;
+            if (nw == 8) rwk = gs ? (xs ? k_assign_f16_rw<true, 8, true, 3, 2, 0, true> : nt_eff ? k_assign_f16_rw<true, 8, true, 3, 2> : k_assign_f16_rw<false, 8, true, 3, 2>)
+                                  : (xs ? k_assign_f16_rw<true, 8, false, 3, 2, 0, true> : nt_eff ? k_assign_f16_rw<true, 8, false, 3, 2> : k_assign_f16_rw<false, 8, false, 3, 2>);
+            else if (gs) rwk = xs ? k_assign_f16_rw<true, 4, true, 2, 0, 0, true> : nt_eff ? k_assign_f16_rw<true, 4, true, 2, 0> : k_assign_f16_rw<false, 4, true, 2, 0>;
+            else if (sched == 2) rwk = xs ? k_assign_f16_rw<true, 4, false, 2, 2, 0, true> : nt_eff ? k_assign_f16_rw<true, 4, false, 2, 2> : k_assign_f16_rw<false, 4, false, 2, 2>;
+            else if (emit && emit_inplace && !emit_gs)
+                rwk = xs ? k_assign_f16_rw<true, 4, false, 2, 0, 2, true> : nt_eff ? k_assign_f16_rw<true, 4, false, 2, 0, 2> : k_assign_f16_rw<false, 4, false, 2, 0, 2>;
+            else rwk = xs ? k_assign_f16_rw<true, 4, false, 2, 0, 0, true> : nt_eff ? k_assign_f16_rw<true, 4, false, 2, 0> : k_assign_f16_rw<false, 4, false, 2, 0>;
         }
         const int fsmem = FD_DX * nw * 4096 + dcr * FD_SLOT;
         const int64_t tile_rows = (int64_t)nw * 32, ntiles = (n + tile_rows - 1) / tile_rows;
@@ -1855,40 +1690,16 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
             ACAV_TRY(dyn_lds_once(reinterpret_cast<const void *>(rwk), km->ctx.device, fsmem));
             ACAV_HIP_TRY(hipEventRecord(km->ev_f0, st));
             hipLaunchKernelGGL(rwk, dim3((unsigned)fgrid), dim3(nw * 64), fsmem, st, static_cast<const float *>(dx), n, fd,
-                               km->cb16.as<__bf16>(), km->cn.as<float>(), km->counts.as<float>(), km->K, km->threshold(),
+                               km->cb16.as<fl16>(), km->cn.as<float>(), km->counts.as<float>(), km->K, km->threshold(),
                                (float)km->reinit_r, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, emit ? und_list : f32_list,
                                emit ? &ctl->und_count : f32_count, ctl, gs ? km->grec.as<Top2Rec>() : (Top2Rec *)nullptr, cout);
             if (gs)
                 hipLaunchKernelGGL(k_assign_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, km->grec.as<Top2Rec>(),
                                    ngroups, n, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, emit_gs ? und_list : f32_list,
                                    emit_gs ? &ctl->und_count : f32_count, emit_gs ? cout.und_T : (float *)nullptr);
-        } else {
-            auto kern = nt ? k_assign_bf16<true> : k_assign_bf16<false>;
-            ACAV_TRY(dyn_lds_once(reinterpret_cast<const void *>(kern), km->ctx.device, FD_SMEM));
-            ACAV_HIP_TRY(hipEventRecord(km->ev_f0, st));
-            hipLaunchKernelGGL(kern, dim3((unsigned)((n + FB_ROWS - 1) / FB_ROWS)), dim3(256), FD_SMEM, st,
-                               static_cast<const float *>(dx), n, fd, km->cb16.as<__bf16>(), km->cn.as<float>(),
-                               km->counts.as<float>(), km->K, km->threshold(), (float)km->reinit_r, km->caux.as<CentersAux>(), e1c,
-                               e1r, e2, dlab, f32_list, f32_count);
         }
         ACAV_HIP_TRY(hipGetLastError());
         ACAV_HIP_TRY(hipEventRecord(km->ev_f1, st));
-#ifdef ACAV_FD_PROF
-        {
-            unsigned long long hp[20];
-            hipStreamSynchronize(st);
-            hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_fd_prof), sizeof(hp));
-            for (int o = 0; o < 16; o += 8)
-                fprintf(stderr, "fd_prof wave%d: stages %llu  vmwait %.0f  barrier %.0f  issue %.0f  compute %.0f cycles/stage\n",
-                        o ? 3 : 0, hp[o + 4], (double)hp[o] / hp[o + 4], (double)hp[o + 1] / hp[o + 4],
-                        (double)hp[o + 2] / hp[o + 4], (double)hp[o + 3] / hp[o + 4]),
-                fprintf(stderr, "   prologue %.0f loop %.0f cycles per WG\n", (double)hp[16 + o / 8 * 2] / hp[o + 7], (double)hp[17 + o / 8 * 2] / hp[o + 7]),
-                fprintf(stderr, "   per WG: %.0f cycles, %.2f us (100 MHz wall clock) -> %.2f GHz\n", (double)hp[o + 5] / hp[o + 7],
-                        (double)hp[o + 6] / hp[o + 7] / 100.0, (double)hp[o + 5] / hp[o + 6] * 0.1);
-            memset(hp, 0, sizeof(hp));
-            hipMemcpyToSymbol(HIP_SYMBOL(g_fd_prof), hp, sizeof(hp));
-        }
-#endif
         // exact pass over the listed rows (no host round trip): a fixed grid of 2 workgroups per CU strides over
         // however many row tiles the list turns out to hold
         if (km->num_cus == 0) {
@@ -1905,14 +1716,15 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
                 // one workgroup per CU either way (rings + lists do not fit twice): for K > 256 and wide rows the 8-wave /
                 // 256-row tile of the main kernel (centre ring 3, DMA pieces spread), else 4 waves / 128 rows
                 const int enw = emit_gs && nw == 8 ? 8 : 4;
-                FilterKern ek = enw == 8 ? (nt ? k_assign_bf16_rw<true, 8, false, 3, 2, 1> : k_assign_bf16_rw<false, 8, false, 3, 2, 1>)
-                                         : (nt ? k_assign_bf16_rw<true, 4, false, 2, 0, 1> : k_assign_bf16_rw<false, 4, false, 2, 0, 1>);
+                const bool xs = km->filter_rows_scaled;
+                FilterKern ek = enw == 8 ? (xs ? k_assign_f16_rw<true, 8, false, 3, 2, 1, true> : nt ? k_assign_f16_rw<true, 8, false, 3, 2, 1> : k_assign_f16_rw<false, 8, false, 3, 2, 1>)
+                                         : (xs ? k_assign_f16_rw<true, 4, false, 2, 0, 1, true> : nt ? k_assign_f16_rw<true, 4, false, 2, 0, 1> : k_assign_f16_rw<false, 4, false, 2, 0, 1>);
                 const int esmem = FD_DX * enw * 4096 + (enw == 8 ? 3 : 2) * FD_SLOT + enw * 32 * (4 + 2 * (int)CAND_MAX);  // rings + lists
                 ACAV_TRY(dyn_lds_once(reinterpret_cast<const void *>(ek), km->ctx.device, esmem));
                 const int64_t erows = (int64_t)enw * 32;
                 const int64_t egrid = std::min<int64_t>((n + erows - 1) / erows, (int64_t)km->num_cus);
                 hipLaunchKernelGGL(ek, dim3((unsigned)egrid), dim3(enw * 64), esmem, st, static_cast<const float *>(dx), n, fd,
-                                   km->cb16.as<__bf16>(), km->cn.as<float>(), km->counts.as<float>(), km->K, km->threshold(),
+                                   km->cb16.as<fl16>(), km->cn.as<float>(), km->counts.as<float>(), km->K, km->threshold(),
                                    (float)km->reinit_r, km->caux.as<CentersAux>(), e1c, e1r, e2, dlab, und_list, &ctl->und_count, ctl,
                                    (Top2Rec *)nullptr, cout);
             }

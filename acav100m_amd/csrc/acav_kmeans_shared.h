@@ -69,8 +69,9 @@ struct acav_kmeans {
     DevBuf cand_ctl, cand_rows, cand_pairs, cand_T;
     DevBuf cpad, xpad;  // zero-padded centres / rows of the assign filter when d % 32 != 0 (acav_kmeans_assign.hip)
     unsigned ctl_pair_cap = 0;  // candidate-restricted re-check of the assign sweep (acav_kmeans_assign.hip)
-    hipEvent_t ev_f0 = nullptr, ev_f1 = nullptr;  // around the last k_assign_bf16 launch (acav_kmeans_filter_time)
-    bool cb16_valid = false;  // bf16 copy of the centres matches `centers`
+    hipEvent_t ev_f0 = nullptr, ev_f1 = nullptr;  // around the last filter launch (acav_kmeans_filter_time)
+    bool cb16_valid = false;  // the filter's half-precision copy of the centres matches `centers`
+    bool filter_rows_scaled = false;  // ... and its sweeps multiply the rows by aux->sx before the conversion (XS instantiations)
     bool rg_attr_set = false; // dynamic-LDS attribute of the large-batch distance kernels set
     int64_t n_filter_launches = 0;
     uint64_t last_recheck = 0, last_rows = 0;

@@ -48,7 +48,7 @@ needs the centres of the step before): what N GPUs do there is a choice, `--mult
 rank hashes every clustering's state (all ranks must agree) and rank 0 re-labels 16 384 of its rows with the oracle.
 
 The JSON line also carries
-  roofline      k_assign_bf16_rw, the HBM-bound kernel of the path: algorithmic bytes N*d*4 + N*8 per launch over the
+  roofline      k_assign_f16_rw, the HBM-bound kernel of the path: algorithmic bytes N*d*4 + N*8 per launch over the
                 kernel's duration measured with HIP events on the library's stream around that launch alone
                 (`sweep_*` keys: the whole calc_best sweep incl. centre preparation and the exact re-check pass)
   roofline_mi   the candidate-permutation stream of the greedy loop (16 L bytes per iteration) vs HBM
@@ -406,7 +406,7 @@ def main():
         for name in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
             if name.endswith(".json") and "_pmc_assign" in name:  # summaries of the separate rocprofv3 --pmc passes (tools/summarize_pmc.py)
                 pm = json.load(open(os.path.join(pdir, name)))
-                if (pm.get("d"), pm.get("K")) == (d, k) and pm.get("kernel", "").startswith("k_assign_bf16"):
+                if (pm.get("d"), pm.get("K")) == (d, k) and pm.get("kernel", "").startswith("k_assign_"):
                     scale = n / pm["rows"]  # per-row traffic of the same kernel shape, scaled to this launch's rows
                     traffic_profile = {"file": "profiles/" + name, "rows_in_profile": pm["rows"],
                                        "bytes_per_launch": pm["traffic_bytes_per_launch"] * scale}
@@ -424,7 +424,7 @@ def main():
                    f"chunked greedy batch-MI selection (chunk_size = {chunk} clips = {chunk // 1000} shards, {-(-n // chunk)} chunks, "
                    f"{wl['width']} in lockstep; every chunk selects 20 % of its clips: {subset} clips, {iters} iterations in all, "
                    f"B={BATCH_B}, k={SELECT_K})")
-        roof = {"kernel": "k_assign_bf16_rw" + (" + k_assign_merge (K > 256: one workgroup per (row tile, centre group) pair)" if k > 256 else ""),
+        roof = {"kernel": "k_assign_f16_rw" + (" + k_assign_merge (K > 256: one workgroup per (row tile, centre group) pair)" if k > 256 else ""),
                 "view": f"{d}-d"}
         if mfma_bound:
             roof.update({"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

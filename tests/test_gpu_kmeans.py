@@ -218,8 +218,10 @@ def test_bf16_filter_path_is_bit_identical(env, case):
     lab_exact, _ = km.calc_best(xt)  # exact path
     assert np.array_equal(lab_exact.cpu().numpy(), lab_ref)
     print(f"{case}: {rechecked}/{n} rows needed the exact re-check")
-    if case in ("unstructured", "tiny_gap", "offset_tiny_gap", "offset_discounted"):
+    if case in ("tiny_gap", "offset_tiny_gap", "offset_discounted"):
         assert rechecked > n // 2   # the exact pass really decided these
+    if case == "unstructured":      # (half-precision operands since round 5: the window is 8 x narrower than bf16's)
+        assert rechecked > n // 10
     if case == "offset":
         assert rechecked < n // 20  # centred centres: the common component costs nothing
 
@@ -268,7 +270,7 @@ def test_filter_on_widths_that_are_not_stage_multiples(env, d, K, kind, monkeypa
     if kind == "clustered":
         assert rechecked < n // 10
     if kind == "unstructured":
-        assert rechecked > n // 20  # the re-check (on the padded copies) really decided rows
+        assert rechecked > n // 50  # the re-check (on the padded copies) really decided rows
     if kind == "tiny_gap":
         assert rechecked > n // 2
     # host rows go through the same path; a second sweep after a state change rebuilds the padded copies
@@ -281,6 +283,48 @@ def test_filter_on_widths_that_are_not_stage_multiples(env, d, K, kind, monkeypa
     monkeypatch.setenv("ACAV_FILTER_PAD", "0")  # the guarded exact sweep, as before round 5
     assert np.array_equal(km.calc_best(xt, need_mean=False)[0].cpu().numpy(), ref2.calc_best(x)[0])
     assert km.filter_stats()[0] == 3
+
+
+@pytest.mark.parametrize("scale,K", [(1.0, 64), (1e-4, 64), (3e4, 64), (2e-7, 32), (1e-4, 300), (1.0, 300)])
+def test_filter_half_precision_operands_any_data_scale(env, scale, K):
+    """Round 5: the filter's MFMA operands are IEEE half (unit roundoff 2^-11; bf16: 2^-8), scaled by exact powers of two so that
+    the narrow exponent range of half does not matter: centres always (the copy holds sc c'), rows only when the data's own scale
+    sits outside half's comfortable range (sx != 1: the XS instantiations).  Labels must equal the oracle's at EVERY data scale --
+    1e-4 and 2e-7 (every element far below half's smallest normal: all of it would flush without the scaling), 3e4 (every element
+    beyond half's largest finite value), with K <= 256 and K > 256 -- and for rows with a few ENORMOUS elements (1e30: half has no
+    such number; the bound refuses the row and the exact path labels it), NaN-free."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    rs = np.random.RandomState(int(K + 1000 * abs(np.log10(scale))))
+    n, d = 3000, 256
+    cen = (2.0 * rs.randn(K, d)).astype(np.float32)
+    x = (cen[rs.randint(0, K, n)] + 0.5 * rs.randn(n, d)).astype(np.float32)
+    centers = (cen + 0.05 * rs.randn(K, d)).astype(np.float32)
+    x[:200] = centers[rs.randint(0, K, 200)] + (1e-4 * rs.randn(200, d)).astype(np.float32)  # near-ties for the re-check
+    x = (x * np.float32(scale)).astype(np.float32)
+    centers = (centers * np.float32(scale)).astype(np.float32)
+    x[7, 3] = np.float32(1e30) * np.float32(scale)   # outliers half cannot hold at any scale
+    x[8, :5] = np.float32(-3e29) * np.float32(scale)
+    counts = np.full(K, 1000, np.float32)
+    count = 10 * K + 2000
+    km = KMeans(None, d, K)
+    km.centers, km.counts, km.count = centers, counts, count
+    km.to("cuda:0")
+    ref = O.KMeans(d, K, O.Rng(0), centers=centers)
+    ref.set_state(None, counts, count)
+    lab_ref, _ = ref.calc_best(x)
+    xt = torch.from_numpy(x).cuda()
+    lab, _ = km.calc_best(xt, need_mean=False)
+    launches, rows, rechecked = km.filter_stats()
+    assert launches == 1 and rows == n
+    assert np.array_equal(lab.cpu().numpy(), lab_ref), f"{(lab.cpu().numpy() != lab_ref).sum()} labels differ"
+    print(f"scale {scale} K {K}: {rechecked}/{n} rows needed the exact re-check")
+    assert 2 <= rechecked < n // 2   # the two outlier rows always; the separated rows never
+    # under-used centres (no centring, raw norms in the bound) at this scale too
+    counts2 = rs.randint(0, 80, K).astype(np.float32)
+    km.counts = counts2
+    ref.set_state(None, counts2, count)
+    assert np.array_equal(km.calc_best(xt, need_mean=False)[0].cpu().numpy(), ref.calc_best(x)[0])
 
 
 @pytest.mark.parametrize("mode", ["plain", "pool_overflow", "cand_off", "discounted", "many_ties", "emission_pass"])
@@ -339,7 +383,7 @@ def test_candidate_restricted_recheck(env, mode, monkeypatch):
         assert not np.isin(lab.cpu().numpy(), np.arange(100, 140)).any()  # the duplicates lose to index 7
 
 
-@pytest.mark.parametrize("switch", [("ACAV_FILTER_V1", "1"), ("ACAV_FILTER_NT", "0"), ("ACAV_ASSIGN_EXACT_ONLY", "1"),
+@pytest.mark.parametrize("switch", [("ACAV_FILTER_NT", "0"), ("ACAV_ASSIGN_EXACT_ONLY", "1"),
                                     ("ACAV_NO_PERSISTENT", "1")])
 def test_diagnostic_switches_keep_the_results(env, switch, monkeypatch):
     """The A/B switches select other kernels, never other results: the round-1 wave layout of the filter, the default

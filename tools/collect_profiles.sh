@@ -30,10 +30,8 @@ pmc fetch "k_assign" FETCH_SIZE python tools/run_assign_only.py 1000000 5 filter
 pmc write "k_assign" WRITE_SIZE python tools/run_assign_only.py 1000000 5 filter
 python tools/summarize_pmc.py "$OUT" "$P"
 for C in SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS SQ_BUSY_CYCLES; do
-    pmc "rw_$C" "k_assign_bf16" $C python tools/run_assign_only.py 1000000 5 filter
-    ACAV_FILTER_V1=1 pmc "v1_$C" "k_assign_bf16" $C python tools/run_assign_only.py 1000000 5 filter
+    pmc "rw_$C" "k_assign_f16" $C python tools/run_assign_only.py 1000000 5 filter
 done
-ACAV_FILTER_V1=1 timeout 300 python tools/run_assign_only.py 1000000 20 filter > "$OUT/${P}_assign_filter_v1.txt" 2> /dev/null
 python tools/summarize_counters.py "$OUT" "$P" > "$OUT/${P}_assign_pipe_counters.json"
 stats assign_exact python tools/run_assign_only.py 1000000 3 exact
 stats assign_k1024 python tools/run_assign_only.py 1000000 3 filter 1024 1024
@@ -81,7 +79,7 @@ stats recheck_hard python tools/recheck_table.py 1000000 1024 0.06,0.05
 : > "$OUT/${P}_cand_pmc.txt"
 for C in "TCC_REQ_sum TCC_HIT_sum" "TCC_MISS_sum TCC_EA0_RDREQ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVES" "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum" "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"; do
     tag=$(echo $C | tr ' ' '_')
-    timeout 300 rocprofv3 --pmc $C --kernel-include-regex "k_assign_cand|k_assign_bf16_rw" --output-format csv -d "$OUT/pmc_cand_$tag" -o pmc -- python tools/recheck_table.py 1000000 1024 0.05 > /dev/null 2>&1
+    timeout 300 rocprofv3 --pmc $C --kernel-include-regex "k_assign_cand|k_assign_f16_rw" --output-format csv -d "$OUT/pmc_cand_$tag" -o pmc -- python tools/recheck_table.py 1000000 1024 0.05 > /dev/null 2>&1
     python - "$OUT/pmc_cand_$tag" >> "$OUT/${P}_cand_pmc.txt" <<'PY'
 import csv, glob, collections, re, sys
 agg = collections.defaultdict(list)

@@ -1,4 +1,4 @@
-// Experiment harness (not product): the assign filter k_assign_bf16_rw<NT, NW, GS> of acav_kmeans.hip launched alone on
+// Experiment harness (not product): the assign filter k_assign_f16_rw<NT, NW, GS> of acav_kmeans.hip launched alone on
 // synthetic rows, for timing-only ablations (-DACAV_ABL_NOMFMA / NOAFRAG / NOCDMA / NOXDMA) and tile-shape comparisons.
 // Labels are garbage under an ablation.  Build: tools/exp/build_assign.sh <name> [-D...]; run: ./<name> rows d K
 #include "../../acav100m_amd/csrc/acav_kmeans_assign.hip"
@@ -15,21 +15,21 @@ __global__ void k_fill(float *p, size_t n, unsigned seed)
         p[i] = (float)(int)(h & 0xffff) * (1.0f / 32768.0f) - 1.0f;
     }
 }
-__global__ void k_tobf(const float *c, __bf16 *o, size_t n)
+__global__ void k_tobf(const float *c, fl16 *o, size_t n)
 {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) o[i] = (__bf16)c[i];
+    if (i < n) o[i] = (fl16)c[i];
 }
 
 template <bool NT, int NW, bool GS, int DCR = 2, int SCHED = 0>
-static void bench(const char *name, const float *x, int64_t n, int d, int K, const __bf16 *cb, const float *cn, const float *counts,
+static void bench(const char *name, const float *x, int64_t n, int d, int K, const fl16 *cb, const float *cn, const float *counts,
                   const CentersAux *aux, int64_t *lab, int *rl, unsigned *rc, Top2Rec *grec)
 {
     const int ngroups = (K + 255) / 256;
     const int fsmem = FD_DX * NW * 4096 + DCR * FD_SLOT;
     const int64_t tile_rows = NW * 32, ntiles = (n + tile_rows - 1) / tile_rows;
     const int64_t grid = GS ? (ntiles + 7) / 8 * 8 * ngroups : ntiles;
-    auto kern = k_assign_bf16_rw<NT, NW, GS, DCR, SCHED>;
+    auto kern = k_assign_f16_rw<NT, NW, GS, DCR, SCHED>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, fsmem));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -71,7 +71,7 @@ int main(int argc, char **argv)
     const int64_t n = argc > 1 ? atoll(argv[1]) : 1000000;
     const int d = argc > 2 ? atoi(argv[2]) : 1024, K = argc > 3 ? atoi(argv[3]) : 1024;
     float *x, *c, *cn, *counts;
-    __bf16 *cb;
+    fl16 *cb;
     CentersAux *aux;
     int64_t *lab;
     int *rl;
@@ -92,7 +92,11 @@ int main(int argc, char **argv)
     hipLaunchKernelGGL(k_tobf, dim3((unsigned)(((size_t)K * d + 255) / 256)), dim3(256), 0, 0, c, cb, (size_t)K * d);
     hipLaunchKernelGGL(k_fill, dim3(4), dim3(256), 0, 0, cn, (size_t)K, 3u);
     hipLaunchKernelGGL(k_fill, dim3(4), dim3(256), 0, 0, counts, (size_t)K, 4u);
-    CK(hipMemset(aux, 0, sizeof(CentersAux)));
+    {  // scales of the half-precision operands: 1 (the harness's values are in [-1, 1))
+        CentersAux h{};
+        h.sx = h.sc = h.inv_ss = 1.0f;
+        CK(hipMemcpy(aux, &h, sizeof(h), hipMemcpyHostToDevice));
+    }
     CK(hipDeviceSynchronize());
     printf("rows %lld d %d K %d\n", (long long)n, d, K);
 #define B(...) bench<__VA_ARGS__>(#__VA_ARGS__, x, n, d, K, cb, cn, counts, aux, lab, rl, rc, grec)

@@ -4,7 +4,7 @@ prescribes.
 
 A sweep is several launches -- the bf16 filter over all rows, for K > 256 k_assign_merge, then the emission-pass
 instantiation of the filter, k_assign_cand and k_assign_f32 over the (usually empty) lists of undecided rows -- and TWO of
-them are instantiations of the same template (`k_assign_bf16_rw<..., 0>` over 1M rows, `<..., 1>` over a handful).  Round
+them are instantiations of the same template (`k_assign_f16_rw<..., 0>` (k_assign_bf16_rw before round 5) over 1M rows, `<..., 1>` over a handful).  Round
 4's version keyed the launches by the bare kernel name and averaged the two instantiations into one "mean per launch"
 (traffic 0.53 x algorithmic: impossible).  Now: every launch is keyed by its FULL instantiation, the number of sweeps is
 the launch count of the instantiation that moves the most bytes, and the traffic of a sweep is the sum over every launch
@@ -61,7 +61,7 @@ assert ratio >= 0.99, (f"traffic {traffic:.4g} B per sweep is below the algorith
 json.dump({
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-include-regex k_assign -- python tools/run_assign_only.py "
                f"{N} 5 filter {D} {K} (separate passes; tools/collect_profiles.sh)",
-    "kernel": "k_assign_bf16_rw (+ k_assign_merge for K > 256) + the launches over the undecided rows (emission-pass "
+    "kernel": "k_assign_f16_rw (+ k_assign_merge for K > 256) + the launches over the undecided rows (emission-pass "
               "instantiation, k_assign_cand, k_assign_f32: empty lists on this data)",
     "rows": N, "d": D, "K": K, "sweeps_in_the_pass": sweeps_f, "main_instantiation": main,
     "per_instantiation": per_launch,
