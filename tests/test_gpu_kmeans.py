@@ -291,8 +291,8 @@ def test_filter_half_precision_operands_any_data_scale(env, scale, K):
     the narrow exponent range of half does not matter: centres always (the copy holds sc c'), rows only when the data's own scale
     sits outside half's comfortable range (sx != 1: the XS instantiations).  Labels must equal the oracle's at EVERY data scale --
     1e-4 and 2e-7 (every element far below half's smallest normal: all of it would flush without the scaling), 3e4 (every element
-    beyond half's largest finite value), with K <= 256 and K > 256 -- and for rows with a few ENORMOUS elements (1e30: half has no
-    such number; the bound refuses the row and the exact path labels it), NaN-free."""
+    beyond half's largest finite value), with K <= 256 and K > 256 -- and for rows with a few ENORMOUS elements (10^9 x the data's scale: half has no
+    such number after any scaling; the bound refuses the row and the exact path labels it)."""
     torch, acav, O = env
     from acav100m_amd.clustering import KMeans
     rs = np.random.RandomState(int(K + 1000 * abs(np.log10(scale))))
@@ -303,8 +303,8 @@ def test_filter_half_precision_operands_any_data_scale(env, scale, K):
     x[:200] = centers[rs.randint(0, K, 200)] + (1e-4 * rs.randn(200, d)).astype(np.float32)  # near-ties for the re-check
     x = (x * np.float32(scale)).astype(np.float32)
     centers = (centers * np.float32(scale)).astype(np.float32)
-    x[7, 3] = np.float32(1e30) * np.float32(scale)   # outliers half cannot hold at any scale
-    x[8, :5] = np.float32(-3e29) * np.float32(scale)
+    x[7, 3] = np.float32(1e9) * np.float32(scale)    # outliers 10^9 x the data's scale: half cannot hold them whatever the scaling
+    x[8, :5] = np.float32(-3e8) * np.float32(scale)  # (fp32 itself still can: 1e30 would overflow ||x||^2 and the dots in fp32 too)
     counts = np.full(K, 1000, np.float32)
     count = 10 * K + 2000
     km = KMeans(None, d, K)
@@ -331,7 +331,7 @@ def test_filter_half_precision_operands_any_data_scale(env, scale, K):
 def test_candidate_restricted_recheck(env, mode, monkeypatch):
     """Round 4: a row the bf16 filter cannot decide is settled by the exact canonical distances of its CANDIDATE centres only
     (those the acceptance inequality cannot rule out against the filter's minimum; k_assign_cand), not by a sweep over all
-    K.  Heavily overlapping clusters (most rows undecided, a handful of candidates each): labels == the exact sweep on every
+    K.  Heavily overlapping clusters (a fifth of the rows undecided, a handful of candidates each): labels == the exact sweep on every
     row and == the oracle; the statistics show the candidate path did the work.  `pool_overflow`: a pair pool of 1 000
     entries -- the rows that do not fit take the full exact sweep, same labels.  `cand_off`: ACAV_ASSIGN_CAND=0 restores the
     round-3 behaviour.  `discounted`: under-used centres (distance / r, raw filter).  `many_ties`: 40 identical centres --
@@ -346,9 +346,11 @@ def test_candidate_restricted_recheck(env, mode, monkeypatch):
         monkeypatch.setenv("ACAV_ASSIGN_EMIT", "1")
     n, d, K = 40_000, 1024, 256
     rs = np.random.RandomState(21)
+    # centre spread << noise radius: the bf16 filter of rounds 1-4 left most of these rows undecided, the half-precision one a
+    # fifth (the fraction does not depend on the spread: gap and bound scale together -- tools/exp/recheck_spread_probe.py)
     cen = (0.02 * rs.randn(K, d)).astype(np.float32)
     x = (cen[rs.randint(0, K, n)] + 0.3 * rs.randn(n, d)).astype(np.float32)
-    centers = (cen + 0.004 * rs.randn(K, d)).astype(np.float32)  # centre spread << noise radius: most rows undecided
+    centers = (cen + 0.004 * rs.randn(K, d)).astype(np.float32)
     if mode == "many_ties":
         centers[100:140] = centers[7]
     counts = np.full(K, 1000, np.float32)
@@ -368,13 +370,13 @@ def test_candidate_restricted_recheck(env, mode, monkeypatch):
         assert rows == n and rechecked == cand_rows + full_rows
         print(f"{mode}: undecided {rechecked}/{n}: {cand_rows} rows by {cand_pairs} candidate pairs, {full_rows} by the full sweep")
         if mode in ("plain", "emission_pass"):
-            assert cand_rows > n // 4 and full_rows < cand_rows // 10 and cand_pairs >= cand_rows
+            assert cand_rows > n // 8 and full_rows < cand_rows // 10 and cand_pairs >= cand_rows
         if mode == "discounted":  # the raw (uncentred) filter's bound is wide: many rows exceed 16 candidates
             assert cand_rows > 0 and cand_rows + full_rows > n // 4
         if mode == "pool_overflow":
-            assert 0 < cand_rows < 1000 and full_rows > n // 4
+            assert 0 < cand_rows < 1000 and full_rows > n // 8
         if mode == "cand_off":
-            assert cand_rows == 0 and full_rows > n // 4
+            assert cand_rows == 0 and full_rows > n // 8
     ref = O.KMeans(d, K, O.Rng(0), centers=centers)
     ref.set_state(None, counts, count)
     idx = np.sort(rs.choice(n, 4096, replace=False))
