@@ -300,7 +300,7 @@ struct CentersAux {
     unsigned any_disc;    // some centre is under-used (distance / r): no centring
     unsigned amax_bits;   // bits of max_kj |c_kj| of the RAW centres: sets the scale of the rows (rows look like centres)
     unsigned amaxc_bits;  // bits of max_kj |c'_kj| of what the filter multiplies by (centred or raw): sets the centres' scale
-    float sx, sc;         // exact powers of two: the filter computes with fl16(sx x) and fl16(sc c'); amax sx, amaxc sc in [2^9, 2^10)
+    float sx, sc;         // exact powers of two: the filter computes with fl16(sx x) and fl16(sc c') (k_centers_scale)
     float inv_ss;         // 1 / (sx sc), exact: the accumulated dot is scaled back in the epilogue's fma
     float eA, eB;         // underflow terms of the acceptance bound: E += eA ||x|| + eB (k_centers_scale)
 };
@@ -365,42 +365,48 @@ __global__ __launch_bounds__(256) void k_centers_amaxc(const float *__restrict__
 }
 
 // The scales of the half-precision filter and the underflow terms of its bound (one thread).
-//   sx = 2^(9 - floor(log2 amax)), sc likewise from amaxc: the largest centre element lands in [2^9, 2^10) -- a row element may be
-//   64 x larger than the largest centre element before sx x leaves half's range (then filter_bound() refuses the row).
+//   sc = 2^(9 - floor(log2 amaxc)): the largest element of what the filter multiplies by lands in [2^9, 2^10) (known exactly: no
+//        headroom needed);
+//   sx = 1 while the largest RAW centre element (rows look like centres) sits in [2^-5, 2^6], else 2^(2 - floor(log2 amax)) -> amax sx
+//        in [4, 8): a row element may be ~10^3..10^4 x larger than the largest centre element before sx x leaves half's range
+//        (then filter_bound() refuses the row: noise-dominated rows over tiny centres are routine, tests/test_gpu_kmeans.py).
 // With x~ = fl16(sx x), c~ = fl16(sc c'):  an element inside half's NORMAL range [2^-14, 65504] is rounded with relative error
-// <= 2^-11; below 2^-14 the hardware may keep a subnormal (error <= 2^-25) or flush to zero (error < 2^-14): the bound charges
-// 2^-14 ABSOLUTE per such element, on either operand.  Hence, divided by sx sc,
+// <= 2^-11; below 2^-14 the result is a subnormal with ABSOLUTE error <= usub = 2^-25 -- on hardware that keeps half subnormals in
+// the conversions and in the MFMA's operands, which gfx950 does and half_subnormals_kept() verifies once per device with the
+// very instructions of this file (tools/exp/f16_denorm_probe.hip was the first look); hardware that flushed them would be charged
+// usub = 2^-14 (ACAV_FILTER_SUBNORMAL=0 forces that).  Hence, divided by sx sc,
 //   |dot~ - dot| <= (2^-10 + 2^-22) ||c'|| ||x||                       both roundings (e1c on the host side, with the fp32 accumulation)
-//                 + 2^-14 1.001 (||c'||_1 / sx  +  ||x||_1 / sc)        one operand under the normal range, the other rounded
-//                 + d 2^-28 / (sx sc)                                   both
+//                 + usub 1.001 (||c'||_1 / sx  +  ||x||_1 / sc)         one operand under the normal range, the other rounded
+//                 + d usub^2 / (sx sc)                                  both
 // and with ||v||_1 <= sqrt(d) ||v||, doubled for the -2 of the distance (2.02 as everywhere in the bound):
-//   eA = 2.02 * 2^-14 * 1.001 * sqrt(d) / sc                                   (x ||x||)
-//   eB = 2.02 * (2^-14 * 1.001 * sqrt(d) * cmax' / sx  +  d 2^-28 / (sx sc))
-// At the working point (amax sx ~ 2^9.5) these are 2^-23.5 sqrt(d) amax-sized: three to four orders below the rounding term.
-__global__ void k_centers_scale(CentersAux *__restrict__ aux, int d)
+//   eA = 2.02 * usub * 1.001 * sqrt(d) / sc                                   (x ||x||)
+//   eB = 2.02 * (usub * 1.001 * sqrt(d) * cmax' / sx  +  d usub^2 / (sx sc))
+// Against the rounding term 2^-10 cmax' ||x|| the row term of eB is 2^-15 sqrt(d) / (sx ||x||): under 1 % for d <= 2304 wherever
+// sx ||x|| >= 0.15, which both branches of sx guarantee for rows that look like the centres (||x|| >~ amax).  (Round 5's first
+// version charged the flush value 2^-14 unconditionally: with sx = 1 that was 4 / ||x|| of the rounding term at d = 1024 -- 40 % on
+// the candidate re-check test's data, 4 x the whole window for unit-norm rows.)
+__global__ void k_centers_scale(CentersAux *__restrict__ aux, int d, float usub)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    auto pow2_for = [](unsigned bits) -> float {
+    auto pow2_for = [](unsigned bits, int target) -> float {
         const float a = __uint_as_float(bits);
         if (!(a > 0.f) || !(a < 3.0e38f)) return 1.0f;
         int e;
         (void)frexpf(a, &e);          // a = m 2^e, m in [0.5, 1): floor(log2 a) = e - 1
-        int p = 9 - (e - 1);
+        int p = target - (e - 1);
         p = p > 100 ? 100 : (p < -100 ? -100 : p);
         return ldexpf(1.0f, p);
     };
-    // rows: no scaling (sx = 1: the multiply costs the filter 4-6 %) while the largest RAW centre element sits in [2^-5, 2^11] --
-    // a row element may then be 32 x larger before it leaves half's range, and elements below 2^-14 (< amax / 512) are charged
-    // through eA / eB like any other underflow.  Outside that window the rows are scaled like the centres.
+    // rows: no scaling (sx = 1: the multiply costs the filter 4-6 %) while the largest RAW centre element sits in [2^-5, 2^6]
     const float amax = __uint_as_float(aux->amax_bits);
-    const float sx = (amax >= 0.03125f && amax <= 2048.0f) ? 1.0f : pow2_for(aux->amax_bits);
-    const float sc = pow2_for(aux->amaxc_bits);
+    const float sx = (amax >= 0.03125f && amax <= 64.0f) ? 1.0f : pow2_for(aux->amax_bits, 2);
+    const float sc = pow2_for(aux->amaxc_bits, 9);
     const float cmaxc = __builtin_sqrtf(__uint_as_float(aux->cmaxc_bits));
     const float sd = __builtin_sqrtf((float)d) * 1.0001f;
     aux->sx = sx, aux->sc = sc;
     aux->inv_ss = (1.0f / sx) * (1.0f / sc);  // powers of two: exact
-    aux->eA = 2.02f * 6.1035156e-5f * 1.002f * sd / sc;
-    aux->eB = 2.02f * (6.1035156e-5f * 1.002f * sd * cmaxc / sx + (float)d * 3.7252903e-9f * 1.01f * (1.0f / sx) * (1.0f / sc));
+    aux->eA = 2.02f * usub * 1.002f * sd / sc;
+    aux->eB = 2.02f * (usub * 1.002f * sd * cmaxc / sx + (float)d * usub * usub * 1.01f * (1.0f / sx) * (1.0f / sc));
 }
 
 // one block per centre slot: the half-precision copy of sc c_k (or of sc (c_k - mu)) and the largest squared norm of what was
@@ -535,24 +541,112 @@ __device__ __forceinline__ void dma16_asm_v64_nt(const char *addr, unsigned lds)
 __device__ __forceinline__ bf16x8 cvt_bf16x8(float4 lo, float4 hi, float sx, bool scaled)
 {
     typedef float f32x2s __attribute__((ext_vector_type(2)));
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     f32x2s p0 = {lo.x, lo.y}, p1 = {lo.z, lo.w}, p2 = {hi.x, hi.y}, p3 = {hi.z, hi.w};
     if (scaled) {
         const f32x2s s2 = {sx, sx};
         p0 = p0 * s2, p1 = p1 * s2, p2 = p2 * s2, p3 = p3 * s2;
     }
-#ifdef ACAV_CVT_RTZ  // experiment: the legacy round-toward-zero pack conversion (is v_cvt_pk_f16_f32 the 5 %?)
-    typedef __fp16 g2 __attribute__((ext_vector_type(2)));
-    const g2 q0 = __builtin_amdgcn_cvt_pkrtz(p0.x, p0.y), q1 = __builtin_amdgcn_cvt_pkrtz(p1.x, p1.y);
-    const g2 q2 = __builtin_amdgcn_cvt_pkrtz(p2.x, p2.y), q3 = __builtin_amdgcn_cvt_pkrtz(p3.x, p3.y);
-    bf16x8 r = {(_Float16)q0.x, (_Float16)q0.y, (_Float16)q1.x, (_Float16)q1.y, (_Float16)q2.x, (_Float16)q2.y, (_Float16)q3.x, (_Float16)q3.y};
-    return r;
-#else
-    const h2 q0 = __builtin_convertvector(p0, h2), q1 = __builtin_convertvector(p1, h2);
-    const h2 q2 = __builtin_convertvector(p2, h2), q3 = __builtin_convertvector(p3, h2);
-    bf16x8 r = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
-    return r;
-#endif
+    // v_cvt_pk_f16_f32 written out, the four dwords bit-cast as a whole: hipcc 7.2's lowering of __builtin_convertvector(float2 ->
+    // half2) is right while the pair is consumed whole, but EXTRACTING element 1 of its result yields element 0 (seen twice:
+    // tools/exp/f16_denorm_probe.hip's `v_cvt_pk_f16_f32 v2, s8, s8`, and the first version of k_half_subnormal_check storing
+    // h[1] = h[0]) -- the product kernel was compiled correctly, by luck of the pattern; the asm form leaves nothing to luck.
+    typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+    u32x4s w;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w.x) : "v"(p0.x), "v"(p0.y));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w.y) : "v"(p1.x), "v"(p1.y));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w.z) : "v"(p2.x), "v"(p2.y));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w.w) : "v"(p3.x), "v"(p3.y));
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+// Does this device keep half-precision subnormals where the filter's bound assumes it (k_centers_scale: usub)?  One wave, the
+// instructions of the product path: the pack conversion of cvt_bf16x8 and the scalar conversion of k_centers_f16 on multiples of a
+// QUARTER of the subnormal spacing 2^-24 (every rounding case: exact, below / above half way, ties to even; the larger values
+// cross into the normal range), then v_mfma_f32_32x32x16_f16 with those subnormals as the A operand against 1024.0, and as the B
+// operand.  The host compares every half and every accumulator with the exact values.
+__global__ __launch_bounds__(64) void k_half_subnormal_check(unsigned short *__restrict__ halves, unsigned short *__restrict__ halves_scalar,
+                                                             float *__restrict__ acc_a, float *__restrict__ acc_b)
+{
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+    const int l = threadIdx.x;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (float)((l * 8 + q) * 33) * 1.4901161e-8f;  // (33 idx / 4) 2^-24: exact in fp32
+    const bf16x8 h = cvt_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), 1.0f, false);
+    const u32x4s hw = __builtin_bit_cast(u32x4s, h);
+    bf16x8 big;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        halves[l * 8 + q] = (unsigned short)(hw[q >> 1] >> (16 * (q & 1)));
+        halves_scalar[l * 8 + q] = __builtin_bit_cast(unsigned short, (fl16)v[q]);  // v_cvt_f16_f32: k_centers_f16's conversion
+        big[q] = (fl16)1024.0f;
+    }
+    f32x16 a = {0}, b = {0};
+    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, big, a, 0, 0, 0);  // out[i][j] = 1024 sum_k h(row i)[k]
+    b = __builtin_amdgcn_mfma_f32_32x32x16_f16(big, h, b, 0, 0, 0);  // out[i][j] = 1024 sum_k h(column j)[k]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_a[l * 16 + r] = a[r], acc_b[l * 16 + r] = b[r];
+}
+
+// -> 2^-25 when the device passed the check above (cached per device), 2^-14 (flush to zero charged) otherwise
+static int half_underflow_unit(int device, hipStream_t st, float *usub)
+{
+    static std::mutex mu;
+    static int state[64] = {0};  // 0 unknown, 1 kept, 2 not kept
+    *usub = 6.1035156e-5f;       // 2^-14
+    if (const char *v = getenv("ACAV_FILTER_SUBNORMAL"))
+        if (v[0] == '0') return ACAV_OK;
+    std::lock_guard<std::mutex> lock(mu);
+    const int slot = device >= 0 && device < 64 ? device : 63;
+    if (state[slot] == 0) {
+        const bool say = getenv("ACAV_FILTER_SUBNORMAL_DEBUG") != nullptr;
+        acav::DevBuf buf;
+        ACAV_TRY(buf.ensure(2 * 512 * sizeof(unsigned short) + 2 * 1024 * sizeof(float)));
+        unsigned short *hv = buf.as<unsigned short>(), *hs = hv + 512;
+        float *aa = reinterpret_cast<float *>(hs + 512), *ab = aa + 1024;
+        hipLaunchKernelGGL(k_half_subnormal_check, dim3(1), dim3(64), 0, st, hv, hs, aa, ab);
+        ACAV_HIP_TRY(hipGetLastError());
+        std::vector<unsigned short> h(1024);
+        std::vector<float> acc(2048);
+        ACAV_HIP_TRY(hipMemcpyAsync(h.data(), hv, 1024 * sizeof(unsigned short), hipMemcpyDeviceToHost, st));
+        ACAV_HIP_TRY(hipMemcpyAsync(acc.data(), aa, 2048 * sizeof(float), hipMemcpyDeviceToHost, st));
+        ACAV_HIP_TRY(hipStreamSynchronize(st));
+        auto dec = [](unsigned short b) {  // a non-negative finite half
+            const int e = (b >> 10) & 31, m = b & 1023;
+            return e ? ldexp(1024.0 + m, e - 25) : ldexp((double)m, -24);
+        };
+        bool ok = true;
+        for (int i = 0; i < 512 && ok; ++i) {
+            // value = (33 i / 4) units of 2^-24.  RNE to a count of units of the result's spacing: one unit while the count fits
+            // 11 bits (subnormals AND the first normal binade -- the encoding simply runs on), doubling beyond
+            const unsigned num = 33u * (unsigned)i;  // quarter units
+            unsigned sh = 2;                          // log2 (quarter units per unit of the result's spacing)
+            while ((num >> sh) > 2047u) ++sh;
+            unsigned q = num >> sh;
+            const unsigned rem = num & ((1u << sh) - 1u), halfway = 1u << (sh - 1);
+            if (rem > halfway || (rem == halfway && (q & 1u))) ++q;
+            const double want = ldexp((double)q, (int)sh - 2 - 24);
+            ok = dec(h[i]) == want && dec(h[512 + i]) == want && !(h[i] & 0x8000) && !(h[512 + i] & 0x8000);
+            if (!ok && say) fprintf(stderr, "half check: %u/4 units of 2^-24 -> pack 0x%04x scalar 0x%04x, want %g\n", num, h[i], h[512 + i], want);
+        }
+        for (int l = 0; l < 64 && ok; ++l)
+            for (int r = 0; r < 16 && ok; ++r) {
+                const int row = 8 * (r / 4) + 4 * (l / 32) + (r % 4), col = l % 32;  // accumulator layout of the 32x32 MFMA
+                double sa = 0, sb = 0;  // operand fragments: lanes i and i + 32 hold k = 0..7 and 8..15 of row / column i
+                for (int q = 0; q < 8; ++q) {
+                    sa += dec(h[row * 8 + q]) + dec(h[(row + 32) * 8 + q]);
+                    sb += dec(h[col * 8 + q]) + dec(h[(col + 32) * 8 + q]);
+                }
+                // 16 exact products of <= 12-bit counts, at most two binades apart: the sums are exact in fp32 in any order
+                ok = (double)acc[l * 16 + r] == 1024.0 * sa && (double)acc[1024 + l * 16 + r] == 1024.0 * sb;
+                if (!ok && say) fprintf(stderr, "half check: mfma lane %d reg %d: %g / %g, want %g / %g\n", l, r, acc[l * 16 + r], acc[1024 + l * 16 + r], 1024.0 * sa, 1024.0 * sb);
+            }
+        if (say) fprintf(stderr, "half check: device %d %s half subnormals\n", device, ok ? "keeps" : "does NOT keep");
+        state[slot] = ok ? 1 : 2;
+    }
+    if (state[slot] == 1) *usub = 2.9802322e-8f;  // 2^-25
+    return ACAV_OK;
 }
 
 #ifdef ACAV_RW_PROF  // tools/exp/assign_bench.hip only: per-stage phase cycles of k_assign_f16_rw (s_memtime)
@@ -1473,7 +1567,9 @@ int acav_kmeans::prepare_filter()
                        counts.as<float>(), K, dp, threshold(), cmu.as<float>(), caux.as<CentersAux>());
     hipLaunchKernelGGL(k_centers_amaxc, dim3((unsigned)K), dim3(256), 0, st, fc, cmu.as<float>(), dp, K, caux.as<CentersAux>());
     hipLaunchKernelGGL(k_centers_norm, dim3((unsigned)K), dim3(256), 0, st, fc, cmu.as<float>(), dp, K, caux.as<CentersAux>());
-    hipLaunchKernelGGL(k_centers_scale, dim3(1), dim3(64), 0, st, caux.as<CentersAux>(), dp);
+    float usub;
+    ACAV_TRY(half_underflow_unit(ctx.device, st, &usub));
+    hipLaunchKernelGGL(k_centers_scale, dim3(1), dim3(64), 0, st, caux.as<CentersAux>(), dp, usub);
     hipLaunchKernelGGL(k_centers_f16, dim3((unsigned)Kp), dim3(256), 0, st, fc, cmu.as<float>(), dp, K, Kp, cb16.as<fl16>(),
                        caux.as<CentersAux>());
     ACAV_HIP_TRY(hipGetLastError());

@@ -327,6 +327,39 @@ def test_filter_half_precision_operands_any_data_scale(env, scale, K):
     assert np.array_equal(km.calc_best(xt, need_mean=False)[0].cpu().numpy(), ref.calc_best(x)[0])
 
 
+@pytest.mark.parametrize("spread", [0.02, 0.006, 0.0004])
+def test_filter_underflow_unit_and_row_headroom(env, spread, monkeypatch):
+    """The half-precision filter's bound charges 2^-25 per operand element below half's normal range when the device keeps half
+    subnormals (checked once per device with the product's own instructions), 2^-14 when it is told to assume a flush
+    (ACAV_FILTER_SUBNORMAL=0): same labels, and never MORE undecided rows with the tighter unit.  Rows that are noise-dominated over
+    tiny centres (row elements 50 ... 750 x the largest centre element: the scaled-row instantiation at 0.006 and below) must not fall
+    off the filter wholesale -- the first round-5 version refused every row of the 0.006 case (scaled rows left half's range)."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    n, d, K = 20_000, 1024, 256
+    rs = np.random.RandomState(5)
+    cen = (spread * rs.randn(K, d)).astype(np.float32)
+    x = (cen[rs.randint(0, K, n)] + 0.3 * rs.randn(n, d)).astype(np.float32)
+    centers = (cen + 0.2 * spread * rs.randn(K, d)).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    und = {}
+    for unit in ("kept", "flush"):
+        if unit == "flush":
+            monkeypatch.setenv("ACAV_FILTER_SUBNORMAL", "0")
+        km = KMeans(None, d, K)
+        km.centers, km.counts, km.count = centers, np.full(K, 1000, np.float32), 10 * K + 200_000
+        km.to("cuda:0")
+        lab, _ = km.calc_best(xt, need_mean=False)
+        und[unit] = km.filter_stats()[2]
+        exact, _ = km.calc_best(xt)
+        assert torch.equal(lab, exact)
+    print(f"spread {spread}: undecided {und}")
+    assert und["kept"] <= und["flush"] and und["kept"] < n // 3
+    ref = O.KMeans(d, K, O.Rng(0), centers=centers)
+    ref.set_state(None, np.full(K, 1000, np.float32), 10 * K + 200_000)
+    assert np.array_equal(lab.cpu().numpy()[:2048], ref.calc_best(x[:2048])[0])
+
+
 @pytest.mark.parametrize("mode", ["plain", "pool_overflow", "cand_off", "discounted", "many_ties", "emission_pass"])
 def test_candidate_restricted_recheck(env, mode, monkeypatch):
     """Round 4: a row the bf16 filter cannot decide is settled by the exact canonical distances of its CANDIDATE centres only
