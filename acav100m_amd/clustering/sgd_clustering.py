@@ -226,7 +226,7 @@ class KMeans:
     # ---------------------------------------------------------------------- compute
     def calc_best(self, batch, need_mean=True):
         """sgd_clustering.py:63-79 -> (best LongTensor[b], mean of the minima).
-        need_mean=False (bulk assign): the library may take its HBM-bound bf16-filter + exact-re-check path
+        need_mean=False (bulk assign): the library may take its HBM-bound half-precision-filter + exact-re-check path
         (bit-identical labels); the second return value is then None."""
         import torch
         h = self._require_handle()

@@ -26,7 +26,7 @@ Other workloads (`--workload`, never the default: the driver's line stays on con
   cfg4   configs[3]: 10M clips / 8 = 1.25M clips per GPU, visual 2048-d + audio 128-d, K = 1024
   cfg5   configs[4]: 100M clips / 8 = 12.5M clips per GPU, two 1024-d views (102 GB resident), K = 1024, selection in
          chunks of 100 shards = 100k clips, 10 chunks in lockstep (computation.concurrent_chunks)
-Their `roofline` is quoted on the K = 1024 filter against the bf16 MFMA roof that binds there (intensity K/2 = 512 flop/B).
+Their `roofline` is quoted on the K = 1024 filter against the 16-bit (half / bf16: 2.5 PFLOP/s dense) MFMA roof that binds there (intensity K/2 = 512 flop/B).
   real10 the reference's REAL pipeline shape: ten clusterings over the 5 + 5 layer outputs of VGGish (64 / 128 / 256 / 512 / 128,
          models/vggish.py:20) and SlowFast (88 / 352 / 704 / 1408 / 2304, models/slowfast.py:31), K = 32 (config.py:41; --k 256),
          `combination` pairing P = 45, one chunk of 1M clips; `roofline` on the widest view's filter (2304-d, HBM-bound)
@@ -75,7 +75,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_COPY_GBS = 6290.0  # same guide: 6.29 TB/s measured with a float4 copy (79 % of the spec) -- context, not the roof
 HBM_MEASURED_READ_GBS = 7100.0  # profiles/r03_stream_bench.txt: read-only coalesced nt stream on this chip (0.888 of the spec)
-FILTER_DMA_SKELETON_MS = 0.75   # same file: the filter's two LDS-DMA streams (rows nt + bf16 centres from L2) with no compute, 1M x 1024
+FILTER_DMA_SKELETON_MS = 0.75   # same file: the filter's two LDS-DMA streams (rows nt + 16-bit centres from L2) with no compute, 1M x 1024
 EPOCHS = 2                 # clustering/code/config.py: clustering.epochs
 RATIO, BATCH_B, SELECT_K = 0.2, 20, 4   # subset_selection/code/config.py: subset.ratio, batch.*
 
@@ -536,7 +536,7 @@ def run_verify(torch, dist, world, rank, last, xs, labels, dims, k, sample=16384
 
 
 def assign_hard_variant(torch, lib, n, d, k, b, dev):
-    """The assign sweep on data the bf16 filter CANNOT decide everywhere (the timed workload's clusters are well separated:
+    """The assign sweep on data the half-precision filter CANNOT decide everywhere (the timed workload's clusters are well separated:
     0 rows undecided): centre spread 0.06 / 0.05 against the 0.3 noise, centres out of real training (tools/recheck_table.py's
     rows).  Undecided rows go through the emission pass + the exact evaluation of their candidate centres (k_assign_cand);
     labels are bit-identical to the exact sweep either way.  Measured once, outside the timed region."""

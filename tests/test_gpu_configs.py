@@ -99,7 +99,7 @@ def test_cfg1_full_pipeline_vs_oracle(env):
     assert np.array_equal(np.array(GAIN), r["GAIN"])
 
 
-@pytest.mark.parametrize("spread", [0.06, 0.25])
+@pytest.mark.parametrize("spread", [0.04, 0.05, 0.06, 0.25])
 def test_cfg2_filter_full_size_trained_centres(env, spread):
     """BASELINE configs[1] shape, the kernel the roofline is quoted on: 1M x 1024, K=256, centres that come out of
     real training on OVERLAPPING clusters (centre spread << noise radius), so the filter's acceptance test fails for

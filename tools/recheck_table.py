@@ -1,4 +1,4 @@
-"""Sweep time of KMeans.calc_best (bf16 filter + exact re-check) against the fraction of rows the filter cannot decide
+"""Sweep time of KMeans.calc_best (half-precision filter + exact re-check) against the fraction of rows the filter cannot decide
 (VERDICT r2 item 2): 1M x 1024, K = 256, centres out of real training, cluster overlap turned up step by step
 (centre spread relative to the 0.3 noise).  argv: [rows [d [spread,spread,...]]]"""
 import os

@@ -2,7 +2,7 @@
 HBM bytes of ONE sweep (acav_kmeans_assign over the whole partition), corrected as MI355X_MICROARCH.md (HBM section)
 prescribes.
 
-A sweep is several launches -- the bf16 filter over all rows, for K > 256 k_assign_merge, then the emission-pass
+A sweep is several launches -- the filter over all rows, for K > 256 k_assign_merge, then the emission-pass
 instantiation of the filter, k_assign_cand and k_assign_f32 over the (usually empty) lists of undecided rows -- and TWO of
 them are instantiations of the same template (`k_assign_f16_rw<..., 0>` (k_assign_bf16_rw before round 5) over 1M rows, `<..., 1>` over a handful).  Round
 4's version keyed the launches by the bare kernel name and averaged the two instantiations into one "mean per launch"
