@@ -97,6 +97,17 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
             sDisc[tid] = k < K ? (counts[k] < thr ? 1 : 0) : -1;
         }
         float4 xr[2], cr[8];
+        // !GUARD: the centre loads as (uniform 64-bit base of the stage) + (32-bit element offset of the thread's centre row): K d < 2^30
+        // elements (acav_kmeans_create), so the eight addresses cost eight registers instead of eight pairs -- with pairs the kernel
+        // spilled 39 dwords, and a kernel with ANY scratch makes its queue wait ~130 us for a scratch allocation the first time
+        unsigned coff[8];
+        if (!GUARD) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int k = kbase + srow + 32 * m;
+                coff[m] = (unsigned)(k < K ? k : K - 1) * (unsigned)d + (unsigned)(sq * 4);
+            }
+        }
         auto issue_loads = [&](int c) {
             const int j = c * AS_BK + sq * 4;
 #pragma unroll
@@ -110,13 +121,14 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
                     xr[m] = *reinterpret_cast<const float4 *>(x + (size_t)src * d + j);
                 }
             }
+            const float *cstage = centers + c * AS_BK;  // uniform
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const int k = kbase + srow + 32 * m;
                 if (GUARD)
                     cr[m] = ld4_guard(centers + (size_t)k * d, j, d, k < K, vec_ok);
                 else
-                    cr[m] = *reinterpret_cast<const float4 *>(centers + (size_t)(k < K ? k : K - 1) * d + j);
+                    cr[m] = *reinterpret_cast<const float4 *>(cstage + coff[m]);
             }
         };
         issue_loads(0);
@@ -186,16 +198,21 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
         __syncthreads();
 
         // epilogue: distances -> per-lane argmin over this wave's 64 centres, both row tiles
+        // (lane coordinates re-derived from a laundered copy of the thread index: what the epilogue addresses with must not stay
+        // live -- hoisted -- across the stage loop, where every register is taken)
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));
+        const int l31e = tid_e & 31, he = (tid_e >> 5) & 1;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            const float xn = sXn[rt * 32 + l31];
+            const float xn = sXn[rt * 32 + l31e];
             float bv = INFINITY;
             int bi = 0x7fffffff;
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int kl = (2 * wave + ct) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int kl = (2 * wave + ct) * 32 + (e & 3) + 8 * (e >> 2) + 4 * he;
                     const int disc = sDisc[kl];
                     if (disc >= 0) {
                         const float t = dist_epilogue(tot[ct][rt][e], xn, sCn[kl], disc != 0, r);
@@ -206,15 +223,15 @@ __global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__
             const float ov = __shfl_xor(bv, 32);
             const int oi = __shfl_xor(bi, 32);
             lexmin(bv, bi, ov, oi);
-            if (h == 0) {
-                sMinV[wave][rt * 32 + l31] = bv;
-                sMinI[wave][rt * 32 + l31] = bi;
+            if (he == 0) {
+                sMinV[wave][rt * 32 + l31e] = bv;
+                sMinI[wave][rt * 32 + l31e] = bi;
             }
         }
         __syncthreads();
-        if (tid < AS_ROWS) {
+        if (tid_e < AS_ROWS) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) lexmin(gbv, gbi, sMinV[w][tid], sMinI[w][tid]);
+            for (int w = 0; w < 4; ++w) lexmin(gbv, gbi, sMinV[w][tid_e], sMinI[w][tid_e]);
         }
         // the next group's first __syncthreads orders these reads before sMin* is rewritten
     }
@@ -775,7 +792,11 @@ struct Top2Rec {
 // outside half's comfortable range: k_centers_scale); XS = false carries no trace of it -- the multiply and the registers behind
 // it cost the K = 256 filter 4.5 % and pushed the product instantiation into scratch.
 template <bool NT, int NW, bool GS, int DCR = FD_DC, int SCHED = 0, int EMIT = 0, bool XS = false>
-__global__ __launch_bounds__(NW * 64, 2) void k_assign_f16_rw(const float *__restrict__ x, int64_t n, int d,
+// (second launch bound = waves per SIMD the register budget is cut for: 2 -> 256 registers, what two 128-row workgroups per CU need.
+// The emission-pass instantiations (EMIT == 1: 64-bit row addresses through a list, the candidate emission) need ~40 registers more
+// and took them from scratch; they only ever cover the undecided rows, so they get one wave per SIMD and the accumulation half of
+// the file instead -- no instantiation the library launches uses scratch, and a queue never waits for a scratch allocation)
+__global__ __launch_bounds__(NW * 64, EMIT == 1 ? 1 : 2) void k_assign_f16_rw(const float *__restrict__ x, int64_t n, int d,
                                                             const fl16 *__restrict__ cb, const float *__restrict__ cn,
                                                             const float *__restrict__ counts, int K, float thr, float r,
                                                             const CentersAux *__restrict__ aux, float e1c, float e1r, float e2coef,
@@ -1811,7 +1832,11 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
             if (!emit_inplace || emit_gs) {
                 // one workgroup per CU either way (rings + lists do not fit twice): for K > 256 and wide rows the 8-wave /
                 // 256-row tile of the main kernel (centre ring 3, DMA pieces spread), else 4 waves / 128 rows
-                const int enw = emit_gs && nw == 8 ? 8 : 4;
+                // (round 5: 4 waves by default everywhere -- the 8-wave instantiations cannot have one wave per SIMD and keep 156-172 B of
+                // scratch, and a queue waits ~130 us for a scratch allocation the first time a kernel with scratch runs on it;
+                // ACAV_EMIT_NW=8 selects them for A/B runs)
+                const char *venw = getenv("ACAV_EMIT_NW");
+                const int enw = emit_gs && nw == 8 && venw && venw[0] == '8' ? 8 : 4;
                 const bool xs = km->filter_rows_scaled;
                 FilterKern ek = enw == 8 ? (xs ? k_assign_f16_rw<true, 8, false, 3, 2, 1, true> : nt ? k_assign_f16_rw<true, 8, false, 3, 2, 1> : k_assign_f16_rw<false, 8, false, 3, 2, 1>)
                                          : (xs ? k_assign_f16_rw<true, 4, false, 2, 0, 1, true> : nt ? k_assign_f16_rw<true, 4, false, 2, 0, 1> : k_assign_f16_rw<false, 4, false, 2, 0, 1>);

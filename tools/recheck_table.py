@@ -14,7 +14,7 @@ import acav100m_amd
 from acav100m_amd import _lib
 from acav100m_amd.clustering import KMeans
 
-n, d, K, b = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, int(sys.argv[2]) if len(sys.argv) > 2 else 1024, 256, 32
+n, d, K, b = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, int(sys.argv[2]) if len(sys.argv) > 2 else 1024, int(os.environ.get("RECHECK_K", 256)), 32
 spreads = [float(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else (1.0, 0.25, 0.12, 0.09, 0.07, 0.06, 0.05, 0.04)
 print("| centre spread | rows undecided | fraction | filter kernel ms | whole sweep ms | of 8 TB/s (sweep) | settled by candidates: rows / pairs | by the full sweep |")
 print("|---|---|---|---|---|---|---|---|")
