@@ -563,16 +563,19 @@ __device__ __forceinline__ bf16x8 cvt_bf16x8(float4 lo, float4 hi, float sx, boo
         const f32x2s s2 = {sx, sx};
         p0 = p0 * s2, p1 = p1 * s2, p2 = p2 * s2, p3 = p3 * s2;
     }
-    // v_cvt_pk_f16_f32 written out, the four dwords bit-cast as a whole: hipcc 7.2's lowering of __builtin_convertvector(float2 ->
-    // half2) is right while the pair is consumed whole, but EXTRACTING element 1 of its result yields element 0 (seen twice:
+    // Four v_cvt_pk_f16_f32 (RNE).  Each float2 -> half2 pair is bit-cast to a dword AS A WHOLE: hipcc 7.2 lowers the vector conversion
+    // correctly while the pair is consumed whole, but EXTRACTING element 1 of its result yields element 0 (seen twice:
     // tools/exp/f16_denorm_probe.hip's `v_cvt_pk_f16_f32 v2, s8, s8`, and the first version of k_half_subnormal_check storing
-    // h[1] = h[0]) -- the product kernel was compiled correctly, by luck of the pattern; the asm form leaves nothing to luck.
+    // h[1] = h[0]).  (An inline-asm v_cvt_pk_f16_f32 instead was WRONG in the XS instantiations with 8 waves: a third of the labels
+    // of a 3 000-row test, nondeterministically -- the hazard recogniser does not look into inline asm next to the packed multiplies;
+    // found by tools/stress_parity.py once it varied the data's scale.  NOTES_r05 section 14.)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
     u32x4s w;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w.x) : "v"(p0.x), "v"(p0.y));
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w.y) : "v"(p1.x), "v"(p1.y));
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w.z) : "v"(p2.x), "v"(p2.y));
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w.w) : "v"(p3.x), "v"(p3.y));
+    w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(p0, h2));
+    w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(p1, h2));
+    w.z = __builtin_bit_cast(unsigned, __builtin_convertvector(p2, h2));
+    w.w = __builtin_bit_cast(unsigned, __builtin_convertvector(p3, h2));
     return __builtin_bit_cast(bf16x8, w);
 }
 

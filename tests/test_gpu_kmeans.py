@@ -327,6 +327,41 @@ def test_filter_half_precision_operands_any_data_scale(env, scale, K):
     assert np.array_equal(km.calc_best(xt, need_mean=False)[0].cpu().numpy(), ref.calc_best(x)[0])
 
 
+@pytest.mark.parametrize("d,K,switch", [(1024, 300, None), (128, 257, None), (1024, 200, ("ACAV_FILTER_NW", "8")),
+                                        (1024, 200, ("ACAV_ASSIGN_EMIT", "1")), (1024, 600, ("ACAV_FILTER_GS", "0")),
+                                        (1024, 300, ("ACAV_EMIT_NW", "8")), (96, 1024, None)])
+@pytest.mark.parametrize("scale", [2.0 ** -20, 1e3])
+def test_filter_scaled_rows_every_instantiation(env, d, K, switch, scale, monkeypatch):
+    """The scaled-row (XS) instantiations of EVERY tile form of the filter -- 8 waves / (tile, group) pairs (K > 256, wide rows), 4-wave
+    pairs (narrow rows), 8 waves with K <= 256, the emission pass, the group loop -- on overlapping mixtures (a tenth of the rows
+    undecided, candidates emitted) at data scales that switch the row scaling on.  An inline-asm pack conversion in round 5 was wrong
+    exactly here (a third of the labels with 8 waves, a handful with 4-wave pairs; right in the default K <= 256 form, which is all the
+    tests of that day covered): found by tools/stress_parity.py when it began to vary the data's scale."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    if switch:
+        monkeypatch.setenv(*switch)
+    n = 3000
+    rs = np.random.RandomState(5)
+    cen0 = rs.randn(K, d).astype(np.float32)
+    x = ((cen0[rs.randint(0, K, n)] + rs.randn(n, d).astype(np.float32)) * np.float32(scale)).astype(np.float32)
+    centers = ((rs.randn(K, d).astype(np.float32)[rs.randint(0, K, K)] + rs.randn(K, d).astype(np.float32)) * np.float32(scale)).astype(np.float32)
+    counts = np.full(K, 500, np.float32)
+    km = KMeans(None, d, K)
+    km.centers, km.counts, km.count = centers, counts, 10 * K + int(counts.sum())
+    km.to("cuda:0")
+    xt = torch.from_numpy(x).cuda()
+    ref = O.KMeans(d, K, O.Rng(0), centers=centers)
+    ref.set_state(None, counts, 10 * K + int(counts.sum()))
+    want = ref.calc_best(x)[0]
+    for rep in range(2):
+        lab, _ = km.calc_best(xt, need_mean=False)
+        assert km.filter_stats()[0] == rep + 1, "the filter did not run"
+        bad = int((lab.cpu().numpy() != want).sum())
+        assert bad == 0, f"{bad} of {n} labels differ from the oracle (undecided {km.filter_stats()[2]}, re-check {km.recheck_stats()})"
+    assert np.array_equal(km.calc_best(xt)[0].cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("spread", [0.02, 0.006, 0.0004])
 def test_filter_underflow_unit_and_row_headroom(env, spread, monkeypatch):
     """The half-precision filter's bound charges 2^-25 per operand element below half's normal range when the device keeps half

@@ -44,6 +44,12 @@ def stress(seed=0, budget=60.0, max_cases=None):
             km = KMeans(None, d, k).to("cuda:0")
             ref = O.KMeans(d, k, O.Rng(s))
             cen = (mixture(k, d, k, 1.0) + offset).astype(np.float32)
+            # the data's overall scale (round 5: half-precision filter operands with exact power-of-two scaling; rows and centres at
+            # 1e-6 are all below half's smallest normal, at 3e4 all above its largest finite value) and, sometimes, centres that are
+            # much smaller than the rows (noise-dominated rows: the row scale is taken from the centres)
+            scale = np.float32(rs.choice([1.0, 1.0, 1e-3, 1e3, 1e-6, 3e4]))
+            x = (x * scale).astype(np.float32)
+            cen = (cen * scale * np.float32(rs.choice([1.0, 1.0, 1.0, 0.02]))).astype(np.float32)
             cnts = rs.randint(0, 50, k).astype(np.float32) if rs.rand() < 0.5 else np.full(k, 500, np.float32)
             km.centers, km.counts, km.count = cen, cnts, 10 * k + int(cnts.sum())
             ref.set_state(cen, cnts, 10 * k + int(cnts.sum()))
@@ -51,7 +57,9 @@ def stress(seed=0, budget=60.0, max_cases=None):
             want = ref.calc_best(x)[0]
             a, _ = km.calc_best(xt, need_mean=False)
             b, _ = km.calc_best(xt, need_mean=True)
-            assert np.array_equal(a.cpu().numpy(), want) and np.array_equal(b.cpu().numpy(), want), ("assign", n, d, k, s)
+            bad_a, bad_b = int((a.cpu().numpy() != want).sum()), int((b.cpu().numpy() != want).sum())
+            assert bad_a == 0 and bad_b == 0, ("assign", n, d, k, s, "scale", float(scale), "offset", offset, "labels that differ: filter path",
+                                               bad_a, "exact path", bad_b, "undecided", km.filter_stats())
             counts["assign"] += 1
         elif which == 1:  # bulk training
             d = int(rs.choice([8, 30, 64, 88, 128, 130, 256, 352, 704, 1000, 1024, 1280, 1408, 2048]))  # 1280 / 2048 with K >= 512: the column-split kernel
