@@ -327,18 +327,22 @@ def test_filter_half_precision_operands_any_data_scale(env, scale, K):
     assert np.array_equal(km.calc_best(xt, need_mean=False)[0].cpu().numpy(), ref.calc_best(x)[0])
 
 
+@pytest.mark.parametrize("K", [2, 300])
 @pytest.mark.parametrize("scale", [1.0, 2.0 ** -18])
-def test_filter_bound_against_aligned_worst_case_roundings(env, scale):
+def test_filter_bound_against_aligned_worst_case_roundings(env, scale, K):
     """Random data never comes near the filter's acceptance bound (a dot's rounding errors add up like a random walk, ~sqrt(d) below
     the worst case) -- which is how a bound HALF as large as the proof needs survived four rounds of tests.  This data is built so
     that every operand rounding of the half-precision filter pushes the same way: 448 coordinates with x = c' = 1 + 2^-11 (a tie,
     rounds DOWN to 1), 448 with x = -c' = 1 + 3 2^-11 (a tie, rounds UP to 1 + 2^-9), and 128 exactly representable coordinates that
     move the TRUE x.c' across zero from row to row.  Two centres +c', -c' (mean 0: the centred copy is c' itself, equal norms).  For
     ~220 rows the filter's own distances name the WRONG centre with an apparent gap of up to 0.87 of twice the proven bound: they
-    must all come out undecided and be labelled by the exact path.  A leading constant a factor 2 too small accepts ~90 of them."""
+    must all come out undecided and be labelled by the exact path.  A leading constant a factor 2 too small accepts ~90 of them.
+    K = 300 (the (tile, group) pair kernel, k_assign_merge and the emission pass): 149 more pairs +-w of centres, w = +-1.25 in a sign
+    pattern that is balanced inside both rounding blocks (x.w = 0 exactly, every partial sum of the mean exact: the centred copy is
+    still c' to the bit) and 376 further away than the two that matter."""
     torch, acav, O = env
     from acav100m_amd.clustering import KMeans
-    d, K = 1024, 2
+    d = 1024
     e = 2.0 ** -11
     cp = np.concatenate([np.full(448, 1 + e), np.full(448, -(1 + 3 * e)), np.ones(128)]).astype(np.float32)
     ms = np.arange(0, 2000, 2)  # row i: the exact block holds m 2^-16 (a half number); true tie at m = 448.4, the filter's at m = 896.9;
@@ -348,7 +352,14 @@ def test_filter_bound_against_aligned_worst_case_roundings(env, scale):
     x[:, :448], x[:, 448:896] = 1 + e, 1 + 3 * e
     x[:, 896:] = (ms * 2.0 ** -16)[:, None]
     x[1::2] *= -1  # every other row mirrored: the other centre wins
-    centers = (np.stack([cp, -cp]) * np.float32(scale)).astype(np.float32)
+    cen = [cp, -cp]
+    rs = np.random.RandomState(3)
+    for _ in range((K - 2) // 2):
+        w = np.zeros(d, np.float32)
+        w[:448] = 1.25 * rs.permutation(np.repeat([1.0, -1.0], 224))
+        w[448:896] = 1.25 * rs.permutation(np.repeat([1.0, -1.0], 224))
+        cen += [w, -w]
+    centers = (np.stack(cen) * np.float32(scale)).astype(np.float32)
     x = (x * np.float32(scale)).astype(np.float32)
     # what an unguarded half-precision filter would say, and the truth (float64)
     x16, c16 = (x / np.float32(scale)).astype(np.float16).astype(np.float64), cp.astype(np.float16).astype(np.float64)
@@ -370,7 +381,10 @@ def test_filter_bound_against_aligned_worst_case_roundings(env, scale):
     assert np.array_equal(got, want), f"{int((got != want).sum())} labels differ from the oracle"
     assert np.array_equal(want, truth)  # (no row of this sweep is a float32-level tie)
     assert fooled <= undecided < n - 200, (undecided, fooled)  # ... and the far ends of the sweep were decided by the filter
-    print(f"scale {scale}: {fooled} rows whose filter distances name the wrong centre, {undecided} of {n} undecided")
+    if K > 2:
+        cand_rows, cand_pairs, full_rows = km.recheck_stats()
+        assert cand_rows + full_rows == undecided and cand_pairs >= 2 * cand_rows  # both centres of the pair are candidates of every such row
+    print(f"scale {scale} K {K}: {fooled} rows whose filter distances name the wrong centre, {undecided} of {n} undecided")
 
 
 @pytest.mark.parametrize("d,K,switch", [(1024, 300, None), (128, 257, None), (1024, 200, ("ACAV_FILTER_NW", "8")),
