@@ -102,7 +102,8 @@ struct StreamCtx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int init(int dev, void *user_stream);
+    // priority_class: 0 = default stream priority, +1 = the device's highest, -1 = its lowest (own streams only)
+    int init(int dev, void *user_stream, int priority_class = 0);
     void fini();
     int timer_begin();
     int timer_end(float *ms);

@@ -121,7 +121,7 @@ int from_device(void *dst, const void *src_dev, size_t bytes, hipStream_t stream
     return ACAV_OK;
 }
 
-int StreamCtx::init(int dev, void *user_stream)
+int StreamCtx::init(int dev, void *user_stream, int priority_class)
 {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -137,7 +137,13 @@ int StreamCtx::init(int dev, void *user_stream)
         stream = static_cast<hipStream_t>(user_stream);
         own_stream = false;
     } else {
-        ACAV_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (priority_class == 0) {
+            ACAV_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        } else {  // (see acav_mi_create: a priority class has its own pool of hardware queues)
+            int lo = 0, hi = 0;
+            ACAV_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            ACAV_HIP_TRY(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, priority_class > 0 ? hi : lo));
+        }
         own_stream = true;
     }
     ACAV_HIP_TRY(hipEventCreate(&ev0));

@@ -1674,7 +1674,20 @@ ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignm
     }
     acav_mi *mi = new (std::nothrow) acav_mi;
     ACAV_REQUIRE(mi, ACAV_ENOMEM, "out of host memory");
-    int rc = mi->ctx.init(device, stream);
+    // The greedy loop runs on three streams (content: gather + select per iteration; positions: the Fisher-Yates kernels, groups ahead;
+    // generator).  They need three different hardware queues: two of them on one queue and the loop takes 43.5 us per iteration
+    // instead of 31, all three on one 48.8 (GPU_MAX_HW_QUEUES = 2 / 1, V = 10^6) -- and which queue a stream gets depends on every
+    // other stream the process has created and destroyed (bench.py once lost a third of its MI speed to two idle k-means handles
+    // that outlived their pass: NOTES_r05 section 13).  The runtime keeps one pool of hardware queues PER PRIORITY CLASS, so three
+    // streams in three classes are on three queues whatever the process's history: ACAV_MI_STREAM_PRIO=hnl (classes of the content /
+    // position / generator stream) does that -- 30.9 us even with GPU_MAX_HW_QUEUES=1.  It is NOT the default: chunks in lockstep run
+    // 40 % slower with any non-default class on any of the three (5.1-5.6 vs 3.7 us per chunk-iteration, all six assignments), and
+    // a fresh process -- the CLI's case -- places three consecutively created streams on three queues anyway.
+    const char *vprio = getenv("ACAV_MI_STREAM_PRIO");
+    const bool prio = vprio && strlen(vprio) == 3;
+    const char *pmap = prio ? vprio : "nnn";  // three letters h / n / l
+    auto cls = [](char ch) { return ch == 'h' ? 1 : ch == 'l' ? -1 : 0; };
+    int rc = mi->ctx.init(device, stream, prio ? cls(pmap[0]) : 0);
     if (rc != ACAV_OK) {
         delete mi;
         return rc;
@@ -1714,7 +1727,10 @@ ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignm
     };
     rc = body();
     if (rc == ACAV_OK) {
-        bool ok = hipStreamCreateWithFlags(&mi->st_mt, hipStreamNonBlocking) == hipSuccess;
+        int plo = 0, phi = 0;
+        bool ok = hipDeviceGetStreamPriorityRange(&plo, &phi) == hipSuccess;
+        ok = ok && (prio ? hipStreamCreateWithPriority(&mi->st_mt, hipStreamNonBlocking, cls(pmap[2]) > 0 ? phi : cls(pmap[2]) < 0 ? plo : (plo + phi) / 2)
+                         : hipStreamCreateWithFlags(&mi->st_mt, hipStreamNonBlocking)) == hipSuccess;
         for (int q = 0; q < 2 && ok; ++q)
             ok = hipEventCreateWithFlags(&mi->ev_mt[q], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&mi->ev_used[q], hipEventDisableTiming) == hipSuccess;
@@ -1724,7 +1740,12 @@ ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignm
         }
     }
     if (rc == ACAV_OK) {
-        bool ok = hipStreamCreateWithFlags(&mi->st_fy, hipStreamNonBlocking) == hipSuccess;
+        // (a caller's own stream for the content path is most likely of the default class: the position stream goes up instead)
+        int plo = 0, phi = 0;
+        bool ok = hipDeviceGetStreamPriorityRange(&plo, &phi) == hipSuccess;
+        const int cfy = stream ? 1 : cls(pmap[1]);
+        ok = ok && (prio ? hipStreamCreateWithPriority(&mi->st_fy, hipStreamNonBlocking, cfy > 0 ? phi : cfy < 0 ? plo : (plo + phi) / 2)
+                         : hipStreamCreateWithFlags(&mi->st_fy, hipStreamNonBlocking)) == hipSuccess;
         for (int q = 0; q < FY_NBUF && ok; ++q)
             ok = hipEventCreateWithFlags(&mi->ev_tile[q], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&mi->ev_gather[q], hipEventDisableTiming) == hipSuccess;
