@@ -482,7 +482,8 @@ def main():
         }
         if not args.no_variants and world == 1 and chunk is None and n >= 200_000:
             out["variants"] = {"chunked_lockstep": chunked_variant(last["a"], types, n, st)}
-            out["roofline"]["back_to_back"] = back_to_back_sweeps(lib, last["kms"][vq], xs[vq], labels[vq], n, bytes_per_launch)
+            if not mfma_bound:  # (an HBM figure: the K = 256 shapes)
+                out["roofline"]["back_to_back"] = back_to_back_sweeps(lib, last["kms"][vq], xs[vq], labels[vq], n, bytes_per_launch)
         if not args.no_variants and world == 1 and k <= 256:
             del xs
             torch.cuda.empty_cache()
