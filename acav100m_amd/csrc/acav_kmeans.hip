@@ -1739,6 +1739,8 @@ ACAV_EXPORT int acav_kmeans_create(acav_kmeans **out, int device, int k, int d, 
     ACAV_REQUIRE(out && centers0, ACAV_EINVAL, "NULL argument");
     ACAV_REQUIRE(k > 0 && d > 0, ACAV_EINVAL, "k and d must be positive (k=%d d=%d)", k, d);
     ACAV_REQUIRE(d <= 16384, ACAV_EINVAL, "d=%d exceeds the supported 16384", d);
+    // (the assign kernels address a centre row as a 32-bit element offset from the matrix: 4 GB of centres is far beyond any use)
+    ACAV_REQUIRE((int64_t)k * d <= ((int64_t)1 << 30), ACAV_EINVAL, "k * d = %lld exceeds the supported 2^30 elements", (long long)k * d);
     acav_kmeans *km = new (std::nothrow) acav_kmeans;
     ACAV_REQUIRE(km, ACAV_ENOMEM, "out of host memory");
     int rc = km->ctx.init(device, stream);
