@@ -99,6 +99,24 @@ SIGNATURES = {
 }
 
 _lib = None
+# entry points that are necessarily the first device call of a handle's life (everything else needs a handle):
+# calling one marks the HIP runtime as initialised for acav100m_amd.configure_runtime()
+_FIRST_DEVICE_CALLS = ("acav_device_count", "acav_device_info", "acav_kmeans_create", "acav_mi_create",
+                       "acav_contrastive_create", "acav_comm_init")
+_device_touched = False
+
+
+def device_touched():
+    return _device_touched
+
+
+def _marking(fn):
+    def call(*args):
+        global _device_touched
+        _device_touched = True
+        return fn(*args)
+    call.argtypes, call.restype, call.__name__ = fn.argtypes, fn.restype, fn.__name__
+    return call
 
 
 class AcavError(RuntimeError):
@@ -126,6 +144,8 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError here = header/library drift
         fn.restype = i32
         fn.argtypes = args
+    for name in _FIRST_DEVICE_CALLS:
+        setattr(lib, name, _marking(getattr(lib, name)))
     _lib = lib
     return lib
 

@@ -46,6 +46,8 @@ def main(argv=None):
     children -- it binds to its GPU (LOCAL_RANK) and joins the process group before anything else."""
     argv = sys.argv[1:] if argv is None else list(argv)
     command, kwargs = parse_cli(argv)
+    from .. import configure_runtime
+    configure_runtime()  # hardware queues for side-by-side clusterings: before the first device call of the process
     from ..parallel import launch
     if launch.env_world() is None:
         want = kwargs.get('computation.num_gpus')

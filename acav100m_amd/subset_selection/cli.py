@@ -94,6 +94,8 @@ def main(argv=None):
     there."""
     argv = sys.argv[1:] if argv is None else list(argv)
     command, kwargs = parse_cli(argv)
+    from .. import configure_runtime
+    configure_runtime()  # hardware queues for side-by-side clusterings: before the first device call of the process
     from ..parallel import launch
     if launch.env_world() is None:
         if command == 'run' and kwargs.get('chunk_size') is not None:

@@ -252,7 +252,8 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime initialises: see acav100m_amd/__init__.py
+    import acav100m_amd
+    acav100m_amd.configure_runtime()  # GPU_MAX_HW_QUEUES, before the HIP runtime initialises
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))

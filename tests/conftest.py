@@ -8,6 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+import acav100m_amd  # noqa: E402
+
+acav100m_amd.configure_runtime(quiet=True)  # the setting the CLIs and bench.py run with (explicit; import alone sets nothing)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

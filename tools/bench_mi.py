@@ -10,6 +10,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import acav100m_amd
+acav100m_amd.configure_runtime(quiet=True)
 from acav100m_amd.subset_selection import get_measure
 
 v = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000

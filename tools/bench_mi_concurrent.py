@@ -12,6 +12,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import acav100m_amd
+acav100m_amd.configure_runtime(quiet=True)
 from acav100m_amd.rng import Generator
 from acav100m_amd.subset_selection import get_measure
 

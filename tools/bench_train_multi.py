@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import acav100m_amd
+acav100m_amd.configure_runtime(quiet=True)
 from acav100m_amd import _lib
 from acav100m_amd.clustering import KMeans
 

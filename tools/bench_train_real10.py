@@ -6,7 +6,8 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import acav100m_amd  # (sets GPU_MAX_HW_QUEUES before the runtime starts)
+import acav100m_amd
+acav100m_amd.configure_runtime(quiet=True)
 import torch
 from acav100m_amd.clustering import KMeans
 

@@ -3,6 +3,7 @@ one dense exact tile per k1 group over that union and assumes ~32 centres.)  Dat
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import acav100m_amd
+acav100m_amd.configure_runtime(quiet=True)
 import numpy as np, torch
 from acav100m_amd.clustering import KMeans
 dev = "cuda:0"

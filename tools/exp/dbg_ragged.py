@@ -2,6 +2,7 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import acav100m_amd
+acav100m_amd.configure_runtime(quiet=True)
 from acav100m_amd.clustering import KMeans
 from oracle import oracle as O
 rs = np.random.RandomState(1)

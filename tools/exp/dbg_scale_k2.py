@@ -2,6 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import acav100m_amd
+acav100m_amd.configure_runtime(quiet=True)
 from acav100m_amd.clustering import KMeans
 def mixture(rs, n, d, k, spread):
     cen = rs.randn(k, d).astype(np.float32) * spread

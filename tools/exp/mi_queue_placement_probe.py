@@ -5,6 +5,7 @@ import itertools, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import acav100m_amd
+acav100m_amd.configure_runtime(quiet=True)
 from acav100m_amd.clustering import KMeans
 from acav100m_amd.subset_selection import get_measure
 keep = os.environ.get("KEEP") == "1"

@@ -4,6 +4,7 @@ import itertools, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import acav100m_amd
+acav100m_amd.configure_runtime(quiet=True)
 from acav100m_amd.subset_selection import get_measure
 extra = int(os.environ.get("MI_EXTRA_STREAMS", "0"))
 keep = []

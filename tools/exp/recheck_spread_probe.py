@@ -2,6 +2,7 @@
 import numpy as np, torch, sys
 sys.path.insert(0, ".")
 import acav100m_amd as acav
+acav100m_amd.configure_runtime(quiet=True)
 from acav100m_amd.clustering import KMeans
 n, d, K = 40_000, 1024, 256
 for spread in (0.016, 0.013, 0.011, 0.0095, 0.008, 0.007):

@@ -4,6 +4,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import acav100m_amd
+acav100m_amd.configure_runtime(quiet=True)
 from acav100m_amd import _lib
 from acav100m_amd.clustering import KMeans
 lib = acav100m_amd.load_library()

@@ -11,6 +11,7 @@ import ctypes as C
 import torch
 
 import acav100m_amd
+acav100m_amd.configure_runtime(quiet=True)
 from acav100m_amd import _lib
 from acav100m_amd.clustering import KMeans
 

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 import acav100m_amd
+acav100m_amd.configure_runtime(quiet=True)
 from acav100m_amd.clustering import KMeans
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
