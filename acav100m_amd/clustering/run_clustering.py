@@ -4,9 +4,12 @@ restructured for a 288 GB-HBM GPU: the feature shards are read once into residen
 synchronisation per step), then one assign sweep per view labels all rows; the reference's per-row
 dict / pkl schema only exists at the file boundary (acav100m_amd/shards.py).
 
-Same observable behaviour as the reference with a single-stream loader (--computation.num_workers=0):
+Same observable behaviour as the reference:
   * KMeans objects are created in args.models order, layer by layer (RNG order of run_clustering.py:32-44)
-  * per batch of 32 consecutive rows, every clustering takes one add() -- the warm-up draws are
+  * the training batches are the ones the reference's DataLoader delivers for the configured computation.num_workers
+    (default 40: whole batches round-robin over worker shard subsets, data/clustering.py:17-66,212-228; 0: one stream),
+    every stream cut / cycled to get_length() samples (parallel/row_plan.py: loader_stream; data.loader_order / loader_tail)
+  * per batch, every clustering takes one add() -- the warm-up draws are
     interleaved across clusterings exactly like the reference's per-batch loop (:229-241)
   * lr = 0.1 ** (2 + epoch // 5), drop_last batches; several GPUs: clustering.multi_gpu (config.py) -- `views` keeps the
     one-GPU batch stream and epoch count, `reference` is the reference's own N-GPU stream with ceil(epochs / num_gpus) epochs
@@ -168,6 +171,7 @@ class _RowGroups:
         nw = int(nw) if nw is not None else int(args.computation.num_workers or 0)
         self.workers = max(0, min(nw, os.cpu_count() or 1))
         self.sizes, self.view_dims = sizes, view_dims
+        self.paths, self.row_bytes, self.budget = list(paths), int(row_bytes), int(budget)
         self._pool_warm = False
         total = sum(sizes[p.stem] for p in paths) * row_bytes
         if total <= budget:
@@ -191,6 +195,109 @@ class _RowGroups:
     @property
     def streamed(self):
         return len(self.groups) > 1
+
+    def iterate_stream(self, paths, extents, lb, row_bytes, budget, views=None):
+        """Training order: -> (table, {view: device tensor [rows, d]}) per ROW GROUP of an epoch's batch stream.
+
+        extents: [(shard index into paths, first row, rows)] in delivery order (row_plan.loader_stream), whole batches of lb
+        rows in total.  Resident data: ONE group -- the resident rows gathered into stream order on the device (no gather when
+        the stream is the rows in order).  Streamed: the stream is cut at batch boundaries where the shards a group touches
+        would exceed half the budget; a group loads exactly the shards it touches (a shard the cut falls into is read by both
+        neighbours; with worker streams a group touches one shard per worker at a time), uploads them and gathers."""
+        import torch
+        dev = _device(self.args)
+
+        def gather(x, idx):
+            if x.shape[1] == 0:
+                return torch.empty((len(idx), 0))
+            if len(idx) and idx[-1] - idx[0] == len(idx) - 1 and bool((np.diff(idx) == 1).all()):
+                return x[int(idx[0]):int(idx[-1]) + 1]  # consecutive rows: a view, no copy
+            return x[torch.from_numpy(idx).to(x.device)]
+
+        def index_of(table, stems, ext):
+            ids = {si: np.asarray(table.shard_rows.get(stems[si]) or (), np.int64) for si in {e[0] for e in ext}}
+            for si, f, n in ext:
+                if f + n > len(ids[si]):
+                    raise RuntimeError("shard {} delivered {} rows, the batch plan (from its metadata) expects at least {}: fix the "
+                                       "metadata or drop the shard from the list".format(stems[si], len(ids[si]), f + n))
+            return np.concatenate([ids[si][f:f + n] for si, f, n in ext]) if ext else np.empty(0, np.int64)
+
+        stems = [p.stem for p in paths]
+        if not self.streamed:
+            for _gi, table, rows in self.iterate(views=views):
+                idx = index_of(table, stems, extents)
+                in_order = len(idx) > 0 and idx[0] == 0 and idx[-1] == len(idx) - 1 and bool((np.diff(idx) == 1).all())
+                # another order (worker streams, a wrapped tail): gathered copies of a few GB of batches at a time -- never a
+                # second copy of the resident matrices; the SGD chain simply continues from call to call (as between row groups)
+                piece = len(idx) if in_order or not len(idx) else max(lb, min(budget // 8, 4 << 30) // max(1, row_bytes) // lb * lb)
+                for a in range(0, len(idx), max(1, piece)):
+                    sub = idx[a:a + piece]
+                    yield table, OrderedDict((v, gather(x, sub)) for v, x in rows.items())
+            return
+        # ---- cut the stream into groups
+        size = [self.sizes[p.stem] * row_bytes for p in paths]
+        cuts, cur, cur_sh, cur_bytes, cur_rows = [], [], set(), 0, 0
+
+        def close():
+            nonlocal cur, cur_sh, cur_bytes, cur_rows
+            keep, head, acc = cur_rows // lb * lb, [], 0
+            rest = []
+            for si, f, n in cur:
+                if acc + n <= keep:
+                    head.append((si, f, n))
+                elif acc >= keep:
+                    rest.append((si, f, n))
+                else:
+                    head.append((si, f, keep - acc))
+                    rest.append((si, f + keep - acc, n - (keep - acc)))
+                acc += n
+            if head:
+                cuts.append(head)
+            cur = rest
+            cur_sh = {e[0] for e in cur}
+            cur_bytes, cur_rows = sum(size[si] for si in cur_sh), sum(e[2] for e in cur)
+
+        for si, f, n in extents:
+            if si not in cur_sh and cur_rows >= lb and cur_bytes + size[si] > budget // 2:
+                close()
+            cur.append((si, f, n))
+            if si not in cur_sh:
+                cur_sh.add(si)
+                cur_bytes += size[si]
+            cur_rows += n
+        close()
+        assert not cur, "the batch stream is not a whole number of batches"
+
+        def load(ext):
+            order = list(OrderedDict.fromkeys(e[0] for e in ext))
+            return self._load([paths[si] for si in sorted(order)])
+
+        def up(v, m):
+            if views is not None and v not in views:
+                return torch.empty((m.shape[0], 0))
+            import time
+            t0 = time.perf_counter()
+            t = torch.from_numpy(np.ascontiguousarray(m)).to(dev)
+            self.t_upload += time.perf_counter() - t0
+            return t
+
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            pending = pool.submit(load, cuts[0]) if cuts else None
+            for k, ext in enumerate(cuts):
+                import time
+                t0 = time.perf_counter()
+                table = pending.result()
+                self.t_wait += time.perf_counter() - t0
+                if k + 1 < len(cuts):
+                    pending = pool.submit(load, cuts[k + 1])  # host work beside the GPU's
+                idx = index_of(table, stems, ext)
+                out = OrderedDict()
+                for v, m in table.views.items():
+                    x = up(v, m)
+                    out[v] = gather(x, idx)
+                    del x
+                yield table, out
 
     def _load(self, group):
         # streamed: every shard is read once per epoch and once more for the assign sweep.  Since the library reads the pkl
@@ -266,6 +373,18 @@ class _RowGroups:
                 yield gi, table, OrderedDict((v, up(v, m)) for v, m in table.views.items())
 
 
+def loader_settings(args):
+    """(computation.num_workers as the batch ORDER sees it, tail) -- config.py: data.loader_order / data.loader_tail"""
+    import os
+    mode = str(os.environ.get('ACAV_LOADER_ORDER') or args.data.loader_order or 'reference').lower()
+    if mode not in ('reference', 'workers', 'single'):
+        raise ValueError("data.loader_order / ACAV_LOADER_ORDER must be 'reference' or 'single', not {!r}".format(mode))
+    tail = str(os.environ.get('ACAV_LOADER_TAIL') or args.data.loader_tail or 'wrap').lower()
+    if tail not in ('wrap', 'drop'):
+        raise ValueError("data.loader_tail / ACAV_LOADER_TAIL must be 'wrap' or 'drop', not {!r}".format(tail))
+    return (0 if mode == 'single' else int(args.computation.num_workers or 0)), tail
+
+
 def _device_budget(args):
     """bytes of feature rows the device may hold at once: data.resident_bytes / ACAV_RESIDENT_BYTES, else 60 % of the
     free HBM (288 GB on MI355X: cfg2/cfg3's 2 x 4.1 GB are resident, cfg5's 2 x 410 GB stream)"""
@@ -294,6 +413,37 @@ def train_clusters(args, probe, groups, shard_stems=()):
     print("training sgd kmeans for views: {}".format([v[1:] for v in cl]))
     if w > 1 and multi_gpu_mode(args) != 'views':
         return _train_clusters_planned(args, cl, groups, pre, epochs, b, multi_gpu_mode(args), shard_stems)
+    # WHICH rows form the batches: the reference's DataLoader for this computation.num_workers (parallel/row_plan.py), as a
+    # stream of (shard, first row, rows) per epoch.  The stream is planned from the shard sizes the metadata states (the
+    # reference sizes its loader from the json files too, data/clustering.py:47-52); resident data: from the rows that loaded.
+    from ..parallel import make_plan
+    paths, sizes, row_bytes, budget = groups.paths, groups.sizes, groups.row_bytes, groups.budget
+    meta_rows = [int(sizes[p.stem]) for p in paths]
+    shard_rows = meta_rows
+    if not groups.streamed:
+        (_gi, table, _rows), = list(groups.iterate(views=set()))  # (reads the shards; uploads nothing yet)
+        shard_rows = [len(table.shard_rows.get(p.stem) or ()) for p in paths]
+    nw_order, tail = loader_settings(args)
+    plan = make_plan('views', shard_rows, 1, b, epochs, num_workers=nw_order, meta_rows=meta_rows, tail=tail)
+    first_row = np.concatenate([[0], np.cumsum(shard_rows)]).astype(np.int64)
+    if plan.steps == 0:
+        print("no whole batch of {} rows in {} rows: nothing to train on".format(b, sum(shard_rows)))
+    print("loader order: {} -> {} steps of {} rows per epoch".format(plan.loader, plan.steps, b))
+
+    def shard_extents(pe):  # the plan's (row range) extents back in (shard, first, rows) form, cut to the epoch
+        out, need = [], pe.steps * b
+        for _o, f, n in pe.extents[0]:
+            n = min(n, need)
+            need -= n
+            while n > 0:
+                si = int(np.searchsorted(first_row, f, side='right')) - 1
+                m = min(n, int(first_row[si + 1]) - f)
+                out.append((si, f - int(first_row[si]), m))
+                f, n = f + m, n - m
+            if need <= 0:
+                break
+        return out
+
     for epoch in range(pre, pre + epochs):
         lr = 0.1 ** (2 + epoch // 5)
         for km in cl.values():
@@ -306,17 +456,13 @@ def train_clusters(args, probe, groups, shard_stems=()):
         gen = next(iter(cl.values()))._generator
         gen.u32()
         gen.u32()
-        carry = None  # rows of the previous group that did not fill a batch: the batch stream runs across groups
-        last = len(groups.groups) - 1
         # several GPUs: a rank only trains (hence only uploads) its share of the views -- view i -> rank i % world
         own = None if w == 1 else {v for i, v in enumerate(cl) if i % w == rank}
-        for gi, table, rows in groups.iterate(views=own):
-            if carry is not None:
-                rows = OrderedDict((v, torch.cat([carry[v], rows[v]])) for v in rows)
-            n = next(iter(rows.values())).shape[0] if rows else 0
-            usable = (n // b) * b  # whole batches; the tail waits for the next group, or is dropped at the very end
-            carry = OrderedDict((v, x[usable:].clone()) for v, x in rows.items()) if gi < last and usable < n else None
-            steps = usable // b
+        ext = shard_extents(plan.at_epoch(epoch - pre))
+        for table, part in groups.iterate_stream(paths, ext, b, row_bytes, budget, views=own):
+            n = next(iter(part.values())).shape[0] if part else 0
+            assert n % b == 0
+            steps = n // b
             if steps == 0:
                 continue
             # warm-up labels, drawn batch by batch across the clusterings like the reference loop (every rank draws
@@ -327,12 +473,14 @@ def train_clusters(args, probe, groups, shard_stems=()):
                 for v, km in cl.items():
                     if t < need[v]:
                         warm[v][t] = km.draw_warmup(b)
-            part = OrderedDict((v, x[:usable]) for v, x in rows.items())
             if w > 1:  # the clusterings are dealt out over the GPUs; states are exchanged once per epoch
                 from ..parallel import train_epoch_view_parallel
                 train_epoch_view_parallel(cl, part, b, lr, warm, broadcast=False)
             else:  # all clusterings of the batch stream side by side on the GPU (independent SGD chains)
                 KMeans.train_epoch_multi(list(cl.values()), [part[v] for v in cl], b, lr=lr, warm_bests=[warm[v] for v in cl])
+            for km in cl.values():  # the gathered copy of this group is released before the next one is built
+                km.synchronize()
+            del part
         if w > 1:  # state identical to the one-GPU run on every rank
             from ..parallel import broadcast_states
             broadcast_states(cl)
@@ -376,6 +524,7 @@ def _train_clusters_planned(args, cl, groups, pre, epochs, b, mode, shard_stems)
         raise RuntimeError("clustering.multi_gpu={} keeps every rank's rows resident: {} groups do not fit the device budget "
                            "(raise data.resident_bytes, use more GPUs, or clustering.multi_gpu=views)".format(mode, len(groups.groups)))
     (_gi, table, rows), = list(groups.iterate())
+    groups_sizes = getattr(groups, 'all_sizes', None)
     # rows every shard REALLY delivered (an unreadable shard was reported and skipped by the loader: 0 rows), from its owner
     mine = {stem: len(table.shard_rows.get(stem) or ()) for stem in shard_stems[rank::w]}
     everyone = [None] * w
@@ -384,18 +533,22 @@ def _train_clusters_planned(args, cl, groups, pre, epochs, b, mode, shard_stems)
     for part in everyone:
         have.update(part)
     shard_rows = [int(have.get(stem, 0)) for stem in shard_stems]
-    plan = make_plan(mode, shard_rows, w, b, epochs)
+    nw_order, tail = loader_settings(args)
+    meta_rows = [int(groups_sizes.get(stem, 0)) for stem in shard_stems] if groups_sizes else None
+    plan = make_plan(mode, shard_rows, w, b, epochs, num_workers=nw_order, meta_rows=meta_rows, tail=tail)
     seg = [sum(shard_rows[r::w]) for r in range(w)]
     # the reference clamps num_gpus to the number of shards (script.py:22,37); a rank without rows (more GPUs than shards,
     # or every shard of a rank unreadable) or an epoch without a single step would leave untrained clusterings behind
     if min(seg) == 0 or plan.steps == 0:
         raise RuntimeError("clustering.multi_gpu={}: rows per rank {} give {} steps of {} rows -- fewer shards than GPUs, or "
                            "unreadable shards; lower computation.num_gpus".format(mode, seg, plan.steps, plan.global_batch))
-    print("rank {}: {} local rows; mode {}: {} steps of {} x {} rows per epoch, {} epochs".format(
-        rank, seg[rank], mode, plan.steps, plan.slots, plan.lb, plan.epochs))
+    print("rank {}: {} local rows; mode {}: {} steps of {} x {} rows per epoch, {} epochs; loader {}".format(
+        rank, seg[rank], mode, plan.steps, plan.slots, plan.lb, plan.epochs, plan.loader))
     kms = list(cl.values())
     xs = [rows[v] for v in cl]
-    for epoch in range(pre, pre + plan.epochs):
+    plan0 = plan
+    for epoch in range(pre, pre + plan0.epochs):
+        plan = plan0.at_epoch(epoch - pre)  # (the in-process loader's stream continues across epochs when it wraps)
         lr = 0.1 ** (2 + epoch // 5)
         for km in kms:
             km.lr = lr
@@ -496,6 +649,7 @@ def run_clustering(args):
                            "steps; lower computation.num_gpus".format(multi_gpu_mode(args), w, len(paths)))
     # reference / rows mode: a rank reads, holds and labels its own shards only (rank::world) -- training included
     groups = _RowGroups(args, paths[rank::w] if partitioned else paths, sizes, row_bytes, _device_budget(args), view_dims)
+    groups.all_sizes = sizes  # metadata sizes of ALL shards (the loader length of a partitioned run is computed over all of them)
     cl = train_clusters(args, probe, groups, [p.stem for p in paths])
     mine = [p.stem for p in paths][rank::w]  # assign: shards strided over ranks (mps/distributed.py:439)
     return assign_clusters(args, groups, cl, mine)

@@ -86,6 +86,16 @@ CLUSTERING_DEFAULTS = {
         'path': 'data',
         'batch_size': 32,
         'resident_bytes': None,  # ours: device budget for feature rows; beyond it the shards stream in groups
+        # ours: WHICH rows form the training batches (acav100m_amd/parallel/row_plan.py: loader_stream).
+        # 'reference' (default): the batches the reference's DataLoader delivers for this computation.num_workers -- with
+        #   num_workers > 0 (its default: 40) whole batches round-robin over worker streams, worker w reading shards [w::num_workers]
+        #   (data/clustering.py:17-66,212-228); num_workers = 0: one stream over the shards in order.
+        # 'single': the single-stream order whatever num_workers says (rounds 1-5 of this build).  ACAV_LOADER_ORDER overrides.
+        'loader_order': 'reference',
+        # 'wrap' (default): every stream is get_length() samples (mps/distributed.py:444-460), a short one starts over -- and the
+        #   in-process loader (num_workers = 0) continues where it stopped in the next epoch -- webdataset.ResizedDataset as the
+        #   reference wraps its dataset (data/clustering.py:61-65).  'drop': whole batches of the rows that exist.  ACAV_LOADER_TAIL overrides.
+        'loader_tail': 'wrap',
         'meta': {'path': None},
         'output': {'path': 'output', 'shard_ok_ratio': 0.99},
     },

@@ -7,7 +7,7 @@ this script and the tiny stand-in modules under _stubs/ for the reference's un-v
 imports (torch_scatter, diffdist, wget, braceexpand).
 
     python tests/golden/gen_golden.py            # all three groups
-    python tests/golden/gen_golden.py kmeans|kmeans_big|mi|mi_exact|mi_ami|mi_nmi|rng|cli|contrastive|ddp_stream
+    python tests/golden/gen_golden.py kmeans|kmeans_big|mi|mi_exact|mi_ami|mi_nmi|rng|cli|contrastive|ddp_stream|loader_order|cli_workers
 
 Groups:
   rng.npz     torch.manual_seed/rand/randperm and random.shuffle streams (G6)
@@ -18,6 +18,9 @@ Groups:
               parameters, infer() scores
   cli_clustering.npz / cli_output.csv   the reference's two CLIs end to end on synthetic shards
               regenerated from a seed by tests/golden/synth.py (G5)
+  cli_clustering_nw3.npz / _nw3_ragged.npz   the clustering CLI with computation.num_workers=3 (group cli_workers)
+  loader_order.npz   the batches the reference's own DataLoader delivers with computation.num_workers > 0 (its default, 40):
+              round-robin over worker shard subsets, ResizedDataset wrap, per rank for W > 1
   ddp_stream.npz   the reference's N-GPU training batch stream: per-rank shard order (node_selection), per-rank batch,
               samples per epoch (get_length), epochs -- what clustering.multi_gpu=reference reproduces
 The two reference stages have clashing top-level module names, so each group runs in its own
@@ -444,8 +447,10 @@ def gen_mi_ami():
 
 
 # ----------------------------------------------------------------------------- cli
-def gen_cli_clustering(root):
-    """reference `cli.py cluster` on 4 synthetic shards (real 5+5 layer dims, K=32, 2 epochs)"""
+def gen_cli_clustering(root, variant=None):
+    """reference `cli.py cluster` on 4 synthetic shards (real 5+5 layer dims, K=32, 2 epochs).
+    variant 'nw3' / 'nw3_ragged': the same with the reference's DataLoader on 3 worker processes (computation.num_workers=3;
+    its default is 40) on 6 shards -- equal worker streams (no wrap) / ragged ones (short streams wrap, ResizedDataset)."""
     sys.path.insert(0, STUBS)
     sys.path.insert(1, os.path.join(REF, "clustering", "code"))
     import pickle
@@ -453,13 +458,18 @@ def gen_cli_clustering(root):
     torch.Tensor.cuda = lambda self, *a, **k: self
     sys.path.insert(2, HERE)
     import synth
-    glob = synth.write_feature_shards(root, n_shards=4, rows=256, seed=0)
+    nshards, rows, nw = 4, 256, 0
+    if variant == "nw3":
+        nshards, rows, nw = 6, 128, 3
+    elif variant == "nw3_ragged":
+        nshards, rows, nw = 6, [150, 100, 130, 90, 170, 60], 3
+    glob = synth.write_feature_shards(root, n_shards=nshards, rows=rows, seed=0 if variant is None else 5)
     from cli import Cli  # noqa: E402  (the reference)
     torch.manual_seed(0)
     Cli().cluster(feature_path=glob, out_path=os.path.join(root, "clusters"), meta_path=os.path.join(root, "videos"),
-                  **{"computation.device": "cpu", "computation.num_gpus": 1, "computation.num_workers": 0})
-    out = {}
-    for s in range(4):
+                  **{"computation.device": "cpu", "computation.num_gpus": 1, "computation.num_workers": nw})
+    out = {"shard_rows": np.array(rows if isinstance(rows, list) else [rows] * nshards, np.int64), "num_workers": nw}
+    for s in range(nshards):
         name = "shard-%06d" % s
         rows = pickle.load(open(os.path.join(root, "clusters", name + ".pkl"), "rb"))
         lab = []
@@ -479,8 +489,11 @@ def gen_cli_clustering(root):
     import json
     out["log_keys"] = np.array(sorted(json.load(open(os.path.join(root, "clusters", logs[0]))).keys()))
     out["out_files"] = np.array(sorted(os.listdir(os.path.join(root, "clusters"))))
-    np.savez_compressed(os.path.join(HERE, "cli_clustering.npz"), **out)
-    print("cli_clustering.npz written:", sorted(os.listdir(os.path.join(root, "clusters"))))
+    fname = "cli_clustering.npz" if variant is None else "cli_clustering_%s.npz" % variant
+    if variant is None:
+        out.pop("shard_rows"), out.pop("num_workers")  # (the round-1 file's keys)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "written:", sorted(os.listdir(os.path.join(root, "clusters"))))
 
 
 def gen_cli_subset(root):
@@ -593,6 +606,70 @@ def gen_ddp_stream():
     print("ddp_stream.npz written")
 
 
+def gen_loader_order():
+    """The reference's TRAINING batch order with its DEFAULT loader (computation.num_workers > 0, config.py:29): the batches its own
+    get_clustering_dataloader(args, drop_last=True, shuffle=True, is_train=True) (run_clustering.py:139) delivers, epoch by epoch,
+    on synthetic shards -- torch's DataLoader round-robins whole batches over the worker processes, worker w streaming
+    urls[w::num_workers] (data/clustering.py:212-228), every worker's stream cut / cycled to get_length() samples by
+    webdataset.ResizedDataset (data/clustering.py:50-65; un-vendored: _stubs/webdataset.py restates the class of the pinned
+    revision).  `*_even` cases: every worker's rows == get_length() (no wrap: independent of the stand-in); `*_ragged`: the wrap
+    and, for num_workers = 0, the source iterator that persists across epochs.  W > 1: WORLD_SIZE + a patched get_rank, per rank."""
+    import tempfile
+    sys.path.insert(0, STUBS)
+    sys.path.insert(1, os.path.join(REF, "clustering", "code"))
+    sys.path.insert(2, HERE)
+    import torch
+    import synth
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import mps.distributed as du  # noqa: E402  (the reference)
+    from args import get_args  # noqa: E402
+    from data.clustering import get_clustering_dataloader  # noqa: E402
+    cases = {
+        # name: (rows per shard, computation.num_workers, world, data.batch_size)
+        "nw2_even": ([64] * 4, 2, 1, 32),
+        "nw3_even": ([96] * 6, 3, 1, 32),
+        "nw4_even": ([32] * 8, 4, 1, 32),
+        "nw3_straddle_even": ([64, 32, 48, 32, 64, 48], 3, 1, 32),  # equal worker sums, batches straddle shard boundaries
+        "nw40_clamped_even": ([32] * 6, 40, 1, 32),                  # the default 40 workers on 6 shards -> 6 workers
+        "nw3_ragged": ([40, 24, 56, 32, 48, 16, 40], 3, 1, 32),
+        "nw2_ragged": ([50, 30, 70], 2, 1, 32),
+        "nw0_ragged": ([40, 24, 56], 0, 1, 32),
+        "nw0_even": ([64] * 3, 0, 1, 32),
+        "w2_nw2_even": ([64] * 8, 2, 2, 32),
+        "w2_nw2_ragged": ([40, 24, 56, 32, 48, 16, 40], 2, 2, 32),
+        "w2_nw0_ragged": ([40, 24, 56, 32, 48], 0, 2, 32),
+    }
+    out = {"cases": np.array(sorted(cases))}
+    for name, (sizes, nw, w, b) in cases.items():
+        root = tempfile.mkdtemp(prefix="acav_golden_lo_")
+        glob = synth.write_feature_shards(root, n_shards=len(sizes), rows=list(sizes), seed=1, comps=4, audio_dims=[4], video_dims=[4])
+        first = np.concatenate([[0], np.cumsum(sizes)])
+        os.environ["WORLD_SIZE"] = str(w)
+        out[name + "_sizes"], out[name + "_nw"], out[name + "_world"], out[name + "_batch_size"] = np.array(sizes, np.int64), nw, w, b
+        for r in range(w):
+            du.get_rank = lambda r=r: r
+            args = get_args(**{"data.path": glob, "data.meta.path": os.path.join(root, "videos"), "data.output.path": os.path.join(root, "out"),
+                               "computation.device": "cpu", "computation.num_gpus": w, "computation.num_workers": nw,
+                               "data.batch_size": b})
+            from pathlib import Path
+            args.data.media.path = Path(glob)  # script.py:36 (parallel_extraction_script hands the shard expression on like this)
+            loader = get_clustering_dataloader(args, drop_last=True, shuffle=True, is_train=True)
+            for epoch in range(2):
+                rows, lens = [], []
+                for batch in loader:
+                    ids = [first[int(s[len("shard-"):])] for s in batch["shard_name"]]
+                    # filename vid%09d: the running row number over all shards
+                    rows += [int(fn[3:12]) for fn in batch["filename"]]
+                    lens.append(len(batch["filename"]))
+                    assert all(first[int(s[6:])] <= g < first[int(s[6:]) + 1] for s, g in zip(batch["shard_name"], rows[-lens[-1]:])), ids
+                out["%s_rank%d_epoch%d_rows" % (name, r, epoch)] = np.array(rows, np.int64)
+                out["%s_rank%d_epoch%d_lens" % (name, r, epoch)] = np.array(lens, np.int64)
+            out["%s_rank%d_len" % (name, r)] = len(loader)
+    os.environ.pop("WORLD_SIZE", None)
+    np.savez_compressed(os.path.join(HERE, "loader_order.npz"), **out)
+    print("loader_order.npz written")
+
+
 def gen_mi_nmi():
     """The reference's EfficientNMI (mi.py:262-271) and ConstantMeasure (mi.py:274-281) -- classes its get_measure registry does
     not name -- through its own _run_greedy (run_greedy.py:9-54) with the registry look-up pointed at the class: per-iteration
@@ -659,17 +736,25 @@ def gen_cli():
     subprocess.check_call([sys.executable, os.path.abspath(__file__), "cli_subset", root])
 
 
+def gen_cli_workers():
+    """the clustering CLI with the reference's DataLoader on worker processes (its default configuration has 40)"""
+    import tempfile
+    for variant in ("nw3", "nw3_ragged"):
+        root = tempfile.mkdtemp(prefix="acav_golden_%s_" % variant)
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "cli_clustering", root, variant])
+
+
 if __name__ == "__main__":
     if sys.argv[1:2] == ["cli_clustering"]:
-        gen_cli_clustering(sys.argv[2])
+        gen_cli_clustering(sys.argv[2], *sys.argv[3:4])
         sys.exit(0)
     if sys.argv[1:2] == ["cli_subset"]:
         gen_cli_subset(sys.argv[2])
         sys.exit(0)
-    which = sys.argv[1:] or ["rng", "kmeans", "kmeans_big", "mi", "mi_exact", "mi_ami", "cli", "contrastive", "ddp_stream", "mi_nmi"]
+    which = sys.argv[1:] or ["rng", "kmeans", "kmeans_big", "mi", "mi_exact", "mi_ami", "cli", "contrastive", "ddp_stream", "mi_nmi", "loader_order", "cli_workers"]
     if len(which) > 1:
         for w in which:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
         {"rng": gen_rng, "kmeans": gen_kmeans, "kmeans_big": gen_kmeans_big, "mi": gen_mi, "mi_exact": gen_mi_exact, "mi_ami": gen_mi_ami, "cli": gen_cli,
-         "contrastive": gen_contrastive, "ddp_stream": gen_ddp_stream, "mi_nmi": gen_mi_nmi}[which[0]]()
+         "contrastive": gen_contrastive, "ddp_stream": gen_ddp_stream, "mi_nmi": gen_mi_nmi, "loader_order": gen_loader_order, "cli_workers": gen_cli_workers}[which[0]]()

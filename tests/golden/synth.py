@@ -24,7 +24,8 @@ def write_feature_shards(root, n_shards=4, rows=256, seed=0, comps=24, audio_dim
     for s in range(n_shards):
         name = "shard-%06d" % s
         rows_out, meta = [], []
-        for _ in range(rows):
+        rows_s = rows[s] if isinstance(rows, (list, tuple)) else rows  # (per-shard sizes: the loader-order goldens)
+        for _ in range(rows_s):
             ga = rs.randint(0, comps)
             gv = ga if rs.rand() < 0.5 else rs.randint(0, comps)  # views share the component w.p. 0.5
             fn = "vid%09d_010.mp4" % vid
@@ -37,7 +38,7 @@ def write_feature_shards(root, n_shards=4, rows=256, seed=0, comps=24, audio_dim
                                     "dataset": "kinetics-400", "array": video}],
                 "audio_features": [{"model_key": "layer_vggish", "extractor_name": "VGGish",
                                     "dataset": "YouTube-8M", "array": audio}],
-                "filename": fn, "shard_size": rows, "shard_name": name,
+                "filename": fn, "shard_size": rows_s, "shard_name": name,
             })
             meta.append({"filename": fn, "id": "vid%09d" % vid, "segment": [10, 20]})
             vid += 1

@@ -34,7 +34,7 @@ def test_cluster_cli_matches_reference_files(workdir, golden_dir):
     g = np.load(os.path.join(golden_dir, "cli_clustering.npz"))
     acav100m_amd.manual_seed(0)
     saved = Cli().cluster(feature_path=glob, out_path=os.path.join(root, "clusters"),
-                          meta_path=os.path.join(root, "videos"))
+                          meta_path=os.path.join(root, "videos"), **{"computation.num_workers": 0})  # as the golden was made
     assert [p.name for p in saved] == ["shard-%06d.pkl" % s for s in range(4)]
     for s in range(4):
         name = "shard-%06d" % s
@@ -59,6 +59,54 @@ def test_cluster_cli_matches_reference_files(workdir, golden_dir):
     # a second run finds every shard already written
     assert Cli().cluster(feature_path=glob, out_path=os.path.join(root, "clusters"),
                          meta_path=os.path.join(root, "videos")) == []
+
+
+@pytest.mark.parametrize("variant", ["nw3", "nw3_ragged"])
+def test_cluster_cli_matches_reference_files_with_loader_workers(tmp_path_factory, golden_dir, variant):
+    """The reference's DEFAULT loader has worker processes (computation.num_workers = 40, config.py:29): its DataLoader hands out
+    whole batches round-robin over the workers, worker w streaming shards [w::num_workers] (data/clustering.py:17-66,212-228).
+    The goldens are the reference CLI's own files with --computation.num_workers=3 on six shards: `nw3` equal worker streams
+    (nothing wraps), `nw3_ragged` streams of 320 / 270 / 110 rows cut / cycled to get_length() = 320 samples each
+    (ResizedDataset).  Our CLI with the same flag -- the batch order is a plan, the shards are read as ever -- must write the
+    same assignment files, bit for bit; with ACAV_LOADER_ORDER=single it must NOT (the order matters)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, golden_dir)
+    import synth
+    import acav100m_amd
+    from acav100m_amd.clustering.cli import Cli
+    g = np.load(os.path.join(golden_dir, "cli_clustering_%s.npz" % variant))
+    sizes = [int(x) for x in g["shard_rows"]]
+    root = str(tmp_path_factory.mktemp("acav_cli_" + variant))
+    glob = synth.write_feature_shards(root, n_shards=len(sizes), rows=sizes, seed=5)
+
+    def labels_of(out):
+        res = {}
+        for s in range(len(sizes)):
+            name = "shard-%06d" % s
+            rows = pickle.load(open(os.path.join(out, name + ".pkl"), "rb"))
+            assert [r["filename"] for r in rows] == list(g[name + "_files"])
+            res[name] = np.array([[int(r["audio_assignments"][0]["array"]["layer_%d" % i]) for i in range(5)] +
+                                  [int(r["video_assignments"][0]["array"]["layer_%d" % i]) for i in range(5)] for r in rows])
+        return res
+
+    acav100m_amd.manual_seed(0)
+    out = os.path.join(root, "clusters")
+    saved = Cli().cluster(feature_path=glob, out_path=out, meta_path=os.path.join(root, "videos"),
+                          **{"computation.num_workers": int(g["num_workers"])})
+    assert [p.name for p in saved] == ["shard-%06d.pkl" % s for s in range(len(sizes))]
+    for name, lab in labels_of(out).items():
+        assert np.array_equal(lab, g[name]), f"{variant} {name}: {(lab != g[name]).sum()} labels differ from the reference CLI"
+    os.environ["ACAV_LOADER_ORDER"] = "single"
+    try:
+        acav100m_amd.manual_seed(0)
+        out1 = os.path.join(root, "clusters_single")
+        Cli().cluster(feature_path=glob, out_path=out1, meta_path=os.path.join(root, "videos"),
+                      **{"computation.num_workers": int(g["num_workers"])})
+        assert any(not np.array_equal(lab, g[name]) for name, lab in labels_of(out1).items())
+    finally:
+        os.environ.pop("ACAV_LOADER_ORDER", None)
 
 
 def test_subset_cli_output_csv(workdir, golden_dir):
@@ -352,7 +400,7 @@ def test_cluster_cli_reference_mode_two_workers(workdir, golden_dir):
     out = os.path.join(root, "cl_reference")
     log = _run_cli("acav100m_amd.clustering.cli",
                    ["cluster", "--feature_path=" + glob, "--meta_path=" + os.path.join(root, "videos"), "--out_path=" + out,
-                    "--computation.num_gpus=2", "--clustering.multi_gpu=reference"], {"ACAV_SEED": "0", "ACAV_DIST_BACKEND": "gloo"})
+                    "--computation.num_gpus=2", "--clustering.multi_gpu=reference", "--computation.num_workers=0"], {"ACAV_SEED": "0", "ACAV_DIST_BACKEND": "gloo"})
     assert log.count("done") == 2 and "mode reference: 64 steps of 2 x 16 rows per epoch, 1 epochs" in log
     caches = sorted(f for f in os.listdir(out) if f.startswith("cache_epoch_"))
     assert len(caches) == 1  # ceil(epochs / num_gpus) = 1 epoch, written by worker 0
