@@ -988,6 +988,26 @@ __device__ __forceinline__ void tpw_refresh_norms(unsigned pend8, const float *s
 // replicated twice instead of four times and TWO clusterings (the audio and the visual view of cfg5) train side by side.
 __device__ __forceinline__ void dot_quad(const float *pc, const float *px, int scz, int sxz, float out[4]);
 
+// MF (round 6): the FMA phase of the 16-centre forms on the f32 matrix core.  v_mfma_f32_16x16x4_f32 is, bit for bit, the ascending
+// v_fma_f32 chain (k = 0 .. 3 in order, one rounding per multiply-add: MI355X_MICROARCH.md; k_step_dist_mfma has relied on it since
+// round 1), so ONE wave computes the canonical 256-column segment sum of all 16 x 16 (centre, row) pairs of a block as 64 dependent
+// MFMAs (40 cycles each: ~2.6k cycles) from 2 x 64 ds_read_b32 -- where the v_fma form read 8 bytes of LDS per multiply-add (every
+// lane its own pair: 1 MB per step and workgroup at K = d = 1024) and took 8.6k cycles of a 24k-cycle step, LDS-bound.
+// Lane l feeds A[i = l & 15][k = l >> 4] = centre i, column 4 t + k of the block, and B[k][j = l & 15] = batch row j, same column;
+// it receives D[4 (l >> 4) + e][l & 15], e = 0 .. 3.  pc / px: the lane's centre / batch row of the block, + k; sc / sx: row & 7
+// (chunk tt of 4 columns sits at float offset ((tt ^ s) << 2), as in dot_blocks).
+__device__ __forceinline__ f32x4 dot_tile_mfma(const float *pc, const float *px, int sc, int sx)
+{
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 64; ++t) {
+        const float a = pc[(((t & 7) ^ sc) << 2) + ((t >> 3) << 5)];
+        const float bq = px[(((t & 7) ^ sx) << 2) + ((t >> 3) << 5)];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 template <bool RAGGED, int NCP, bool ONE_X = false, int NRP = 1>
 __global__ __launch_bounds__(256) void k_train_persistent_wide(
     const float *__restrict__ x, const float *__restrict__ xn, int b, int d, int ds, int K, float *__restrict__ centers,
@@ -997,14 +1017,19 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
     constexpr int NCW = 8 * NCP;  // centres per workgroup
     constexpr int NRW = 8 * NRP;  // batch rows per workgroup
     static_assert(NRP == 1 || (NRP == 2 && NCP == 2 && ONE_X), "two row passes: 16 centres x 16 rows, one row buffer");
+#ifdef ACAV_WIDE_NO_MFMA  // experiment builds: the v_fma chains of rounds 2-5 in the 16-centre forms (A/B)
+    constexpr bool MF = false;
+#else
+    constexpr bool MF = NCP == 2;  // 16 centres: one 16 x 16 matrix-core tile per column block (dot_tile_mfma)
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char tpw_smem[];
     float *sC = reinterpret_cast<float *>(tpw_smem);  // [NCW][ds]
     const int nblk = (d + 255) >> 8;
     float *sX0 = sC + NCW * ds;                        // [2 or 1][8][ds]
     float *sCn = sX0 + (ONE_X ? NRP : 2) * 8 * ds;     // [NCW]
     float *sCnt = sCn + NCW;                           // [NCW]
-    float *sPart = sCnt + NCW;                         // [NCP * NRP][nblk][64] (NRP = 2: quadrant 2 cp + rp)
-    int *sBest = reinterpret_cast<int *>(sPart + NCP * NRP * nblk * 64);  // [32]
+    float *sPart = sCnt + NCW;                         // [NCP * NRP][nblk][64] (NRP = 2: quadrant 2 cp + rp); MF: [nblk][4][64]
+    int *sBest = reinterpret_cast<int *>(sPart + (MF ? 4 : NCP * NRP) * nblk * 64);  // [32]
     __shared__ int sDead;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1076,12 +1101,20 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
             if (wave == 0) {  // in flight under the FMA chain
 #pragma unroll
                 for (int rp = 0; rp < NRP; ++rp) xn_t[rp] = xn[(size_t)t * b + rbase + (rp * 8 + ii < nrv ? rp * 8 + ii : 0)];
+                if (MF) xn_t[0] = xn[(size_t)t * b + rbase + ((lane & 15) < nrv ? (lane & 15) : 0)];  // the lane's tile column
                 thr_t = thr[t];
             }
             if (!ONE_X && t + 1 < T) dma_rows(t + 1);
             const float *xs = sX(t & 1);
             // (centre pass, column block) pairs: a wave multiplies the blocks it fetched (wave, wave + 4, ...) for every pass
-            if constexpr (NRP == 2) {  // ds == TS_COLS: the four quadrants of a block as four chains
+            if constexpr (MF) {  // one 16 x 16 tile per block on the matrix core (NRP = 1: batch rows 8 .. 15 of the tile repeat 0 .. 7, unread)
+                const int i15 = lane & 15, kq = lane >> 4, jx = NRP == 2 ? i15 : (i15 & 7);
+                for (int blk = wave; blk < nblk; blk += 4) {
+                    const f32x4 q4 = dot_tile_mfma(sC + i15 * ds + blk * 256 + kq, xs + jx * ds + blk * 256 + kq, i15 & 7, jx & 7);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sPart[(blk * 4 + e) * 64 + lane] = q4[e];
+                }
+            } else if constexpr (NRP == 2) {  // ds == TS_COLS: the four quadrants of a block as four chains
                 for (int blk = wave; blk < nblk; blk += 4) {
                     float q4[4];
                     dot_quad(sC + kk * ds + blk * 256, xs + ii * ds + blk * 256, kk << 2, ii << 2, q4);
@@ -1106,6 +1139,26 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
             if (wave == 0) {
                 unsigned long long keys[NRP];
                 unsigned long long o;
+                unsigned long long key;
+                if constexpr (MF) {  // lane l: centres 4 (l >> 4) + e of batch row l & 15
+                    const int i15 = lane & 15, kq = lane >> 4;
+                    key = ~0ull;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float acc = sPart[e * 64 + lane];
+                        for (int w = 1; w < nblk; ++w) acc = acc + sPart[(w * 4 + e) * 64 + lane];  // canonical left fold
+                        const int lc = 4 * kq + e;
+                        if (lc < nck && i15 < nrv) {
+                            const unsigned long long kc = pack_key(dist_epilogue(acc, xn_t[0], sCn[lc], sCnt[lc] < thr_t, r), kbase + lc);
+                            key = kc < key ? kc : key;
+                        }
+                    }
+                    o = __shfl_xor(key, 16);
+                    key = o < key ? o : key;
+                    o = __shfl_xor(key, 32);
+                    key = o < key ? o : key;  // lane l < 16 holds the key of row l
+                    (void)keys;
+                } else {
 #pragma unroll
                 for (int rp = 0; rp < NRP; ++rp) {
                     unsigned long long key = ~0ull;
@@ -1128,7 +1181,8 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                     keys[rp] = key;
                 }
                 // lane l < 8 NRP holds the key of row l: its ii is l & 7 and every lane of an ii column holds that row's minimum
-                const unsigned long long key = (NRP == 2 && (lane >> 3) == 1) ? keys[NRP - 1] : keys[0];
+                key = (NRP == 2 && (lane >> 3) == 1) ? keys[NRP - 1] : keys[0];
+                }
                 const unsigned long long tag = (unsigned long long)((nsync % 65535u) + 1u) << 48;
                 unsigned long long(*ring)[TP_MAXB] = ctl->gran[nsync % TP_RING];
                 if (lane < nrv) {
@@ -2083,7 +2137,7 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
         for (int c : {1, 2}) {
             for (int xrows : {16, 8}) {
                 const int groups = (km->K + 8 * c - 1) / (8 * c);
-                const size_t smem = sizeof(float) * ((size_t)(8 * c + xrows) * ds + 2 * 8 * c + 64 * c * nblk_t + 32);
+                const size_t smem = sizeof(float) * ((size_t)(8 * c + xrows) * ds + 2 * 8 * c + 64 * (c == 2 ? 4 : c) * nblk_t + 32);  // (16 centres: matrix-core tile sums, 4 per lane and block)
                 if (!wide && groups <= 64 && smem <= 160 * 1024 - 1024 && groups * rgroups <= km->num_cus && groups * rgroups <= room) {
                     ncp = c, wide_wg = groups * rgroups, wide_smem = smem, one_x = xrows == 8;
                     wide = persistent = true;
@@ -2103,7 +2157,7 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
             for (int c : {2, 4, 8}) {
                 if (fncp && atoi(fncp) != c) continue;
                 const int groups = (km->K + 8 * c - 1) / (8 * c);
-                const size_t smem = sizeof(float) * ((size_t)(8 * c + 16) * ds + 2 * 8 * c + 256 * c + 32);
+                const size_t smem = sizeof(float) * ((size_t)(8 * c + 16) * ds + 2 * 8 * c + 256 * (c == 2 ? 4 : c) + 32);
                 const int lim = pass == 0 ? (3 * km->num_cus) / 4 : km->num_cus;
                 if (groups <= 64 && smem <= 160 * 1024 - 1024 && groups * rgroups <= lim && groups * rgroups <= room) {
                     best_ncp = c, wide_wg = groups * rgroups, wide_smem = smem;
