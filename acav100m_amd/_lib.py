@@ -157,6 +157,8 @@ def check(rc):
             raise ValueError(f"acav: {msg}")
         if rc == -5:
             raise RuntimeError(f"acav: {msg}")
+        if rc == -7:
+            raise TimeoutError(f"acav: {msg}")
         raise AcavError(f"acav error {rc}: {msg}")
 
 

@@ -17,6 +17,8 @@
 #include <rccl/rccl.h>
 
 #include "acav_common.h"
+#include <chrono>
+#include <thread>
 
 using namespace acav;
 
@@ -647,6 +649,34 @@ ACAV_EXPORT int acav_kmeans_train_plan_multi(acav_kmeans *const *kms, acav_comm 
             }
         }
     }
+    // Watchdog (round 6; first contact with a real multi-GPU node is the driver's): a rank never waits for a peer for ever.  Every
+    // rank -- the ones that only feed a clustering's exchange too -- waits on the host for chunk ci's exchange before it goes on
+    // (the next chunk is already enqueued, so nothing is serialised); a wait longer than ACAV_COMM_TIMEOUT_S seconds (default 120;
+    // 0 = wait for ever) ends the call with the chunk, the clustering and the rank its chain runs on in acav_last_error().
+    double timeout_s = 120.0;
+    if (const char *vt = getenv("ACAV_COMM_TIMEOUT_S")) timeout_s = atof(vt);
+    auto wait_exchange = [&](int v, int64_t ci, int par) -> int {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            const hipError_t e = hipEventQuery(comms[v]->ev_gathered[par]);
+            if (e == hipSuccess) return ACAV_OK;
+            (void)hipGetLastError();  // hipErrorNotReady stays behind as the thread's last error otherwise
+            if (e != hipErrorNotReady) {
+                acav::set_error("hipEventQuery failed while waiting for the row exchange: %s", hipGetErrorString(e));
+                return ACAV_EHIP;
+            }
+            if (spins > 256) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            if (timeout_s > 0 && (spins & 1023) == 1023) {
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (waited > timeout_s) {
+                    acav::set_error("rank %d of %d waited %.0f s for the rows of plan chunk %lld / %lld (steps %lld ..) of clustering %d, whose chain runs "
+                                    "on rank %d: a peer never fed the exchange (crashed, blocked, or running another plan?) -- ACAV_COMM_TIMEOUT_S",
+                                    me, w, waited, (long long)ci, (long long)n_chunks, (long long)(ci * chunk_steps), v, roots[(size_t)v]);
+                    return ACAV_ETIMEOUT;
+                }
+            }
+        }
+    };
     auto gather = [&](int v, int64_t ci, int par) -> int {  // chunk ci of every owner -> batches[par] of clustering v
         acav_comm *c = comms[v];
         const Chunk &ch = chunks[(size_t)ci];
@@ -683,6 +713,7 @@ ACAV_EXPORT int acav_kmeans_train_plan_multi(acav_kmeans *const *kms, acav_comm 
         if (ci + 1 < n_chunks)
             for (int v = 0; v < count; ++v) ACAV_TRY(gather(v, ci + 1, par ^ 1));  // next chunk travels while this one trains
         lk.clear(), lx.clear(), ln.clear(), lnw.clear(), lw.clear();
+        for (int v = 0; v < count; ++v) ACAV_TRY(wait_exchange(v, ci, par));  // (bounded: see wait_exchange)
         for (int v = 0; v < count; ++v) {
             if (!here[(size_t)v]) continue;
             ACAV_HIP_TRY(hipStreamWaitEvent((hipStream_t)st_train[(size_t)v], comms[v]->ev_gathered[par], 0));

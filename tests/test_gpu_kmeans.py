@@ -387,6 +387,113 @@ def test_filter_bound_against_aligned_worst_case_roundings(env, scale, K):
     print(f"scale {scale} K {K}: {fooled} rows whose filter distances name the wrong centre, {undecided} of {n} undecided")
 
 
+@pytest.mark.parametrize("K", [4, 300])
+def test_candidate_threshold_against_aligned_worst_case_roundings(env, K):
+    """The second "proven" inequality of the filter (cand_threshold, acav_kmeans_assign.hip): a centre may be left out of an undecided
+    row's candidate list only if its filter value lies more than 2 E + slack above the row's filter minimum.  Random data never tests
+    the 2: a true minimiser sits within a fraction of E of the filter's minimum.  Here the true minimiser T is the THIRD centre by the
+    filter's values, 1.15 .. 1.64 E above the minimum: the aligned-rounding construction of the test above (+-c': every operand rounding
+    pushes the filter's value of the true winner T UP by ~0.82 E and that of the named centre N DOWN by as much) plus a DECOY centre D
+    whose operands are exactly representable (its filter value is its true value) placed at 0.6 of the way from N to T -- the filter's
+    top two are (N, D), truth is T < D < N.  The row is undecided (D - N < 2 E) and T must be among the emitted candidates; with a
+    window of E instead of 2 E it is not, and the exact evaluation of {N, D} returns D.  K = 300: the same through the (tile, group)
+    pairs, k_assign_merge's thresholds and the emission pass."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    d = 1024
+    e = 2.0 ** -11
+    g = 4.0
+    cp = np.concatenate([np.full(448, 1 + e), np.full(448, -(1 + 3 * e)), np.ones(64), np.zeros(64)]).astype(np.float32)
+    dc = np.concatenate([np.zeros(960), np.full(64, g)]).astype(np.float32)  # the decoy: support where +-c' is zero
+    ms = np.arange(900, 1160, 2)  # the exact block holds m 2^-16 in 64 coordinates: x.c' = -0.8758 + m / 1024 (true), -1.7517 + m / 1024 (filter)
+    n = len(ms)
+    qf = -(448 * (8 * e + 16 * e * e)) + ms / 1024.0  # the filter's dot of the un-mirrored row with c' (exact arithmetic of rounded operands)
+    qt = -(448 * (4 * e + 8 * e * e)) + ms / 1024.0   # the true dot
+    assert (qf < 0).all() and (qt > 0).all()           # every row: the filter names -c', the truth is +c'
+    cnA = float(np.float64(cp.astype(np.float64) @ cp.astype(np.float64)))
+    gap = -4.0 * qf                                     # v(T) - v(N) by the filter
+    t = (g * g * 64 - cnA + 0.4 * qf) / (2 * 64 * g)    # v(D) = v(N) + 0.6 gap  <=>  -2 * 64 g t + (|D|^2 - |c'|^2) = -0.4 qf
+    t = np.round(t * 2.0 ** 14) / 2.0 ** 14             # on half's grid at 2^-4 .. 2^-3: the products t g and their sums are exact
+    x = np.empty((n, d), np.float32)
+    x[:, :448], x[:, 448:896] = 1 + e, 1 + 3 * e
+    x[:, 896:960] = (ms * 2.0 ** -16)[:, None]
+    x[:, 960:] = 0.0
+    x[1::2] *= -1  # every other row mirrored: the roles of +c' and -c' swap (the decoy coordinates stay positive)
+    x[:, 960:] = t[:, None].astype(np.float32)
+    cen = [cp, -cp, dc, -dc]
+    rs = np.random.RandomState(3)
+    for _ in range((K - 4) // 2):  # far pairs +-w, balanced inside both rounding blocks: x.w = 0, the centres' mean stays exactly 0
+        w = np.zeros(d, np.float32)
+        w[:448] = 1.25 * rs.permutation(np.repeat([1.0, -1.0], 224))
+        w[448:896] = 1.25 * rs.permutation(np.repeat([1.0, -1.0], 224))
+        cen += [w, -w]
+    centers = np.stack(cen).astype(np.float32)
+    # the construction, checked in float64: truth and what a half-precision filter sees
+    x64, c64 = x.astype(np.float64), centers.astype(np.float64)
+    true_d = (x64 * x64).sum(1)[:, None] - 2 * x64 @ c64.T + (c64 * c64).sum(1)[None]
+    truth = true_d.argmin(1)
+    xh, ch = x.astype(np.float16).astype(np.float64), centers.astype(np.float16).astype(np.float64)
+    filt = -2 * xh @ ch.T + (c64 * c64).sum(1)[None]
+    order = np.argsort(filt, axis=1)
+    named, second, third = order[:, 0], order[:, 1], order[:, 2]
+    want_named = np.where(np.arange(n) % 2 == 0, 1, 0)
+    assert np.array_equal(named, want_named) and (second == 2).all() and np.array_equal(third, 1 - want_named)
+    assert np.array_equal(truth, 1 - want_named)  # the true minimiser is the filter's THIRD
+    E = (2.103e-3 + 1.248e-4) * 32.0 * np.sqrt((x64 * x64).sum(1)) + 2.0 ** -20 * (np.sqrt((x64 * x64).sum(1)) + 32.0) ** 2  # filter_bound, to ~1 %
+    rel = (filt[np.arange(n), third] - filt[np.arange(n), named]) / E
+    assert rel.min() > 1.1 and rel.max() < 1.8, (rel.min(), rel.max())  # beyond a window of E, inside the proven 2 E
+    counts = np.full(K, 1000, np.float32)
+    km = KMeans(None, d, K)
+    km.centers, km.counts, km.count = centers, counts, 10 * K + int(counts.sum())
+    km.to("cuda:0")
+    lab, _ = km.calc_best(torch.from_numpy(x).cuda(), need_mean=False)
+    launches, rows, undecided = km.filter_stats()
+    assert launches == 1 and rows == n and undecided == n
+    ref = O.KMeans(d, K, O.Rng(0), centers=centers)
+    ref.set_state(None, counts, 10 * K + int(counts.sum()))
+    want = ref.calc_best(x)[0]
+    got = lab.cpu().numpy()
+    assert np.array_equal(want, truth)
+    assert np.array_equal(got, want), f"{int((got != want).sum())} of {n} labels differ: the true minimiser was not among the candidates"
+    cand_rows, cand_pairs, full_rows = km.recheck_stats()
+    assert cand_rows + full_rows == n and cand_pairs >= 3 * cand_rows  # N, D and T of every row
+    print(f"K {K}: true minimiser third by the filter at {rel.min():.2f} .. {rel.max():.2f} E above its minimum in {n} rows; "
+          f"{cand_rows} rows by candidates ({cand_pairs} pairs), {full_rows} by the full exact sweep")
+
+
+def test_position_tag_may_reorder_the_filters_top_two(env):
+    """The filter's compare-free top-2 scan overwrites the 7 low mantissa bits of every distance with the centre's position in the
+    lane (acav_kmeans_assign.hip: "tagged", c = 1.6e-5 of |d1| + |d2| in the acceptance test).  Two centres whose filter values are
+    closer than the tag's reach come out of the scan in the order of their POSITIONS, not of their values.  Integer data (every product
+    and partial sum exact, filter value == true value): pairs of centres 1 .. 100 units of the last place apart at ~2^21, the nearer
+    one at the higher position -- the scan names the wrong one of every pair; the rows must be undecided and the exact path must
+    return the true minimiser (ties: the first index)."""
+    torch, acav, O = env
+    from acav100m_amd.clustering import KMeans
+    d, K = 64, 130
+    rs = np.random.RandomState(11)
+    centers = np.zeros((K, d), np.float32)
+    base = rs.randint(-8, 9, size=d).astype(np.float32) * 64.0
+    for k in range(K):
+        centers[k] = base
+        centers[k, k % d] += 16.0 * (K - k)  # all centres close together, each in its own direction; later centres nearer to `base`
+    n = 512
+    x = (base[None, :] + rs.randint(-2, 3, size=(n, d)).astype(np.float32)) * 1.0
+    x[:, 0] += 512.0  # a common offset: distances ~ 2.6e5 .. with ulp-level differences between neighbours in k
+    counts = np.full(K, 1000, np.float32)
+    km = KMeans(None, d, K)
+    km.centers, km.counts, km.count = centers, counts, 10 * K + int(counts.sum())
+    km.to("cuda:0")
+    lab, _ = km.calc_best(torch.from_numpy(x).cuda(), need_mean=False)
+    ref = O.KMeans(d, K, O.Rng(0), centers=centers)
+    ref.set_state(None, counts, 10 * K + int(counts.sum()))
+    want = ref.calc_best(x)[0]
+    assert np.array_equal(lab.cpu().numpy(), want)
+    x64, c64 = x.astype(np.float64), centers.astype(np.float64)
+    true_d = (x64 * x64).sum(1)[:, None] - 2 * x64 @ c64.T + (c64 * c64).sum(1)[None]
+    assert np.array_equal(want, true_d.argmin(1))  # integer data: float32 evaluates these distances exactly
+
+
 @pytest.mark.parametrize("d,K,switch", [(1024, 300, None), (128, 257, None), (1024, 200, ("ACAV_FILTER_NW", "8")),
                                         (1024, 200, ("ACAV_ASSIGN_EMIT", "1")), (1024, 600, ("ACAV_FILTER_GS", "0")),
                                         (1024, 300, ("ACAV_EMIT_NW", "8")), (96, 1024, None)])

@@ -3,6 +3,7 @@ oracle (bit-exact ids, identical float64 gains) and vs the golden traces recorde
 reference (teacher-forced: identical batch ids every iteration, scores within 1e-5)."""
 import itertools
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -409,3 +410,32 @@ def test_lockstep_chunks_equal_individual_runs(env):
         m1, m2 = build(0, 1), build(1, 2)
         m1._generator = m2._generator = g
         EfficientBatchMI.run_greedy_multi([m1, m2], [10, 10], [[0], [0]])
+
+
+def test_greedy_loop_speed_does_not_depend_on_the_process_history():
+    """The loop's three streams (content, positions, generator) need three HARDWARE queues; which queue the runtime gives a new
+    stream depends on every stream the process created and destroyed before (round 5: two idle k-means handles cost the loop a
+    third of its speed).  acav_mi_create now measures whether two of its streams serialise and replaces the one that does
+    (mi_separate_queues).  Ten k-means handles created, used and partly destroyed before the handle exists, two of them still alive:
+    the 1M-clip loop must run within 10 % of the clean process's speed (tools/mi_history_probe.py, loop time by ACAV_MI_TIMING;
+    best of two runs each, fresh processes)."""
+    import re
+    import subprocess
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "mi_history_probe.py")
+
+    def run(*argv):
+        best = None
+        for _ in range(2):
+            r = subprocess.run([sys.executable, tool] + [str(a) for a in argv], capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-1500:]
+            us = float(re.search(r"us_per_iteration ([\d.]+)", r.stdout).group(1))
+            best = us if best is None else min(best, us)
+        return best
+
+    clean = run(0, 0, 6000)
+    history = run(10, 2, 6000)
+    assert history <= 1.10 * clean + 0.5, (clean, history)
