@@ -64,7 +64,10 @@ void devbuf_free(void *p, size_t bytes);
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    hipStream_t owner = nullptr;  // bind(): the ONE stream every use of this buffer is ordered on (k-means handles)
+    bool bound = false;
     ~DevBuf() { release(); }
+    void bind(hipStream_t s) { owner = s, bound = true; }
     void release()
     {
         if (p) devbuf_free(p, bytes);
@@ -77,9 +80,11 @@ struct DevBuf {
         // Growing a buffer that kernels already in flight may still read or write (an asynchronous assign / step enqueued
         // with the old block): hipFree used to synchronise the device implicitly, a PARKED block is handed to the next
         // request at once -- possibly another handle on another stream.  Growth is rare (first use of a larger shape), so
-        // it pays for the synchronisation the free no longer does.  Destructors run after the owner's *_destroy has
-        // synchronised its stream.
-        if (p) (void)hipDeviceSynchronize();
+        // it pays for the synchronisation the free no longer does: of the owning stream when the buffer is bound to one
+        // (a k-means handle's buffers: growing clustering B's staging must not wait for clustering A's persistent epoch or a
+        // pending send / receive of another communicator), else of the device.  Destructors run after the owner's *_destroy
+        // has synchronised its stream.
+        if (p) (void)(bound ? hipStreamSynchronize(owner) : hipDeviceSynchronize());
         release();
         return devbuf_alloc(&p, &bytes, n);
     }

@@ -529,6 +529,12 @@ constexpr unsigned TP_SPIN_LIMIT = 1u << 24;
 #define ACAV_TP_FIRST_SLEEP 32
 #endif
 constexpr int TP_FIRST_SWEEP_PAUSE = ACAV_TP_FIRST_SLEEP;  // x 64 clocks between a workgroup's publish and its first sweep
+#ifndef ACAV_TPW_FIRST_SLEEP
+#define ACAV_TPW_FIRST_SLEEP 0
+#endif
+#ifndef ACAV_TPW_PASS_SLEEP
+#define ACAV_TPW_PASS_SLEEP 0
+#endif
 
 #if defined(ACAV_WIDE_NO_MFMA) && !defined(ACAV_EXPERIMENT_BUILD)
 #error "ACAV_WIDE_NO_MFMA is an A/B switch of experiment builds (add -DACAV_EXPERIMENT_BUILD)"
@@ -537,14 +543,15 @@ constexpr int TP_FIRST_SWEEP_PAUSE = ACAV_TP_FIRST_SLEEP;  // x 64 clocks betwee
 #error "ACAV_WIDE_PROF is a diagnostic switch of experiment builds (add -DACAV_EXPERIMENT_BUILD)"
 #endif
 constexpr int TP_RING = 4;
-// Where a granule lives (round 6).  Every workgroup's sweep reads EVERY centre group's granules of the step: 128-256 readers of the
-// same lines at the same moment.  With the granules of a ring slot contiguous (64 groups x 256 B = 16 KB: a handful of memory
-// channels) a sweep pass took 2-2.6 us -- 8 x the idle latency of a device-scope load -- whatever the number of granules it
-// re-read: queueing at the channels that own those 16 KB.  Each 128-byte line of 16 granules (rows 16 h .. 16 h + 15 of one centre
-// group) now sits TP_LSTRIDE granules from the next one: 4 KB + 128 B apart, i.e. in another page AND at another line offset, so
-// that consecutive lines fall into different channels for any power-of-two interleave between 128 B and 4 KB.
+// Where a granule lives.  Every workgroup's sweep reads EVERY centre group's granules of the step: 128-256 readers of the same 128
+// lines at the same moment, and a sweep pass takes 2-2.6 us -- 8 x the idle latency of a device-scope load -- whatever the number of
+// granules it re-reads.  Round 6 tested whether that is queueing at the few memory channels that own a contiguous 16 KB ring slot:
+// with each 128-byte line of 16 granules (rows 16 h .. 16 h + 15 of one centre group) 4 KB + 128 B from the next one (another page
+// AND another line offset: different channels for any power-of-two interleave between 128 B and 4 KB; -DACAV_TP_LSTRIDE=528) the
+// K = 1024 forms got SLOWER (9.02 vs 8.66 us per step alone, the pair 9.12 vs 8.77), K = 256 the same (6.32 vs 6.39): not a channel
+// hot spot -- 128 pages instead of 4 cost more than the spreading gains.  Contiguous (16) stays.
 #ifndef ACAV_TP_LSTRIDE
-#define ACAV_TP_LSTRIDE 528
+#define ACAV_TP_LSTRIDE 16
 #endif
 constexpr int TP_LSTRIDE = ACAV_TP_LSTRIDE;  // granules from one 16-granule line to the next (16 = contiguous, rounds 1-5)
 constexpr int TP_MAXCG = 128;                // centre groups a sweep can address (the launch conditions keep to 64)
@@ -687,6 +694,8 @@ __global__ __launch_bounds__(256) void k_step_dist_dma_rg(const float *__restric
 // runs the segment's FMA chain for all 64 (centre, row) pairs, and applies the centre update to it.
 // One wave can only issue ~1 ds_read_b128 per 20+ cycles, so the 4 waves quadruple the LDS read rate;
 // the 4 segment sums are folded in order ((s0+s1)+s2)+s3 -- exactly the canonical dot.
+__device__ __forceinline__ f32x4 dot_tile_mfma(const float *pc, const float *px, int sc, int sx);  // (below, with the 16-centre forms)
+
 template <bool RAGGED, bool PROF>  // RAGGED: d % 256 != 0 (guarded DMA / update lanes, zero-padded last block)
 __global__ __launch_bounds__(256) void k_train_persistent(
     const float *__restrict__ x, const float *__restrict__ xn, int b, int d, int K, float *__restrict__ centers,
@@ -752,12 +761,28 @@ __global__ __launch_bounds__(256) void k_train_persistent(
             if (t + 1 < T && active) tp_dma_block<RAGGED>(sX[(t + 1) & 1], x + (size_t)(t + 1) * b * d, rbase, nrv, d, wave, lane);
             const long long c1 = TP_CLK();
             pr[0] += c1 - c0;
+#ifndef ACAV_WIDE_NO_MFMA
+            // round 6: the block's 8 x 8 (centre, row) pairs as one quarter of a 16 x 16 tile on the f32 matrix core (dot_tile_mfma:
+            // bit for bit the v_fma chain; tile rows / columns 8 .. 15 repeat 0 .. 7 and are dropped): 64 dependent MFMAs = 2.6k
+            // cycles and 128 ds_read_b32 per wave against 3.3k cycles and 2 x 64 ds_read_b128 of the per-lane chain
+            if (active) {
+                const int i15 = lane & 15, kq = lane >> 4, r8 = i15 & 7;
+                const f32x4 q4 = dot_tile_mfma(sC + r8 * TP_DS + wave * 256 + kq, sX[t & 1] + r8 * TP_DS + wave * 256 + kq, r8, r8);
+                if (kq < 2 && i15 < 8) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sPart[wave][(4 * kq + e) * 8 + i15] = q4[e];  // slot (centre kk, row ii) = kk * 8 + ii
+                }
+            } else
+                sPart[wave][lane] = 0.f;
+            if (PROF) pr[5] += TP_CLK() - c1;  // the chain alone
+#else
             float part = 0.f;
             if (active)
                 part = dot_blocks<1>(sC + kk * TP_DS + wave * 256, sX[t & 1] + ii * TP_DS + wave * 256, kk << 2, ii << 2,
                                      0.f, true);
             if (PROF) pr[5] += TP_CLK() - c1;  // the chain alone
             sPart[wave][lane] = part;
+#endif
             if (pend) {  // uniform: the previous update's norm refresh, off the update's critical path
                 tp_refresh_norms(pend, sC, sCn, wave, lane, d);
                 pend = 0;
@@ -1014,13 +1039,45 @@ __device__ __forceinline__ void dot_quad(const float *pc, const float *px, int s
 // (chunk tt of 4 columns sits at float offset ((tt ^ s) << 2), as in dot_blocks).
 __device__ __forceinline__ f32x4 dot_tile_mfma(const float *pc, const float *px, int sc, int sx)
 {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // Two windows of 16 k-steps (32 operand registers each).  Left to itself the compiler loads a window, waits for ALL of it
+    // (lgkmcnt(0)) and multiplies -- the last reads are issued right before the wait, ~120 cycles of LDS latency per window on a
+    // 40-cycle-per-instruction chain (3.4k cycles per block instead of 2.6k, ACAV_PROFILE_STEPS).  Pinned order: the 16 ds_read2 of
+    // window w + 1 go out between the FIRST eight MFMAs of window w, the last eight MFMAs cover their latency.  Same chain, same
+    // order of the k-steps: bit-identical.
+    const float *pcu[8], *pxu[8];
 #pragma unroll
-    for (int t = 0; t < 64; ++t) {
-        const float a = pc[(((t & 7) ^ sc) << 2) + ((t >> 3) << 5)];
-        const float bq = px[(((t & 7) ^ sx) << 2) + ((t >> 3) << 5)];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc, 0, 0, 0);
+    for (int u = 0; u < 8; ++u) {
+        pcu[u] = pc + ((u ^ sc) << 2);
+        pxu[u] = px + ((u ^ sx) << 2);
     }
+    float A[2][16], B[2][16];
+#define ACAV_LDW(slot, w)                                              \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                    \
+        A[slot][u] = pcu[u][(2 * (w)) << 5];                           \
+        A[slot][u + 8] = pcu[u][(2 * (w) + 1) << 5];                   \
+        B[slot][u] = pxu[u][(2 * (w)) << 5];                           \
+        B[slot][u + 8] = pxu[u][(2 * (w) + 1) << 5];                   \
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    ACAV_LDW(0, 0)
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int s = w & 1;
+        if (w + 1 < 4) { ACAV_LDW(s ^ 1, w + 1) }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s][i], B[s][i], acc, 0, 0, 0);
+        if (w + 1 < 4) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA ...
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // ... two ds_read2 of the next window
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        } else
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    }
+#undef ACAV_LDW
     return acc;
 }
 
@@ -1214,7 +1271,13 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
 #pragma unroll
                 for (int u = 0; u < TPW_SW; ++u)
                     if (srow < b && half + 2 * u < ncg) needm |= 1u << u;
+#if ACAV_TPW_FIRST_SLEEP > 0
+                __builtin_amdgcn_s_sleep(ACAV_TPW_FIRST_SLEEP);  // experiment knob: x 64 clocks between the publish and the first sweep
+#endif
                 for (unsigned spins = 0;; ++spins) {
+#if ACAV_TPW_PASS_SLEEP > 0
+                    if (spins) __builtin_amdgcn_s_sleep(ACAV_TPW_PASS_SLEEP);  // experiment knob: pause before a repeated pass
+#endif
 #ifdef ACAV_WIDE_PROF
                     wpr[7] += 1;  // sweep passes
 #endif
@@ -1858,6 +1921,7 @@ ACAV_EXPORT int acav_kmeans_create(acav_kmeans **out, int device, int k, int d, 
     }
     km->K = k;
     km->d = d;
+    km->bind_buffers();
     auto fail = [&](int code) {
         km->ctx.fini();
         delete km;
@@ -2177,7 +2241,9 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
                           ((uintptr_t)fx & 15) == 0;
     // the exchange sweep of k_train_persistent reads 2 x TP_SW = 32 centre groups per row: K <= 256; more groups go to the
     // wide kernel (64 groups of NCP x 8 centres)
-    const bool narrow_ok = (km->K + TP_NC - 1) / TP_NC <= 32;
+    // (ACAV_FORCE_WIDE=1: experiments -- the 16-centre forms for shapes the narrow kernel would take)
+    const char *vfw = getenv("ACAV_FORCE_WIDE");
+    const bool narrow_ok = (km->K + TP_NC - 1) / TP_NC <= 32 && !(vfw && vfw[0] == '1');
     bool persistent = shape_ok && narrow_ok && nwg <= room && nwg <= occ * km->num_cus;
     // more 8-centre groups than CUs (K = 1024): NCP x 8 centres per workgroup (k_train_persistent_wide) -- the smallest
     // NCP whose grid fits 3/4 of the device, else the whole device, within the LDS of a CU

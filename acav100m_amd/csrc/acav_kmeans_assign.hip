@@ -35,8 +35,10 @@ struct AssignCtl;
 __device__ __forceinline__ void assign_ctl_finish(AssignCtl *ctl, unsigned nblocks);
 __device__ __forceinline__ AssignCtl *ctl_of_f32_count(const unsigned *f32_count);
 
+// (GUARD: the ragged / unaligned form needs ~280 registers; cut for two waves per SIMD it carried 112 B of scratch -- and a queue
+// waits ~130 us for a scratch allocation the first time such a kernel runs on it.  One wave per SIMD: the spills live in AGPRs.)
 template <bool GUARD>
-__global__ __launch_bounds__(256, 2) void k_assign_f32(const float *__restrict__ x, int64_t n, int d,
+__global__ __launch_bounds__(256, GUARD ? 1 : 2) void k_assign_f32(const float *__restrict__ x, int64_t n, int d,
                                                        const float *__restrict__ centers,
                                                        const float *__restrict__ cn,
                                                        const float *__restrict__ counts, int K, float thr,
@@ -1833,17 +1835,13 @@ ACAV_EXPORT int acav_kmeans_assign(acav_kmeans *km, const float *x, int64_t n, i
             // of the list), the epilogue emits each row's candidate centres; then the exact canonical chains of those (row,
             // centre) pairs and the labels of those rows
             if (!emit_inplace || emit_gs) {
-                // one workgroup per CU either way (rings + lists do not fit twice): for K > 256 and wide rows the 8-wave /
-                // 256-row tile of the main kernel (centre ring 3, DMA pieces spread), else 4 waves / 128 rows
-                // (round 5: 4 waves by default everywhere -- the 8-wave instantiations cannot have one wave per SIMD and keep 156-172 B of
-                // scratch, and a queue waits ~130 us for a scratch allocation the first time a kernel with scratch runs on it;
-                // ACAV_EMIT_NW=8 selects them for A/B runs)
-                const char *venw = getenv("ACAV_EMIT_NW");
-                const int enw = emit_gs && nw == 8 && venw && venw[0] == '8' ? 8 : 4;
+                // one workgroup per CU (rings + lists do not fit twice), 4 waves / 128 rows
+                // (round 6: the 8-wave emission instantiations are gone -- they kept 156-172 B of scratch and no run ever selected them
+                // outside A/B tests; the emission pass always runs 128-row tiles)
+                constexpr int enw = 4;
                 const bool xs = km->filter_rows_scaled;
-                FilterKern ek = enw == 8 ? (xs ? k_assign_f16_rw<true, 8, false, 3, 2, 1, true> : nt ? k_assign_f16_rw<true, 8, false, 3, 2, 1> : k_assign_f16_rw<false, 8, false, 3, 2, 1>)
-                                         : (xs ? k_assign_f16_rw<true, 4, false, 2, 0, 1, true> : nt ? k_assign_f16_rw<true, 4, false, 2, 0, 1> : k_assign_f16_rw<false, 4, false, 2, 0, 1>);
-                const int esmem = FD_DX * enw * 4096 + (enw == 8 ? 3 : 2) * FD_SLOT + enw * 32 * (4 + 2 * (int)CAND_MAX);  // rings + lists
+                FilterKern ek = xs ? k_assign_f16_rw<true, 4, false, 2, 0, 1, true> : nt ? k_assign_f16_rw<true, 4, false, 2, 0, 1> : k_assign_f16_rw<false, 4, false, 2, 0, 1>;
+                const int esmem = FD_DX * enw * 4096 + 2 * FD_SLOT + enw * 32 * (4 + 2 * (int)CAND_MAX);  // rings + lists
                 ACAV_TRY(dyn_lds_once(reinterpret_cast<const void *>(ek), km->ctx.device, esmem));
                 const int64_t erows = (int64_t)enw * 32;
                 const int64_t egrid = std::min<int64_t>((n + erows - 1) / erows, (int64_t)km->num_cus);

@@ -80,6 +80,13 @@ struct acav_kmeans {
     int key_phase = 0;  // which half of `keys` the next step's distance kernel folds into
     int64_t n_assign_launches = 0, n_step_launches = 0;
 
+    void bind_buffers()  // every buffer of the handle is only ever used on the handle's stream (DevBuf::ensure synchronises that one)
+    {
+        for (DevBuf *b : {&centers, &cn, &counts, &scalars, &stage_x, &stage_lab, &stage_forced, &keys, &xn, &wg_sum, &minval, &thr, &ctl,
+                          &cb16, &caux, &cmu, &recheck_list, &backup, &grec, &split_rings, &cand_ctl, &cand_rows, &cand_pairs, &cand_T,
+                          &cpad, &xpad})
+            b->bind(ctx.stream);
+    }
     float threshold() const { return (float)pow((double)count / (double)K, reinit_p); }
     bool warm() const { return count < (int64_t)initial_rounds * K; }
     int filter_d() const { return (d + 31) / 32 * 32; }  // the width the assign filter runs at (d padded to its 32-column stage)

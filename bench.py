@@ -49,7 +49,9 @@ rank hashes every clustering's state (all ranks must agree) and rank 0 re-labels
 
 The JSON line also carries
   roofline      k_assign_f16_rw, the HBM-bound kernel of the path: algorithmic bytes N*d*4 + N*8 per launch over the
-                kernel's duration measured with HIP events on the library's stream around that launch alone
+                kernel's duration measured with HIP events on the library's stream around that launch alone.  `frac` / `achieved`
+                are the SUSTAINED figures (160 launches back to back, the median of the last third: the socket's power cap has
+                throttled the shader clock by then); `*_timed_region` = the launches inside the timed pass (device at rest)
                 (`sweep_*` keys: the whole calc_best sweep incl. centre preparation and the exact re-check pass)
   roofline_mi   the candidate-permutation stream of the greedy loop (16 L bytes per iteration) vs HBM
   variants      the same pipeline with the selection chunked (chunk_size = 100 shards = 100k clips, 10 chunks in
@@ -485,7 +487,21 @@ def main():
         if not args.no_variants and world == 1 and chunk is None and n >= 200_000:
             out["variants"] = {"chunked_lockstep": chunked_variant(last["a"], types, n, st)}
             if not mfma_bound:  # (an HBM figure: the K = 256 shapes)
-                out["roofline"]["back_to_back"] = back_to_back_sweeps(lib, last["kms"][vq], xs[vq], labels[vq], n, bytes_per_launch)
+                bb = back_to_back_sweeps(lib, last["kms"][vq], xs[vq], labels[vq], n, bytes_per_launch)
+                out["roofline"]["back_to_back"] = bb
+                if "frac_settled" in bb:
+                    # the HEADLINE fraction is the sustained one: what a sweep over more than a few million rows
+                    # sees once the power controller has settled; the launch inside the timed pass (after a latency-bound training
+                    # stage: the device at rest) is the `*_timed_region` figure
+                    rf = out["roofline"]
+                    rf["frac_timed_region"], rf["achieved_timed_region"], rf["launch_ms_timed_region"] = rf["frac"], rf["achieved"], rf["launch_ms"]
+                    rf["frac"], rf["launch_ms"] = bb["frac_settled"], bb["launch_ms_settled"]
+                    rf["achieved"] = bytes_per_launch / (bb["launch_ms_settled"] * 1e-3) / 1e9
+                    rf["frac_of_measured_copy_rate"] = rf["achieved"] / HBM_MEASURED_COPY_GBS
+                    rf["frac_of_measured_read_rate"] = rf["achieved"] / HBM_MEASURED_READ_GBS
+                    rf["what_caps_it"] = ("socket power: back to back the filter pulls ~1.35 kW of the 1.4 kW cap (PVIOL 95-100 %), the shader "
+                                          "clock falls 2.4 -> 1.55-1.65 GHz within ~50 ms; without the MFMAs (timing-only ablation) 0.93 kW, no "
+                                          "throttling, 0.685-0.69: profiles/r06_filter_sustained.txt")
         if not args.no_variants and world == 1 and k <= 256:
             del xs
             torch.cuda.empty_cache()
@@ -556,11 +572,13 @@ def run_verify(torch, dist, world, rank, last, xs, labels, dims, k, sample=16384
     return verdict
 
 
-def back_to_back_sweeps(lib, km, x, lab, n, bytes_per_launch, reps=12):
-    """The roofline kernel under SUSTAINED load: `reps` sweeps of the timed workload's widest view with nothing between them.  The
-    timed pass launches the filter after a latency-bound training stage; back to back the same launch settles 10-20 % slower on
-    the boxes of round 5 (0.76 -> 0.86 ms after ~3 ms; with 2 ms of idle time between sweeps it stays at 0.76: the device's clock /
-    power management, tools/exp/sweep_overhead_probe.py).  Reported beside `frac`, measured once after the timed region."""
+def back_to_back_sweeps(lib, km, x, lab, n, bytes_per_launch, reps=160):
+    """The roofline kernel under SUSTAINED load: `reps` sweeps of the timed workload's widest view with nothing between them (~0.13 s of
+    load).  The timed pass launches the filter after a latency-bound training stage, i.e. on a device at rest; back to back the same
+    launch runs into the socket's POWER cap: ~1.35 of 1.4 kW, PVIOL 95-100 %, the shader clock drops from 2.4 to ~1.1 GHz within
+    ~5 ms (the controller overshoots: launches of 1.0-1.1 ms) and settles at 1.55-1.65 GHz after ~50 ms (0.80-0.82 ms per launch;
+    tools/filter_sustained.py, profiles/r06_filter_sustained.txt -- the 12-sweep window of round 5 sat inside the overshoot and read
+    0.555).  Settled = the median of the last third.  Measured once after the timed region."""
     try:
         from acav100m_amd import _lib
         ms = []
@@ -570,9 +588,11 @@ def back_to_back_sweeps(lib, km, x, lab, n, bytes_per_launch, reps=12):
             fm = C.c_float(0)
             _lib.check(lib.acav_kmeans_filter_time(km._h, C.byref(fm)))
             ms.append(fm.value)
-        settled = float(np.mean(ms[reps // 2:]))
-        return {"sweeps": reps, "launch_ms_first": ms[0], "launch_ms_settled": settled,
-                "frac_settled": bytes_per_launch / (settled * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch_ms_all": [round(v, 4) for v in ms]}
+        settled = float(np.median(ms[2 * reps // 3:]))
+        return {"sweeps": reps, "launch_ms_first": ms[0], "launch_ms_settled": settled, "launch_ms_worst": float(max(ms)),
+                "frac_settled": bytes_per_launch / (settled * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "frac_worst_of_the_transient": bytes_per_launch / (max(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "launch_ms_every_8th": [round(v, 4) for v in ms[::8]]}
     except Exception as exc:  # informational leg: never takes the driver line down
         return {"error": repr(exc)}
 

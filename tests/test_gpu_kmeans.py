@@ -496,7 +496,7 @@ def test_position_tag_may_reorder_the_filters_top_two(env):
 
 @pytest.mark.parametrize("d,K,switch", [(1024, 300, None), (128, 257, None), (1024, 200, ("ACAV_FILTER_NW", "8")),
                                         (1024, 200, ("ACAV_ASSIGN_EMIT", "1")), (1024, 600, ("ACAV_FILTER_GS", "0")),
-                                        (1024, 300, ("ACAV_EMIT_NW", "8")), (96, 1024, None)])
+                                        (96, 1024, None)])
 @pytest.mark.parametrize("scale", [2.0 ** -20, 1e3])
 def test_filter_scaled_rows_every_instantiation(env, d, K, switch, scale, monkeypatch):
     """The scaled-row (XS) instantiations of EVERY tile form of the filter -- 8 waves / (tile, group) pairs (K > 256, wide rows), 4-wave

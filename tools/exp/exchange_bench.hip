@@ -1,0 +1,148 @@
+// Experiment (not product): what does ONE round of the persistent SGD kernels' cross-workgroup exchange cost on an MI355X, and which
+// polling structure gets closest to the hardware's store -> load latency?  The product pattern (k_train_persistent_wide, 16 x 16
+// form at K = 1024): NWG = 128 workgroups (64 centre groups x 2 row groups); per round every workgroup publishes 16 granules of 8
+// bytes {tag | payload} with device-scope stores into ring[cg][row] and then needs ALL 64 x 32 granules of the round.
+//   ./exchange_bench [rounds] [work_cycles]
+// Modes:
+//   0  the product's sweep: lane (row = l & 31, half = l >> 5) loads its 32 granules, waits for all of them, re-reads the missing ones
+//   1  the same, but a pass re-reads ALL granules (what "only the missing ones" saves)
+//   2  counter hint: after its stores a workgroup adds 1 to one of 8 arrival counters (device-scope atomic, no fence); the sweep polls
+//      the 8 counters (one 64-byte line) until they sum to NWG, then reads the granules (tags still checked: a late store -> mode 0 loop)
+//   3  ping-pong between TWO workgroups (store -> seen -> store back), for the raw round trip
+// Every workgroup "works" work_cycles (s_sleep) before it publishes; one workgroup in three works 1 500 cycles longer (the update of a
+// touched workgroup).  Reported: us per round.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+constexpr int NCG = 64, NRG = 2, NWG = NCG * NRG, RING = 4;
+struct Ctl {
+    unsigned long long gran[RING][NCG][32];
+    unsigned cnt[RING][8][16];  // 8 arrival counters per ring slot, one 64-byte line each
+    unsigned long long pp[2][16];
+};
+
+__device__ __forceinline__ void work(int cycles)
+{
+    const long long t0 = clock64();
+    while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_xchg(Ctl *ctl, int rounds, int work_cycles, unsigned long long *sink)
+{
+    __shared__ float pad[24 * 1024];  // 96 KB: one workgroup per CU, like the product
+    if (threadIdx.x == 1000) pad[0] = 1.f;
+    const int lane = threadIdx.x;
+    const int cg = blockIdx.x % NCG, rg = blockIdx.x / NCG;
+    const int srow = lane & 31, half = lane >> 5;
+    unsigned long long acc = 0;
+    for (int t = 0; t < rounds; ++t) {
+        work(work_cycles + ((blockIdx.x + t) % 3 == 0 ? 1500 : 0));
+        const unsigned long long tag = (unsigned long long)(t + 1) << 48;
+        unsigned long long(*ring)[32] = ctl->gran[t % RING];
+        if (lane < 16) __hip_atomic_store(&ring[cg][rg * 16 + lane], tag | (unsigned)(blockIdx.x * 64 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MODE == 2) {
+            if (lane == 0) __hip_atomic_fetch_add(&ctl->cnt[t % RING][blockIdx.x & 7][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the counters of ring slot t % RING count up over the rounds that use the slot: target = arrivals so far
+            const unsigned target = (unsigned)(NWG / 8) * (unsigned)(t / RING + 1);
+            for (;;) {
+                unsigned c = target;
+                if (lane < 8) c = __hip_atomic_load(&ctl->cnt[t % RING][lane][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(c >= target)) break;
+            }
+        }
+        unsigned long long g[32];
+        unsigned need = 0xFFFFFFFFu;
+        for (;;) {
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                if ((need >> u) & 1u) g[u] = __hip_atomic_load(&ring[half + 2 * u][srow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned still = 0;
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                if (((need >> u) & 1u) && (g[u] >> 48) != (tag >> 48)) still |= 1u << u;
+            if (MODE == 1) {
+                if (__all(still == 0)) break;  // need stays all ones: every pass re-reads everything
+            } else {
+                need = still;
+                if (__all(need == 0)) break;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc += g[u] & 0xffff;
+    }
+    if (lane == 0) sink[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(64) void k_pingpong(Ctl *ctl, int rounds, unsigned long long *sink)
+{
+    __shared__ float pad[24 * 1024];
+    if (threadIdx.x == 1000) pad[0] = 1.f;
+    if (threadIdx.x != 0) return;
+    const int me = blockIdx.x;  // 0 or 1
+    for (int t = 1; t <= rounds; ++t) {
+        if (me == 0) {
+            __hip_atomic_store(&ctl->pp[0][0], (unsigned long long)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(&ctl->pp[1][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)t) {}
+        } else {
+            while (__hip_atomic_load(&ctl->pp[0][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)t) {}
+            __hip_atomic_store(&ctl->pp[1][0], (unsigned long long)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    sink[me] = 1;
+}
+
+template <int MODE>
+static void run(const char *name, Ctl *ctl, unsigned long long *sink, int rounds, int work_cycles)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipMemset(ctl, 0, sizeof(Ctl)));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_xchg<MODE>, dim3(NWG), dim3(64), 0, 0, ctl, rounds, work_cycles, sink);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    printf("%-72s %.2f us per round\n", name, best * 1e3 / rounds);
+    fflush(stdout);
+}
+
+int main(int argc, char **argv)
+{
+    const int rounds = argc > 1 ? atoi(argv[1]) : 20000;
+    const int work_cycles = argc > 2 ? atoi(argv[2]) : 3500;
+    Ctl *ctl;
+    unsigned long long *sink;
+    CK(hipMalloc(&ctl, sizeof(Ctl)));
+    CK(hipMalloc(&sink, 8 * NWG));
+    printf("%d workgroups (%d centre groups x %d row groups), %d rounds, %d cycles of work per round (+1500 in a third of the workgroups)\n", NWG, NCG,
+           NRG, rounds, work_cycles);
+    run<0>("product sweep (re-read the missing granules)", ctl, sink, rounds, work_cycles);
+    run<1>("every pass re-reads all granules", ctl, sink, rounds, work_cycles);
+    run<2>("arrival counters as a hint, then the granules", ctl, sink, rounds, work_cycles);
+    run<0>("product sweep, no work at all (the exchange alone)", ctl, sink, rounds, 0);
+    run<2>("arrival counters, no work at all", ctl, sink, rounds, 0);
+    {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        CK(hipMemset(ctl, 0, sizeof(Ctl)));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_pingpong, dim3(2), dim3(64), 0, 0, ctl, rounds, sink);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-72s %.2f us per round trip (two store -> load hops)\n", "ping-pong between two workgroups (blocks 0 and 1)", ms * 1e3 / rounds);
+    }
+    return 0;
+}
