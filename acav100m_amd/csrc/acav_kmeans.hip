@@ -529,6 +529,9 @@ constexpr unsigned TP_SPIN_LIMIT = 1u << 24;
 #define ACAV_TP_FIRST_SLEEP 32
 #endif
 constexpr int TP_FIRST_SWEEP_PAUSE = ACAV_TP_FIRST_SLEEP;  // x 64 clocks between a workgroup's publish and its first sweep
+#ifndef ACAV_SWEEP_REREAD_ALL
+#define ACAV_SWEEP_REREAD_ALL 1
+#endif
 #ifndef ACAV_TPW_FIRST_SLEEP
 #define ACAV_TPW_FIRST_SLEEP 0
 #endif
@@ -828,10 +831,13 @@ __global__ __launch_bounds__(256) void k_train_persistent(
                 // pass is more often complete and the pause costs more than it saves (K = 64: 7.34 -> 7.43)
                 if (ncg >= 16) __builtin_amdgcn_s_sleep(TP_FIRST_SWEEP_PAUSE);
                 for (unsigned spins = 0;; ++spins) {
-                    // only the granules still missing are re-read: later passes are short and load the fabric less
+                    // round 6: EVERY pass re-reads every granule of the existing centre groups (a wave-uniform condition).  Re-reading
+                    // only the lanes' missing granules -- rounds 1-5 -- put an exec-mask save / branch / restore around each of the
+                    // loads and sent nearly as many (sparse) memory instructions: tools/exp/exchange_bench.hip, 128 workgroups,
+                    // 3 500 cycles of work per round: 4.85 us per round against 3.75 with full re-reads
 #pragma unroll
                     for (int u = 0; u < TP_SW; ++u)
-                        if ((need >> u) & 1u)
+                        if (ACAV_SWEEP_REREAD_ALL ? 2 * u < ncg : (int)((need >> u) & 1u))
                             g[u] = __hip_atomic_load(&ring[tp_gran_index(half + 2 * u, srow)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int u = 0; u < TP_SW; ++u)
@@ -1194,7 +1200,20 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
 #pragma unroll
                     for (int q = 0; q < 4; ++q) sPart[(q * nblk + blk) * 64 + lane] = q4[q];
                 }
-            } else
+            }
+#ifndef ACAV_WIDE_NO_MFMA
+            else if constexpr (NCP == 1) {  // 8 centres x 8 rows (the tall forms, d > 1024): a quarter of a matrix-core tile per block, as k_train_persistent
+                const int i15 = lane & 15, kq = lane >> 4, r8 = i15 & 7;
+                for (int blk = wave; blk < nblk; blk += 4) {
+                    const f32x4 q4 = dot_tile_mfma(sC + r8 * ds + blk * 256 + kq, xs + r8 * ds + blk * 256 + kq, r8, r8);
+                    if (kq < 2 && i15 < 8) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sPart[blk * 64 + (4 * kq + e) * 8 + i15] = q4[e];  // slot (kk, ii) = kk * 8 + ii
+                    }
+                }
+            }
+#endif
+            else
                 for (int blk = wave; blk < nblk; blk += 4)
                     for (int cp = 0; cp < NCP; ++cp)
                         sPart[(cp * nblk + blk) * 64 + lane] =
@@ -1283,7 +1302,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
 #endif
 #pragma unroll
                     for (int u = 0; u < TPW_SW; ++u)
-                        if ((needm >> u) & 1u)
+                        if (ACAV_SWEEP_REREAD_ALL ? 2 * u < ncg : (int)((needm >> u) & 1u))  // (every pass re-reads all: see k_train_persistent)
                             g[u] = __hip_atomic_load(&ring[tp_gran_index(half + 2 * u, srow)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int u = 0; u < TPW_SW; ++u)
@@ -1758,7 +1777,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
                 for (unsigned spins = 0;; ++spins) {
 #pragma unroll
                     for (int u = 0; u < TPW_SW; ++u)
-                        if ((needm >> u) & 1u)
+                        if (ACAV_SWEEP_REREAD_ALL ? 2 * u < ncg : (int)((needm >> u) & 1u))  // (every pass re-reads all: see k_train_persistent)
                             g[u] = __hip_atomic_load(&ring[tp_gran_index(half + 2 * u, srow)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int u = 0; u < TPW_SW; ++u)

@@ -9,6 +9,10 @@
 //   2  counter hint: after its stores a workgroup adds 1 to one of 8 arrival counters (device-scope atomic, no fence); the sweep polls
 //      the 8 counters (one 64-byte line) until they sum to NWG, then reads the granules (tags still checked: a late store -> mode 0 loop)
 //   3  ping-pong between TWO workgroups (store -> seen -> store back), for the raw round trip
+//   4  every pass re-reads all granules with 16-byte loads (two granules per lane: 16 memory instructions per pass instead of 32)
+//   6  two-level: per XCD (blockIdx % 8: round-robin dispatch) ONE leader sweeps memory (8 x 16 KB per pass over the fabric instead
+//      of 128 x 16 KB) and republishes the round's granules into a per-XCD buffer with plain stores; the other workgroups of the XCD
+//      poll that buffer with sc0 loads (bypass L1, hit the XCD's L2)
 // Every workgroup "works" work_cycles (s_sleep) before it publishes; one workgroup in three works 1 500 cycles longer (the update of a
 // touched workgroup).  Reported: us per round.
 #include <hip/hip_runtime.h>
@@ -22,6 +26,7 @@ struct Ctl {
     unsigned long long gran[RING][NCG][32];
     unsigned cnt[RING][8][16];  // 8 arrival counters per ring slot, one 64-byte line each
     unsigned long long pp[2][16];
+    unsigned long long xbuf[8][RING][NCG][32];  // mode 6: the round's granules again, one copy per XCD
 };
 
 __device__ __forceinline__ void work(int cycles)
@@ -77,6 +82,98 @@ __global__ __launch_bounds__(64) void k_xchg(Ctl *ctl, int rounds, int work_cycl
     if (lane == 0) sink[blockIdx.x] = acc;
 }
 
+// mode 6 (two-level)
+__device__ __forceinline__ unsigned long long load_l2(const unsigned long long *p)
+{
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__global__ __launch_bounds__(64) void k_xchg2(Ctl *ctl, int rounds, int work_cycles, unsigned long long *sink, int nrg)
+{
+    __shared__ float pad[24 * 1024];
+    if (threadIdx.x == 1000) pad[0] = 1.f;
+    const int lane = threadIdx.x;
+    const int cg = blockIdx.x % NCG, rg = blockIdx.x / NCG, xcd = blockIdx.x & 7;
+    const bool leader = blockIdx.x < 8;
+    const int rows_per = 32 / nrg;
+    const int srow = lane & 31, half = lane >> 5;
+    unsigned long long acc = 0;
+    for (int t = 0; t < rounds; ++t) {
+        work(work_cycles + ((blockIdx.x + t) % 3 == 0 ? 1500 : 0));
+        const unsigned long long tag = (unsigned long long)(t + 1) << 48;
+        unsigned long long(*ring)[32] = ctl->gran[t % RING];
+        unsigned long long(*xb)[32] = ctl->xbuf[xcd][t % RING];
+        if (lane < rows_per) __hip_atomic_store(&ring[cg][rg * rows_per + lane], tag | (unsigned)(blockIdx.x * 64 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long g[32];
+        if (leader) {
+            for (;;) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) g[u] = __hip_atomic_load(&ring[half + 2 * u][srow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < 32; ++u) ok = ok && (g[u] >> 48) == (tag >> 48);
+                if (__all(ok)) break;
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) xb[half + 2 * u][srow] = g[u];  // plain stores: they stop in this XCD's L2
+        } else {
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    unsigned long long v;
+                    asm volatile("global_load_dwordx2 %0, %1, off sc0" : "=v"(v) : "v"(&xb[half + 2 * u][srow]) : "memory");
+                    g[u] = v;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < 32; ++u) ok = ok && (g[u] >> 48) == (tag >> 48);
+                if (__all(ok)) break;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc += g[u] & 0xffff;
+    }
+    if (lane == 0) sink[blockIdx.x] = acc;
+}
+
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+// mode 4: lane l reads the two granules of rows 2 (l & 15), 2 (l & 15) + 1 of centre group 4 u + (l >> 4): 16 loads of 16 bytes per pass
+__global__ __launch_bounds__(64) void k_xchg16(Ctl *ctl, int rounds, int work_cycles, unsigned long long *sink, int nwg_rg)
+{
+    __shared__ float pad[24 * 1024];
+    if (threadIdx.x == 1000) pad[0] = 1.f;
+    const int lane = threadIdx.x;
+    const int cg = blockIdx.x % NCG, rg = blockIdx.x / NCG;
+    const int rows_per = 32 / nwg_rg;
+    unsigned long long acc = 0;
+    for (int t = 0; t < rounds; ++t) {
+        work(work_cycles + ((blockIdx.x + t) % 3 == 0 ? 1500 : 0));
+        const unsigned long long tag = (unsigned long long)(t + 1) << 48;
+        unsigned long long(*ring)[32] = ctl->gran[t % RING];
+        if (lane < rows_per) __hip_atomic_store(&ring[cg][rg * rows_per + lane], tag | (unsigned)(blockIdx.x * 64 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u64x2 g[16];
+        for (;;) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const u64x2 *p = reinterpret_cast<const u64x2 *>(&ring[4 * u + (lane >> 4)][2 * (lane & 15)]);
+                u64x2 v;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+                g[u] = v;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) ok = ok && (g[u].x >> 48) == (tag >> 48) && (g[u].y >> 48) == (tag >> 48);
+            if (__all(ok)) break;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += (g[u].x & 0xffff) + (g[u].y & 0xffff);
+    }
+    if (lane == 0) sink[blockIdx.x] = acc;
+}
+
 __global__ __launch_bounds__(64) void k_pingpong(Ctl *ctl, int rounds, unsigned long long *sink)
 {
     __shared__ float pad[24 * 1024];
@@ -123,13 +220,53 @@ int main(int argc, char **argv)
     Ctl *ctl;
     unsigned long long *sink;
     CK(hipMalloc(&ctl, sizeof(Ctl)));
-    CK(hipMalloc(&sink, 8 * NWG));
+    CK(hipMalloc(&sink, 8 * NCG * 4));
     printf("%d workgroups (%d centre groups x %d row groups), %d rounds, %d cycles of work per round (+1500 in a third of the workgroups)\n", NWG, NCG,
            NRG, rounds, work_cycles);
     run<0>("product sweep (re-read the missing granules)", ctl, sink, rounds, work_cycles);
     run<1>("every pass re-reads all granules", ctl, sink, rounds, work_cycles);
     run<2>("arrival counters as a hint, then the granules", ctl, sink, rounds, work_cycles);
+    for (int nrg : {2, 4}) {
+        for (int wc : {3500, 0}) {
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0));
+            CK(hipEventCreate(&e1));
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipMemset(ctl, 0, sizeof(Ctl)));
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k_xchg16, dim3(NCG * nrg), dim3(64), 0, 0, ctl, rounds, wc, sink, nrg);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                best = ms < best ? ms : best;
+            }
+            printf("16-byte loads, every pass re-reads all; %3d workgroups, %4d cycles of work:  %.2f us per round\n", NCG * nrg, wc, best * 1e3 / rounds);
+        }
+    }
+    for (int nrg : {2, 4}) {
+        for (int wc : {3500, 0}) {
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0));
+            CK(hipEventCreate(&e1));
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipMemset(ctl, 0, sizeof(Ctl)));
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k_xchg2, dim3(NCG * nrg), dim3(64), 0, 0, ctl, rounds, wc, sink, nrg);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                best = ms < best ? ms : best;
+            }
+            printf("two-level (one leader per XCD sweeps memory, the rest its L2 copy); %3d workgroups, %4d cycles of work:  %.2f us per round\n", NCG * nrg, wc,
+                   best * 1e3 / rounds);
+        }
+    }
     run<0>("product sweep, no work at all (the exchange alone)", ctl, sink, rounds, 0);
+    run<1>("every pass re-reads all granules, no work at all", ctl, sink, rounds, 0);
     run<2>("arrival counters, no work at all", ctl, sink, rounds, 0);
     {
         hipEvent_t e0, e1;
