@@ -834,7 +834,8 @@ __global__ __launch_bounds__(256) void k_train_persistent(
                     // round 6: EVERY pass re-reads every granule of the existing centre groups (a wave-uniform condition).  Re-reading
                     // only the lanes' missing granules -- rounds 1-5 -- put an exec-mask save / branch / restore around each of the
                     // loads and sent nearly as many (sparse) memory instructions: tools/exp/exchange_bench.hip, 128 workgroups,
-                    // 3 500 cycles of work per round: 4.85 us per round against 3.75 with full re-reads
+                    // 3 500 cycles of work per round: 4.85-5.05 us per round against 3.75-3.85 with full re-reads; in this kernel
+                    // K = 256 / d = 1024 5.98 -> 5.87 us per step, K = 64 / d = 512 6.58 -> 6.34
 #pragma unroll
                     for (int u = 0; u < TP_SW; ++u)
                         if (ACAV_SWEEP_REREAD_ALL ? 2 * u < ncg : (int)((need >> u) & 1u))
@@ -1287,6 +1288,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                 unsigned ok = 1;
                 unsigned long long g[TPW_SW];
                 unsigned needm = 0;  // bit u: granule u of this lane not yet seen with this step's tag
+                const bool reread_all = gridDim.x * gridDim.y <= 128u;
 #pragma unroll
                 for (int u = 0; u < TPW_SW; ++u)
                     if (srow < b && half + 2 * u < ncg) needm |= 1u << u;
@@ -1300,10 +1302,20 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
 #ifdef ACAV_WIDE_PROF
                     wpr[7] += 1;  // sweep passes
 #endif
+                    // up to 128 workgroups (the 16 x 16 form at K = 1024): every pass re-reads everything under a wave-uniform
+                    // condition (k_train_persistent); more pollers than that (16 x 8 forms: 256) and the volume of full re-reads costs
+                    // more than the per-lane conditions -- d = 128 / K = 1024 on 256 workgroups 9.05 vs 8.38 us per step
+                    if (ACAV_SWEEP_REREAD_ALL && reread_all) {
 #pragma unroll
-                    for (int u = 0; u < TPW_SW; ++u)
-                        if (ACAV_SWEEP_REREAD_ALL ? 2 * u < ncg : (int)((needm >> u) & 1u))  // (every pass re-reads all: see k_train_persistent)
-                            g[u] = __hip_atomic_load(&ring[tp_gran_index(half + 2 * u, srow)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int u = 0; u < TPW_SW; ++u)
+                            if (2 * u < ncg)
+                                g[u] = __hip_atomic_load(&ring[tp_gran_index(half + 2 * u, srow)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < TPW_SW; ++u)
+                            if ((needm >> u) & 1u)
+                                g[u] = __hip_atomic_load(&ring[tp_gran_index(half + 2 * u, srow)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
 #pragma unroll
                     for (int u = 0; u < TPW_SW; ++u)
                         if (((needm >> u) & 1u) && (g[u] >> 48) == (tag >> 48)) needm &= ~(1u << u);
@@ -1777,7 +1789,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
                 for (unsigned spins = 0;; ++spins) {
 #pragma unroll
                     for (int u = 0; u < TPW_SW; ++u)
-                        if (ACAV_SWEEP_REREAD_ALL ? 2 * u < ncg : (int)((needm >> u) & 1u))  // (every pass re-reads all: see k_train_persistent)
+                        if ((needm >> u) & 1u)  // (256 workgroups: only the missing granules -- full re-reads measured 10.68 vs 10.50 us per step)
                             g[u] = __hip_atomic_load(&ring[tp_gran_index(half + 2 * u, srow)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int u = 0; u < TPW_SW; ++u)

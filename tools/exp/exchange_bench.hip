@@ -12,7 +12,8 @@
 //   4  every pass re-reads all granules with 16-byte loads (two granules per lane: 16 memory instructions per pass instead of 32)
 //   6  two-level: per XCD (blockIdx % 8: round-robin dispatch) ONE leader sweeps memory (8 x 16 KB per pass over the fabric instead
 //      of 128 x 16 KB) and republishes the round's granules into a per-XCD buffer with plain stores; the other workgroups of the XCD
-//      poll that buffer with sc0 loads (bypass L1, hit the XCD's L2)
+//      poll that buffer with sc1 loads (bypass L1, hit the XCD's L2; `sc0` alone is served by a stale L1 line and
+//      never ends -- every spin here is BOUNDED since that run: a round that gives up shows as an absurdly fast or slow figure)
 // Every workgroup "works" work_cycles (s_sleep) before it publishes; one workgroup in three works 1 500 cycles longer (the update of a
 // touched workgroup).  Reported: us per round.
 #include <hip/hip_runtime.h>
@@ -26,6 +27,7 @@ struct Ctl {
     unsigned long long gran[RING][NCG][32];
     unsigned cnt[RING][8][16];  // 8 arrival counters per ring slot, one 64-byte line each
     unsigned long long pp[2][16];
+    unsigned dead[16];  // a spin ran out somewhere: every workgroup leaves its round loop (the figure printed is then meaningless)
     unsigned long long xbuf[8][RING][NCG][32];  // mode 6: the round's granules again, one copy per XCD
 };
 
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(64) void k_xchg(Ctl *ctl, int rounds, int work_cycl
     const int srow = lane & 31, half = lane >> 5;
     unsigned long long acc = 0;
     for (int t = 0; t < rounds; ++t) {
+        if ((t & 15) == 0 && __hip_atomic_load(&ctl->dead[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         work(work_cycles + ((blockIdx.x + t) % 3 == 0 ? 1500 : 0));
         const unsigned long long tag = (unsigned long long)(t + 1) << 48;
         unsigned long long(*ring)[32] = ctl->gran[t % RING];
@@ -53,7 +56,11 @@ __global__ __launch_bounds__(64) void k_xchg(Ctl *ctl, int rounds, int work_cycl
             if (lane == 0) __hip_atomic_fetch_add(&ctl->cnt[t % RING][blockIdx.x & 7][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // the counters of ring slot t % RING count up over the rounds that use the slot: target = arrivals so far
             const unsigned target = (unsigned)(NWG / 8) * (unsigned)(t / RING + 1);
-            for (;;) {
+            for (unsigned spin_ = 0;; ++spin_) {
+            if (spin_ >= (1u << 16) || ((spin_ & 255u) == 255u && __hip_atomic_load(&ctl->dead[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(&ctl->dead[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
                 unsigned c = target;
                 if (lane < 8) c = __hip_atomic_load(&ctl->cnt[t % RING][lane][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__all(c >= target)) break;
@@ -61,7 +68,11 @@ __global__ __launch_bounds__(64) void k_xchg(Ctl *ctl, int rounds, int work_cycl
         }
         unsigned long long g[32];
         unsigned need = 0xFFFFFFFFu;
-        for (;;) {
+        for (unsigned spin_ = 0;; ++spin_) {
+            if (spin_ >= (1u << 16) || ((spin_ & 255u) == 255u && __hip_atomic_load(&ctl->dead[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(&ctl->dead[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
 #pragma unroll
             for (int u = 0; u < 32; ++u)
                 if ((need >> u) & 1u) g[u] = __hip_atomic_load(&ring[half + 2 * u][srow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -96,10 +107,15 @@ __global__ __launch_bounds__(64) void k_xchg2(Ctl *ctl, int rounds, int work_cyc
     const int lane = threadIdx.x;
     const int cg = blockIdx.x % NCG, rg = blockIdx.x / NCG, xcd = blockIdx.x & 7;
     const bool leader = blockIdx.x < 8;
+    if (lane == 0) {  // is block i really on XCD i % 8?  (HW_REG_XCC_ID = hwreg 20, bits 3:0)
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
+        if (xcc != (unsigned)xcd) atomicAdd(&ctl->dead[1], 1u);
+    }
     const int rows_per = 32 / nrg;
     const int srow = lane & 31, half = lane >> 5;
     unsigned long long acc = 0;
     for (int t = 0; t < rounds; ++t) {
+        if ((t & 15) == 0 && __hip_atomic_load(&ctl->dead[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         work(work_cycles + ((blockIdx.x + t) % 3 == 0 ? 1500 : 0));
         const unsigned long long tag = (unsigned long long)(t + 1) << 48;
         unsigned long long(*ring)[32] = ctl->gran[t % RING];
@@ -107,7 +123,11 @@ __global__ __launch_bounds__(64) void k_xchg2(Ctl *ctl, int rounds, int work_cyc
         if (lane < rows_per) __hip_atomic_store(&ring[cg][rg * rows_per + lane], tag | (unsigned)(blockIdx.x * 64 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned long long g[32];
         if (leader) {
-            for (;;) {
+            for (unsigned spin_ = 0;; ++spin_) {
+            if (spin_ >= (1u << 16) || ((spin_ & 255u) == 255u && __hip_atomic_load(&ctl->dead[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(&ctl->dead[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
 #pragma unroll
                 for (int u = 0; u < 32; ++u) g[u] = __hip_atomic_load(&ring[half + 2 * u][srow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 bool ok = true;
@@ -118,12 +138,16 @@ __global__ __launch_bounds__(64) void k_xchg2(Ctl *ctl, int rounds, int work_cyc
 #pragma unroll
             for (int u = 0; u < 32; ++u) xb[half + 2 * u][srow] = g[u];  // plain stores: they stop in this XCD's L2
         } else {
-            for (;;) {
+            for (unsigned spin_ = 0;; ++spin_) {
+            if (spin_ >= (1u << 16) || ((spin_ & 255u) == 255u && __hip_atomic_load(&ctl->dead[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(&ctl->dead[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
                 bool ok = true;
 #pragma unroll
                 for (int u = 0; u < 32; ++u) {
                     unsigned long long v;
-                    asm volatile("global_load_dwordx2 %0, %1, off sc0" : "=v"(v) : "v"(&xb[half + 2 * u][srow]) : "memory");
+                    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(&xb[half + 2 * u][srow]) : "memory");
                     g[u] = v;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -149,12 +173,17 @@ __global__ __launch_bounds__(64) void k_xchg16(Ctl *ctl, int rounds, int work_cy
     const int rows_per = 32 / nwg_rg;
     unsigned long long acc = 0;
     for (int t = 0; t < rounds; ++t) {
+        if ((t & 15) == 0 && __hip_atomic_load(&ctl->dead[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         work(work_cycles + ((blockIdx.x + t) % 3 == 0 ? 1500 : 0));
         const unsigned long long tag = (unsigned long long)(t + 1) << 48;
         unsigned long long(*ring)[32] = ctl->gran[t % RING];
         if (lane < rows_per) __hip_atomic_store(&ring[cg][rg * rows_per + lane], tag | (unsigned)(blockIdx.x * 64 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         u64x2 g[16];
-        for (;;) {
+        for (unsigned spin_ = 0;; ++spin_) {
+            if (spin_ >= (1u << 16) || ((spin_ & 255u) == 255u && __hip_atomic_load(&ctl->dead[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(&ctl->dead[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const u64x2 *p = reinterpret_cast<const u64x2 *>(&ring[4 * u + (lane >> 4)][2 * (lane & 15)]);
@@ -183,9 +212,9 @@ __global__ __launch_bounds__(64) void k_pingpong(Ctl *ctl, int rounds, unsigned 
     for (int t = 1; t <= rounds; ++t) {
         if (me == 0) {
             __hip_atomic_store(&ctl->pp[0][0], (unsigned long long)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (__hip_atomic_load(&ctl->pp[1][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)t) {}
+            for (unsigned sp_ = 0; sp_ < (1u << 22) && __hip_atomic_load(&ctl->pp[1][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)t; ++sp_) {}
         } else {
-            while (__hip_atomic_load(&ctl->pp[0][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)t) {}
+            for (unsigned sp_ = 0; sp_ < (1u << 22) && __hip_atomic_load(&ctl->pp[0][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)t; ++sp_) {}
             __hip_atomic_store(&ctl->pp[1][0], (unsigned long long)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -209,7 +238,9 @@ static void run(const char *name, Ctl *ctl, unsigned long long *sink, int rounds
         CK(hipEventElapsedTime(&ms, e0, e1));
         best = ms < best ? ms : best;
     }
-    printf("%-72s %.2f us per round\n", name, best * 1e3 / rounds);
+    unsigned dead = 0;
+    CK(hipMemcpy(&dead, ctl->dead, 4, hipMemcpyDeviceToHost));
+    printf("%-72s %.2f us per round%s\n", name, best * 1e3 / rounds, dead ? "   (GAVE UP: a spin ran out -- figure meaningless)" : "");
     fflush(stdout);
 }
 
@@ -242,7 +273,9 @@ int main(int argc, char **argv)
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 best = ms < best ? ms : best;
             }
-            printf("16-byte loads, every pass re-reads all; %3d workgroups, %4d cycles of work:  %.2f us per round\n", NCG * nrg, wc, best * 1e3 / rounds);
+            unsigned dead = 0;
+            CK(hipMemcpy(&dead, ctl->dead, 4, hipMemcpyDeviceToHost));
+            printf("16-byte loads, every pass re-reads all; %3d workgroups, %4d cycles of work:  %.2f us per round%s\n", NCG * nrg, wc, best * 1e3 / rounds, dead ? "   (GAVE UP)" : "");
         }
     }
     for (int nrg : {2, 4}) {
@@ -261,8 +294,12 @@ int main(int argc, char **argv)
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 best = ms < best ? ms : best;
             }
-            printf("two-level (one leader per XCD sweeps memory, the rest its L2 copy); %3d workgroups, %4d cycles of work:  %.2f us per round\n", NCG * nrg, wc,
-                   best * 1e3 / rounds);
+            unsigned dead = 0;
+            CK(hipMemcpy(&dead, ctl->dead, 4, hipMemcpyDeviceToHost));
+            unsigned off_xcd = 0;
+            CK(hipMemcpy(&off_xcd, &ctl->dead[1], 4, hipMemcpyDeviceToHost));
+            printf("two-level (one leader per XCD sweeps memory, the rest its L2 copy); %3d workgroups, %4d cycles of work:  %.2f us per round%s; %u workgroups "
+                   "NOT on XCD blockIdx %% 8\n", NCG * nrg, wc, best * 1e3 / rounds, dead ? "   (GAVE UP)" : "", off_xcd);
         }
     }
     run<0>("product sweep, no work at all (the exchange alone)", ctl, sink, rounds, 0);
