@@ -529,6 +529,12 @@ constexpr unsigned TP_SPIN_LIMIT = 1u << 24;
 #define ACAV_TP_FIRST_SLEEP 32
 #endif
 constexpr int TP_FIRST_SWEEP_PAUSE = ACAV_TP_FIRST_SLEEP;  // x 64 clocks between a workgroup's publish and its first sweep
+#ifndef ACAV_WIDE_PIN
+// pinned MFMA / LDS-read order (dot_tile_mfma<true>) in the wide and column-split kernels too?  No: same-box A/B (profiles/r06_train_pin_ab.txt)
+// K = d = 1024 9.34 vs 8.91 us per step, the pair 9.45 vs 8.99, d = 2048 / K = 512 10.53 vs 10.12 -- phase timers: fma 3.86k vs 3.47k cycles;
+// in these kernels the compiler's own windows do better than the pinned ones, in k_train_persistent the pinned order wins (3.38k -> 2.98k)
+#define ACAV_WIDE_PIN 0
+#endif
 #ifndef ACAV_SWEEP_REREAD_ALL
 #define ACAV_SWEEP_REREAD_ALL 1
 #endif
@@ -697,6 +703,7 @@ __global__ __launch_bounds__(256) void k_step_dist_dma_rg(const float *__restric
 // runs the segment's FMA chain for all 64 (centre, row) pairs, and applies the centre update to it.
 // One wave can only issue ~1 ds_read_b128 per 20+ cycles, so the 4 waves quadruple the LDS read rate;
 // the 4 segment sums are folded in order ((s0+s1)+s2)+s3 -- exactly the canonical dot.
+template <bool PIN>
 __device__ __forceinline__ f32x4 dot_tile_mfma(const float *pc, const float *px, int sc, int sx);  // (below, with the 16-centre forms)
 
 template <bool RAGGED, bool PROF>  // RAGGED: d % 256 != 0 (guarded DMA / update lanes, zero-padded last block)
@@ -770,7 +777,7 @@ __global__ __launch_bounds__(256) void k_train_persistent(
             // cycles and 128 ds_read_b32 per wave against 3.3k cycles and 2 x 64 ds_read_b128 of the per-lane chain
             if (active) {
                 const int i15 = lane & 15, kq = lane >> 4, r8 = i15 & 7;
-                const f32x4 q4 = dot_tile_mfma(sC + r8 * TP_DS + wave * 256 + kq, sX[t & 1] + r8 * TP_DS + wave * 256 + kq, r8, r8);
+                const f32x4 q4 = dot_tile_mfma<true>(sC + r8 * TP_DS + wave * 256 + kq, sX[t & 1] + r8 * TP_DS + wave * 256 + kq, r8, r8);
                 if (kq < 2 && i15 < 8) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) sPart[wave][(4 * kq + e) * 8 + i15] = q4[e];  // slot (centre kk, row ii) = kk * 8 + ii
@@ -1044,8 +1051,19 @@ __device__ __forceinline__ void dot_quad(const float *pc, const float *px, int s
 // Lane l feeds A[i = l & 15][k = l >> 4] = centre i, column 4 t + k of the block, and B[k][j = l & 15] = batch row j, same column;
 // it receives D[4 (l >> 4) + e][l & 15], e = 0 .. 3.  pc / px: the lane's centre / batch row of the block, + k; sc / sx: row & 7
 // (chunk tt of 4 columns sits at float offset ((tt ^ s) << 2), as in dot_blocks).
+template <bool PIN = true>
 __device__ __forceinline__ f32x4 dot_tile_mfma(const float *pc, const float *px, int sc, int sx)
 {
+    if constexpr (!PIN) {  // the compiler's own schedule: windows of 16 k-steps, lgkmcnt(0) before each
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 64; ++t) {
+            const float a = pc[(((t & 7) ^ sc) << 2) + ((t >> 3) << 5)];
+            const float bq = px[(((t & 7) ^ sx) << 2) + ((t >> 3) << 5)];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc0, 0, 0, 0);
+        }
+        return acc0;
+    }
     // Two windows of 16 k-steps (32 operand registers each).  Left to itself the compiler loads a window, waits for ALL of it
     // (lgkmcnt(0)) and multiplies -- the last reads are issued right before the wait, ~120 cycles of LDS latency per window on a
     // 40-cycle-per-instruction chain (3.4k cycles per block instead of 2.6k, ACAV_PROFILE_STEPS).  Pinned order: the 16 ds_read2 of
@@ -1190,7 +1208,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
             if constexpr (MF) {  // one 16 x 16 tile per block on the matrix core (NRP = 1: batch rows 8 .. 15 of the tile repeat 0 .. 7, unread)
                 const int i15 = lane & 15, kq = lane >> 4, jx = NRP == 2 ? i15 : (i15 & 7);
                 for (int blk = wave; blk < nblk; blk += 4) {
-                    const f32x4 q4 = dot_tile_mfma(sC + i15 * ds + blk * 256 + kq, xs + jx * ds + blk * 256 + kq, i15 & 7, jx & 7);
+                    const f32x4 q4 = dot_tile_mfma<(ACAV_WIDE_PIN != 0)>(sC + i15 * ds + blk * 256 + kq, xs + jx * ds + blk * 256 + kq, i15 & 7, jx & 7);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) sPart[(blk * 4 + e) * 64 + lane] = q4[e];
                 }
@@ -1206,7 +1224,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
             else if constexpr (NCP == 1) {  // 8 centres x 8 rows (the tall forms, d > 1024): a quarter of a matrix-core tile per block, as k_train_persistent
                 const int i15 = lane & 15, kq = lane >> 4, r8 = i15 & 7;
                 for (int blk = wave; blk < nblk; blk += 4) {
-                    const f32x4 q4 = dot_tile_mfma(sC + r8 * ds + blk * 256 + kq, xs + r8 * ds + blk * 256 + kq, r8, r8);
+                    const f32x4 q4 = dot_tile_mfma<(ACAV_WIDE_PIN != 0)>(sC + r8 * ds + blk * 256 + kq, xs + r8 * ds + blk * 256 + kq, r8, r8);
                     if (kq < 2 && i15 < 8) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) sPart[blk * 64 + (4 * kq + e) * 8 + i15] = q4[e];  // slot (kk, ii) = kk * 8 + ii
@@ -1690,7 +1708,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
                 thr_t = thr[t];
             }
             if (active) {
-                const f32x4 seg = dot_tile_mfma(sC + i15 * TS_COLS + wave * 256 + kq, sX + i15 * TS_COLS + wave * 256 + kq, i15 & 7, i15 & 7);
+                const f32x4 seg = dot_tile_mfma<(ACAV_WIDE_PIN != 0)>(sC + i15 * TS_COLS + wave * 256 + kq, sX + i15 * TS_COLS + wave * 256 + kq, i15 & 7, i15 & 7);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) sPart[(q * 4 + wave) * 64 + lane] = seg[q];
             }

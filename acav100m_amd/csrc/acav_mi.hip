@@ -1389,6 +1389,7 @@ struct acav_mi {
     DevBuf lnk, lf;   // ln k and ln k! tables of the `ami` score (acav_mi_set_measure)
     int measure = 0;  // exact greedy: 0 = calc_MI, 1 = calc_AMI, 2 = calc_NMI, 3 = constant
     int queue_probe_replaced = 0;  // streams replaced by mi_separate_queues (diagnostics: ACAV_MI_TIMING prints it)
+    bool queue_probe_pending = false;  // the three streams have not been checked for a shared hardware queue yet
     DevBuf fy_table, fy_bounds, fy_bucket, fy_count, fy_src[FY_GROUP], fy_g[FY_GROUP], fy_perm[FY_NBUF], fy_tail, fy_err;  // tiled Fisher-Yates
     hipStream_t st_fy = nullptr;               // the position kernels of group g+1 run beside the gathers of group g
     hipEvent_t ev_tile[FY_NBUF] = {}, ev_gather[FY_NBUF] = {};
@@ -1792,10 +1793,8 @@ ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignm
         acav_mi_destroy(mi);
         return rc;
     }
-    {
-        const char *vq = getenv("ACAV_MI_QUEUE_PROBE");
-        if (!(vq && vq[0] == '0') && !prio) mi_separate_queues(mi, stream == nullptr, 0, 0);
-    }
+    // (the queue probe runs lazily, at the handle's first single-chunk greedy loop over a long candidate list: run_greedy_tiled)
+    mi->queue_probe_pending = !prio;
     *out = mi;
     return ACAV_OK;
 }
@@ -1867,6 +1866,15 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
                             int64_t *n_selected, int64_t *n_iters, const TiledExtras &ex)
 {
     acav_mi *lead = mis[0];
+    // Three streams on three hardware queues (mi_separate_queues): checked once per handle, and only where it matters and cannot
+    // hurt -- ONE chunk over a long candidate list (the position and content streams of a 10^6-candidate loop overlap for ~30 us
+    // per iteration).  Chunks in lockstep share streams by design and create a handle per chunk: probing each of the 125 handles of
+    // the cfg5 slice at creation cost the slice 0.6 s (2.49 -> 3.15 s of selection), which is why the probe moved here.
+    if (nchunks == 1 && lead->queue_probe_pending && L[0] >= 250000) {
+        const char *vq = getenv("ACAV_MI_QUEUE_PROBE");
+        if (!(vq && vq[0] == '0')) mi_separate_queues(lead, true, 0, 0);
+        lead->queue_probe_pending = false;
+    }
     hipStream_t st = lead->ctx.stream, sf = lead->st_fy;
     const int64_t dl = B - (keep_unselected ? B - k : 0);  // candidates consumed per iteration
     std::vector<TileChunk> desc((size_t)nchunks);

@@ -104,12 +104,25 @@ int main(int argc, char **argv)
     constexpr int NW = 8;
     auto kern = k_assign_f16_rw<true, NW, false, 3, 2>;
     const int fsmem = FD_DX * NW * 4096 + 3 * FD_SLOT;
+#elif defined(SUSTAINED_K1024)  // K > 256: the product's (row tile, centre group) pair kernel -- MFMA-bound; is ITS clock capped too?
+    constexpr int NW = 8;
+    auto kern = k_assign_f16_rw<true, NW, true, 3, 2>;
+    const int fsmem = FD_DX * NW * 4096 + 3 * FD_SLOT;
 #else
     constexpr int NW = 4;
     auto kern = k_assign_f16_rw<true, NW, false, 2, 0>;
     const int fsmem = FD_DX * NW * 4096 + 2 * FD_SLOT;
 #endif
+#ifdef SUSTAINED_K1024
+    const int ngroups = (K + 255) / 256;
+    const int64_t ntiles = (n + NW * 32 - 1) / (NW * 32);
+    const int64_t grid = (ntiles + 7) / 8 * 8 * ngroups;
+    Top2Rec *grec;
+    CK(hipMalloc(&grec, sizeof(Top2Rec) * (size_t)ngroups * n));
+#else
     const int64_t grid = (n + NW * 32 - 1) / (NW * 32);
+    Top2Rec *grec = nullptr;
+#endif
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, fsmem));
     hipStream_t sk, sp;
     CK(hipStreamCreateWithFlags(&sk, hipStreamNonBlocking));
@@ -132,7 +145,7 @@ int main(int argc, char **argv)
     for (int i = 0; i < launches; ++i) {
         CK(hipEventRecord(ev[2 * i], sk));
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), fsmem, sk, x, n, d, cb, cn, counts, K, 1.0f, 5.0f, aux, 1e-2f, 1e-4f,
-                           1e-6f, lab, rl, rc, (AssignCtl *)nullptr, (Top2Rec *)nullptr, CandOut{});
+                           1e-6f, lab, rl, rc, (AssignCtl *)nullptr, grec, CandOut{});
         CK(hipEventRecord(ev[2 * i + 1], sk));
         if (gap_us > 0) {
             CK(hipEventSynchronize(ev[2 * i + 1]));
@@ -159,6 +172,8 @@ int main(int argc, char **argv)
            "no MFMA"
 #elif defined(SUSTAINED_NW8)
            "none (256-row tile)"
+#elif defined(SUSTAINED_K1024)
+           "none (K > 256 pair kernel)"
 #else
            "none"
 #endif
@@ -183,7 +198,7 @@ int main(int argc, char **argv)
     std::vector<float> tail(ms.begin() + launches / 2, ms.end());
     std::sort(tail.begin(), tail.end());
     const double settled = tail[tail.size() / 2];
-    printf("],\n \"first_ms\": %.4f, \"settled_ms\": %.4f, \"frac_first\": %.4f, \"frac_settled\": %.4f}\n", ms[0], settled,
+    printf("],\n \"tflops_settled\": %.1f, \"first_ms\": %.4f, \"settled_ms\": %.4f, \"frac_first\": %.4f, \"frac_settled\": %.4f}\n", 2.0 * n * (double)K * d / (settled * 1e-3) * 1e-12, ms[0], settled,
            bytes / (ms[0] * 1e-3) / 8e12, bytes / (settled * 1e-3) / 8e12);
     return 0;
 }

@@ -182,6 +182,7 @@ def main():
     time.sleep(0.3)
     exe, exe_nm = os.path.join(ROOT, "tools/exp/sustained_bench"), os.path.join(ROOT, "tools/exp/sustained_bench_nomfma")
     exe_nw8 = os.path.join(ROOT, "tools/exp/sustained_bench_nw8")
+    exe_k1024, exe_k1024_nm = os.path.join(ROOT, "tools/exp/sustained_bench_k1024"), os.path.join(ROOT, "tools/exp/sustained_bench_k1024_nomfma")
     n, L = args.rows, args.launches
     runs = []
     plan = [(exe, [n, 1024, 256, L, 0, "mix"], "filter, back to back, mixture rows"),
@@ -190,7 +191,11 @@ def main():
             (exe, [n, 1024, 256, L, 0, "uni"], "filter, back to back, uniform rows"),
             (exe, [n, 1024, 256, L, 0, "mix"], "filter, back to back, mixture rows (repeat)"),
             (exe_nw8, [n, 1024, 256, L, 0, "mix"], "256-row tile (8 waves, centre ring 3, spread issue), back to back"),
-            (exe_nw8, [n, 1024, 256, L // 4, 2000, "mix"], "256-row tile, 2 ms pause between launches")]
+            (exe_nw8, [n, 1024, 256, L // 4, 2000, "mix"], "256-row tile, 2 ms pause between launches"),
+            # K = 1024 (the MFMA-bound regime of cfg4 / cfg5): is the (tile, group) pair kernel's clock capped too?
+            (exe_k1024, [n, 1024, 1024, L // 2, 0, "mix"], "K = 1024 pair kernel, back to back"),
+            (exe_k1024, [n, 1024, 1024, L // 8, 10000, "mix"], "K = 1024 pair kernel, 10 ms pause between launches"),
+            (exe_k1024_nm, [n, 1024, 1024, L // 2, 0, "mix"], "K = 1024 pair kernel WITHOUT the MFMAs (timing-only ablation), back to back")]
     for e, a, label in plan:
         if not os.path.exists(e):
             runs.append({"label": label, "error": "not built: " + e})
@@ -214,11 +219,11 @@ def main():
     json.dump(doc, open(args.out + ".json", "w"), indent=1, default=str)
     with open(args.out + ".txt", "w") as f:
         f.write("K = 256 assign filter under sustained load (1M x 1024 fp32 rows, 4.104 GB algorithmic per launch); sampler: %s\n" % sampler.kind)
-        f.write("%-66s %8s %8s %6s %6s | %9s %9s %8s %8s %7s %7s\n" % ("regime", "first ms", "settled", "frac1", "fracS", "probe GHz0", "probe GHzS",
+        f.write("%-76s %8s %8s %6s %6s %7s | %9s %9s %8s %8s %7s %7s\n" % ("regime", "first ms", "settled", "frac1", "fracS", "TFLOP/s", "probe GHz0", "probe GHzS",
                                                                            "gfx MHz", "power W", "PVIOL %", "hot C"))
         for r in runs:
             if "error" in r:
-                f.write("%-66s ERROR %s\n" % (r["label"], r["error"][:200]))
+                f.write("%-76s ERROR %s\n" % (r["label"], r["error"][:200]))
                 continue
             pg = r.get("probe_ghz") or []
             pm = r.get("probe_ms") or []
@@ -227,8 +232,8 @@ def main():
             load_end = 300 + (r.get("launch_at_ms") or [0])[-1]
             load = [g for g, t in zip(pg, pm) if 300 + 0.66 * (load_end - 300) < t < load_end]
             sm = r.get("smu", {})
-            f.write("%-66s %8.4f %8.4f %6.3f %6.3f | %9s %9s %8s %8s %7s %7s\n" % (
-                r["label"][:66], r["first_ms"], r["settled_ms"], r["frac_first"], r["frac_settled"],
+            f.write("%-76s %8.4f %8.4f %6.3f %6.3f %7s | %9s %9s %8s %8s %7s %7s\n" % (
+                r["label"][:76], r["first_ms"], r["settled_ms"], r["frac_first"], r["frac_settled"], "%.0f" % r["tflops_settled"] if "tflops_settled" in r else "-",
                 "%.3f" % (sum(idle) / len(idle)) if idle else "-", "%.3f" % (sum(load) / len(load)) if load else "-",
                 "%.0f" % sm["current_gfxclks"]["mean"] if "current_gfxclks" in sm else "-",
                 "%.0f" % sm["current_socket_power"]["mean"] if "current_socket_power" in sm else "-",
