@@ -1868,8 +1868,11 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
     acav_mi *lead = mis[0];
     // Three streams on three hardware queues (mi_separate_queues): checked once per handle, and only where it matters and cannot
     // hurt -- ONE chunk over a long candidate list (the position and content streams of a 10^6-candidate loop overlap for ~30 us
-    // per iteration).  Chunks in lockstep share streams by design and create a handle per chunk: probing each of the 125 handles of
-    // the cfg5 slice at creation cost the slice 0.6 s (2.49 -> 3.15 s of selection), which is why the probe moved here.
+    // per iteration).  Probing each of the 125 handles of the cfg5 slice at creation cost the slice 0.6 s (2.49 -> 3.15 s of selection),
+    // which is why the probe moved here.  Probing the LEAD of every lockstep group was tried as well (its three streams carry the
+    // group's launches): 3-8 streams replaced over 52 groups and no effect on the lockstep loop's own bimodality -- the cfg5 slice's
+    // selection takes 2.46-2.52 s in most processes and 3.3-4.0 s in about one of three, with the probe (3.98 / 2.46) and without
+    // (3.53 / 2.48 / 2.50): tools/exp/NOTES_r06.md section 5.
     if (nchunks == 1 && lead->queue_probe_pending && L[0] >= 250000) {
         const char *vq = getenv("ACAV_MI_QUEUE_PROBE");
         if (!(vq && vq[0] == '0')) mi_separate_queues(lead, true, 0, 0);
