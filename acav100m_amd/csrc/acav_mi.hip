@@ -1390,6 +1390,8 @@ struct acav_mi {
     int measure = 0;  // exact greedy: 0 = calc_MI, 1 = calc_AMI, 2 = calc_NMI, 3 = constant
     int queue_probe_replaced = 0;  // streams replaced by mi_separate_queues (diagnostics: ACAV_MI_TIMING prints it)
     bool queue_probe_pending = false;  // the three streams have not been checked for a shared hardware queue yet
+    bool prio_streams = false;         // ACAV_MI_STREAM_PRIO: priority classes of the generator / position stream (created lazily)
+    int class_mt = 0, class_fy = 0;
     DevBuf fy_table, fy_bounds, fy_bucket, fy_count, fy_src[FY_GROUP], fy_g[FY_GROUP], fy_perm[FY_NBUF], fy_tail, fy_err;  // tiled Fisher-Yates
     hipStream_t st_fy = nullptr;               // the position kernels of group g+1 run beside the gathers of group g
     hipEvent_t ev_tile[FY_NBUF] = {}, ev_gather[FY_NBUF] = {};
@@ -1689,6 +1691,7 @@ static bool mi_streams_share_queue(hipStream_t a, hipStream_t b)
     return best >= 160.0;
 }
 static void mi_separate_queues(acav_mi *mi, bool own_content, int class_mt, int class_fy);
+static int mi_ensure_streams(acav_mi *mi);  // st_mt / st_fy on first need
 
 
 ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignments, int64_t V, int D, int C,
@@ -1762,32 +1765,24 @@ ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignm
     };
     rc = body();
     if (rc == ACAV_OK) {
-        int plo = 0, phi = 0;
-        bool ok = hipDeviceGetStreamPriorityRange(&plo, &phi) == hipSuccess;
-        ok = ok && (prio ? hipStreamCreateWithPriority(&mi->st_mt, hipStreamNonBlocking, cls(pmap[2]) > 0 ? phi : cls(pmap[2]) < 0 ? plo : (plo + phi) / 2)
-                         : hipStreamCreateWithFlags(&mi->st_mt, hipStreamNonBlocking)) == hipSuccess;
+        // The generator and position STREAMS are created when a greedy loop first needs them (mi_ensure_streams): a lockstep group
+        // creates a handle per chunk and runs every launch on the LEAD's streams -- ten chunks used to create 30 streams per group
+        // for the 12 they use, and the lockstep loop slows down with the number of hardware queues the process keeps busy
+        // (3.6 us per chunk-iteration with up to 16, 5.6-6.1 with 32: profiles/r06_mi_lockstep_by_hw_queues.txt).
+        bool ok = true;
         for (int q = 0; q < 2 && ok; ++q)
             ok = hipEventCreateWithFlags(&mi->ev_mt[q], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&mi->ev_used[q], hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-            set_error("could not create the MT stream / events");
-            rc = ACAV_EHIP;
-        }
-    }
-    if (rc == ACAV_OK) {
-        // (a caller's own stream for the content path is most likely of the default class: the position stream goes up instead)
-        int plo = 0, phi = 0;
-        bool ok = hipDeviceGetStreamPriorityRange(&plo, &phi) == hipSuccess;
-        const int cfy = stream ? 1 : cls(pmap[1]);
-        ok = ok && (prio ? hipStreamCreateWithPriority(&mi->st_fy, hipStreamNonBlocking, cfy > 0 ? phi : cfy < 0 ? plo : (plo + phi) / 2)
-                         : hipStreamCreateWithFlags(&mi->st_fy, hipStreamNonBlocking)) == hipSuccess;
         for (int q = 0; q < FY_NBUF && ok; ++q)
             ok = hipEventCreateWithFlags(&mi->ev_tile[q], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&mi->ev_gather[q], hipEventDisableTiming) == hipSuccess;
         if (!ok) {
-            set_error("could not create the Fisher-Yates stream / events");
+            set_error("could not create the greedy loop's events");
             rc = ACAV_EHIP;
         }
+        mi->prio_streams = prio;
+        mi->class_mt = cls(pmap[2]);
+        mi->class_fy = stream ? 1 : cls(pmap[1]);  // (a caller's own content stream is most likely of the default class: the position stream goes up instead)
     }
     if (rc != ACAV_OK) {
         acav_mi_destroy(mi);
@@ -1799,8 +1794,25 @@ ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignm
     return ACAV_OK;
 }
 
+static int mi_ensure_streams(acav_mi *mi)
+{
+    if (mi->st_mt && mi->st_fy) return ACAV_OK;
+    ACAV_HIP_TRY(hipSetDevice(mi->ctx.device));
+    int plo = 0, phi = 0;
+    ACAV_HIP_TRY(hipDeviceGetStreamPriorityRange(&plo, &phi));
+    auto make = [&](hipStream_t *s, int cl) -> hipError_t {
+        if (*s) return hipSuccess;
+        return mi->prio_streams ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, cl > 0 ? phi : cl < 0 ? plo : (plo + phi) / 2)
+                                : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    };
+    ACAV_HIP_TRY(make(&mi->st_mt, mi->class_mt));
+    ACAV_HIP_TRY(make(&mi->st_fy, mi->class_fy));
+    return ACAV_OK;
+}
+
 static void mi_separate_queues(acav_mi *mi, bool own_content, int class_mt, int class_fy)
 {
+    if (mi_ensure_streams(mi) != ACAV_OK) return;
     (void)own_content, (void)class_mt, (void)class_fy;
     std::vector<hipStream_t> parked;
     for (int attempt = 0; attempt < 6; ++attempt) {
@@ -1878,6 +1890,7 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
         if (!(vq && vq[0] == '0')) mi_separate_queues(lead, true, 0, 0);
         lead->queue_probe_pending = false;
     }
+    ACAV_TRY(mi_ensure_streams(lead));
     hipStream_t st = lead->ctx.stream, sf = lead->st_fy;
     const int64_t dl = B - (keep_unselected ? B - k : 0);  // candidates consumed per iteration
     std::vector<TileChunk> desc((size_t)nchunks);
@@ -1943,6 +1956,8 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
         // on one shared stream 3.66 at either setting.  ACAV_MI_SHARE_GEN=0: a stream per chunk again, =n: n streams (A/B).
         const char *vsh = getenv("ACAV_MI_SHARE_GEN");
         const int nshare = vsh ? atoi(vsh) : 1;
+        if (nshare > 0) ACAV_TRY(mi_ensure_streams(mis[c % nshare]));
+        else ACAV_TRY(mi_ensure_streams(mi));
         ACAV_TRY(ms.plan(mi, sf, mtbuf, idx, draws, L[c], (int64_t)FY_GROUP * L[c], nshare > 0 ? mis[c % nshare]->st_mt : nullptr));
         TileChunk &d = desc[(size_t)c];
         d.ring = ms.ring + MtStream::PAD;
@@ -2101,6 +2116,7 @@ ACAV_EXPORT int acav_mi_run_greedy_multi(acav_mi **mis, int nchunks, const int64
             return run_greedy_tiled(mis, nchunks, candidates, L, start, ns, subset, B, k, keep_unselected, rngs, S_out, GAIN_out,
                                     n_selected, n_iters, TiledExtras());
     }
+    ACAV_TRY(mi_ensure_streams(lead));
     hipStream_t st = lead->ctx.stream, smt = lead->st_mt;
     const int64_t dl = B - (keep_unselected ? B - k : 0);
     std::vector<ChunkDesc> desc((size_t)nchunks);
@@ -2512,7 +2528,7 @@ ACAV_EXPORT int acav_mi_run_greedy(acav_mi *mi, const int64_t *candidates, int64
         if (trace_ids) ACAV_HIP_TRY(hipMemcpyAsync(trace_ids, mi->tr_ids.p, sizeof(long long) * (size_t)(iters * B), hipMemcpyDeviceToHost, st));
         if (trace_scores) ACAV_HIP_TRY(hipMemcpyAsync(trace_scores, mi->tr_sc.p, sizeof(double) * (size_t)(iters * B), hipMemcpyDeviceToHost, st));
     }
-    ACAV_HIP_TRY(hipStreamSynchronize(mi->st_mt));
+    if (mi->st_mt) ACAV_HIP_TRY(hipStreamSynchronize(mi->st_mt));
     ACAV_HIP_TRY(hipStreamSynchronize(st));
     ACAV_TRY(ms.final_state(mtbuf, &idx));
     ACAV_TRY(acav_rng_set_state(rng, mtbuf, idx));  // the stream continues on the host
