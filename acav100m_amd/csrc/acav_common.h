@@ -18,7 +18,7 @@
 // stray -D (ACAV_EXTRA_HIPCC_FLAGS in __graft_entry__.build()): a build that defines one of them has to say so.
 #if (defined(ACAV_ABL_NOAFRAG) || defined(ACAV_ABL_NOCDMA) || defined(ACAV_ABL_NOMFMA) || defined(ACAV_ABL_NOXDMA) || \
      defined(ACAV_ABL_NOXDMA_G123) || defined(ACAV_ABL_XHALF_G123) || \
-     defined(ACAV_FY_ABL_BKSEQ) || defined(ACAV_FY_ABL_NOWALK) || defined(ACAV_FY_ABL_SRCSEQ) || defined(ACAV_MI_ABL_EMPTY)) && \
+     defined(ACAV_DBG_HALF_CAND_WINDOW) || defined(ACAV_FY_ABL_BKSEQ) || defined(ACAV_FY_ABL_NOWALK) || defined(ACAV_FY_ABL_SRCSEQ) || defined(ACAV_MI_ABL_EMPTY)) && \
     !defined(ACAV_EXPERIMENT_BUILD)
 #error "ACAV_ABL_* / ACAV_FY_ABL_* / ACAV_MI_ABL_* select timing-only kernels with wrong results: experiment harnesses only (-DACAV_EXPERIMENT_BUILD)"
 #endif

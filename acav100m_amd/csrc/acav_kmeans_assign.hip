@@ -760,7 +760,11 @@ struct CandOut {  // where the emission writes: candidate rows / pairs, and the 
 // |d1| + W) sixfold.  NaN / inf bounds give T = NaN: `!(v > T)` holds for every v -> everything is a candidate -> full exact sweep.
 __device__ __forceinline__ float cand_threshold(float d1, float E)
 {
+#ifdef ACAV_DBG_HALF_CAND_WINDOW  // experiment builds: HALF the proven window -- tests/test_gpu_kmeans.py::test_candidate_threshold_... must FAIL
+    const float W = 1.0f * E + 1.6e-5f * fabsf(d1);
+#else
     const float W = 2.0f * E + 1.6e-5f * fabsf(d1);
+#endif
     const float u = d1 + W;
     return u + 3.2e-5f * fabsf(u) + 1.6e-6f * (fabsf(d1) + W);
 }
