@@ -202,4 +202,6 @@ def stress(seed=0, budget=60.0, max_cases=None):
 
 
 if __name__ == "__main__":
-    print("stress ok", stress(int(sys.argv[2]) if len(sys.argv) > 2 else 0, float(sys.argv[1]) if len(sys.argv) > 1 else 60.0))
+    res = stress(int(sys.argv[2]) if len(sys.argv) > 2 else 0, float(sys.argv[1]) if len(sys.argv) > 1 else 60.0)
+    print("stress ok", res, flush=True)
+    print("stress ok", res, file=sys.stderr, flush=True)  # (RCCL prints its banner to stdout at exit: the last stdout line is not ours)
