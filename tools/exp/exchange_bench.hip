@@ -9,6 +9,8 @@
 //   2  counter hint: after its stores a workgroup adds 1 to one of 8 arrival counters (device-scope atomic, no fence); the sweep polls
 //      the 8 counters (one 64-byte line) until they sum to NWG, then reads the granules (tags still checked: a late store -> mode 0 loop)
 //   3  ping-pong between TWO workgroups (store -> seen -> store back), for the raw round trip
+//   7  a pass re-issues only the load INSTRUCTIONS (one per pair of centre groups) whose 64 granules are not all there yet: a
+//      wave-uniform mask (no exec juggling), later passes are short
 //   4  every pass re-reads all granules with 16-byte loads (two granules per lane: 16 memory instructions per pass instead of 32)
 //   6  two-level: per XCD (blockIdx % 8: round-robin dispatch) ONE leader sweeps memory (8 x 16 KB per pass over the fabric instead
 //      of 128 x 16 KB) and republishes the round's granules into a per-XCD buffer with plain stores; the other workgroups of the XCD
@@ -82,6 +84,13 @@ __global__ __launch_bounds__(64) void k_xchg(Ctl *ctl, int rounds, int work_cycl
                 if (((need >> u) & 1u) && (g[u] >> 48) != (tag >> 48)) still |= 1u << u;
             if (MODE == 1) {
                 if (__all(still == 0)) break;  // need stays all ones: every pass re-reads everything
+            } else if (MODE == 7) {
+                unsigned um = 0;  // wave-uniform: instruction u still has a lane without this round's tag
+#pragma unroll
+                for (int u = 0; u < 32; ++u)
+                    if (((need >> u) & 1u) && __any((still >> u) & 1u)) um |= 1u << u;
+                need = um;
+                if (need == 0) break;
             } else {
                 need = still;
                 if (__all(need == 0)) break;
@@ -256,6 +265,8 @@ int main(int argc, char **argv)
            NRG, rounds, work_cycles);
     run<0>("product sweep (re-read the missing granules)", ctl, sink, rounds, work_cycles);
     run<1>("every pass re-reads all granules", ctl, sink, rounds, work_cycles);
+    run<7>("a pass re-issues the load instructions that are still incomplete (uniform mask)", ctl, sink, rounds, work_cycles);
+    run<7>("... the same, no work at all", ctl, sink, rounds, 0);
     run<2>("arrival counters as a hint, then the granules", ctl, sink, rounds, work_cycles);
     for (int nrg : {2, 4}) {
         for (int wc : {3500, 0}) {
