@@ -576,6 +576,121 @@ struct TrainCtl {
     unsigned long long gran[TP_RING][TP_MAXCG * 2 * TP_LSTRIDE];
 };
 
+#ifndef ACAV_SWEEP_LEAN
+#define ACAV_SWEEP_LEAN 1
+#endif
+#ifndef ACAV_LEAN_PASS_SLEEP
+#define ACAV_LEAN_PASS_SLEEP 0
+#endif
+#ifndef ACAV_LEAN_MAX_WG
+#define ACAV_LEAN_MAX_WG 4096u  // grids up to this many workgroups sweep with tp_sweep_lean (every pass re-reads everything); 128u: round 6's first cut
+#endif
+// Round 6, late: the instruction stream of the exchange, not the fabric, was half of its cost.  Phase timers inside wave 0 of the
+// 16 x 16 form at K = d = 1024 (-DACAV_WIDE_PROF): keys epilogue 2.9k cycles (4 x nblk DEPENDENT LDS reads, an s_waitcnt between each),
+// a sweep pass ~1.3k cycles to issue its 32 loads (one spilled scalar condition + branch per load) + the round trip + ~1.5k to
+// check the tags (the granules sat in AGPRs: 64 v_accvgpr_read, then v_cmp_eq_u64 + mask arithmetic per granule), and 3.1k from the
+// last pass to the closing barrier (32 lexicographic 64-bit minima) -- against ~2.1k per pass for the same loads written
+// straight-line (tools/exp/exchange_bench.hip, mode 8).  tp_fold_parts / tp_sweep_lean are those three pieces rewritten:
+//   * the segment sums are loaded four (x NE chains) at a time, then folded in the canonical left-to-right order;
+//   * a pass is NU unconditional loads (NU = 4 .. 32, chosen once per launch; groups past ncg read unused slots of the ring),
+//     one XOR + OR per granule and a single ballot: done <=> every needed tag is this step's;
+//   * the minimum is a strict `<` scan on the 32-bit distance in ascending group order (the first group of equal distances wins =
+//     the smaller index, as the 64-bit key compares), the two halves of a row merge through the 64-bit key as before.  A row whose
+//     best distance is 0xFFFFFFFF (no candidate, or NaN rows) is re-done with the 64-bit form -- never on finite data.
+template <int NE>
+__device__ __forceinline__ void tp_fold_parts(const float *p, int se, int sw, int nblk, float acc[NE])
+{
+#pragma unroll
+    for (int e = 0; e < NE; ++e) acc[e] = p[e * se];
+    for (int w0 = 1; w0 < nblk; w0 += 4) {  // uniform
+        float v[NE][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int w = w0 + j < nblk ? w0 + j : nblk - 1;  // clamped: a valid slot, dropped below
+#pragma unroll
+            for (int e = 0; e < NE; ++e) v[e][j] = p[e * se + w * sw];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (w0 + j < nblk) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) acc[e] = acc[e] + v[e][j];
+            }
+    }
+}
+
+// wave-level: returns 0 if a bounded spin gave up (ctl->err set); *best = the row's label for lanes < b (both halves hold it)
+template <int NU>
+__device__ __forceinline__ unsigned tp_sweep_lean(const unsigned long long *ring, int ncg, int b, int ncw, unsigned tag16, int lane, TrainCtl *ctl,
+                                                  int *best, unsigned *npass)
+{
+    const int srow = lane & 31, half = lane >> 5;
+    const unsigned long long *p = ring + tp_gran_index(half, srow);  // granule u of this lane: group half + 2 u = p + 4 u TP_LSTRIDE
+    const int nval = srow < b ? (ncg - half + 1) >> 1 : 0;         // this lane needs u < nval
+    const bool allvalid = __all(nval == NU);
+    const unsigned T = tag16 << 16;
+    unsigned hi[NU], lo[NU];
+    unsigned ok = 1;
+    for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const unsigned long long v = __hip_atomic_load(p + u * 4 * TP_LSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lo[u] = (unsigned)v, hi[u] = (unsigned)(v >> 32);
+        }
+        unsigned x = 0;
+        if (allvalid) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) x |= hi[u] ^ T;
+        } else {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) x |= u < nval ? hi[u] ^ T : 0u;
+        }
+        *npass += 1;
+        if (__all((x >> 16) == 0u)) break;
+#if ACAV_LEAN_PASS_SLEEP > 0
+        __builtin_amdgcn_s_sleep(ACAV_LEAN_PASS_SLEEP);  // experiment knob: x 64 clocks before a repeated pass
+#endif
+        if (spins > TP_SPIN_LIMIT || (spins & 1023) == 1023) {
+            if (spins > TP_SPIN_LIMIT || __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (lane == 0) __hip_atomic_store(&ctl->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+    }
+    unsigned bd = 0xFFFFFFFFu, bh = 0u, bu = 0u;
+    if (allvalid) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const bool c = lo[u] < bd;
+            bd = c ? lo[u] : bd, bh = c ? hi[u] : bh, bu = c ? (unsigned)u : bu;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const bool c = u < nval && lo[u] < bd;
+            bd = c ? lo[u] : bd, bh = c ? hi[u] : bh, bu = c ? (unsigned)u : bu;
+        }
+    }
+    unsigned long long key = ~0ull;
+    if (bd != 0xFFFFFFFFu) key = ((unsigned long long)bd << 32) | (unsigned)((half + 2 * (int)bu) * ncw + (int)(bh & 0xFFFFu));
+    if (__any(bd == 0xFFFFFFFFu && nval > 0)) {  // cold: the lexicographic form of rounds 1-5 (a granule without a candidate, distance bits all ones)
+        key = ~0ull;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+            if (u < nval) {
+                const unsigned loc = hi[u] & 0xFFFFu;
+                const unsigned long long cand = loc == 0xFFFFu ? ~0ull : (((unsigned long long)lo[u] << 32) | (unsigned)((half + 2 * u) * ncw + (int)loc));
+                key = cand < key ? cand : key;
+            }
+    }
+    if (!ok) key = ~0ull;
+    const unsigned long long o = __shfl_xor(key, 32);
+    key = o < key ? o : key;
+    *best = (int)(key & 0xffffffffull);
+    return ok;
+}
+
 __device__ __forceinline__ int tp_off(int row, int j)
 {
     return row * TP_DS + (j & ~255) + (((((j >> 2) & 63) ^ (row & 7))) << 2) + (j & 3);
@@ -801,8 +916,9 @@ __global__ __launch_bounds__(256) void k_train_persistent(
             const long long c2 = TP_CLK();
             pr[1] += c2 - c1;
             if (wave == 0) {
-                float acc = sPart[0][lane];
-                for (int w = 1; w < nblk; ++w) acc = acc + sPart[w][lane];  // canonical left fold of the segments
+                float acc1[1];
+                tp_fold_parts<1>(&sPart[0][lane], 0, 64, nblk, acc1);  // canonical left fold of the segments (loads four at a time)
+                const float acc = acc1[0];
                 const int k = kbase + kk;
                 unsigned long long key = ~0ull;
                 if (kk < nck && ii < nrv) key = pack_key(dist_epilogue(acc, xn_t, sCn[kk], sCnt[kk] < thr_t, r), k);
@@ -820,6 +936,21 @@ __global__ __launch_bounds__(256) void k_train_persistent(
                     __hip_atomic_store(&ring[tp_gran_index(blockIdx.x, rbase + lane)], tag | (local << 32) | (key >> 32), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
+#if ACAV_SWEEP_LEAN
+                {  // gather: tp_sweep_lean (above); the pause before the first pass as tuned in round 2 (comment in the #else branch)
+                    if (ncg >= 16) __builtin_amdgcn_s_sleep(TP_FIRST_SWEEP_PAUSE);
+                    const unsigned tag16 = (nsync % 65535u) + 1u;
+                    const int nu = (ncg + 1) >> 1;
+                    int bl = -1;
+                    unsigned np = 0, ok;
+                    if (nu <= 4) ok = tp_sweep_lean<4>(ring, ncg, b, TP_NC, tag16, lane, ctl, &bl, &np);
+                    else if (nu <= 8) ok = tp_sweep_lean<8>(ring, ncg, b, TP_NC, tag16, lane, ctl, &bl, &np);
+                    else ok = tp_sweep_lean<16>(ring, ncg, b, TP_NC, tag16, lane, ctl, &bl, &np);
+                    if (PROF) pr[7] += np;  // sweep passes (diagnostics)
+                    if (lane < b) sBest[lane] = bl;
+                    if (!ok && lane == 0) sDead = 1;
+                }
+#else
                 // gather: lane (row = l & 31, half = l >> 5) sweeps the granules of its row from half of the
                 // centre groups until every tag is this step's; then the lexicographic minimum
                 const int srow = lane & 31, half = lane >> 5;
@@ -875,6 +1006,7 @@ __global__ __launch_bounds__(256) void k_train_persistent(
                 bestkey = o < bestkey ? o : bestkey;
                 if (lane < b) sBest[lane] = (int)(bestkey & 0xffffffffull);
                 if (!ok && lane == 0) sDead = 1;
+#endif
             }
             ++nsync;
             __syncthreads();
@@ -1177,6 +1309,8 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
 #define TPW_CLK() ((long long)clock64())
     long long wpr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long wup[4] = {0, 0, 0, 0};  // touched steps: lr / labels, row loads issued -> landed, the rest of the update, closing barrier
+    long long wsw[4] = {0, 0, 0, 0};  // wave 0: keys epilogue, all sweep passes, the first pass, sweep end -> past the closing barrier
+    long long wsw_end = 0;
 #else
 #define TPW_CLK() 0ll
 #endif
@@ -1254,10 +1388,11 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                 if constexpr (MF) {  // lane l: centres 4 (l >> 4) + e of batch row l & 15
                     const int i15 = lane & 15, kq = lane >> 4;
                     key = ~0ull;
+                    float acc4[4];
+                    tp_fold_parts<4>(sPart + lane, 64, 256, nblk, acc4);  // canonical left fold per chain, loads in batches
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float acc = sPart[e * 64 + lane];
-                        for (int w = 1; w < nblk; ++w) acc = acc + sPart[(w * 4 + e) * 64 + lane];  // canonical left fold
+                        const float acc = acc4[e];
                         const int lc = 4 * kq + e;
                         if (lc < nck && i15 < nrv) {
                             const unsigned long long kc = pack_key(dist_epilogue(acc, xn_t[0], sCn[lc], sCnt[lc] < thr_t, r), kbase + lc);
@@ -1275,8 +1410,9 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                     unsigned long long key = ~0ull;
                     for (int cp = 0; cp < NCP; ++cp) {
                         const int q = NRP == 1 ? cp : 2 * cp + rp;
-                        float acc = sPart[(q * nblk) * 64 + lane];
-                        for (int w = 1; w < nblk; ++w) acc = acc + sPart[(q * nblk + w) * 64 + lane];  // canonical left fold
+                        float acc1[1];
+                        tp_fold_parts<1>(sPart + (q * nblk) * 64 + lane, 0, 64, nblk, acc1);  // canonical left fold
+                        const float acc = acc1[0];
                         const int lc = cp * 8 + kk;
                         if (lc < nck && rp * 8 + ii < nrv) {
                             const unsigned long long kc = pack_key(dist_epilogue(acc, xn_t[rp], sCn[lc], sCnt[lc] < thr_t, r), kbase + lc);
@@ -1294,6 +1430,10 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                 // lane l < 8 NRP holds the key of row l: its ii is l & 7 and every lane of an ii column holds that row's minimum
                 key = (NRP == 2 && (lane >> 3) == 1) ? keys[NRP - 1] : keys[0];
                 }
+#ifdef ACAV_WIDE_PROF
+                if (t >= need) wsw[0] += TPW_CLK() - wc2;
+                const long long wsw0 = TPW_CLK();
+#endif
                 const unsigned long long tag = (unsigned long long)((nsync % 65535u) + 1u) << 48;
                 unsigned long long *ring = ctl->gran[nsync % TP_RING];
                 if (lane < nrv) {
@@ -1301,6 +1441,27 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                     __hip_atomic_store(&ring[tp_gran_index(blockIdx.x, rbase + lane)], tag | (local << 32) | (key >> 32), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
+#if ACAV_SWEEP_LEAN
+                if (ACAV_SWEEP_REREAD_ALL && gridDim.x * gridDim.y <= ACAV_LEAN_MAX_WG) {  // uniform; the other grids keep the per-lane form below
+#if ACAV_TPW_FIRST_SLEEP > 0
+                    __builtin_amdgcn_s_sleep(ACAV_TPW_FIRST_SLEEP);
+#endif
+                    const unsigned tag16 = (nsync % 65535u) + 1u;
+                    const int nu = (ncg + 1) >> 1;
+                    int bl = -1;
+                    unsigned np = 0, okl;
+                    if (nu <= 16) okl = tp_sweep_lean<16>(ring, ncg, b, NCW, tag16, lane, ctl, &bl, &np);
+                    else okl = tp_sweep_lean<TPW_SW>(ring, ncg, b, NCW, tag16, lane, ctl, &bl, &np);
+#ifdef ACAV_WIDE_PROF
+                    wpr[7] += np;
+                    wsw_end = TPW_CLK();
+                    if (t >= need) wsw[1] += wsw_end - wsw0;
+#endif
+                    if (lane < b) sBest[lane] = bl;
+                    if (!okl && lane == 0) sDead = 1;
+                } else
+#endif
+                {
                 const int srow = lane & 31, half = lane >> 5;
                 unsigned long long bestkey = ~0ull;
                 unsigned ok = 1;
@@ -1319,6 +1480,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
 #endif
 #ifdef ACAV_WIDE_PROF
                     wpr[7] += 1;  // sweep passes
+                    const long long wpass0 = TPW_CLK();
 #endif
                     // up to 128 workgroups (the 16 x 16 form at K = 1024): every pass re-reads everything under a wave-uniform
                     // condition (k_train_persistent); more pollers than that (16 x 8 forms: 256) and the volume of full re-reads costs
@@ -1337,6 +1499,9 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
 #pragma unroll
                     for (int u = 0; u < TPW_SW; ++u)
                         if (((needm >> u) & 1u) && (g[u] >> 48) == (tag >> 48)) needm &= ~(1u << u);
+#ifdef ACAV_WIDE_PROF
+                    if (t >= need && spins == 0) wsw[2] += TPW_CLK() - wpass0;
+#endif
                     if (__all(needm == 0)) break;
                     if (spins > TP_SPIN_LIMIT || (spins & 1023) == 1023) {
                         if (spins > TP_SPIN_LIMIT || __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -1346,6 +1511,10 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                         }
                     }
                 }
+#ifdef ACAV_WIDE_PROF
+                wsw_end = TPW_CLK();
+                if (t >= need) wsw[1] += wsw_end - wsw0;
+#endif
 #pragma unroll
                 for (int u = 0; u < TPW_SW; ++u) {
                     const int cg = half + 2 * u;
@@ -1360,10 +1529,14 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                 bestkey = o < bestkey ? o : bestkey;
                 if (lane < b) sBest[lane] = (int)(bestkey & 0xffffffffull);
                 if (!ok && lane == 0) sDead = 1;
+                }
             }
             ++nsync;
             __syncthreads();
             wc3 = TPW_CLK();
+#ifdef ACAV_WIDE_PROF
+            if (t >= need && wave == 0) wsw[3] += wc3 - wsw_end;
+#endif
             if (sDead) break;  // uniform
         }
         // ---- update: every replica of a centre group does the same arithmetic; wave w owns column block w
@@ -1487,6 +1660,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
     {
         for (int q = 0; q < 8; ++q) ctl->prof[q] = (unsigned long long)wpr[q];
         for (int q = 0; q < 4; ++q) ctl->prof_wg[0][q] = (unsigned long long)wup[q];
+        for (int q = 0; q < 4; ++q) ctl->prof_wg[0][4 + q] = (unsigned long long)wsw[q];
     }
 #endif
 #undef TPW_CLK
@@ -1748,8 +1922,13 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
                     for (int w = 1; w < 4; ++w) acc = acc + sPart[(q * 4 + w) * 64 + lane];  // canonical left fold
                     __hip_atomic_store(my_t0, ts_granule(acc, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
+                    float v4[4];  // this half's segment sums: in flight while the partner's partial sum is polled
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v4[w] = sPart[(q * 4 + (w < nblk ? w : nblk - 1)) * 64 + lane];
                     ok = ts_poll(my_t0, tag, ctl, &acc) && ok;
-                    for (int w = 0; w < nblk; ++w) acc = acc + sPart[(q * 4 + w) * 64 + lane];  // ... continued over this half
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        if (w < nblk) acc = acc + v4[w];  // ... continued over this half, left to right
                     unsigned long long key = ~0ull;
                     if (c < nck && i < nrv) key = pack_key(dist_epilogue(acc, xn_t, sCn[c], sCnt[c] < thr_t, r), kbase + c);
 #ifndef ACAV_WIDE_NO_MFMA
@@ -1796,6 +1975,17 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
                     __hip_atomic_store(&ring[tp_gran_index(cg, rbase + lane)], tag16 | (local << 32) | (key >> 32), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
+#if ACAV_SWEEP_LEAN
+                {
+                    const int nu = (ncg + 1) >> 1;
+                    int bl = -1;
+                    unsigned np = 0, okl;
+                    if (nu <= 16) okl = tp_sweep_lean<16>(ring, ncg, b, TS_NC, (nsync % 65535u) + 1u, lane, ctl, &bl, &np);
+                    else okl = tp_sweep_lean<TPW_SW>(ring, ncg, b, TS_NC, (nsync % 65535u) + 1u, lane, ctl, &bl, &np);
+                    if (lane < b) sBest[lane] = bl;
+                    if (!okl && lane == 0) sDead = 1;
+                }
+#else
                 const int srow = lane & 31, half = lane >> 5;
                 unsigned long long bestkey = ~0ull;
                 unsigned okw = 1;
@@ -1835,6 +2025,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
                 bestkey = o < bestkey ? o : bestkey;
                 if (lane < b) sBest[lane] = (int)(bestkey & 0xffffffffull);
                 if (!okw && lane == 0) sDead = 1;
+#endif
             }
             ++nsync;
             __syncthreads();
@@ -2467,6 +2658,9 @@ static int train_finish(acav_kmeans *km, TrainCall &tc)
                 fprintf(stderr, "[acav] wide epoch (%d workgroups): cycles/step of workgroup (1, 0): row wait %.0f, fma %.0f, keys + exchange %.0f, update %.0f, "
                                 "total %.0f; sweep passes/step %.2f; steps with an update of mine %.3f\n", tc.nwg, hw.prof[0] / den, hw.prof[1] / den,
                         hw.prof[2] / den, hw.prof[3] / den, hw.prof[4] / den, hw.prof[7] / den, hw.prof[6] / den);
+            if (hw.prof[5])
+                fprintf(stderr, "[acav]   wave 0 inside keys + exchange: keys epilogue %.0f, publish + sweep %.0f (first pass %.0f), sweep end -> past the barrier %.0f\n",
+                        hw.up[4] / den, hw.up[5] / den, hw.up[6] / den, hw.up[7] / den);
             if (hw.prof[6]) {
                 const double dt = (double)hw.prof[6];
                 fprintf(stderr, "[acav]   per step WITH an update of mine: lr / labels %.0f, row loads issued -> landed %.0f, ballots + accumulate + centre rows "

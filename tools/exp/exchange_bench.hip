@@ -171,6 +171,69 @@ __global__ __launch_bounds__(64) void k_xchg2(Ctl *ctl, int rounds, int work_cyc
     if (lane == 0) sink[blockIdx.x] = acc;
 }
 
+
+// mode 8: the product's WORKGROUP, not just its sweep -- 256 threads, 132 KB of LDS; after the "FMA phase" waves 1 .. 3 fetch the next round's
+// batch rows (dma_kb KB per workgroup, global_load ... lds, 1 KB per instruction) while wave 0 publishes and sweeps (every pass re-reads all),
+// a barrier closes the round.  xsrc: 0 = no fetch, 1 = fresh rows every round (first touch comes from HBM, as the product's), 2 = the same
+// 128 KB every round (L2 hits: the CU-side share of the interference alone), 3 = fresh rows, fetched AFTER the sweep (exposed, for the bound).
+__global__ __launch_bounds__(256) void k_xchg_wg(Ctl *ctl, int rounds, int work_cycles, unsigned long long *sink, const float *xrows, long long xrounds,
+                                                 int dma_kb, int xsrc, long long *cyc)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_[];
+    float *lds = reinterpret_cast<float *>(smem_);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = blockIdx.x % NCG, rg = blockIdx.x / NCG;
+    const int srow = lane & 31, half = lane >> 5;
+    unsigned long long acc = 0;
+    long long c_exch = 0, c_pass = 0, n_pass = 0;
+    auto fetch = [&](int t) {
+        const float *src = xrows + (xsrc == 2 ? 0 : (size_t)(t % xrounds) * 32768) + (size_t)rg * 16384;  // 32 rows x 1024 floats per round
+        for (int it = wave - 1; it < dma_kb; it += 3)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + it * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void *)(lds + it * 256), 16, 0, 0);
+    };
+    for (int t = 0; t < rounds; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if ((t & 15) == 0 && __hip_atomic_load(&ctl->dead[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        work(work_cycles + ((blockIdx.x + t) % 3 == 0 ? 1500 : 0));
+        __syncthreads();
+        if (wave > 0 && (xsrc == 1 || xsrc == 2)) fetch(t + 1);
+        if (wave == 0) {
+            const long long c0 = clock64();
+            const unsigned long long tag = (unsigned long long)(t + 1) << 48;
+            unsigned long long(*ring)[32] = ctl->gran[t % RING];
+            if (lane < 16) __hip_atomic_store(&ring[cg][rg * 16 + lane], tag | (unsigned)(blockIdx.x * 64 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long g[32];
+            for (unsigned spin_ = 0;; ++spin_) {
+                if (spin_ >= (1u << 16) || ((spin_ & 255u) == 255u && __hip_atomic_load(&ctl->dead[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_store(&ctl->dead[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                const long long p0 = clock64();
+#pragma unroll
+                for (int u = 0; u < 32; ++u) g[u] = __hip_atomic_load(&ring[half + 2 * u][srow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < 32; ++u) ok = ok && (g[u] >> 48) == (tag >> 48);
+                c_pass += clock64() - p0, n_pass += 1;
+                if (__all(ok)) break;
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc += g[u] & 0xffff;
+            c_exch += clock64() - c0;
+        }
+        if (xsrc == 3) {
+            __syncthreads();
+            if (wave > 0) fetch(t + 1);
+        }
+    }
+    if (tid == 0) {
+        sink[blockIdx.x] = acc;
+        cyc[blockIdx.x * 4 + 0] = c_exch, cyc[blockIdx.x * 4 + 1] = c_pass, cyc[blockIdx.x * 4 + 2] = n_pass;
+    }
+}
+
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 // mode 4: lane l reads the two granules of rows 2 (l & 15), 2 (l & 15) + 1 of centre group 4 u + (l >> 4): 16 loads of 16 bytes per pass
 __global__ __launch_bounds__(64) void k_xchg16(Ctl *ctl, int rounds, int work_cycles, unsigned long long *sink, int nwg_rg)
@@ -312,6 +375,47 @@ int main(int argc, char **argv)
             printf("two-level (one leader per XCD sweeps memory, the rest its L2 copy); %3d workgroups, %4d cycles of work:  %.2f us per round%s; %u workgroups "
                    "NOT on XCD blockIdx %% 8\n", NCG * nrg, wc, best * 1e3 / rounds, dead ? "   (GAVE UP)" : "", off_xcd);
         }
+    }
+
+    {  // mode 8: the product's workgroup shape with the row fetch under the exchange
+        const long long xrounds = 4096;  // 4096 x 128 KB = 512 MB of "batch rows", cycled
+        float *xrows;
+        long long *cyc;
+        CK(hipMalloc(&xrows, (size_t)xrounds * 32768 * 4));
+        CK(hipMemset(xrows, 0, (size_t)xrounds * 32768 * 4));
+        CK(hipMalloc(&cyc, NWG * 4 * 8));
+        CK(hipFuncSetAttribute((const void *)k_xchg_wg, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
+        struct { int kb, src; const char *what; } cases[] = {
+            {0, 0, "no row fetch"}, {64, 1, "64 KB of FRESH rows under the exchange (the product)"}, {64, 2, "64 KB of L2-resident rows under the exchange"},
+            {64, 3, "64 KB of fresh rows AFTER the sweep (exposed)"}, {16, 1, "16 KB of fresh rows under the exchange"}};
+        for (auto &c : cases)
+            for (int wc : {3500, 0}) {
+                hipEvent_t e0, e1;
+                CK(hipEventCreate(&e0));
+                CK(hipEventCreate(&e1));
+                float best = 1e30f;
+                std::vector<long long> h(NWG * 4);
+                for (int rep = 0; rep < 3; ++rep) {
+                    CK(hipMemset(ctl, 0, sizeof(Ctl)));
+                    CK(hipEventRecord(e0));
+                    hipLaunchKernelGGL(k_xchg_wg, dim3(NWG), dim3(256), 132 * 1024, 0, ctl, rounds, wc, sink, xrows, xrounds, c.kb, c.src, cyc);
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms < best) {
+                        best = ms;
+                        CK(hipMemcpy(h.data(), cyc, NWG * 4 * 8, hipMemcpyDeviceToHost));
+                    }
+                }
+                unsigned dead = 0;
+                CK(hipMemcpy(&dead, ctl->dead, 4, hipMemcpyDeviceToHost));
+                double ex = 0, ps = 0, np = 0;
+                for (int i = 0; i < NWG; ++i) ex += h[i * 4], ps += h[i * 4 + 1], np += h[i * 4 + 2];
+                printf("workgroup of 4 waves, %-58s %4d cycles of work: %.2f us per round; exchange %.0f cycles, %.2f passes of %.0f cycles%s\n", c.what, wc,
+                       best * 1e3 / rounds, ex / NWG / rounds, np / NWG / rounds, ps / (np > 0 ? np : 1), dead ? "   (GAVE UP)" : "");
+                fflush(stdout);
+            }
     }
     run<0>("product sweep, no work at all (the exchange alone)", ctl, sink, rounds, 0);
     run<1>("every pass re-reads all granules, no work at all", ctl, sink, rounds, 0);
