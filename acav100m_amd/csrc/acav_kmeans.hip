@@ -582,9 +582,6 @@ struct TrainCtl {
 #ifndef ACAV_LEAN_PASS_SLEEP
 #define ACAV_LEAN_PASS_SLEEP 0
 #endif
-#ifndef ACAV_LEAN_MAX_WG
-#define ACAV_LEAN_MAX_WG 4096u  // grids up to this many workgroups sweep with tp_sweep_lean (every pass re-reads everything); 128u: round 6's first cut
-#endif
 // Round 6, late: the instruction stream of the exchange, not the fabric, was half of its cost.  Phase timers inside wave 0 of the
 // 16 x 16 form at K = d = 1024 (-DACAV_WIDE_PROF): keys epilogue 2.9k cycles (4 x nblk DEPENDENT LDS reads, an s_waitcnt between each),
 // a sweep pass ~1.3k cycles to issue its 32 loads (one spilled scalar condition + branch per load) + the round trip + ~1.5k to
@@ -916,12 +913,23 @@ __global__ __launch_bounds__(256) void k_train_persistent(
             const long long c2 = TP_CLK();
             pr[1] += c2 - c1;
             if (wave == 0) {
+                const float cn_k = sCn[kk], ct_k = sCnt[kk];  // (with the segment sums: one LDS round trip)
                 float acc1[1];
                 tp_fold_parts<1>(&sPart[0][lane], 0, 64, nblk, acc1);  // canonical left fold of the segments (loads four at a time)
                 const float acc = acc1[0];
                 const int k = kbase + kk;
                 unsigned long long key = ~0ull;
-                if (kk < nck && ii < nrv) key = pack_key(dist_epilogue(acc, xn_t, sCn[kk], sCnt[kk] < thr_t, r), k);
+                {
+                    float tq = -2.0f * acc;  // dist_epilogue; the discount's division only in steps where some lane needs it
+                    tq = tq + xn_t;
+                    tq = tq + cn_k;
+                    const bool disc = ct_k < thr_t;
+                    if (__any(disc)) {
+                        const float q = tq / r;
+                        tq = disc ? q : tq;
+                    }
+                    if (kk < nck && ii < nrv) key = pack_key(tq, k);
+                }
                 unsigned long long o = __shfl_xor(key, 8);
                 key = o < key ? o : key;
                 o = __shfl_xor(key, 16);
@@ -1388,16 +1396,35 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                 if constexpr (MF) {  // lane l: centres 4 (l >> 4) + e of batch row l & 15
                     const int i15 = lane & 15, kq = lane >> 4;
                     key = ~0ull;
+                    // every operand of the four epilogues first (the centre norms / counts sit in LDS too: one round trip, not five),
+                    // the epilogues of all lanes unconditionally (an invalid lane's result is dropped by the select at the end), and
+                    // the discount's division only in steps where some lane of the wave needs it (wave-uniform branch)
+                    float cn4[4], ct4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cn4[e] = sCn[4 * kq + e], ct4[e] = sCnt[4 * kq + e];
                     float acc4[4];
                     tp_fold_parts<4>(sPart + lane, 64, 256, nblk, acc4);  // canonical left fold per chain, loads in batches
+                    float t4[4];
+                    bool disc[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float acc = acc4[e];
-                        const int lc = 4 * kq + e;
-                        if (lc < nck && i15 < nrv) {
-                            const unsigned long long kc = pack_key(dist_epilogue(acc, xn_t[0], sCn[lc], sCnt[lc] < thr_t, r), kbase + lc);
-                            key = kc < key ? kc : key;
+                        float t = -2.0f * acc4[e];  // dist_epilogue, the discount apart
+                        t = t + xn_t[0];
+                        t4[e] = t + cn4[e];
+                        disc[e] = ct4[e] < thr_t;
+                    }
+                    if (__any(disc[0] || disc[1] || disc[2] || disc[3])) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float q = t4[e] / r;
+                            t4[e] = disc[e] ? q : t4[e];
                         }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int lc = 4 * kq + e;
+                        const unsigned long long kc = (lc < nck && i15 < nrv) ? pack_key(t4[e], kbase + lc) : ~0ull;
+                        key = kc < key ? kc : key;
                     }
                     o = __shfl_xor(key, 16);
                     key = o < key ? o : key;
@@ -1442,7 +1469,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
 #if ACAV_SWEEP_LEAN
-                if (ACAV_SWEEP_REREAD_ALL && gridDim.x * gridDim.y <= ACAV_LEAN_MAX_WG) {  // uniform; the other grids keep the per-lane form below
+                {  // (the per-lane form of rounds 1-5 below: -DACAV_SWEEP_LEAN=0)
 #if ACAV_TPW_FIRST_SLEEP > 0
                     __builtin_amdgcn_s_sleep(ACAV_TPW_FIRST_SLEEP);
 #endif
@@ -1459,8 +1486,8 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
 #endif
                     if (lane < b) sBest[lane] = bl;
                     if (!okl && lane == 0) sDead = 1;
-                } else
-#endif
+                }
+#else
                 {
                 const int srow = lane & 31, half = lane >> 5;
                 unsigned long long bestkey = ~0ull;
@@ -1530,6 +1557,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                 if (lane < b) sBest[lane] = (int)(bestkey & 0xffffffffull);
                 if (!ok && lane == 0) sDead = 1;
                 }
+#endif
             }
             ++nsync;
             __syncthreads();
@@ -1922,6 +1950,11 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
                     for (int w = 1; w < 4; ++w) acc = acc + sPart[(q * 4 + w) * 64 + lane];  // canonical left fold
                     __hip_atomic_store(my_t0, ts_granule(acc, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
+#ifndef ACAV_WIDE_NO_MFMA
+                    const float cn_c = sCn[c], ct_c = sCnt[c];  // (c <= 15 always; in flight with the segment sums)
+#else
+                    const float cn_c = sCn[c < TS_NC ? c : 0], ct_c = sCnt[c < TS_NC ? c : 0];
+#endif
                     float v4[4];  // this half's segment sums: in flight while the partner's partial sum is polled
 #pragma unroll
                     for (int w = 0; w < 4; ++w) v4[w] = sPart[(q * 4 + (w < nblk ? w : nblk - 1)) * 64 + lane];
@@ -1930,7 +1963,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
                     for (int w = 0; w < 4; ++w)
                         if (w < nblk) acc = acc + v4[w];  // ... continued over this half, left to right
                     unsigned long long key = ~0ull;
-                    if (c < nck && i < nrv) key = pack_key(dist_epilogue(acc, xn_t, sCn[c], sCnt[c] < thr_t, r), kbase + c);
+                    if (c < nck && i < nrv) key = pack_key(dist_epilogue(acc, xn_t, cn_c, ct_c < thr_t, r), kbase + c);
 #ifndef ACAV_WIDE_NO_MFMA
                     unsigned long long o = __shfl_xor(key, 16);
                     key = o < key ? o : key;
