@@ -54,5 +54,14 @@ def configure_runtime(hw_queues=16, quiet=False):
 
 
 
+def trim_device_cache():
+    """Return every parked device block of the library to the driver (`acav_trim_device_cache`, include/acav_hip.h); bytes freed."""
+    import ctypes as _C
+    from ._lib import check as _check, load_library as _load
+    freed = _C.c_int64(0)
+    _check(_load().acav_trim_device_cache(_C.byref(freed)))
+    return int(freed.value)
+
+
 __all__ = ["AcavError", "LIB_PATH", "device_count", "load_library", "Generator", "default_generator",
-           "manual_seed", "configure_runtime", "runtime_initialised"]
+           "manual_seed", "configure_runtime", "runtime_initialised", "trim_device_cache"]

@@ -18,6 +18,7 @@ SIGNATURES = {
     "acav_version": [],
     "acav_device_count": [C.POINTER(i32)],
     "acav_device_info": [i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i64)],
+    "acav_trim_device_cache": [C.POINTER(i64)],
     "acav_rng_create": [pp, u32],
     "acav_rng_destroy": [vp],
     "acav_rng_seed": [vp, u32],

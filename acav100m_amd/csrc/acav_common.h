@@ -53,17 +53,67 @@ void set_error(const char *fmt, ...);
 // true when p is a device (or managed) pointer usable from kernels
 bool is_device_ptr(const void *p);
 
-// Blocks of up to 256 MB that a DevBuf gives back are parked (up to 2 GB per process) instead of hipFree'd, and handed
+// Blocks of up to 256 MB that a DevBuf gives back are parked (up to 16 GB / 16 384 blocks per process: ACAV_PARK_MAX_MB,
+// ACAV_PARK_MAX_BLOCKS; acav_trim_device_cache() returns them) instead of hipFree'd, and handed
 // out again to the next request of a similar size on the same device: hipMalloc / hipFree are synchronous and cost
 // 50-200 us each -- a KMeans handle created per pass (bench.py, one CLI run per group) paid ~150 us of allocations inside
 // its first assign sweep.  The owner of a DevBuf synchronises its stream before the buffer goes (all *_destroy do).
 int devbuf_alloc(void **p, size_t *bytes, size_t want);
 void devbuf_free(void *p, size_t bytes);
+size_t devbuf_trim();
+
+// Pinned host staging for host -> device copies (round 6).  hipMemcpyAsync from PAGEABLE memory pins the pages on the fly: 3.9 ms per
+// 800 KB on this runtime (the candidate ids of a 100 k chunk; ten per lockstep group = 40 of a group's 50 ms of set-up), and pinning /
+// unpinning from a helper thread updates the GPU's page tables under the kernels another thread has in flight.  A HostPinned block
+// is hipHostMalloc'd once, parked when its owner goes (as device blocks are: hostpin_alloc / hostpin_free) and guarded by an event:
+// the host may overwrite it only after the last copy that read it has completed (wait()).
+int hostpin_alloc(void **p, size_t *bytes, size_t want);
+void hostpin_free(void *p, size_t bytes);
+struct HostPinned {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    ~HostPinned() { release(); }
+    void wait()
+    {
+        if (pending && ev) (void)hipEventSynchronize(ev);
+        pending = false;
+    }
+    void release()
+    {
+        wait();
+        if (p) hostpin_free(p, bytes);
+        if (ev) (void)hipEventDestroy(ev);
+        p = nullptr, bytes = 0, ev = nullptr;
+    }
+    int ensure(size_t n)
+    {
+        if (n <= bytes) return ACAV_OK;
+        wait();
+        if (p) hostpin_free(p, bytes);
+        p = nullptr, bytes = 0;
+        return hostpin_alloc(&p, &bytes, n);
+    }
+    int mark(hipStream_t s)  // a copy out of the block was just enqueued on s
+    {
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            ev = nullptr;
+            return hipStreamSynchronize(s) == hipSuccess ? ACAV_OK : ACAV_EHIP;
+        }
+        if (hipEventRecord(ev, s) != hipSuccess) return ACAV_EHIP;
+        pending = true;
+        return ACAV_OK;
+    }
+};
+constexpr size_t HOSTPIN_MIN = 32u << 10, HOSTPIN_MAX = 64u << 20;  // copies of this size range go through a pinned shadow
 
 // A device allocation that frees itself.
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    HostPinned shadow;  // to_device(): the pinned staging of host data on its way into this buffer
     hipStream_t owner = nullptr;  // bind(): the ONE stream every use of this buffer is ordered on (k-means handles)
     bool bound = false;
     ~DevBuf() { release(); }

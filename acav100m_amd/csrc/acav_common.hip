@@ -1,5 +1,6 @@
 // acav_common.hip -- error model, device/pointer helpers, library-level entry points, and the
 // host MT19937 stream (torch's CPU generator) of libacav_hip.so.
+#include <map>
 #include <mutex>
 
 #include "acav_common.h"
@@ -31,16 +32,112 @@ bool is_device_ptr(const void *p)
 
 // ---- parked device blocks (see acav_common.h)
 namespace {
-struct Parked {
-    void *p;
-    size_t bytes;
-    int device;
-};
+// (device, bytes) -> block: the smallest parked block that fits is a lower_bound.  Round 6: the pool used to hold 256 blocks / 2 GB and
+// was searched linearly -- a lockstep group of ten MI handles gives back ~1 000 blocks (80 position buffers per handle), so three
+// quarters of them went through hipFree (a device-wide synchronisation each, issued from bench.py's helper thread while the next
+// group's loop was running) and came back as hipMalloc in the next group's set-up: the cfg5 slice's selection took 2.5-3.7 s
+// depending on how those calls interleaved.  Caps: ACAV_PARK_MAX_BLOCKS (16 384), ACAV_PARK_MAX_MB (16 384 MB; an out-of-memory
+// hipMalloc gives everything back and retries, acav_trim_device_cache() gives it back on request).
 std::mutex g_park_mutex;
-std::vector<Parked> g_parked;
+std::multimap<std::pair<int, size_t>, void *> g_parked;
 size_t g_parked_bytes = 0;
-constexpr size_t PARK_MAX_BLOCK = 256ull << 20, PARK_MAX_TOTAL = 2048ull << 20;
+constexpr size_t PARK_MAX_BLOCK = 256ull << 20;
+size_t park_max_total()
+{
+    static const size_t v = [] {
+        const char *e = getenv("ACAV_PARK_MAX_MB");
+        const long long mb = e ? atoll(e) : 16384;
+        return (size_t)(mb < 0 ? 0 : mb) << 20;
+    }();
+    return v;
+}
+size_t park_max_blocks()
+{
+    static const size_t v = [] {
+        const char *e = getenv("ACAV_PARK_MAX_BLOCKS");
+        const long long n = e ? atoll(e) : 16384;
+        return (size_t)(n < 0 ? 0 : n);
+    }();
+    return v;
+}
+void drop_all_parked()
+{
+    std::vector<void *> drop;
+    {
+        std::lock_guard<std::mutex> lock(g_park_mutex);
+        for (auto &kv : g_parked) drop.push_back(kv.second);
+        g_parked.clear();
+        g_parked_bytes = 0;
+    }
+    for (void *q : drop) (void)hipFree(q);
+}
 }  // namespace
+
+// ---- parked pinned host blocks (HostPinned, acav_common.h): size -> block; up to 1 GB / 4 096 blocks
+namespace {
+std::mutex g_pin_mutex;
+std::multimap<size_t, void *> g_pinned;
+size_t g_pinned_bytes = 0;
+}  // namespace
+
+int hostpin_alloc(void **p, size_t *bytes, size_t want)
+{
+    want = want < 4096 ? 4096 : want;
+    {
+        std::lock_guard<std::mutex> lock(g_pin_mutex);
+        auto it = g_pinned.lower_bound(want);
+        if (it != g_pinned.end() && it->first <= 2 * want + 4096) {
+            *p = it->second, *bytes = it->first;
+            g_pinned_bytes -= it->first;
+            g_pinned.erase(it);
+            return ACAV_OK;
+        }
+    }
+    hipError_t e = hipHostMalloc(p, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *p = nullptr, *bytes = 0;
+        set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return ACAV_ENOMEM;
+    }
+    *bytes = want;
+    return ACAV_OK;
+}
+
+void hostpin_free(void *p, size_t bytes)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lock(g_pin_mutex);
+        if (g_pinned_bytes + bytes <= (1024ull << 20) && g_pinned.size() < 4096) {
+            g_pinned.emplace(bytes, p);
+            g_pinned_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+
+size_t devbuf_trim()
+{
+    {
+        std::vector<void *> dropp;
+        {
+            std::lock_guard<std::mutex> lock(g_pin_mutex);
+            for (auto &kv : g_pinned) dropp.push_back(kv.second);
+            g_pinned.clear();
+            g_pinned_bytes = 0;
+        }
+        for (void *q : dropp) (void)hipHostFree(q);
+    }
+    size_t b;
+    {
+        std::lock_guard<std::mutex> lock(g_park_mutex);
+        b = g_parked_bytes;
+    }
+    drop_all_parked();
+    return b;
+}
 
 int devbuf_alloc(void **p, size_t *bytes, size_t want)
 {
@@ -48,29 +145,19 @@ int devbuf_alloc(void **p, size_t *bytes, size_t want)
     (void)hipGetDevice(&dev);
     if (want <= PARK_MAX_BLOCK) {
         std::lock_guard<std::mutex> lock(g_park_mutex);
-        size_t best = g_parked.size();
-        for (size_t i = 0; i < g_parked.size(); ++i)  // smallest parked block of this device that fits without wasting > 2x
-            if (g_parked[i].device == dev && g_parked[i].bytes >= want && g_parked[i].bytes <= 2 * want + 4096 &&
-                (best == g_parked.size() || g_parked[i].bytes < g_parked[best].bytes))
-                best = i;
-        if (best != g_parked.size()) {
-            *p = g_parked[best].p;
-            *bytes = g_parked[best].bytes;
-            g_parked_bytes -= g_parked[best].bytes;
-            g_parked.erase(g_parked.begin() + (long)best);
+        auto it = g_parked.lower_bound({dev, want});  // smallest parked block of this device that fits ...
+        if (it != g_parked.end() && it->first.first == dev && it->first.second <= 2 * want + 4096) {  // ... without wasting > 2x
+            *p = it->second;
+            *bytes = it->first.second;
+            g_parked_bytes -= it->first.second;
+            g_parked.erase(it);
             return ACAV_OK;
         }
     }
     hipError_t e = hipMalloc(p, want);
     if (e != hipSuccess) {  // out of memory: give the parked blocks back and try once more
         (void)hipGetLastError();
-        std::vector<Parked> drop;
-        {
-            std::lock_guard<std::mutex> lock(g_park_mutex);
-            drop.swap(g_parked);
-            g_parked_bytes = 0;
-        }
-        for (const Parked &b : drop) (void)hipFree(b.p);
+        drop_all_parked();
         e = hipMalloc(p, want);
     }
     if (e != hipSuccess) {
@@ -92,8 +179,8 @@ void devbuf_free(void *p, size_t bytes)
         if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device;
         else (void)hipGetLastError();
         std::lock_guard<std::mutex> lock(g_park_mutex);
-        if (dev >= 0 && g_parked_bytes + bytes <= PARK_MAX_TOTAL && g_parked.size() < 256) {
-            g_parked.push_back({p, bytes, dev});
+        if (dev >= 0 && g_parked_bytes + bytes <= park_max_total() && g_parked.size() < park_max_blocks()) {
+            g_parked.emplace(std::make_pair(dev, bytes), p);
             g_parked_bytes += bytes;
             return;
         }
@@ -108,6 +195,15 @@ int to_device(const void *src, size_t bytes, DevBuf &stage, hipStream_t stream, 
         return ACAV_OK;
     }
     ACAV_TRY(stage.ensure(bytes));
+    if (bytes >= HOSTPIN_MIN && bytes <= HOSTPIN_MAX) {  // through the buffer's pinned shadow: no pinning of the caller's pages on the fly
+        ACAV_TRY(stage.shadow.ensure(bytes));
+        stage.shadow.wait();  // the previous copy out of the shadow has left it
+        memcpy(stage.shadow.p, src, bytes);
+        ACAV_HIP_TRY(hipMemcpyAsync(stage.p, stage.shadow.p, bytes, hipMemcpyHostToDevice, stream));
+        ACAV_TRY(stage.shadow.mark(stream));
+        *out = stage.p;
+        return ACAV_OK;
+    }
     ACAV_HIP_TRY(hipMemcpyAsync(stage.p, src, bytes, hipMemcpyHostToDevice, stream));
     *out = stage.p;
     return ACAV_OK;
@@ -180,6 +276,13 @@ using namespace acav;
 
 ACAV_EXPORT const char *acav_last_error(void) { return g_err; }
 ACAV_EXPORT int acav_version(void) { return 100; }
+
+ACAV_EXPORT int acav_trim_device_cache(int64_t *freed_bytes)
+{
+    const size_t b = acav::devbuf_trim();
+    if (freed_bytes) *freed_bytes = (int64_t)b;
+    return ACAV_OK;
+}
 
 ACAV_EXPORT int acav_device_count(int *count)
 {

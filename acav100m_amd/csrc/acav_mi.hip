@@ -1639,22 +1639,32 @@ static int fy_setup(acav_mi *mi, int64_t L, FyPlan &fp, hipStream_t st)
     return ACAV_OK;
 }
 
-static int ids_to_device32(acav_mi *mi, const int64_t *ids, int64_t n, DevBuf &stage, DevBuf &out32)
+// candidate / sample ids (int64 at the boundary, as the reference's lists) -> int32 on the device.  Host ids are range-checked and
+// narrowed in ONE pass into the pinned shadow of the destination (half the bytes of the int64 copy, no conversion kernel, and no
+// pinning of the caller's pages on the fly: a pageable 800 KB copy cost 3.9 ms, ten per lockstep group); device ids are converted
+// by k_i64_to_i32.  `on`: the stream to order the copy on (default: the handle's own).
+static int ids_to_device32(acav_mi *mi, const int64_t *ids, int64_t n, DevBuf &stage, DevBuf &out32, hipStream_t on = nullptr)
 {
-    hipStream_t st = mi->ctx.stream;
-    if (!is_device_ptr(ids)) {
-        for (int64_t i = 0; i < n; ++i)
-            ACAV_REQUIRE(ids[i] >= 0 && ids[i] < mi->V, ACAV_EINVAL, "id %lld out of range [0,%lld)",
-                         (long long)ids[i], (long long)mi->V);
-    }
-    const void *d = nullptr;
-    ACAV_TRY(to_device(ids, sizeof(int64_t) * (size_t)n, stage, st, &d));
+    hipStream_t st = on ? on : mi->ctx.stream;
     ACAV_TRY(out32.ensure(sizeof(int) * (size_t)(n > 0 ? n : 1)));
-    if (n > 0) {
-        hipLaunchKernelGGL(k_i64_to_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           static_cast<const long long *>(d), out32.as<int>(), (long long)n);
-        ACAV_HIP_TRY(hipGetLastError());
+    if (n <= 0) return ACAV_OK;
+    if (!is_device_ptr(ids)) {
+        const size_t nb = sizeof(int) * (size_t)n;
+        ACAV_TRY(out32.shadow.ensure(nb));
+        out32.shadow.wait();
+        int *h = static_cast<int *>(out32.shadow.p);
+        for (int64_t i = 0; i < n; ++i) {
+            ACAV_REQUIRE(ids[i] >= 0 && ids[i] < mi->V, ACAV_EINVAL, "id %lld out of range [0,%lld)", (long long)ids[i], (long long)mi->V);
+            h[i] = (int)ids[i];
+        }
+        ACAV_HIP_TRY(hipMemcpyAsync(out32.p, h, nb, hipMemcpyHostToDevice, st));
+        ACAV_TRY(out32.shadow.mark(st));
+        return ACAV_OK;
     }
+    (void)stage;
+    hipLaunchKernelGGL(k_i64_to_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const long long *>(ids),
+                       out32.as<int>(), (long long)n);
+    ACAV_HIP_TRY(hipGetLastError());
     return ACAV_OK;
 }
 
@@ -1892,6 +1902,11 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
     }
     ACAV_TRY(mi_ensure_streams(lead));
     hipStream_t st = lead->ctx.stream, sf = lead->st_fy;
+    const bool timing = getenv("ACAV_MI_TIMING") != nullptr;
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+    const auto t_setup0 = clk::now();
+    double t_ids = 0, t_fy = 0, t_mt = 0, t_add = 0;
     const int64_t dl = B - (keep_unselected ? B - k : 0);  // candidates consumed per iteration
     std::vector<TileChunk> desc((size_t)nchunks);
     std::vector<int64_t> iters((size_t)nchunks, 0), r0((size_t)nchunks, 0);
@@ -1903,7 +1918,9 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
     for (int c = 0; c < nchunks; ++c) {
         acav_mi *mi = mis[c];
         ACAV_HIP_TRY(hipStreamSynchronize(mi->ctx.stream));  // whatever the handle was doing on its own stream is over
+        { const auto t0 = clk::now();
         if (ns[c]) ACAV_TRY(acav_mi_add_samples(mi, start[c], ns[c]));  // batch.py:215
+        t_add += ms_since(t0); }
         // plan: the number of iterations and every L_t are known on the host (no device feedback)
         int64_t nS = 0, l = L[c], itc = 0, draws = 0;
         while (nS < subset[c] && (ex.max_iters < 0 || itc < ex.max_iters)) {
@@ -1922,7 +1939,12 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
         dmax = mi->D > dmax ? mi->D : dmax;
         const size_t Lc = (size_t)L[c];
         ACAV_TRY(mi->A0.ensure(sizeof(int) * (Lc + B)));  // before the conversion: ensure() does not copy
-        ACAV_TRY(ids_to_device32(mi, candidates[c], L[c], mi->stage, mi->A0));
+        { const auto t0 = clk::now();
+        // on the LEAD's content stream, the one the loop's gathers run on: ordered before them by the stream itself (on the chunk's
+        // own stream the conversion kernel was ordered by nothing but its brevity), and a chunk handle's own stream -- never used
+        // otherwise in a lockstep group -- does not have to acquire a hardware queue for one 800 KB copy (3.9 ms per chunk)
+        ACAV_TRY(ids_to_device32(mi, candidates[c], L[c], mi->stage, mi->A0, st));
+        t_ids += ms_since(t0); }
         ACAV_TRY(mi->A1.ensure(sizeof(int) * (Lc + B)));
         ACAV_TRY(mi->batch.ensure(sizeof(int) * 2 * SEL_MAXB * (size_t)(1 + mi->D)));
         ACAV_TRY(mi->S.ensure(sizeof(long long) * (size_t)(itc * k + 1)));
@@ -1937,7 +1959,9 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
             ACAV_HIP_TRY(hipMemcpyAsync(mi->forced.p, ex.forced_pos, sizeof(int) * (size_t)(itc * k), hipMemcpyHostToDevice, st));
         }
         FyPlan &fp = plans[(size_t)c];
+        { const auto t0 = clk::now();
         ACAV_TRY(fy_setup(mi, L[c], fp, st));
+        t_fy += ms_since(t0); }
         ntmax = fp.NT > ntmax ? fp.NT : ntmax;
         const size_t ps = fy_part_smem(fp.NT, fp.table.size(), false), pss = fy_part_smem(fp.NT, fp.table.size(), true);
         part_smem = ps > part_smem ? ps : part_smem;
@@ -1958,7 +1982,9 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
         const int nshare = vsh ? atoi(vsh) : 1;
         if (nshare > 0) ACAV_TRY(mi_ensure_streams(mis[c % nshare]));
         else ACAV_TRY(mi_ensure_streams(mi));
+        { const auto t0 = clk::now();
         ACAV_TRY(ms.plan(mi, sf, mtbuf, idx, draws, L[c], (int64_t)FY_GROUP * L[c], nshare > 0 ? mis[c % nshare]->st_mt : nullptr));
+        t_mt += ms_since(t0); }
         TileChunk &d = desc[(size_t)c];
         d.ring = ms.ring + MtStream::PAD;
         d.head = ms.head;
@@ -1983,7 +2009,9 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
     }
     ACAV_TRY(lead->chunk_desc.ensure(sizeof(TileChunk) * (size_t)nchunks));
     ACAV_HIP_TRY(hipMemcpyAsync(lead->chunk_desc.p, desc.data(), sizeof(TileChunk) * (size_t)nchunks, hipMemcpyHostToDevice, st));
+    const double t_chunks = ms_since(t_setup0);
     ACAV_HIP_TRY(hipStreamSynchronize(st));  // tables, counters, candidate lists, forced positions and descriptors are in place
+    const double t_setup = ms_since(t_setup0);
     ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fy_tile_multi), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)tile_smem));
     // the staged form of k_fy_part wants 64 KB of LDS beside the tile table (which grows with L: 64 KB at 16 Mi candidates)
@@ -1999,7 +2027,6 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
     if (sel_smem > 48 * 1024)
         ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fy_gather_select_multi),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_smem));
-    const bool timing = getenv("ACAV_MI_TIMING") != nullptr;
     const auto t_loop0 = std::chrono::steady_clock::now();
     for (int64_t g0 = 0; g0 < iters_max; g0 += FY_GROUP) {
         const int64_t g1 = g0 + FY_GROUP < iters_max ? g0 + FY_GROUP : iters_max;
@@ -2053,6 +2080,7 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
                 std::chrono::duration<double, std::micro>(t_loop2 - t_loop0).count() / (double)(iters_max ? iters_max : 1),
                 plans[0].NT, plans[0].ecap, streams[0].W, mis[0]->queue_probe_replaced);
     }
+    const auto t_tail0 = clk::now();
     for (int c = 0; c < nchunks; ++c) {
         acav_mi *mi = mis[c];
         const int64_t itc = iters[(size_t)c];
@@ -2083,6 +2111,9 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
         ACAV_REQUIRE(ferr == 0, ACAV_ESTATE, "tiled Fisher-Yates: a tile bucket of chunk %d overflowed (flags %u); re-run with "
                                              "ACAV_FY_LEGACY=1", c, ferr);
     }
+    if (timing)
+        fprintf(stderr, "[acav]   set-up %.1f ms (per-chunk work %.1f: add_samples %.1f, ids %.1f, tables %.1f, generator plan %.1f; then the sync), "
+                        "read-back + generator states %.1f ms\n", t_setup, t_chunks, t_add, t_ids, t_fy, t_mt, ms_since(t_tail0));
     return ACAV_OK;
 }
 
