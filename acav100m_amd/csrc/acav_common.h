@@ -58,69 +58,22 @@ bool is_device_ptr(const void *p);
 // out again to the next request of a similar size on the same device: hipMalloc / hipFree are synchronous and cost
 // 50-200 us each -- a KMeans handle created per pass (bench.py, one CLI run per group) paid ~150 us of allocations inside
 // its first assign sweep.  The owner of a DevBuf synchronises its stream before the buffer goes (all *_destroy do).
-int devbuf_alloc(void **p, size_t *bytes, size_t want);
-void devbuf_free(void *p, size_t bytes);
+int devbuf_alloc(void **p, size_t *bytes, size_t want, int *dev = nullptr);
+void devbuf_free(void *p, size_t bytes, int dev = -1);  // dev: the device the block was allocated on (-1: ask the runtime)
 size_t devbuf_trim();
-
-// Pinned host staging for host -> device copies (round 6).  hipMemcpyAsync from PAGEABLE memory pins the pages on the fly: 3.9 ms per
-// 800 KB on this runtime (the candidate ids of a 100 k chunk; ten per lockstep group = 40 of a group's 50 ms of set-up), and pinning /
-// unpinning from a helper thread updates the GPU's page tables under the kernels another thread has in flight.  A HostPinned block
-// is hipHostMalloc'd once, parked when its owner goes (as device blocks are: hostpin_alloc / hostpin_free) and guarded by an event:
-// the host may overwrite it only after the last copy that read it has completed (wait()).
-int hostpin_alloc(void **p, size_t *bytes, size_t want);
-void hostpin_free(void *p, size_t bytes);
-struct HostPinned {
-    void *p = nullptr;
-    size_t bytes = 0;
-    hipEvent_t ev = nullptr;
-    bool pending = false;
-    ~HostPinned() { release(); }
-    void wait()
-    {
-        if (pending && ev) (void)hipEventSynchronize(ev);
-        pending = false;
-    }
-    void release()
-    {
-        wait();
-        if (p) hostpin_free(p, bytes);
-        if (ev) (void)hipEventDestroy(ev);
-        p = nullptr, bytes = 0, ev = nullptr;
-    }
-    int ensure(size_t n)
-    {
-        if (n <= bytes) return ACAV_OK;
-        wait();
-        if (p) hostpin_free(p, bytes);
-        p = nullptr, bytes = 0;
-        return hostpin_alloc(&p, &bytes, n);
-    }
-    int mark(hipStream_t s)  // a copy out of the block was just enqueued on s
-    {
-        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
-            ev = nullptr;
-            return hipStreamSynchronize(s) == hipSuccess ? ACAV_OK : ACAV_EHIP;
-        }
-        if (hipEventRecord(ev, s) != hipSuccess) return ACAV_EHIP;
-        pending = true;
-        return ACAV_OK;
-    }
-};
-constexpr size_t HOSTPIN_MIN = 32u << 10, HOSTPIN_MAX = 64u << 20;  // copies of this size range go through a pinned shadow
 
 // A device allocation that frees itself.
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
-    HostPinned shadow;  // to_device(): the pinned staging of host data on its way into this buffer
+    int dev = -1;       // the device the block lives on (devbuf_free parks it without asking the runtime)
     hipStream_t owner = nullptr;  // bind(): the ONE stream every use of this buffer is ordered on (k-means handles)
     bool bound = false;
     ~DevBuf() { release(); }
     void bind(hipStream_t s) { owner = s, bound = true; }
     void release()
     {
-        if (p) devbuf_free(p, bytes);
+        if (p) devbuf_free(p, bytes, dev);
         p = nullptr;
         bytes = 0;
     }
@@ -136,7 +89,7 @@ struct DevBuf {
         // has synchronised its stream.
         if (p) (void)(bound ? hipStreamSynchronize(owner) : hipDeviceSynchronize());
         release();
-        return devbuf_alloc(&p, &bytes, n);
+        return devbuf_alloc(&p, &bytes, n, &dev);
     }
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
@@ -144,6 +97,8 @@ struct DevBuf {
 // Returns a device pointer for `src` (n bytes): src itself when it already is one, otherwise a
 // staged copy in `stage` (async on stream).
 int to_device(const void *src, size_t bytes, DevBuf &stage, hipStream_t stream, const void **out);
+// dst <- host `src` (n bytes), async on stream (grows dst as needed)
+int upload(DevBuf &dst, const void *src, size_t bytes, hipStream_t stream);
 // Copies a device result to `dst` (host or device), async on stream.
 int from_device(void *dst, const void *src_dev, size_t bytes, hipStream_t stream);
 

@@ -73,63 +73,8 @@ void drop_all_parked()
 }
 }  // namespace
 
-// ---- parked pinned host blocks (HostPinned, acav_common.h): size -> block; up to 1 GB / 4 096 blocks
-namespace {
-std::mutex g_pin_mutex;
-std::multimap<size_t, void *> g_pinned;
-size_t g_pinned_bytes = 0;
-}  // namespace
-
-int hostpin_alloc(void **p, size_t *bytes, size_t want)
-{
-    want = want < 4096 ? 4096 : want;
-    {
-        std::lock_guard<std::mutex> lock(g_pin_mutex);
-        auto it = g_pinned.lower_bound(want);
-        if (it != g_pinned.end() && it->first <= 2 * want + 4096) {
-            *p = it->second, *bytes = it->first;
-            g_pinned_bytes -= it->first;
-            g_pinned.erase(it);
-            return ACAV_OK;
-        }
-    }
-    hipError_t e = hipHostMalloc(p, want, hipHostMallocDefault);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        *p = nullptr, *bytes = 0;
-        set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
-        return ACAV_ENOMEM;
-    }
-    *bytes = want;
-    return ACAV_OK;
-}
-
-void hostpin_free(void *p, size_t bytes)
-{
-    if (!p) return;
-    {
-        std::lock_guard<std::mutex> lock(g_pin_mutex);
-        if (g_pinned_bytes + bytes <= (1024ull << 20) && g_pinned.size() < 4096) {
-            g_pinned.emplace(bytes, p);
-            g_pinned_bytes += bytes;
-            return;
-        }
-    }
-    (void)hipHostFree(p);
-}
-
 size_t devbuf_trim()
 {
-    {
-        std::vector<void *> dropp;
-        {
-            std::lock_guard<std::mutex> lock(g_pin_mutex);
-            for (auto &kv : g_pinned) dropp.push_back(kv.second);
-            g_pinned.clear();
-            g_pinned_bytes = 0;
-        }
-        for (void *q : dropp) (void)hipHostFree(q);
-    }
     size_t b;
     {
         std::lock_guard<std::mutex> lock(g_park_mutex);
@@ -139,10 +84,11 @@ size_t devbuf_trim()
     return b;
 }
 
-int devbuf_alloc(void **p, size_t *bytes, size_t want)
+int devbuf_alloc(void **p, size_t *bytes, size_t want, int *dev_out)
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
+    if (dev_out) *dev_out = dev;
     if (want <= PARK_MAX_BLOCK) {
         std::lock_guard<std::mutex> lock(g_park_mutex);
         auto it = g_parked.lower_bound({dev, want});  // smallest parked block of this device that fits ...
@@ -170,14 +116,15 @@ int devbuf_alloc(void **p, size_t *bytes, size_t want)
     return ACAV_OK;
 }
 
-void devbuf_free(void *p, size_t bytes)
+void devbuf_free(void *p, size_t bytes, int dev)
 {
     if (!p) return;
     if (bytes <= PARK_MAX_BLOCK) {
-        hipPointerAttribute_t attr;
-        int dev = -1;
-        if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device;
-        else (void)hipGetLastError();
+        if (dev < 0) {
+            hipPointerAttribute_t attr;
+            if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device;
+            else (void)hipGetLastError();
+        }
         std::lock_guard<std::mutex> lock(g_park_mutex);
         if (dev >= 0 && g_parked_bytes + bytes <= park_max_total() && g_parked.size() < park_max_blocks()) {
             g_parked.emplace(std::make_pair(dev, bytes), p);
@@ -195,17 +142,16 @@ int to_device(const void *src, size_t bytes, DevBuf &stage, hipStream_t stream, 
         return ACAV_OK;
     }
     ACAV_TRY(stage.ensure(bytes));
-    if (bytes >= HOSTPIN_MIN && bytes <= HOSTPIN_MAX) {  // through the buffer's pinned shadow: no pinning of the caller's pages on the fly
-        ACAV_TRY(stage.shadow.ensure(bytes));
-        stage.shadow.wait();  // the previous copy out of the shadow has left it
-        memcpy(stage.shadow.p, src, bytes);
-        ACAV_HIP_TRY(hipMemcpyAsync(stage.p, stage.shadow.p, bytes, hipMemcpyHostToDevice, stream));
-        ACAV_TRY(stage.shadow.mark(stream));
-        *out = stage.p;
-        return ACAV_OK;
-    }
     ACAV_HIP_TRY(hipMemcpyAsync(stage.p, src, bytes, hipMemcpyHostToDevice, stream));
     *out = stage.p;
+    return ACAV_OK;
+}
+
+int upload(DevBuf &dst, const void *src, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return ACAV_OK;
+    ACAV_TRY(dst.ensure(bytes));
+    ACAV_HIP_TRY(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, stream));
     return ACAV_OK;
 }
 

@@ -1412,6 +1412,7 @@ struct acav_rng;  // state access through the C ABI below
 //                                                                    the wrap still reads one contiguous range)
 // Nothing depends on what the greedy selects, so the whole schedule (which superblock an iteration needs, when a slot
 // may be overwritten) is computed on the host; the two streams meet through events only.
+static int mi_ensure_gen_events(acav_mi *mi);
 struct MtStream {
     static constexpr int NSLOT = 2;
     static constexpr int64_t PAD = 624;
@@ -1456,6 +1457,7 @@ struct MtStream {
         wraps = nsuper > NSLOT;
         st = consumer;
         smt = generator ? generator : mi->st_mt;
+        ACAV_TRY(mi_ensure_gen_events(mi));  // (created on first need: acav_mi_create)
         for (int q = 0; q < NSLOT; ++q) ev_mt[q] = mi->ev_mt[q], ev_used[q] = mi->ev_used[q];
         const int64_t slots = nsuper < NSLOT ? nsuper : NSLOT;
         ACAV_TRY(mi->ring.ensure(sizeof(unsigned) * (size_t)(PAD + slots * S + (wraps ? lmax : 0) + 8)));
@@ -1639,32 +1641,24 @@ static int fy_setup(acav_mi *mi, int64_t L, FyPlan &fp, hipStream_t st)
     return ACAV_OK;
 }
 
-// candidate / sample ids (int64 at the boundary, as the reference's lists) -> int32 on the device.  Host ids are range-checked and
-// narrowed in ONE pass into the pinned shadow of the destination (half the bytes of the int64 copy, no conversion kernel, and no
-// pinning of the caller's pages on the fly: a pageable 800 KB copy cost 3.9 ms, ten per lockstep group); device ids are converted
-// by k_i64_to_i32.  `on`: the stream to order the copy on (default: the handle's own).
+// candidate / sample ids (int64 at the boundary, as the reference's lists) -> int32 on the device; `on`: the stream the copy and the
+// conversion are ordered on (default: the handle's own)
 static int ids_to_device32(acav_mi *mi, const int64_t *ids, int64_t n, DevBuf &stage, DevBuf &out32, hipStream_t on = nullptr)
 {
     hipStream_t st = on ? on : mi->ctx.stream;
-    ACAV_TRY(out32.ensure(sizeof(int) * (size_t)(n > 0 ? n : 1)));
-    if (n <= 0) return ACAV_OK;
     if (!is_device_ptr(ids)) {
-        const size_t nb = sizeof(int) * (size_t)n;
-        ACAV_TRY(out32.shadow.ensure(nb));
-        out32.shadow.wait();
-        int *h = static_cast<int *>(out32.shadow.p);
-        for (int64_t i = 0; i < n; ++i) {
-            ACAV_REQUIRE(ids[i] >= 0 && ids[i] < mi->V, ACAV_EINVAL, "id %lld out of range [0,%lld)", (long long)ids[i], (long long)mi->V);
-            h[i] = (int)ids[i];
-        }
-        ACAV_HIP_TRY(hipMemcpyAsync(out32.p, h, nb, hipMemcpyHostToDevice, st));
-        ACAV_TRY(out32.shadow.mark(st));
-        return ACAV_OK;
+        for (int64_t i = 0; i < n; ++i)
+            ACAV_REQUIRE(ids[i] >= 0 && ids[i] < mi->V, ACAV_EINVAL, "id %lld out of range [0,%lld)",
+                         (long long)ids[i], (long long)mi->V);
     }
-    (void)stage;
-    hipLaunchKernelGGL(k_i64_to_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const long long *>(ids),
-                       out32.as<int>(), (long long)n);
-    ACAV_HIP_TRY(hipGetLastError());
+    const void *d = nullptr;
+    ACAV_TRY(to_device(ids, sizeof(int64_t) * (size_t)n, stage, st, &d));
+    ACAV_TRY(out32.ensure(sizeof(int) * (size_t)(n > 0 ? n : 1)));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_i64_to_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           static_cast<const long long *>(d), out32.as<int>(), (long long)n);
+        ACAV_HIP_TRY(hipGetLastError());
+    }
     return ACAV_OK;
 }
 
@@ -1750,7 +1744,6 @@ ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignm
     phi[0] = 0.0;
     for (int64_t k = 1; k < V + 2; ++k) phi[(size_t)k] = (double)k * log((double)k);
     auto body = [&]() -> int {
-        ACAV_TRY(mi->asg.ensure(sizeof(int) * a32.size()));
         ACAV_TRY(mi->pairs.ensure(sizeof(int) * 2 * (size_t)P));
         ACAV_TRY(mi->Nc.ensure(sizeof(int) * cc));
         ACAV_TRY(mi->ac.ensure(sizeof(int) * pc));
@@ -1758,11 +1751,10 @@ ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignm
         ACAV_TRY(mi->SN.ensure(sizeof(double) * P));
         ACAV_TRY(mi->Sa.ensure(sizeof(double) * P));
         ACAV_TRY(mi->Sb.ensure(sizeof(double) * P));
-        ACAV_TRY(mi->phi.ensure(sizeof(double) * phi.size()));
         ACAV_TRY(mi->scalars.ensure(sizeof(MiScalars)));
-        ACAV_HIP_TRY(hipMemcpyAsync(mi->asg.p, a32.data(), sizeof(int) * a32.size(), hipMemcpyHostToDevice, st));
+        ACAV_TRY(upload(mi->asg, a32.data(), sizeof(int) * a32.size(), st));
         ACAV_HIP_TRY(hipMemcpyAsync(mi->pairs.p, pairs, sizeof(int) * 2 * (size_t)P, hipMemcpyHostToDevice, st));
-        ACAV_HIP_TRY(hipMemcpyAsync(mi->phi.p, phi.data(), sizeof(double) * phi.size(), hipMemcpyHostToDevice, st));
+        ACAV_TRY(upload(mi->phi, phi.data(), sizeof(double) * phi.size(), st));
         ACAV_HIP_TRY(hipMemsetAsync(mi->Nc.p, 0, sizeof(int) * cc, st));
         ACAV_HIP_TRY(hipMemsetAsync(mi->ac.p, 0, sizeof(int) * pc, st));
         ACAV_HIP_TRY(hipMemsetAsync(mi->bc.p, 0, sizeof(int) * pc, st));
@@ -1779,17 +1771,8 @@ ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignm
         // creates a handle per chunk and runs every launch on the LEAD's streams -- ten chunks used to create 30 streams per group
         // for the 12 they use, and the lockstep loop slows down with the number of hardware queues the process keeps busy
         // (3.6 us per chunk-iteration with up to 16, 5.6-6.1 with 32: profiles/r06_mi_lockstep_by_hw_queues.txt).
-        bool ok = true;
-        for (int q = 0; q < 2 && ok; ++q)
-            ok = hipEventCreateWithFlags(&mi->ev_mt[q], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&mi->ev_used[q], hipEventDisableTiming) == hipSuccess;
-        for (int q = 0; q < FY_NBUF && ok; ++q)
-            ok = hipEventCreateWithFlags(&mi->ev_tile[q], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&mi->ev_gather[q], hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-            set_error("could not create the greedy loop's events");
-            rc = ACAV_EHIP;
-        }
+        // ... and so are the loop's EVENTS (mi_ensure_gen_events / mi_ensure_streams): 100 per handle, of which a chunk that is not its
+        // group's lead uses four
         mi->prio_streams = prio;
         mi->class_mt = cls(pmap[2]);
         mi->class_fy = stream ? 1 : cls(pmap[1]);  // (a caller's own content stream is most likely of the default class: the position stream goes up instead)
@@ -1804,8 +1787,22 @@ ACAV_EXPORT int acav_mi_create(acav_mi **out, int device, const int64_t *assignm
     return ACAV_OK;
 }
 
+static int mi_ensure_gen_events(acav_mi *mi)  // the generator ring's events of THIS handle's draws (MtStream::plan, legacy loop)
+{
+    for (int q = 0; q < 2; ++q) {
+        if (!mi->ev_mt[q]) ACAV_HIP_TRY(hipEventCreateWithFlags(&mi->ev_mt[q], hipEventDisableTiming));
+        if (!mi->ev_used[q]) ACAV_HIP_TRY(hipEventCreateWithFlags(&mi->ev_used[q], hipEventDisableTiming));
+    }
+    return ACAV_OK;
+}
+
 static int mi_ensure_streams(acav_mi *mi)
 {
+    ACAV_TRY(mi_ensure_gen_events(mi));
+    for (int q = 0; q < FY_DEPTH; ++q) {  // the group hand-offs between the position and the content stream (indices < FY_DEPTH are used)
+        if (!mi->ev_tile[q]) ACAV_HIP_TRY(hipEventCreateWithFlags(&mi->ev_tile[q], hipEventDisableTiming));
+        if (!mi->ev_gather[q]) ACAV_HIP_TRY(hipEventCreateWithFlags(&mi->ev_gather[q], hipEventDisableTiming));
+    }
     if (mi->st_mt && mi->st_fy) return ACAV_OK;
     ACAV_HIP_TRY(hipSetDevice(mi->ctx.device));
     int plo = 0, phi = 0;
@@ -1941,8 +1938,9 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
         ACAV_TRY(mi->A0.ensure(sizeof(int) * (Lc + B)));  // before the conversion: ensure() does not copy
         { const auto t0 = clk::now();
         // on the LEAD's content stream, the one the loop's gathers run on: ordered before them by the stream itself (on the chunk's
-        // own stream the conversion kernel was ordered by nothing but its brevity), and a chunk handle's own stream -- never used
-        // otherwise in a lockstep group -- does not have to acquire a hardware queue for one 800 KB copy (3.9 ms per chunk)
+        // own stream the conversion kernel was ordered by nothing but its brevity).  The copy itself is 3.9 ms per 800 KB of pageable
+        // ids (the runtime pins the pages on the fly); staging through pooled pinned blocks was built and measured: set-up 50 -> 4-10 ms
+        // per group, and the loops of the same processes 26.7 -> 33 us per lockstep iteration -- removed (tools/exp/NOTES_r06.md section 10)
         ACAV_TRY(ids_to_device32(mi, candidates[c], L[c], mi->stage, mi->A0, st));
         t_ids += ms_since(t0); }
         ACAV_TRY(mi->A1.ensure(sizeof(int) * (Lc + B)));
@@ -1982,6 +1980,7 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
         const int nshare = vsh ? atoi(vsh) : 1;
         if (nshare > 0) ACAV_TRY(mi_ensure_streams(mis[c % nshare]));
         else ACAV_TRY(mi_ensure_streams(mi));
+        ACAV_TRY(mi_ensure_gen_events(mi));
         { const auto t0 = clk::now();
         ACAV_TRY(ms.plan(mi, sf, mtbuf, idx, draws, L[c], (int64_t)FY_GROUP * L[c], nshare > 0 ? mis[c % nshare]->st_mt : nullptr));
         t_mt += ms_since(t0); }
