@@ -228,7 +228,11 @@ def select_chunked(a, types, chunk, width, seed0=1):
             res = EfficientBatchMI.run_greedy_multi([p[0] for p in prepared], [p[2] for p in prepared],
                                                     [p[1] for p in prepared])
             out.extend((r[0], r[1]) for r in res)
-            pool.submit(list.clear, prepared)  # the handles' device blocks are released on the helper thread too (a free syncs)
+            # the group's handles go HERE, on the launching thread, before the next group's set-up: their device blocks are parked
+            # (no hipFree since the pool holds a group's ~1 000 blocks) and the next set-up finds them -- released from the helper
+            # thread they raced with that set-up, and a set-up that misses the pool is a storm of hipMalloc under the next loop
+            # (tools/exp/NOTES_r06.md section 10); the product's own runner (subset_selection/run.py) drops them the same way
+            prepared.clear()
             del prepared
     return out
 
