@@ -30,6 +30,11 @@ def test_header_symbols_exported(acav):
     assert lib.acav_version() >= 100
 
 
+def test_trim_device_cache_is_callable_without_a_gpu(acav):
+    import acav100m_amd
+    assert acav100m_amd.trim_device_cache() >= 0  # nothing parked in a process that never allocated
+
+
 def test_no_gpu_is_a_loud_error(acav):
     from acav100m_amd.clustering import KMeans
     if acav.device_count() > 0:

@@ -412,6 +412,38 @@ def test_lockstep_chunks_equal_individual_runs(env):
         EfficientBatchMI.run_greedy_multi([m1, m2], [10, 10], [[0], [0]])
 
 
+def test_recycled_device_blocks_change_nothing_and_can_be_trimmed(env):
+    """Handles are re-created per chunk (chunk.py:21-53) and their device blocks come from the library's pool of parked blocks
+    (acav_trim_device_cache, include/acav_hip.h): a selection whose every buffer is a RECYCLED block -- still holding another
+    chunk's lists, tables and counters -- gives the oracle's result, and trimming returns the parked bytes to the driver."""
+    import gc
+    torch, acav, O = env
+    from acav100m_amd.rng import Generator
+    from acav100m_amd.subset_selection import get_measure
+    specs = [(6000, 2, 64, 240), (6000, 2, 64, 240), (4000, 3, 32, 120)]
+
+    def run(i, v, dd, c, subset):
+        a = _correlated(700 + i, v, dd, c)
+        cand = np.random.RandomState(70 + i).permutation(v)
+        pairs = list(itertools.combinations(range(dd), 2))
+        m = get_measure("batch_mi")(a, ncentroids=c, batch_size=20, selection_size=4, device="cuda:0", keep_unselected=True,
+                                    generator=Generator(90 + i))
+        m.init(pairs, [int(j) for j in cand[1:]])
+        got = m.run_greedy(subset, [int(cand[0])], None)
+        r = O.BatchMI(a, c, pairs).run_greedy(cand[1:], cand[:1], subset, 20, 4, O.Rng(90 + i))
+        assert got[0] == r["S"].tolist(), f"run {i}"
+        del m
+
+    acav.trim_device_cache()
+    for i, sp in enumerate(specs):  # runs 1 and 2 take the blocks run 0 parked (same sizes; a smaller third one takes what fits)
+        run(i, *sp)
+        gc.collect()
+    freed = acav.trim_device_cache()
+    assert freed > 0, "destroyed handles parked nothing"
+    assert acav.trim_device_cache() == 0
+    run(0, *specs[0])  # and from an empty pool again
+
+
 def test_greedy_loop_speed_does_not_depend_on_the_process_history():
     """The loop's three streams (content, positions, generator) need three HARDWARE queues; which queue the runtime gives a new
     stream depends on every stream the process created and destroyed before (round 5: two idle k-means handles cost the loop a
