@@ -73,8 +73,50 @@ void drop_all_parked()
 }
 }  // namespace
 
+namespace {
+std::mutex g_retired_mutex;
+std::vector<hipStream_t> g_retired_streams;
+std::vector<hipEvent_t> g_retired_events;
+}  // namespace
+
+void flush_retired(bool force)
+{
+    std::vector<hipStream_t> ss;
+    std::vector<hipEvent_t> es;
+    {
+        std::lock_guard<std::mutex> lock(g_retired_mutex);
+        if (!force && g_retired_streams.size() + g_retired_events.size() < 512) return;
+        ss.swap(g_retired_streams);
+        es.swap(g_retired_events);
+    }
+    for (hipEvent_t e : es) (void)hipEventDestroy(e);
+    for (hipStream_t q : ss) (void)hipStreamDestroy(q);
+    (void)hipGetLastError();
+}
+
+void retire_stream(hipStream_t s)
+{
+    if (!s) return;
+    {
+        std::lock_guard<std::mutex> lock(g_retired_mutex);
+        g_retired_streams.push_back(s);
+    }
+    flush_retired(false);
+}
+
+void retire_event(hipEvent_t e)
+{
+    if (!e) return;
+    {
+        std::lock_guard<std::mutex> lock(g_retired_mutex);
+        g_retired_events.push_back(e);
+    }
+    flush_retired(false);
+}
+
 size_t devbuf_trim()
 {
+    flush_retired(true);
     size_t b;
     {
         std::lock_guard<std::mutex> lock(g_park_mutex);
@@ -193,11 +235,22 @@ int StreamCtx::init(int dev, void *user_stream, int priority_class)
     return ACAV_OK;
 }
 
-void StreamCtx::fini()
+void StreamCtx::fini(bool retire)
 {
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
-    if (own_stream && stream) (void)hipStreamDestroy(stream);
+    if (!retire) {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+        ev0 = ev1 = nullptr;
+        stream = nullptr;
+        return;
+    }
+    retire_event(ev0);
+    retire_event(ev1);
+    if (own_stream && stream) {
+        (void)hipStreamSynchronize(stream);
+        retire_stream(stream);
+    }
     ev0 = ev1 = nullptr;
     stream = nullptr;
 }

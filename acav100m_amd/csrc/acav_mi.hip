@@ -1389,6 +1389,7 @@ struct acav_mi {
     DevBuf lnk, lf;   // ln k and ln k! tables of the `ami` score (acav_mi_set_measure)
     int measure = 0;  // exact greedy: 0 = calc_MI, 1 = calc_AMI, 2 = calc_NMI, 3 = constant
     int queue_probe_replaced = 0;  // streams replaced by mi_separate_queues (diagnostics: ACAV_MI_TIMING prints it)
+    bool lockstep_member = false;  // ran as one of several chunks of acav_mi_run_greedy_multi: its streams / events are RETIRED at destroy
     bool queue_probe_pending = false;  // the three streams have not been checked for a shared hardware queue yet
     bool prio_streams = false;         // ACAV_MI_STREAM_PRIO: priority classes of the generator / position stream (created lazily)
     int class_mt = 0, class_fy = 0;
@@ -1843,23 +1844,28 @@ ACAV_EXPORT int acav_mi_destroy(acav_mi *mi)
     if (!mi) return ACAV_OK;
     (void)hipSetDevice(mi->ctx.device);
     (void)hipStreamSynchronize(mi->ctx.stream);
-    if (mi->st_mt) {
-        (void)hipStreamSynchronize(mi->st_mt);
-        (void)hipStreamDestroy(mi->st_mt);
-    }
-    if (mi->st_fy) {
-        (void)hipStreamSynchronize(mi->st_fy);
-        (void)hipStreamDestroy(mi->st_fy);
-    }
-    for (int q = 0; q < 2; ++q) {
-        if (mi->ev_mt[q]) (void)hipEventDestroy(mi->ev_mt[q]);
-        if (mi->ev_used[q]) (void)hipEventDestroy(mi->ev_used[q]);
-    }
-    for (int q = 0; q < FY_NBUF; ++q) {
-        if (mi->ev_tile[q]) (void)hipEventDestroy(mi->ev_tile[q]);
-        if (mi->ev_gather[q]) (void)hipEventDestroy(mi->ev_gather[q]);
-    }
-    mi->ctx.fini();
+    // A handle that ran in a lockstep group RETIRES its streams and events (destroyed later, in bulk: acav_common.h): the ten handles
+    // of a group cost 45-90 ms to destroy between two groups (cfg5 slice: selection 2.98 -> 2.51 s).  Every other handle destroys them
+    // on the spot, as always: with retired streams alive the NEXT single-chunk loop's streams are placed differently (bench.py 28.9
+    // instead of 28.6 us per iteration; 37.8 when the retired ones are flushed right before that loop -- the placement of three
+    // streams on hardware queues is the process's history, tools/exp/NOTES_r06.md sections 5 and 10).
+    const bool retire = mi->lockstep_member;
+    auto drop_stream = [&](hipStream_t s) {
+        if (!s) return;
+        (void)hipStreamSynchronize(s);
+        if (retire) retire_stream(s);
+        else (void)hipStreamDestroy(s);
+    };
+    auto drop_event = [&](hipEvent_t e) {
+        if (!e) return;
+        if (retire) retire_event(e);
+        else (void)hipEventDestroy(e);
+    };
+    drop_stream(mi->st_mt);
+    drop_stream(mi->st_fy);
+    for (int q = 0; q < 2; ++q) drop_event(mi->ev_mt[q]), drop_event(mi->ev_used[q]);
+    for (int q = 0; q < FY_NBUF; ++q) drop_event(mi->ev_tile[q]), drop_event(mi->ev_gather[q]);
+    mi->ctx.fini(retire);
     delete mi;
     return ACAV_OK;
 }
@@ -1915,6 +1921,11 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
     for (int c = 0; c < nchunks; ++c) {
         acav_mi *mi = mis[c];
         ACAV_HIP_TRY(hipStreamSynchronize(mi->ctx.stream));  // whatever the handle was doing on its own stream is over
+        if (nchunks > 1) mi->lockstep_member = true;
+        // the staging block at its final size BEFORE the start samples use it: growing a DevBuf that is in use synchronises the
+        // device (it cannot know which stream still reads the old block) -- 4.2 ms in a process with a few dozen streams, ten times
+        // per lockstep group = 38 of a group's 41 ms of set-up (what the timers called "ids": the copy itself takes 0.02 ms)
+        if (!is_device_ptr(candidates[c])) ACAV_TRY(mi->stage.ensure(sizeof(int64_t) * (size_t)L[c]));
         { const auto t0 = clk::now();
         if (ns[c]) ACAV_TRY(acav_mi_add_samples(mi, start[c], ns[c]));  // batch.py:215
         t_add += ms_since(t0); }
@@ -1938,9 +1949,7 @@ static int run_greedy_tiled(acav_mi **mis, int nchunks, const int64_t *const *ca
         ACAV_TRY(mi->A0.ensure(sizeof(int) * (Lc + B)));  // before the conversion: ensure() does not copy
         { const auto t0 = clk::now();
         // on the LEAD's content stream, the one the loop's gathers run on: ordered before them by the stream itself (on the chunk's
-        // own stream the conversion kernel was ordered by nothing but its brevity).  The copy itself is 3.9 ms per 800 KB of pageable
-        // ids (the runtime pins the pages on the fly); staging through pooled pinned blocks was built and measured: set-up 50 -> 4-10 ms
-        // per group, and the loops of the same processes 26.7 -> 33 us per lockstep iteration -- removed (tools/exp/NOTES_r06.md section 10)
+        // own stream the conversion kernel was ordered by nothing but its brevity)
         ACAV_TRY(ids_to_device32(mi, candidates[c], L[c], mi->stage, mi->A0, st));
         t_ids += ms_since(t0); }
         ACAV_TRY(mi->A1.ensure(sizeof(int) * (Lc + B)));
