@@ -58,8 +58,8 @@ bool is_device_ptr(const void *p);
 // out again to the next request of a similar size on the same device: hipMalloc / hipFree are synchronous and cost
 // 50-200 us each -- a KMeans handle created per pass (bench.py, one CLI run per group) paid ~150 us of allocations inside
 // its first assign sweep.  The owner of a DevBuf synchronises its stream before the buffer goes (all *_destroy do).
-// Streams and events a handle no longer needs: destroyed LATER, in bulk (when 512 have gathered, at acav_trim_device_cache(), never
-// in between).  hipStreamDestroy / hipEventDestroy take the runtime's locks for milliseconds: the ten handles of a lockstep group cost
+// Streams and events a handle no longer needs: destroyed LATER, in bulk (when ACAV_RETIRE_MAX = 512 have gathered, at
+// acav_trim_device_cache(), never in between).  hipStreamDestroy / hipEventDestroy take the runtime's locks for milliseconds: the ten handles of a lockstep group cost
 // 45-90 ms to destroy, on the launching thread between two groups or -- from a helper thread -- under the next group's loop, which
 // then runs at 35-46 us per lockstep iteration instead of 26.7 (tools/exp/NOTES_r06.md section 10).  A retired stream is idle
 // (its owner synchronised it) and stays alive until the flush.

@@ -85,7 +85,8 @@ void flush_retired(bool force)
     std::vector<hipEvent_t> es;
     {
         std::lock_guard<std::mutex> lock(g_retired_mutex);
-        if (!force && g_retired_streams.size() + g_retired_events.size() < 512) return;
+        static const size_t cap = [] { const char *e = getenv("ACAV_RETIRE_MAX"); return (size_t)(e && atoi(e) > 0 ? atoi(e) : 512); }();
+        if (!force && g_retired_streams.size() + g_retired_events.size() < cap) return;
         ss.swap(g_retired_streams);
         es.swap(g_retired_events);
     }

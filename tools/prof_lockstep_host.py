@@ -57,7 +57,10 @@ with contextlib.redirect_stdout(io.StringIO()), ThreadPoolExecutor(helpers) as p
         t0 = time.perf_counter()
         res = EfficientBatchMI.run_greedy_multi([p[0] for p in prepared], [p[2] for p in prepared], [p[1] for p in prepared])
         t_loop.append(time.perf_counter() - t0)
-        pool.submit(clear, prepared)
+        if os.environ.get("CLEAR_IN_HELPER"):
+            pool.submit(clear, prepared)  # rounds 4-6: under the next group's loop
+        else:
+            clear(prepared)  # on the launching thread before the next set-up, as bench.select_chunked does now
         del prepared
 total = time.perf_counter() - T0
 f = lambda v: " ".join("%.0f" % (x * 1e3) for x in v)
