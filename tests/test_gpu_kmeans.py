@@ -89,7 +89,11 @@ def test_bulk_train_equals_stepwise_and_oracle(env):
                                      (2048, 88, 40, 32), (2048, 704, 64, 32), (1024, 64, 16, 32), (1536, 352, 24, 32),
                                      (2048, 128, 32, 32), (1024, 1000, 24, 32),
                                      # more than 32 centre groups (256 < K): the wide kernel's exchange, not the narrow one's
-                                     (4096, 256, 264, 32), (4096, 256, 300, 32), (8192, 64, 512, 32)])
+                                     (4096, 256, 264, 32), (4096, 256, 300, 32), (8192, 64, 512, 32),
+                                     # round 6: every pass width of the lean sweep (tp_sweep_lean<NU>), full and masked: 9-16 centre
+                                     # groups (NU = 8), a ragged batch under it, 63 groups of 16 centres with a ragged batch (NU = 32,
+                                     # masked), 64 full (NU = 32, the unmasked path)
+                                     (2048, 256, 128, 32), (2000, 512, 100, 20), (3072, 128, 1000, 24), (4096, 128, 1024, 32)])
 def test_persistent_epoch_kernel(env, n, d, K, b):
     """acav_kmeans_train takes the persistent one-launch path for d % 4 == 0, d <= 1024, b <= 32:
     centres resident in LDS, per-step device-scope key exchange.  Must equal the oracle bit for bit
@@ -120,7 +124,8 @@ def test_persistent_epoch_kernel(env, n, d, K, b):
     ref2.rng = rng2
     km2.train_epoch(xt, b, lr=0.3)
     ref2.train_epoch(x, b, lr=0.3)
-    assert km2.fallback == ref2.fallback and km2.fallback > 0
+    assert km2.fallback == ref2.fallback
+    assert km2.fallback > 0 or K >= 1000  # (with a thousand centres no batch of 24-32 rows puts four on one centre: the path is not taken)
     assert np.array_equal(km2.centers.numpy(), ref2.centers)
 
 
