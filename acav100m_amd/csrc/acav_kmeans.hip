@@ -594,6 +594,34 @@ struct TrainCtl {
 //   * the minimum is a strict `<` scan on the 32-bit distance in ascending group order (the first group of equal distances wins =
 //     the smaller index, as the 64-bit key compares), the two halves of a row merge through the 64-bit key as before.  A row whose
 //     best distance is 0xFFFFFFFF (no candidate, or NaN rows) is re-done with the 64-bit form -- never on finite data.
+// min(key, key of lane ^ 32 / ^ 16 / ^ 8) without the LDS: v_permlane32_swap / v_permlane16_swap (gfx950) put the lower and the upper
+// half (the even and the odd 16-lane rows) of a register side by side in two registers of EVERY lane, a row rotation by 8 is a DPP
+// modifier -- against two ds_bpermute + address arithmetic + an LDS round trip per 64-bit __shfl_xor, three to four times per step on
+// the slowest publisher's chain (tools/exp/permlane_probe.hip checks the lane mapping against __shfl_xor on the device).
+typedef unsigned tp_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned long long tp_min_xor32(unsigned long long key)
+{
+    const tp_u32x2 a = __builtin_amdgcn_permlane32_swap((unsigned)key, (unsigned)key, false, false);
+    const tp_u32x2 b = __builtin_amdgcn_permlane32_swap((unsigned)(key >> 32), (unsigned)(key >> 32), false, false);
+    const unsigned long long k0 = ((unsigned long long)b[0] << 32) | a[0], k1 = ((unsigned long long)b[1] << 32) | a[1];
+    return k1 < k0 ? k1 : k0;  // k0 = the key of lane & 31, k1 = of lane | 32, in both lanes
+}
+__device__ __forceinline__ unsigned long long tp_min_xor16(unsigned long long key)
+{
+    const tp_u32x2 a = __builtin_amdgcn_permlane16_swap((unsigned)key, (unsigned)key, false, false);
+    const tp_u32x2 b = __builtin_amdgcn_permlane16_swap((unsigned)(key >> 32), (unsigned)(key >> 32), false, false);
+    const unsigned long long k0 = ((unsigned long long)b[0] << 32) | a[0], k1 = ((unsigned long long)b[1] << 32) | a[1];
+    return k1 < k0 ? k1 : k0;  // the keys of the even and of the odd row of the pair
+}
+__device__ __forceinline__ unsigned long long tp_min_xor8(unsigned long long key)
+{
+    const unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32);
+    const unsigned plo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x128, 0xf, 0xf, false);  // row_ror:8 = lane ^ 8 within the row
+    const unsigned phi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x128, 0xf, 0xf, false);
+    const unsigned long long o = ((unsigned long long)phi << 32) | plo;
+    return o < key ? o : key;
+}
+
 template <int NE>
 __device__ __forceinline__ void tp_fold_parts(const float *p, int se, int sw, int nblk, float acc[NE])
 {
@@ -682,8 +710,7 @@ __device__ __forceinline__ unsigned tp_sweep_lean(const unsigned long long *ring
             }
     }
     if (!ok) key = ~0ull;
-    const unsigned long long o = __shfl_xor(key, 32);
-    key = o < key ? o : key;
+    key = tp_min_xor32(key);
     *best = (int)(key & 0xffffffffull);
     return ok;
 }
@@ -930,12 +957,9 @@ __global__ __launch_bounds__(256) void k_train_persistent(
                     }
                     if (kk < nck && ii < nrv) key = pack_key(tq, k);
                 }
-                unsigned long long o = __shfl_xor(key, 8);
-                key = o < key ? o : key;
-                o = __shfl_xor(key, 16);
-                key = o < key ? o : key;
-                o = __shfl_xor(key, 32);
-                key = o < key ? o : key;
+                key = tp_min_xor32(tp_min_xor16(tp_min_xor8(key)));  // (the minimum over the 8 centres kk of row ii: lanes ^ 8, ^ 16, ^ 32)
+                unsigned long long o;
+                (void)o;
                 // publish: one tagged granule per (my centre group, my row), a single 8-byte device-scope store
                 const unsigned long long tag = (unsigned long long)((nsync % 65535u) + 1u) << 48;
                 unsigned long long *ring = ctl->gran[nsync % TP_RING];
@@ -1426,10 +1450,8 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                         const unsigned long long kc = (lc < nck && i15 < nrv) ? pack_key(t4[e], kbase + lc) : ~0ull;
                         key = kc < key ? kc : key;
                     }
-                    o = __shfl_xor(key, 16);
-                    key = o < key ? o : key;
-                    o = __shfl_xor(key, 32);
-                    key = o < key ? o : key;  // lane l < 16 holds the key of row l
+                    key = tp_min_xor32(tp_min_xor16(key));  // lane l < 16 holds the key of row l
+                    (void)o;
                     (void)keys;
                 } else {
 #pragma unroll
@@ -1446,12 +1468,8 @@ __global__ __launch_bounds__(256) void k_train_persistent_wide(
                             key = kc < key ? kc : key;
                         }
                     }
-                    o = __shfl_xor(key, 8);
-                    key = o < key ? o : key;
-                    o = __shfl_xor(key, 16);
-                    key = o < key ? o : key;
-                    o = __shfl_xor(key, 32);
-                    key = o < key ? o : key;
+                    key = tp_min_xor32(tp_min_xor16(tp_min_xor8(key)));
+                    (void)o;
                     keys[rp] = key;
                 }
                 // lane l < 8 NRP holds the key of row l: its ii is l & 7 and every lane of an ii column holds that row's minimum
@@ -1965,10 +1983,7 @@ __global__ __launch_bounds__(256) void k_train_persistent_split(
                     unsigned long long key = ~0ull;
                     if (c < nck && i < nrv) key = pack_key(dist_epilogue(acc, xn_t, cn_c, ct_c < thr_t, r), kbase + c);
 #ifndef ACAV_WIDE_NO_MFMA
-                    unsigned long long o = __shfl_xor(key, 16);
-                    key = o < key ? o : key;
-                    o = __shfl_xor(key, 32);
-                    key = o < key ? o : key;
+                    key = tp_min_xor32(tp_min_xor16(key));
                     if (lane < 16) sKey[q * 16 + lane] = key;  // best of centres q, 4 + q, 8 + q, 12 + q for row `lane`
 #else
                     unsigned long long o = __shfl_xor(key, 8);
