@@ -2459,11 +2459,13 @@ struct TrainCall {
     const void *x_user = nullptr, *w_user = nullptr;
     int nwg = 0;
     bool launched = false, prof = false, split_prof = false, active = false;
+    bool is_split = false;  // the column-split kernel: one 130 KB workgroup on every CU, 256 registers per lane
+    bool shared = false;    // launched BESIDE such a kernel, in the LDS it leaves (books no CUs of the budget)
     std::vector<float> thr;  // staging of the per-step thresholds: alive until the launch has been waited for
 };
 
 static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t n, int64_t b, double lr,
-                        const int64_t *warm_best, int64_t n_warm, int *budget)
+                        const int64_t *warm_best, int64_t n_warm, int *budget, int share_lds = 0)
 {
     // a pending clustering of acav_kmeans_train_multi is tried again whenever CUs come back: its inputs are staged ONCE (device copy of
     // host rows, warm-up labels, the row norms over the whole epoch) -- a retry only re-evaluates the fit and enqueues the kernel
@@ -2592,6 +2594,19 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
                 best_ncp = 2, nrp = 2, one_x = true, wide_wg = groups * rg2, wide_smem = smem;
             }
         }
+        // Round 6 (ACAV_TRAIN_SHARE_CU=0 switches it off): no CUs left, but the ONE launch in flight is the column-split kernel (a 130 KB workgroup
+        // on every CU, 252 + 4 registers per lane since the exchange rewrite) -- a 16-centre form with one row buffer fits the LDS it
+        // leaves (26 KB at ds = 256) and the register file beside it (231-243 + 4: profiles/r06_train_regs.txt), one workgroup per CU:
+        // cfg4's 2048-d and 128-d views train side by side instead of one after the other.
+        if (!best_ncp && share_lds > 0 && ds <= 512) {
+            const int groups = (km->K + 15) / 16;
+            const size_t smem = sizeof(float) * ((size_t)(16 + 8) * ds + 2 * 16 + 4 * 64 * (size_t)(ds / 256) + 32);  // (tile sums: 4 x 64 per column block)
+            if (groups <= 64 && (int)smem + 512 <= share_lds && groups * rgroups <= km->num_cus) {
+                best_ncp = 2, nrp = 1, one_x = true, wide_wg = groups * rgroups, wide_smem = smem;
+                tc.shared = true;
+                if (getenv("ACAV_TRAIN_SHARE_DEBUG")) fprintf(stderr, "[acav] shared launch: d = %d, K = %d, %d workgroups of %zu B beside the split kernel (%d B free per CU)\n", km->d, km->K, wide_wg, smem, share_lds);
+            }
+        }
         if (best_ncp) ncp = best_ncp, persistent = wide = true;
     }
     // 1024 < d <= 2048 (cfg4's visual view): the columns are split over pairs of workgroups (k_train_persistent_split)
@@ -2613,7 +2628,8 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
     }
     if (!persistent) return ACAV_OK;
     tc.nwg = split ? split_wg : wide ? wide_wg : nwg;
-    if (budget) *budget -= tc.nwg;
+    tc.is_split = split;
+    if (budget && !tc.shared) *budget -= tc.nwg;
     tc.thr.resize((size_t)steps);
     for (int64_t t = 0; t < steps; ++t)
         tc.thr[(size_t)t] = (float)pow((double)(km->count + t * b) / (double)km->K, km->reinit_p);
@@ -2656,6 +2672,7 @@ static int train_launch(acav_kmeans *km, TrainCall &tc, const float *x, int64_t 
             else wk = ncp == 1 ? (one_x ? k_train_persistent_wide<false, 1, true> : k_train_persistent_wide<false, 1, false>)
                                : (one_x ? k_train_persistent_wide<false, 2, true> : k_train_persistent_wide<false, 2, false>);
         } else if (nrp == 2) wk = ragged ? k_train_persistent_wide<true, 2, true, 2> : k_train_persistent_wide<false, 2, true, 2>;
+        else if (one_x && ncp == 2) wk = ragged ? k_train_persistent_wide<true, 2, true> : k_train_persistent_wide<false, 2, true>;  // (beside the split kernel)
         else if (ragged) wk = ncp == 2 ? k_train_persistent_wide<true, 2> : ncp == 4 ? k_train_persistent_wide<true, 4> : k_train_persistent_wide<true, 8>;
         else wk = ncp == 2 ? k_train_persistent_wide<false, 2> : ncp == 4 ? k_train_persistent_wide<false, 4> : k_train_persistent_wide<false, 8>;
         ACAV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_smem));
@@ -2788,6 +2805,8 @@ ACAV_EXPORT int acav_kmeans_train_multi(acav_kmeans *const *kms, int count, cons
     // are independent.
     const int cus = prop.multiProcessorCount;
     int budget = cus;
+    const char *vshare = getenv("ACAV_TRAIN_SHARE_CU");
+    const bool share_cu = !(vshare && vshare[0] == '0');  // on by default; ACAV_TRAIN_SHARE_CU=0: the views of such a pair one after the other
     std::vector<int> pending, inflight;
     for (int i = 0; i < count; ++i) pending.push_back(i);
     int tried_at = -1;  // budget at the last round of attempts: a pending launch is only tried again once CUs have come back
@@ -2799,7 +2818,11 @@ ACAV_EXPORT int acav_kmeans_train_multi(acav_kmeans *const *kms, int count, cons
                 // (the last clustering of the call with nothing else in flight is a call for ONE clustering: it gets the form that
                 // is fastest alone, not the one that leaves room for a neighbour)
                 int *bp = (inflight.empty() && pending.size() == 1) ? nullptr : &budget;
-                ACAV_TRY(train_launch(kms[i], tc, xs[i], ns[i], b, lr, warm_best ? warm_best[i] : nullptr, n_warm[i], bp));
+                // LDS a second launch may use on every CU: only beside ONE in-flight column-split kernel
+                int share_lds = 0;
+                if (share_cu && bp != nullptr && inflight.size() == 1 && calls[(size_t)inflight[0]].is_split && !calls[(size_t)inflight[0]].shared)
+                    share_lds = 160 * 1024 - (int)TS_SMEM - 512;  // (LDS is handed out in 512-byte units; both kernels' static __shared__ is a few bytes)
+                ACAV_TRY(train_launch(kms[i], tc, xs[i], ns[i], b, lr, warm_best ? warm_best[i] : nullptr, n_warm[i], bp, share_lds));
                 if (tc.active && !tc.launched && inflight.empty() && bp != nullptr && budget == cus) {
                     // does not fit beside others even on an empty device: as a call for one clustering (whole-device forms)
                     ACAV_TRY(train_launch(kms[i], tc, xs[i], ns[i], b, lr, warm_best ? warm_best[i] : nullptr, n_warm[i], nullptr));
@@ -2837,7 +2860,7 @@ ACAV_EXPORT int acav_kmeans_train_multi(acav_kmeans *const *kms, int count, cons
         (void)hipGetLastError();  // a hipErrorNotReady of this sweep must not surface in the next launch's error check
         const int i = inflight[done];
         inflight.erase(inflight.begin() + (long)done);
-        const int gave = calls[(size_t)i].nwg;
+        const int gave = calls[(size_t)i].shared ? 0 : calls[(size_t)i].nwg;  // (a shared launch booked no CUs)
         ACAV_TRY(train_finish(kms[i], calls[(size_t)i]));  // a launch that gave up is re-run on the per-step path in here
         ACAV_TRY(kms[i]->prepare_filter());
         budget = budget + gave > cus ? cus : budget + gave;
